@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/neat_oracle.py) to golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from neat_amd import synth
+from oracle import neat_oracle as O
+
+T = torch.tensor
+
+
+def params(variant, grad=False):
+    return O.params_from_numpy(synth.synth_state_dict(42, variant), requires_grad=grad)
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    tol = tol * max(1.0, float(np.abs(b).max()) if b.size else 1.0)      # relative to the tensor's scale
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol}"
+
+
+def test_posenc(golden):
+    g = golden("g1_posenc")
+    close(O.posenc(T(g["x"]), 6), g["pe6"], 0, "pe6")
+    close(O.posenc(T(g["x"]), 4), g["pe4"], 0, "pe4")
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_networks(golden, variant):
+    g = golden(f"g2g3_networks_{variant}")
+    p = params(variant)
+    x, view = T(g["x"]), T(g["view"])
+    close(O.sdf_forward(p, x), g["forward"], 2e-6, "forward")
+    close(O.sdf_values(p, x), g["sdf_vals"], 2e-6, "sdf_vals")
+    s, f, gr = O.sdf_outputs(p, x)
+    close(s, g["out_sdf"], 2e-6, "sdf")
+    close(f, g["out_feat"], 2e-6, "feat")
+    close(gr, g["out_grad"], 2e-5, "grad")
+    close(O.sdf_gradient(p, x), g["grad_raw"], 2e-5, "grad_raw")
+    # sphere clamp must be active on some points and inactive on others
+    assert (g["out_sdf"] != g["forward"][:, :1]).any() and (g["out_sdf"] == g["forward"][:, :1]).any()
+    close(O.render_head(p, x, T(g["out_grad"]), view, T(g["out_feat"])), g["rgb"], 2e-6, "rgb")
+    close(O.attraction_head(p, x, T(g["out_grad"]), view, T(g["out_feat"])), g["lines"], 5e-6, "lines")
+
+
+def test_density_and_weights(golden):
+    g = golden("g4_density")
+    for b in (1e-3, 1e-2, 0.1):
+        close(O.laplace_density(T(g["sdf"]), T(b)), g[f"sigma_{b:g}"], 0, f"sigma {b}")
+    g = golden("g5_volume_rendering")
+    sig = O.laplace_density(T(g["sdf"]).reshape(g["z"].shape), T(g["beta"]))
+    close(O.free_energy_weights(T(g["z"]), sig)[0], g["weights"], 0, "weights")
+
+
+def test_camera(golden):
+    g = golden("g10_camera")
+    for tag, K in (("", "K"), ("_skew", "K_skew")):
+        d, c = O.camera_rays(T(g["uv"]), T(g["pose"]), T(g[K]))
+        close(d, g["dirs" + tag], 1e-7, "dirs" + tag)
+        close(c, g["cam" + tag], 0, "cam" + tag)
+
+
+def test_hierarchical(golden):
+    g = golden("g9_hierarchical")
+    z, w = T(g["z_coarse"]), T(g["weights"])
+    close(O.uniform_z(16, 64, 0.0, 6.0), g["z_coarse"], 0, "coarse")
+    u = torch.linspace(0.0, 1.0, 64)[None].expand(16, 64)
+    close(O.z_vals_fine(z, w, u), g["z_fine_det"], 0, "fine det")
+    close(O.z_vals_fine(z, w, T(g["u_rand"])), g["z_fine_rand"], 0, "fine rand")
+
+
+def _rays(g):
+    d, o = O.camera_rays(T(g["uv"]), T(g["pose"]), T(g["intrinsics"]))
+    d = d.reshape(-1, 3)
+    return d, o.expand(d.shape[0], 3)
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_sampler_eval(golden, variant):
+    g = golden(f"g6_sampler_eval_{variant}")
+    p = params(variant)
+    d, o = _rays(g)
+    tr = {}
+    z, ze = O.error_bound_sampler(lambda x: O.sdf_values(p, x), O.beta_of(p), d, o, training=False,
+                                  rand={"eik_idx": T(g["eik_idx"])}, trace=tr)
+    close(z, g["z_vals"], 2e-5, "z_vals")
+    close(ze, g["z_eik"], 2e-5, "z_eik")
+    if variant == "rough":
+        assert tr["rounds"] >= 2
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_sampler_train(golden, variant):
+    g = golden(f"g6_sampler_train_{variant}")
+    p = params(variant)
+    d, o = _rays(g)
+    rand = {k: T(g[k]) for k in ("t_rand", "u_final", "perm", "eik_idx")}
+    z, ze = O.error_bound_sampler(lambda x: O.sdf_values(p, x), O.beta_of(p), d, o, training=True, rand=rand)
+    close(z, g["z_vals"], 2e-5, "z_vals")
+    close(ze, g["z_eik"], 2e-5, "z_eik")
+
+
+def _inp(g):
+    return {k: T(g[k]) for k in ("intrinsics", "pose", "uv", "uv_proj")}
+
+
+def _wf(g):
+    v, e, w = T(g["wf_vertices"]), T(g["wf_edges"]), T(g["wf_weights"])
+    ok = w > 0.97
+    return torch.cat([v[e[ok, 0]], v[e[ok, 1]], w[ok, None]], -1), v
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_full_forward_eval(golden, variant):
+    g = golden(f"g7_forward_eval_{variant}")
+    p = params(variant)
+    lines, verts = _wf(g)
+    out = O.full_forward(p, _inp(g), lines, verts, training=False, rand={"eik_idx": T(g["eik_idx"])})
+    for k in ("points", "rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf",
+              "normal_map"):
+        close(out[k], g["out_" + k], 5e-5, k)
+    close(out["lines2d"], g["out_lines2d"], 2e-2, "lines2d (pixels)")
+
+
+def test_train_step(golden):
+    g = golden("g8_train_step_rough")
+    p = params("rough", grad=True)
+    lines, verts = _wf(g)
+    rand = {k: T(g[k]) for k in ("t_rand", "u_final", "perm", "eik_idx", "eik_uniform")}
+    out = O.full_forward(p, _inp(g), lines, verts, training=True, rand=rand)
+    for k in ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+              "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median"):
+        close(out[k], g["out_" + k], 5e-5, k)
+    lo = O.neat_loss(out, T(g["gt_rgb"]), T(g["gt_lines2d"]))
+    for k in ("loss", "rgb_loss", "eikonal_loss", "line_loss", "j3d_loss", "j2d_loss"):
+        close(lo[k].float(), g["loss_" + k], 2e-5, "loss " + k)
+    assert int(lo["count"]) == int(g["loss_count"]) and int(lo["jcount"]) == int(g["loss_jcount"])
+    lo["loss"].backward()
+    from tests.golden.make_golden import GRAD_STRIDE
+    worst = 0.0
+    for k, v in p.items():
+        gr = v.grad.reshape(-1).numpy()
+        ref, (nrm, _) = g["grad_" + k], g["gradnorm_" + k]
+        err = np.abs(gr[::GRAD_STRIDE] - ref).max()
+        scale = max(np.abs(ref).max(), 1e-6)
+        worst = max(worst, err / scale)
+        assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
+        assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - nrm) <= 2e-4 * nrm + 1e-7, k
+    print("worst relative grad err", worst)
