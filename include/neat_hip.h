@@ -1,0 +1,100 @@
+/* neat_hip.h -- C ABI of libneat_hip.so: the MI355X (gfx950) implementation of NEAT's volumetric-
+ * rendering hot path.  Plain pointers and sizes only (no torch types): every pointer is a DEVICE
+ * pointer to float32 unless stated, `stream` is a hipStream_t passed as void*, every call is
+ * asynchronous on that stream, never synchronises, never allocates, never keeps caller memory.
+ * Return value: 0 on success, otherwise a hipError_t (or -1 for bad arguments).
+ *
+ * The reference (cherubicXN/neat) has no native layer: these entry points replace the ATen op
+ * sequences issued by the Python lines cited on each function (paths relative to the reference's
+ * code/ directory).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Layouts: "row-major [P,C]" is the torch layout the reference uses.  Workspaces are opaque float
+ * arenas sized by the *_ws_floats() queries; they carry the activations saved for backward.
+ */
+#ifndef NEAT_HIP_H
+#define NEAT_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEAT_NUM_LAYERS 19   /* implicit_network.lin0..8, rendering_network.lin0..4, attraction_network.lin0..4 */
+#define NEAT_FEATURE 256
+
+/* Raw parameters exactly as in the reference state_dict (weight-normed Linear layers:
+ * model/networks/neat_wfr_rend_a.py:71-72,167-168,227-228): weight_v [out,in], weight_g [out,1], bias [out]. */
+typedef struct neat_net_params {
+  const float* v[NEAT_NUM_LAYERS];
+  const float* g[NEAT_NUM_LAYERS];
+  const float* b[NEAT_NUM_LAYERS];
+} neat_net_params;
+
+/* Gradient destinations, same shapes as neat_net_params (overwritten, not accumulated).  A NULL dv[l]
+ * skips layer l (e.g. the heads when only the SDF network was run). */
+typedef struct neat_net_grads {
+  float* dv[NEAT_NUM_LAYERS];
+  float* dg[NEAT_NUM_LAYERS];
+  float* db[NEAT_NUM_LAYERS];
+} neat_net_grads;
+
+int neat_abi_version(void);
+
+/* ---- a15: weight norm + packing (replaces the per-call `_weight_norm` pre-hook) -------------------
+ * Computes W = g * v/|v| for all 19 layers once per step and stores W and W^T in MFMA-fragment order. */
+size_t neat_packed_floats(void);
+int neat_pack_weights(const neat_net_params* net, float* packed, void* stream);
+
+/* ---- a1: pixel -> unit ray directions (utils/rend_util.py:55-81 get_camera_params, :95-108 lift) --
+ * uv [R,2], pose [4,4] cam-to-world, K row stride `kstride` (3 or 4).  dirs [R,3].  Origin = pose[:3,3]. */
+int neat_camera_rays(const float* uv, const float* pose, const float* K, int kstride, int R, float* dirs, void* stream);
+
+/* ---- a4+a5: SDF / implicit network (neat_wfr_rend_a.py:78-137) -----------------------------------
+ * mode 0: values only  -> sdf[P] = get_sdf_vals(x)            (:131-137), nothing saved
+ * mode 1: outputs      -> forward() [P,257], clamped sdf, feature, d sdf/dx (get_outputs :111-129 /
+ *                         gradient :98-109 when radius <= 0), activations saved in `ws` for backward.
+ * radius > 0 enables the bounding-sphere clamp min(sdf, scale*(radius-|x|)).
+ * Any of out257 / sdf / feat / grad may be NULL.  x is row-major [P,3]. */
+size_t neat_sdf_ws_floats(int P, int mode);
+int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode,
+                     float radius, float scale, float* ws,
+                     float* out257, float* sdf, float* feat, float* grad, void* stream);
+/* Backward of mode-1 forward (autograd incl. the double backward through d sdf/dx, which the reference
+ * gets from create_graph=True at :121-127).  Cotangents are row-major and may be NULL (= zero):
+ * d_out257 [P,257] (of forward()), d_sdf [P] (of the clamped sdf), d_feat [P,256], d_grad [P,3].
+ * Writes grads->dv/dg/db[0..8]. */
+int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P,
+                      const float* d_out257, const float* d_sdf, const float* d_feat, const float* d_grad,
+                      const neat_net_grads* grads, void* stream);
+
+/* ---- a6+a7: the two heads on given inputs (RenderingNetwork.forward :235-255,
+ * AttractionFieldNetwork.forward :175-197), row-major inputs; rgb [P,3], lines [P,2,3]. */
+size_t neat_heads_ws_floats(int P);
+int neat_heads_forward(const float* packed, const neat_net_params* net, const float* points, const float* normals,
+                       const float* view_dirs, const float* feats, int P, float* ws,
+                       float* rgb, float* lines, void* stream);
+
+/* ---- a5-a10 fused main pass: VolSDFNetwork.forward :392-422 (+ :530-536 normal_map in eval) -------
+ * origins/dirs [R,3], z [R,S] sorted depths, beta = DEVICE pointer to one float holding
+ * |density.beta| + beta_min (model/density.py:28-30) -- a pointer so that no host sync is needed.
+ * Outputs (row-major, NULL to skip where noted): points [R,S,3] (opt), weights [R,S] (opt),
+ * sdf [R,S] (opt), rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], normal_map [R,3] (opt). */
+size_t neat_render_ws_floats(int R, int S);
+int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
+                        const float* z, int R, int S, const float* beta, float radius, float scale, float* ws,
+                        float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
+                        float* xyz, float* normal_map, void* stream);
+/* Backward of neat_render_forward.  Cotangents d_rgb [R,3], d_lines3d [R,6], d_depth [R], d_xyz [R,3]
+ * (NULL = zero).  lines3d uses detached weights exactly as :410.  Writes all 19 layers' grads and the
+ * per-ray partial derivative wrt beta, dbeta_ray [R] (sum it, times sign(density.beta)). */
+int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs,
+                         const float* z, int R, int S, const float* beta,
+                         const float* d_rgb, const float* d_lines3d, const float* d_depth, const float* d_xyz,
+                         const neat_net_grads* grads, float* dbeta_ray, void* stream);
+
+/* ---- a9 alone: volume_rendering :540-554 given sdf [R,S] -> weights [R,S] (used by tests) -------- */
+int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

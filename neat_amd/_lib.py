@@ -1,0 +1,70 @@
+"""ctypes binding of libneat_hip.so (C ABI declared in include/neat_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+NUM_LAYERS = 19
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libneat_hip.so")
+
+c_fp = ctypes.c_void_p      # device float* (passed as integer addresses)
+
+
+class NetParams(ctypes.Structure):
+    _fields_ = [("v", c_fp * NUM_LAYERS), ("g", c_fp * NUM_LAYERS), ("b", c_fp * NUM_LAYERS)]
+
+
+class NetGrads(ctypes.Structure):
+    _fields_ = [("dv", c_fp * NUM_LAYERS), ("dg", c_fp * NUM_LAYERS), ("db", c_fp * NUM_LAYERS)]
+
+
+_SIGNATURES = {
+    "neat_abi_version": (ctypes.c_int, []),
+    "neat_packed_floats": (ctypes.c_size_t, []),
+    "neat_pack_weights": (ctypes.c_int, [ctypes.POINTER(NetParams), c_fp, c_fp]),
+    "neat_camera_rays": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "neat_sdf_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "neat_sdf_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "neat_sdf_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp,
+                                         ctypes.POINTER(NetGrads), c_fp]),
+    "neat_heads_ws_floats": (ctypes.c_size_t, [ctypes.c_int]),
+    "neat_heads_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp,
+                                          c_fp, c_fp, c_fp]),
+    "neat_render_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "neat_render_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int,
+                                           c_fp, ctypes.c_float, ctypes.c_float, c_fp,
+                                           c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int,
+                                            c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
+    "neat_volume_weights": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names declared in include/neat_hip.h (kept in sync by tests/test_abi.py)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or neat_amd/csrc/build.sh).  neat_amd has no CPU/PyTorch fallback for the hot path.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"libneat_hip: {what} failed with code {code}")

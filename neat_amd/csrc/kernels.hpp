@@ -1,0 +1,783 @@
+// Device kernels for the NEAT hot path on gfx950 (MI355X).  fp32 build: exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32), activations kept FEATURE-MAJOR in HBM/LDS ([feature][point], points
+// contiguous) so that (i) the point tile is the MFMA B operand with conflict-free ds_read_b32,
+// (ii) accumulator rows go straight back to memory as 128-byte row segments, no transposes.
+//
+//   out[n][p] = epi( sum_k Wm[n][k] * in[k][p] + bias[n] )       one workgroup = 64 points x all n
+//
+// Wm is W (forward / tangent chains) or W^T (adjoint / reverse chains); both are pre-packed in MFMA
+// A-fragment order by pack_kernel so that a wave's weight fetch is one coalesced 256-byte load.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace neat {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64;          // points per workgroup tile
+constexpr int WG = 256;         // threads per workgroup (4 waves, one per SIMD)
+
+// ---------------------------------------------------------------------------------------------
+// activation helpers (reference: nn.Softplus(beta=100), threshold 20 -- neat_wfr_rend_a.py:76)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus100(float a) {
+  const float t = 100.0f * a;
+  return t > 20.0f ? a : log1pf(expf(t)) * 0.01f;
+}
+// softplus'(a) = sigmoid(100 a) = 1 - exp(-100 h), h = softplus(a)
+__device__ __forceinline__ float dphi_from_h(float h) { return -expm1f(-100.0f * h); }
+
+enum Epi : int {
+  EPI_LINEAR = 0,    // out = acc (+bias) ; rows >= n_split go to out1 ; optional accumulate into out0
+  EPI_SOFTPLUS = 1,  // out0 = softplus100(acc + bias)
+  EPI_RELU = 2,      // out0 = max(acc + bias, 0)
+  EPI_SIGMOID = 3,   // out0 = sigmoid(acc + bias)
+  EPI_REV = 4,       // adjoint chain: rows < n_split: out0 = acc * phi'(aux0) ; rows >= n_split: out1 = acc
+  EPI_TAN = 5,       // tangent chain: s = phi'(aux0); out0 = acc*s ; out1 = acc * aux1 * 100 (1-s)
+  EPI_BWD = 6,       // reverse chain: out0 = acc * phi'(aux0) + aux1
+  EPI_BWD_RELU = 7,  // out0 = aux0 > 0 ? acc : 0
+};
+
+struct LayerArgs {
+  const float* in0; const float* in1;   // input row segments, feature-major [rows][ldp]
+  int rows0, rows1;                     // K = rows0 + rows1
+  int Kpad;                             // K rounded up to a multiple of 8 (zero rows / zero weights)
+  const float* Wp;                      // packed weights [NT][Kpad/2][64]
+  const float* bias;                    // [N] or null
+  int N, NT;                            // valid output rows, number of 32-row tiles
+  int ldp;                              // point stride of every array (multiple of 64)
+  float* out0; float* out1; int n_split; int accumulate;
+  const float* aux0; const float* aux1;
+};
+
+template <int NTW>
+__device__ __forceinline__ void mma_rows(f32x16 (&acc)[3][2], const float* __restrict__ wp0, int tile_stride,
+                                         const float* __restrict__ bl, int s_begin, int s_end) {
+  // wp0: this wave's first tile, already offset by lane; consecutive owned tiles are tile_stride floats apart.
+  for (int s = s_begin; s < s_end; s += 4) {
+    float av[NTW][4], bv[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) av[i][u] = wp0[(size_t)i * tile_stride + (s + u) * 64];
+      bv[0][u] = bl[(2 * (s + u)) * BM];
+      bv[1][u] = bl[(2 * (s + u)) * BM + 32];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[0][u], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[1][u], acc[i][1], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile(const LayerArgs& a, const f32x16& acc, int nt, int pt, int lane, int p0) {
+  const int p = p0 + pt * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (n >= a.N) continue;
+    float v = acc[r];
+    const size_t idx = (size_t)n * a.ldp + p;
+    if (EPI == EPI_LINEAR) {
+      if (a.bias) v += a.bias[n];
+      if (n < a.n_split) {
+        if (a.accumulate) v += a.out0[idx];
+        a.out0[idx] = v;
+      } else {
+        a.out1[(size_t)(n - a.n_split) * a.ldp + p] = v;
+      }
+    } else if (EPI == EPI_SOFTPLUS) {
+      a.out0[idx] = softplus100(v + a.bias[n]);
+    } else if (EPI == EPI_RELU) {
+      a.out0[idx] = fmaxf(v + a.bias[n], 0.0f);
+    } else if (EPI == EPI_SIGMOID) {
+      a.out0[idx] = 1.0f / (1.0f + expf(-(v + a.bias[n])));
+    } else if (EPI == EPI_REV) {
+      if (n < a.n_split) a.out0[idx] = v * dphi_from_h(a.aux0[idx]);
+      else a.out1[(size_t)(n - a.n_split) * a.ldp + p] = v;
+    } else if (EPI == EPI_TAN) {
+      const float s = dphi_from_h(a.aux0[idx]);
+      const float u = a.aux1[idx];
+      a.out0[idx] = v * s;
+      a.out1[idx] = v * u * (100.0f * (1.0f - s));
+    } else if (EPI == EPI_BWD) {
+      a.out0[idx] = v * dphi_from_h(a.aux0[idx]) + a.aux1[idx];
+    } else if (EPI == EPI_BWD_RELU) {
+      a.out0[idx] = a.aux0[idx] > 0.0f ? v : 0.0f;
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(WG, 2) void layer_kernel(LayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [Kpad][BM]; reused for split-K reduce
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p0 = blockIdx.x * BM;
+  const int K = a.rows0 + a.rows1;
+  {  // stage the 64-point input tile: 16 rows x 64 points per pass, float4 per lane
+    const int c4 = (tid & 15) * 4;
+    for (int r = tid >> 4; r < a.Kpad; r += 16) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < a.rows0) v = *reinterpret_cast<const float4*>(a.in0 + (size_t)r * a.ldp + p0 + c4);
+      else if (r < K) v = *reinterpret_cast<const float4*>(a.in1 + (size_t)(r - a.rows0) * a.ldp + p0 + c4);
+      *reinterpret_cast<float4*>(lds + r * BM + c4) = v;
+    }
+  }
+  __syncthreads();
+  const int KS = a.Kpad >> 1;
+  const float* bl = lds + (lane >> 5) * BM + (lane & 31);
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
+
+  if (a.NT > 2) {
+    // wave w owns tiles w, w+4, w+8
+    const int ntw = (a.NT - wave + 3) >> 2;          // tiles owned (wave-uniform, 1..3 here)
+    const float* wp0 = a.Wp + (size_t)wave * KS * 64 + lane;
+    const int tstride = 4 * KS * 64;
+    if (ntw >= 3) mma_rows<3>(acc, wp0, tstride, bl, 0, KS);
+    else if (ntw == 2) mma_rows<2>(acc, wp0, tstride, bl, 0, KS);
+    else if (ntw == 1) mma_rows<1>(acc, wp0, tstride, bl, 0, KS);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {            // static indices: a runtime-indexed accumulator array would live in scratch
+      if (i < ntw) {
+        epilogue_tile<EPI>(a, acc[i][0], wave + 4 * i, 0, lane, p0);
+        epilogue_tile<EPI>(a, acc[i][1], wave + 4 * i, 1, lane, p0);
+      }
+    }
+  } else {
+    // narrow outputs (N <= 64): split K across waves, then reduce through LDS
+    const int ksplit = 4 / a.NT;                     // 4 (NT=1) or 2 (NT=2)
+    const int tile = wave % a.NT, kpart = wave / a.NT;
+    const int per = ((KS / 4 + ksplit - 1) / ksplit) * 4;
+    const int sb = kpart * per, se = min(KS, sb + per);
+    const float* wp0 = a.Wp + (size_t)tile * KS * 64 + lane;
+    if (sb < se) mma_rows<1>(acc, wp0, 0, bl, sb, se);
+    __syncthreads();                                 // everyone is done reading the input tile
+    float* red = lds;                                // [4 waves][2 ptiles][16][64]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * 2 + q) * 16 + r) * 64 + lane] = acc[0][q][r];
+    __syncthreads();
+    if (kpart == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x16 sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.0f;
+          for (int kp = 0; kp < ksplit; ++kp) v += red[(((kp * a.NT + tile) * 2 + q) * 16 + r) * 64 + lane];
+          sum[r] = v;
+        }
+        epilogue_tile<EPI>(a, sum, tile, q, lane, p0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  dW[n][k] = sum_p A[n][p] * B[k][p]   (both feature-major, reduction over points)
+// up to two (A,B) pairs accumulate into the same tile (primal term + double-backward term);
+// B may be the concatenation of up to 3 row segments (e.g. [h4 | PE | ones] -> the ones row yields
+// the bias gradient as column K).  Split over points: grid.y chunks write partial tiles.
+// ---------------------------------------------------------------------------------------------
+struct WgradPair {
+  const float* A; int rowsA;
+  const float* B[3]; int rowsB[3];
+};
+struct WgradArgs {
+  WgradPair pair[2]; int npairs;
+  int N, Kt;                 // valid rows / cols (Kt includes the ones column if present)
+  int P, ldp, chunk;         // points per grid.y slice (multiple of 32)
+  float* partial;            // [gridDim.y][Nld][Kld]
+  int Nld, Kld, ktiles;
+};
+
+constexpr int WBP = 32;      // points per staging step
+constexpr int WLD = WBP + 1; // padded LDS row
+
+__global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
+  __shared__ float As[128 * WLD];
+  __shared__ float Bs[128 * WLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = blockIdx.x / a.ktiles, tk = blockIdx.x % a.ktiles;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  // which 32x32 sub-tiles of this wave hold any valid output
+  bool live[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) live[i][j] = (n0 + wr + 32 * i < a.N) && (k0 + wc + 32 * j < a.Kt);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int pbeg = blockIdx.y * a.chunk;
+  const int pend = min(a.P, pbeg + a.chunk);
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;       // 32 rows x 8 float4 per pass
+  for (int q = 0; q < a.npairs; ++q) {
+    const WgradPair& pr = a.pair[q];
+    for (int pb = pbeg; pb < pend; pb += WBP) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = lrow + 32 * it;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        const int p = pb + lc4;
+        const int n = n0 + r;
+        if (n < pr.rowsA) va = *reinterpret_cast<const float4*>(pr.A + (size_t)n * a.ldp + p);
+        int k = k0 + r;
+        const float* src = nullptr;
+        if (k < pr.rowsB[0]) src = pr.B[0] ? pr.B[0] + (size_t)k * a.ldp : nullptr;
+        else if ((k -= pr.rowsB[0]) < pr.rowsB[1]) src = pr.B[1] ? pr.B[1] + (size_t)k * a.ldp : nullptr;
+        else if ((k -= pr.rowsB[1]) < pr.rowsB[2]) src = pr.B[2] ? pr.B[2] + (size_t)k * a.ldp : nullptr;
+        if (src) vb = *reinterpret_cast<const float4*>(src + p);
+        if (p + 3 >= pend) {      // ragged tail of the point range: mask columns >= pend
+          if (p + 0 >= pend) { va.x = 0.f; vb.x = 0.f; }
+          if (p + 1 >= pend) { va.y = 0.f; vb.y = 0.f; }
+          if (p + 2 >= pend) { va.z = 0.f; vb.z = 0.f; }
+          if (p + 3 >= pend) { va.w = 0.f; vb.w = 0.f; }
+        }
+        float* da = As + r * WLD + lc4; float* db = Bs + r * WLD + lc4;
+        da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
+        db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
+      }
+      __syncthreads();
+      const float* ap = As + (wr + (lane & 31)) * WLD + (lane >> 5);
+      const float* bp = Bs + (wc + (lane & 31)) * WLD + (lane >> 5);
+#pragma unroll
+      for (int s = 0; s < WBP / 2; ++s) {
+        const float a0 = ap[2 * s], a1 = ap[32 * WLD + 2 * s];
+        const float b0 = bp[2 * s], b1 = bp[32 * WLD + 2 * s];
+        if (live[0][0]) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        if (live[0][1]) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        if (live[1][0]) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        if (live[1][1]) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  float* dst = a.partial + (size_t)blockIdx.y * a.Nld * a.Kld;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (!live[i][j]) continue;
+      const int k = k0 + wc + 32 * j + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < a.N && k < a.Kt) dst[(size_t)n * a.Kld + k] = acc[i][j][r];
+      }
+    }
+}
+
+// Reduce the split partials for one output row, undo the input-column permutation / fold scale, and
+// apply the weight-norm backward:  W = g v/|v|  =>  dg = <dW, v>/|v| ;  dv = g/|v| (dW - <dW,v> v/|v|^2).
+struct WreduceArgs {
+  const float* partial; int splits, Nld, Kld;
+  int O, I;                  // layer dims (torch layout [O][I])
+  int perm_split;            // source columns [0,perm_split) sit at the END of the packed input order
+  float scale;               // folded input scale (1/sqrt2 for the skip layer)
+  const float* v; const float* g;      // weight_v [O][I], weight_g [O]
+  float* dv; float* dg; float* db;     // outputs (db may be null -> no bias column)
+  int bias_col;              // column of the partial holding the bias gradient (= packed K), or -1
+};
+
+__global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= a.O) return;
+  constexpr int MAXC = 5;                 // up to 320 input columns
+  float dw[MAXC], vv[MAXC];
+  float dot = 0.0f, nrm2 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = lane + 64 * c;          // source column
+    dw[c] = 0.0f; vv[c] = 0.0f;
+    if (i < a.I) {
+      const int j = (i < a.perm_split) ? i + (a.I - a.perm_split) : i - a.perm_split;   // packed column
+      float s = 0.0f;
+      for (int sp = 0; sp < a.splits; ++sp) s += a.partial[((size_t)sp * a.Nld + o) * a.Kld + j];
+      dw[c] = s * a.scale;
+      vv[c] = a.v[(size_t)o * a.I + i];
+      dot += dw[c] * vv[c];
+      nrm2 += vv[c] * vv[c];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off); nrm2 += __shfl_xor(nrm2, off); }
+  const float inv = 1.0f / sqrtf(nrm2);
+  const float go = a.g[o];
+  const float coef = dot * inv * inv;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = lane + 64 * c;
+    if (i < a.I) a.dv[(size_t)o * a.I + i] = go * inv * (dw[c] - coef * vv[c]);
+  }
+  if (lane == 0) {
+    a.dg[o] = dot * inv;
+    if (a.db && a.bias_col >= 0) {
+      float s = 0.0f;
+      for (int sp = 0; sp < a.splits; ++sp) s += a.partial[((size_t)sp * a.Nld + o) * a.Kld + a.bias_col];
+      a.db[o] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation: row scale g/|v| (weight norm), then gather into MFMA A-fragment order
+// ---------------------------------------------------------------------------------------------
+constexpr int NLAYERS = 19;     // 0..8 SDF, 9..13 render head, 14..18 attraction head
+struct NetPtrs {
+  const float* v[NLAYERS]; const float* g[NLAYERS]; const float* b[NLAYERS];
+  int O[NLAYERS], I[NLAYERS];
+};
+struct RowScaleArgs { NetPtrs net; float* rowscale; int row_off[NLAYERS + 1]; };
+
+__global__ __launch_bounds__(WG) void rowscale_kernel(RowScaleArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.row_off[NLAYERS]) return;
+  int l = 0;
+  while (row >= a.row_off[l + 1]) ++l;
+  const int o = row - a.row_off[l], I = a.net.I[l];
+  if (!a.net.v[l]) return;                      // layer not supplied (e.g. SDF network used without the heads)
+  const float* v = a.net.v[l] + (size_t)o * I;
+  float s = 0.0f;
+  for (int i = lane; i < I; i += 64) s += v[i] * v[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) a.rowscale[row] = a.net.g[l][o] / sqrtf(s);
+}
+
+struct PackDesc { int layer, transpose, N, K, Kpad, NT, perm_split; float scale; int offset; int blk0; };
+constexpr int MAXPACKS = 40;
+struct PackArgs { NetPtrs net; const float* rowscale; int row_off[NLAYERS + 1]; PackDesc d[MAXPACKS]; int npacks; float* out; };
+
+// one workgroup per (pack, 32-row tile): out[off + (nt*KS + s)*64 + lane] = Wm[nt*32+(lane&31)][2s+(lane>>5)]
+__global__ __launch_bounds__(WG) void pack_kernel(PackArgs a) {
+  int pk = 0;
+  while (pk + 1 < a.npacks && (int)blockIdx.x >= a.d[pk + 1].blk0) ++pk;
+  const PackDesc d = a.d[pk];
+  const int nt = blockIdx.x - d.blk0;
+  const int KS = d.Kpad >> 1;
+  const int O = a.net.O[d.layer], I = a.net.I[d.layer];
+  const float* v = a.net.v[d.layer];
+  const float* rs = a.rowscale + a.row_off[d.layer];
+  float* out = a.out + d.offset + (size_t)nt * KS * 64;
+  for (int e = threadIdx.x; e < KS * 64; e += WG) {
+    const int s = e >> 6, ln = e & 63;
+    const int n = nt * 32 + (ln & 31), k = 2 * s + (ln >> 5);
+    float w = 0.0f;
+    if (v && n < d.N && k < d.K) {
+      const int o = d.transpose ? k : n;        // output-feature index in the torch weight
+      const int j = d.transpose ? n : k;        // packed input index
+      const int i = (j < I - d.perm_split) ? j + d.perm_split : j - (I - d.perm_split);
+      if (o < O && i < I) w = v[(size_t)o * I + i] * rs[o] * d.scale;
+    }
+    out[e] = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small per-point kernels (feature-major outputs)
+// ---------------------------------------------------------------------------------------------
+// x = o + z d for p = r*S + i ; also writes row-major points if requested
+__global__ void points_from_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                        const float* __restrict__ z, int R, int S, int ldp,
+                                        float* __restrict__ x_fm, float* __restrict__ pts_rm) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+  float xv[3] = {0.f, 0.f, 0.f};
+  if (p < R * S) {
+    const int r = p / S;
+    const float zz = z[p];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xv[c] = o[r * 3 + c] + zz * d[r * 3 + c];
+    if (pts_rm) { pts_rm[p * 3 + 0] = xv[0]; pts_rm[p * 3 + 1] = xv[1]; pts_rm[p * 3 + 2] = xv[2]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) x_fm[(size_t)c * ldp + p] = xv[c];
+}
+
+__global__ void rm_to_fm_kernel(const float* __restrict__ src, int P, int C, int ldp, float* __restrict__ dst) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+  for (int c = 0; c < C; ++c) dst[(size_t)c * ldp + p] = (p < P) ? src[(size_t)p * C + c] : 0.0f;
+}
+__global__ void fm_to_rm_kernel(const float* __restrict__ src, int P, int C, int ldp, float* __restrict__ dst, int accumulate) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  for (int c = 0; c < C; ++c) {
+    const float v = src[(size_t)c * ldp + p];
+    if (accumulate) dst[(size_t)p * C + c] += v; else dst[(size_t)p * C + c] = v;
+  }
+}
+__global__ void fill_kernel(float* __restrict__ dst, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+__global__ void ones_kernel(float* __restrict__ dst, int P, int ldp) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < ldp) dst[p] = p < P ? 1.0f : 0.0f;
+}
+
+// PE-6 rows (embedder.py:12-36): [x, sin(2^k x), cos(2^k x)]_k  -> E[39][ldp]
+__global__ void posenc6_kernel(const float* __restrict__ x_fm, int ldp, float* __restrict__ E) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xc = x_fm[(size_t)c * ldp + p];
+    E[(size_t)c * ldp + p] = xc;
+    float f = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      E[(size_t)(3 + 6 * k + c) * ldp + p] = sinf(xc * f);
+      E[(size_t)(6 + 6 * k + c) * ldp + p] = cosf(xc * f);
+      f *= 2.0f;
+    }
+  }
+}
+
+// tangent seed  E^ = J g^ : derivative of PE-6 along g^ (rows as posenc6_kernel)
+__global__ void posenc6_tangent_kernel(const float* __restrict__ x_fm, const float* __restrict__ gh_fm, int ldp,
+                                       float* __restrict__ Eh) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xc = x_fm[(size_t)c * ldp + p], gc = gh_fm[(size_t)c * ldp + p];
+    Eh[(size_t)c * ldp + p] = gc;
+    float f = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      Eh[(size_t)(3 + 6 * k + c) * ldp + p] = f * cosf(xc * f) * gc;
+      Eh[(size_t)(6 + 6 * k + c) * ldp + p] = -f * sinf(xc * f) * gc;
+      f *= 2.0f;
+    }
+  }
+}
+
+// adjoint seed: u7 = W8[0,:] * phi'(h8)
+__global__ void adjoint_seed_kernel(const float* __restrict__ v8, const float* __restrict__ rs8,
+                                    const float* __restrict__ h8, int ldp, float* __restrict__ u7) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= ldp) return;
+  const float w = v8[n] * rs8[0];             // row 0 of lin8's effective weight
+  const size_t idx = (size_t)n * ldp + p;
+  u7[idx] = w * dphi_from_h(h8[idx]);
+}
+
+// normals + sphere clamp:  g = J^T (e0 + eskip) ; sdf = min(raw, scale (radius - |x|))  (rend_a :111-129)
+__global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float* __restrict__ out8,
+                                    const float* __restrict__ e0, const float* __restrict__ es, int P, int ldp,
+                                    float radius, float scale, float* __restrict__ sdf, float* __restrict__ g_fm,
+                                    float* __restrict__ mask, float* __restrict__ sdf_rm, float* __restrict__ g_rm) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+  float xv[3], gv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) xv[c] = x_fm[(size_t)c * ldp + p];
+  float s = out8[p], m = 0.0f;
+  if (e0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = e0[(size_t)c * ldp + p] + es[(size_t)c * ldp + p];
+      float f = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float es_ = e0[(size_t)(3 + 6 * k + c) * ldp + p] + es[(size_t)(3 + 6 * k + c) * ldp + p];
+        const float ec_ = e0[(size_t)(6 + 6 * k + c) * ldp + p] + es[(size_t)(6 + 6 * k + c) * ldp + p];
+        acc += f * cosf(xv[c] * f) * es_ - f * sinf(xv[c] * f) * ec_;
+        f *= 2.0f;
+      }
+      gv[c] = acc;
+    }
+  }
+  if (radius > 0.0f) {
+    const float nr = sqrtf(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
+    const float sph = scale * (radius - nr);
+    if (sph < s) {
+      s = sph; m = 1.0f;
+      const float inv = nr > 0.0f ? -scale / nr : 0.0f;
+      gv[0] = xv[0] * inv; gv[1] = xv[1] * inv; gv[2] = xv[2] * inv;
+    }
+  }
+  sdf[p] = s;
+  if (mask) mask[p] = m;
+  if (g_fm) { g_fm[p] = gv[0]; g_fm[(size_t)ldp + p] = gv[1]; g_fm[(size_t)2 * ldp + p] = gv[2]; }
+  if (p < P) {
+    if (sdf_rm) sdf_rm[p] = s;
+    if (g_rm && e0) { g_rm[p * 3 + 0] = gv[0]; g_rm[p * 3 + 1] = gv[1]; g_rm[p * 3 + 2] = gv[2]; }
+  }
+}
+
+// head inputs besides the feature rows:
+//   render  (rend_a :235-241): [p(3), PE4(view)(27), normal(3)] = 33 rows
+//   attract (rend_a :175-181): [p(3), view(3), normal(3)]      =  9 rows
+// view dir of point p is dirs[p / S] (S=1: per-point dirs)
+__global__ void head_inputs_kernel(const float* __restrict__ x_fm, const float* __restrict__ g_fm,
+                                   const float* __restrict__ dirs, int P, int S, int ldp,
+                                   float* __restrict__ small_r, float* __restrict__ small_a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+  const int r = (p < P ? p : 0) / S;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xc = x_fm[(size_t)c * ldp + p], gc = g_fm[(size_t)c * ldp + p];
+    const float dc = (p < P) ? dirs[r * 3 + c] : 0.0f;
+    small_r[(size_t)c * ldp + p] = xc;
+    small_r[(size_t)(3 + c) * ldp + p] = dc;
+    float f = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      small_r[(size_t)(6 + 6 * k + c) * ldp + p] = sinf(dc * f);
+      small_r[(size_t)(9 + 6 * k + c) * ldp + p] = cosf(dc * f);
+      f *= 2.0f;
+    }
+    small_r[(size_t)(30 + c) * ldp + p] = gc;
+    small_a[(size_t)c * ldp + p] = xc;
+    small_a[(size_t)(3 + c) * ldp + p] = dc;
+    small_a[(size_t)(6 + c) * ldp + p] = gc;
+  }
+}
+
+// cotangent of the normals: g^ = (1-mask) (sc_r[30..32] + sc_a[6..8] + extra) ; also masks the sdf cotangent row
+__global__ void normal_cotangent_kernel(const float* __restrict__ sc_r, const float* __restrict__ sc_a,
+                                        const float* __restrict__ extra_rm, const float* __restrict__ mask,
+                                        int P, int ldp, float* __restrict__ gh_fm) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+  const float keep = (p < P) ? 1.0f - (mask ? mask[p] : 0.0f) : 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = 0.0f;
+    if (sc_r) v += sc_r[(size_t)(30 + c) * ldp + p];
+    if (sc_a) v += sc_a[(size_t)(6 + c) * ldp + p];
+    if (extra_rm && p < P) v += extra_rm[p * 3 + c];
+    gh_fm[(size_t)c * ldp + p] = v * keep;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compositing (rend_a :540-554 volume_rendering, :406-426 integrals); one wave per ray
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+// Laplace density (density.py:21-26) and its derivative pieces
+__device__ __forceinline__ float laplace_sigma(float s, float beta) {
+  const float sg = (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f);
+  return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+}
+
+struct CompositeArgs {
+  const float* z; const float* sdf; const float* dirs;   // [R,S], [P], [R,3]
+  const float* x_fm; const float* rgb_fm; const float* lin_fm; const float* g_fm;   // [3|3|6|3][ldp]
+  int R, S, ldp; const float* beta_ptr;
+  float* weights; float* rgb; float* lines3d; float* depth; float* xyz; float* normal_map;   // outputs (row-major)
+};
+
+__global__ __launch_bounds__(WG) void composite_fwd_kernel(CompositeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const float dn = sqrtf(a.dirs[r * 3] * a.dirs[r * 3] + a.dirs[r * 3 + 1] * a.dirs[r * 3 + 1] + a.dirs[r * 3 + 2] * a.dirs[r * 3 + 2]);
+  const float beta = *a.beta_ptr;
+  float carry = 0.0f;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+  for (int i0 = 0; i0 < a.S; i0 += 64) {
+    const int i = i0 + lane;
+    const bool ok = i < a.S;
+    const int p = r * a.S + (ok ? i : a.S - 1);
+    const float zi = a.z[p];
+    const float delta = (i + 1 < a.S) ? a.z[p + 1] - zi : 1e10f;
+    const float e = ok ? delta * laplace_sigma(a.sdf[p], beta) : 0.0f;
+    const float incl = wave_incl_scan(e, lane);
+    float excl = __shfl_up(incl, 1);             // exclusive prefix: never contains the 1e10 tail interval
+    if (lane == 0) excl = 0.0f;
+    const float T = expf(-(carry + excl));
+    const float w = ok ? (1.0f - expf(-e)) * T : 0.0f;
+    carry += __shfl(incl, 63);
+    if (ok) {
+      if (a.weights) a.weights[p] = w;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float xc = a.x_fm[(size_t)c * a.ldp + p];
+        acc[c] += w * a.rgb_fm[(size_t)c * a.ldp + p];
+        acc[3 + c] += w * (xc + a.lin_fm[(size_t)c * a.ldp + p]);            // endpoint 0 = p + offset[0:3]
+        acc[6 + c] += w * (xc + a.lin_fm[(size_t)(3 + c) * a.ldp + p]);      // endpoint 1
+        acc[10 + c] += w * xc;
+      }
+      acc[9] += w * fabsf(zi) * dn;                                           // |z d|
+      if (a.normal_map) {
+        const float g0 = a.g_fm[p], g1 = a.g_fm[(size_t)a.ldp + p], g2 = a.g_fm[(size_t)2 * a.ldp + p];
+        const float gn = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+        acc[13] += w * g0 / gn; acc[14] += w * g1 / gn; acc[15] += w * g2 / gn;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a.rgb[r * 3 + c] = acc[c];
+      a.lines3d[r * 6 + c] = acc[3 + c];
+      a.lines3d[r * 6 + 3 + c] = acc[6 + c];
+      a.xyz[r * 3 + c] = acc[10 + c];
+      if (a.normal_map) a.normal_map[r * 3 + c] = acc[13 + c];
+    }
+    a.depth[r] = acc[9];
+  }
+}
+
+struct CompositeBwdArgs {
+  const float* z; const float* sdf; const float* dirs; const float* mask;
+  const float* x_fm; const float* rgb_fm;
+  int R, S, ldp; const float* beta_ptr;
+  const float* d_rgb; const float* d_lines3d; const float* d_depth; const float* d_xyz;   // [R,3],[R,6],[R],[R,3] (null = 0)
+  float* zrgb_fm;      // [3][ldp]  cotangent of the pre-sigmoid colour logits
+  float* dlin_fm;      // [6][ldp]  cotangent of the attraction offsets
+  float* dsdf_row;     // [ldp]     cotangent of raw sdf (0 where the sphere clamp is active)
+  float* dbeta_ray;    // [R]       per-ray partial of d loss / d beta
+};
+
+__global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const float dn = sqrtf(a.dirs[r * 3] * a.dirs[r * 3] + a.dirs[r * 3 + 1] * a.dirs[r * 3 + 1] + a.dirs[r * 3 + 2] * a.dirs[r * 3 + 2]);
+  const float beta = *a.beta_ptr;
+  float drgb[3] = {0.f, 0.f, 0.f}, dxyz[3] = {0.f, 0.f, 0.f}, dl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (a.d_rgb) drgb[c] = a.d_rgb[r * 3 + c];
+    if (a.d_xyz) dxyz[c] = a.d_xyz[r * 3 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) if (a.d_lines3d) dl[c] = a.d_lines3d[r * 6 + c];
+  const float ddepth = a.d_depth ? a.d_depth[r] : 0.0f;
+  // pass 1: total of w^_j w_j (needed for the suffix sums) while walking forward
+  const int nchunk = (a.S + 63) / 64;
+  float carry = 0.0f, total = 0.0f;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int i = ch * 64 + lane;
+    const bool ok = i < a.S;
+    const int p = r * a.S + (ok ? i : a.S - 1);
+    const float zi = a.z[p];
+    const float delta = (i + 1 < a.S) ? a.z[p + 1] - zi : 1e10f;
+    const float e = ok ? delta * laplace_sigma(a.sdf[p], beta) : 0.0f;
+    const float incl = wave_incl_scan(e, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0.0f;
+    const float T = expf(-(carry + excl));
+    const float w = ok ? (1.0f - expf(-e)) * T : 0.0f;
+    carry += __shfl(incl, 63);
+    float wh = ddepth * fabsf(zi) * dn;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      wh += drgb[c] * a.rgb_fm[(size_t)c * a.ldp + p] + dxyz[c] * a.x_fm[(size_t)c * a.ldp + p];
+    total += wave_sum(ok ? wh * w : 0.0f);
+  }
+  // pass 2: forward again with a running prefix of w^ w ; suffix_i = total - prefix_incl_i
+  carry = 0.0f;
+  float pref = 0.0f, dbeta = 0.0f;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int i = ch * 64 + lane;
+    const bool ok = i < a.S;
+    const int p = r * a.S + (ok ? i : a.S - 1);
+    const float zi = a.z[p];
+    const float delta = (i + 1 < a.S) ? a.z[p + 1] - zi : 1e10f;
+    const float s = a.sdf[p];
+    const float sigma = laplace_sigma(s, beta);
+    const float e = ok ? delta * sigma : 0.0f;
+    const float incl = wave_incl_scan(e, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0.0f;
+    const float T = expf(-(carry + excl));
+    const float em = expf(-e);
+    const float w = ok ? (1.0f - em) * T : 0.0f;
+    carry += __shfl(incl, 63);
+    float wh = ddepth * fabsf(zi) * dn;
+    float rgbv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      rgbv[c] = a.rgb_fm[(size_t)c * a.ldp + p];
+      wh += drgb[c] * rgbv[c] + dxyz[c] * a.x_fm[(size_t)c * a.ldp + p];
+    }
+    const float ww = ok ? wh * w : 0.0f;
+    const float inclw = wave_incl_scan(ww, lane);
+    const float suffix = total - (pref + inclw);           // sum_{j>i} w^_j w_j
+    pref += __shfl(inclw, 63);
+    if (ok) {
+      const float dE = wh * em * T - suffix;               // d w_i/d E_i = e^-E_i T_i ; d w_j/d E_i = -w_j (j>i)
+      const float dsig = dE * delta;
+      const float sg = (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f);
+      const float q = expf(-fabsf(s) / beta);
+      const float ib = 1.0f / beta;
+      const float dsig_ds = -0.5f * sg * sg * q * ib * ib;
+      const float dsig_db = -sigma * ib + 0.5f * sg * q * fabsf(s) * ib * ib * ib;
+      const float keep = 1.0f - (a.mask ? a.mask[p] : 0.0f);
+      a.dsdf_row[p] = dsig * dsig_ds * keep;
+      dbeta += dsig * dsig_db;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.zrgb_fm[(size_t)c * a.ldp + p] = w * drgb[c] * rgbv[c] * (1.0f - rgbv[c]);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a.dlin_fm[(size_t)c * a.ldp + p] = w * dl[c];
+    }
+  }
+  dbeta = wave_sum(dbeta);
+  if (lane == 0 && a.dbeta_ray) a.dbeta_ray[r] = dbeta;
+}
+
+// pixel -> ray (rend_util.py:55-81,95-108)
+__global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ Kin,
+                                   int kstride, int R, float* __restrict__ dirs) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float fx = Kin[0], sk = Kin[1], cx = Kin[2], fy = Kin[kstride + 1], cy = Kin[kstride + 2];
+  const float u = uv[r * 2], v = uv[r * 2 + 1];
+  const float xl = (u - cx + cy * sk / fy - sk * v / fy) / fx;
+  const float yl = (v - cy) / fy;
+  float w[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float wc = pose[c * 4 + 0] * xl + pose[c * 4 + 1] * yl + pose[c * 4 + 2] * 1.0f + pose[c * 4 + 3] * 1.0f;
+    w[c] = wc - pose[c * 4 + 3];
+  }
+  const float n = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);
+  dirs[r * 3 + 0] = w[0] / n; dirs[r * 3 + 1] = w[1] / n; dirs[r * 3 + 2] = w[2] / n;
+}
+
+}  // namespace neat

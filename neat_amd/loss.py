@@ -1,0 +1,75 @@
+"""VolSDFLoss with the reference's constructor and output keys (code/model/networks/loss_wfr.py:16-139).
+R-sized reductions; torch ops on the device.  The Hungarian assignment runs on the host as in the reference."""
+import torch
+from torch import nn
+
+from .general import get_class
+
+
+def _symmetric_line_l1(pred, gt, weight, threshold=100):
+    """Endpoint-order-invariant L1 between 2-D segments [N,4], gated at `threshold` px (loss_wfr.py:34-45)."""
+    flipped = gt[:, [2, 3, 0, 1]]
+    with torch.no_grad():
+        straight = ((pred - gt) ** 2).sum(-1, keepdim=True) < ((pred - flipped) ** 2).sum(-1, keepdim=True)
+    per_line = (pred - torch.where(straight, gt, flipped)).abs().mean(-1)
+    gate = (per_line.detach() < threshold).long()
+    return (per_line * weight.flatten() * gate).sum() / gate.sum().clamp_min(1), per_line.detach()
+
+
+class VolSDFLoss(nn.Module):
+    def __init__(self, rgb_loss, eikonal_weight, line_weight, junction_3d_weight=0.1, junction_2d_weight=0.01):
+        super().__init__()
+        self.eikonal_weight, self.line_weight = eikonal_weight, line_weight
+        self.junction_3d_weight, self.junction_2d_weight = junction_3d_weight, junction_2d_weight
+        self.rgb_loss = get_class(rgb_loss)(reduction="mean")
+        self.steps = 0
+
+    def get_rgb_loss(self, rgb_values, rgb_gt):
+        return self.rgb_loss(rgb_values, rgb_gt.reshape(-1, 3))
+
+    def get_eikonal_loss(self, grad_theta):
+        return ((grad_theta.norm(2, dim=1) - 1) ** 2).mean()
+
+    def get_line_loss(self, lines2d, lines2d_gt, lines_weight, threshold=100):
+        return _symmetric_line_l1(lines2d, lines2d_gt, lines_weight, threshold)
+
+    def forward(self, model_outputs, ground_truth):
+        self.steps += 1
+        dev = model_outputs["rgb_values"].device
+        seg_gt, seg_w = ground_truth["lines2d"][0].to(dev).split(4, dim=-1)
+        if "labels" in ground_truth:
+            seg_w = seg_w * ground_truth["labels"][0, :, None].to(dev)
+        l2d_uncalib, per_line = self.get_line_loss(model_outputs["lines2d"].reshape(-1, 4), seg_gt, seg_w)
+        close = per_line < 100
+        # bring the GT segments into calibrated (K^-1) coordinates for the differentiable term (:59-65)
+        ends = seg_gt.reshape(-1, 2)
+        ends_h = (model_outputs["K"].inverse() @ torch.cat([ends, torch.ones_like(ends[:, :1])], -1).t()).t()
+        seg_gt_calib = (ends_h[:, :2] / ends_h[:, 2, None]).reshape(-1, 4)
+        line_loss, _ = self.get_line_loss(model_outputs["lines2d_calib"].reshape(-1, 4), seg_gt_calib,
+                                          seg_w * close.reshape(-1, 1))
+        if torch.isnan(line_loss):
+            raise FloatingPointError("line loss is NaN (the reference drops into pdb here, loss_wfr.py:66-67)")
+        rgb_loss = self.get_rgb_loss(model_outputs["rgb_values"], ground_truth["rgb"].to(dev))
+        zero = torch.tensor(0.0, device=dev)
+        eikonal = self.get_eikonal_loss(model_outputs["grad_theta"]) if "grad_theta" in model_outputs else zero
+        loss = rgb_loss + self.eikonal_weight * eikonal + self.line_weight * line_loss
+        out = {"rgb_loss": rgb_loss, "eikonal_loss": eikonal, "line_loss": line_loss, "l2d_loss": l2d_uncalib,
+               "count": close.sum(), "j3d_loss": zero, "j2d_loss": zero, "j2d_stat": zero, "jcount": zero}
+        if model_outputs["j3d_local"].shape[0] > 0:
+            from scipy.optimize import linear_sum_assignment
+            loc3, glo3 = model_outputs["j3d_local"], model_outputs["j3d_global"]
+            loc2c, glo2c = model_outputs["j2d_local_calib"], model_outputs["j2d_global_calib"]
+            with torch.no_grad():
+                pair_cost = torch.cdist(loc3, glo3, p=1) + 0.1 * torch.cdist(loc2c, glo2c, p=1)
+            ri, ci = linear_sum_assignment(pair_cost.detach().cpu().numpy())
+            ri, ci = torch.as_tensor(ri, device=dev), torch.as_tensor(ci, device=dev)
+            j3 = (loc3[ri] - glo3[ci]).abs().sum(-1).mean()
+            j2 = (loc2c[ri] - glo2c[ci]).abs().sum(-1).mean()
+            with torch.no_grad():
+                j2_px = (model_outputs["j2d_local"][ri] - model_outputs["j2d_global"][ci]).abs().sum(-1).mean()
+            loss = loss + self.junction_3d_weight * j3 + self.junction_2d_weight * j2
+            out.update(j3d_loss=j3, j2d_loss=j2, j2d_stat=j2_px, jcount=(pair_cost[ri, ci] < 10).sum())
+        out["loss"] = loss
+        if "median" in model_outputs:
+            out["median"] = model_outputs["median"]
+        return out

@@ -1,0 +1,341 @@
+"""Model classes with the reference's plug-in API (code/model/networks/neat_wfr_rend_a.py), backed by HIP.
+
+Drop-in: set `train.model_class = neat_amd.networks.VolSDFNetwork` in a reference conf; constructor,
+forward(input)->dict, sub-module names and state_dict keys are the reference's.
+All P-sized work (PE, the three MLPs, normals, compositing, and their backward incl. the double backward)
+runs in neat_amd/csrc; what stays in torch here is the R-sized glue of the attraction-field block.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops, rend_util
+from .conf import ConfTree, from_dict
+from .density import LaplaceDensity
+from .ray_sampler import ErrorBoundSampler
+
+
+def _wn_linear(in_dim, out_dim, weight_norm=True):
+    """Parameter container with the reference's names: bias, weight_g [out,1], weight_v [out,in].
+    Its own forward is never used -- the HIP kernels read weight_v / weight_g / bias directly."""
+    lin = nn.Linear(in_dim, out_dim)
+    if not weight_norm:
+        raise NotImplementedError("the HIP path implements the weight-normed layers of the shipped confs")
+    return lin
+
+
+def _wrap_wn(lin):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return nn.utils.weight_norm(lin)
+
+
+def _triples(module, n):
+    out = []
+    for l in range(n):
+        lin = getattr(module, f"lin{l}")
+        out.append((lin.weight_v, lin.weight_g, lin.bias))
+    return out
+
+
+class _HipModule(nn.Module):
+    """Keeps a NetHandle that always points at the module's *current* parameter tensors."""
+
+    def _handle(self):
+        h = self.__dict__.get("_neat_handle")
+        if h is None:
+            h = ops.NetHandle()
+            self.__dict__["_neat_handle"] = h
+        return h
+
+
+class ImplicitNetwork(_HipModule):
+    """SDF MLP: PE-6 -> 8 x 256 softplus(100) with a skip into layer 4 -> [sdf, 256 features]  (rend_a :14-137)."""
+
+    def __init__(self, feature_vector_size, sdf_bounding_sphere, d_in, d_out, dims, geometric_init=True, bias=1.0,
+                 skip_in=(), weight_norm=True, multires=0, sphere_scale=1.0, inside_out=False):
+        super().__init__()
+        if inside_out:
+            raise NotImplementedError("inside_out is not used by any shipped conf")
+        self.sdf_bounding_sphere, self.sphere_scale = sdf_bounding_sphere, sphere_scale
+        self.skip_in, self.inside_out = tuple(skip_in), inside_out
+        pe_dim = d_in * (1 + 2 * multires) if multires > 0 else d_in
+        widths = [pe_dim] + list(dims) + [d_out + feature_vector_size]
+        if widths != [39] + [256] * 8 + [257] or self.skip_in != (4,) or d_in != 3:
+            raise NotImplementedError(f"HIP path implements dims [39,256x8,257] skip (4,), got {widths} {self.skip_in}")
+        self.num_layers = len(widths)
+        self.multires = multires
+        last = self.num_layers - 2
+        for l in range(last + 1):
+            fan_out = widths[l + 1] - widths[0] if (l + 1) in self.skip_in else widths[l + 1]
+            lin = _wn_linear(widths[l], fan_out, weight_norm)
+            if geometric_init:          # sphere-like start (rend_a :55-69); init precedes weight_norm, so g = |v|
+                with torch.no_grad():
+                    if l == last:
+                        lin.weight.normal_(math.sqrt(math.pi) / math.sqrt(widths[l]), 0.0001)
+                        lin.bias.fill_(-bias)
+                    else:
+                        lin.bias.zero_()
+                        std = math.sqrt(2.0) / math.sqrt(fan_out)
+                        if l == 0:
+                            lin.weight[:, 3:].zero_()
+                            lin.weight[:, :3].normal_(0.0, std)
+                        else:
+                            lin.weight.normal_(0.0, std)
+                            if l in self.skip_in:
+                                lin.weight[:, -(widths[0] - 3):].zero_()
+            setattr(self, f"lin{l}", _wrap_wn(lin))
+        self.softplus = nn.Softplus(beta=100)
+
+    def handle(self):
+        h = self._handle()
+        h.set_layers(0, _triples(self, 9))
+        return h
+
+    def _outputs(self, x, radius):
+        return ops.sdf_outputs(self.handle(), x, radius, self.sphere_scale)
+
+    def forward(self, input):
+        return self._outputs(input, 0.0)[0]
+
+    def gradient(self, x):
+        """d raw-sdf / dx, differentiable wrt the parameters (eikonal term, rend_a :98-109)."""
+        return self._outputs(x, 0.0)[3]
+
+    def get_outputs(self, x):
+        _, sdf, feat, grad = self._outputs(x, self.sdf_bounding_sphere)
+        return sdf, feat, grad
+
+    def get_sdf_vals(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._outputs(x, self.sdf_bounding_sphere)[1]
+        return ops.sdf_values(self.handle(), x, self.sdf_bounding_sphere, self.sphere_scale)
+
+
+class _Head(_HipModule):
+    first_layer = None
+
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0, expect_in=None):
+        super().__init__()
+        if mode != "idr":
+            raise NotImplementedError("only mode='idr' (all shipped confs)")
+        self.mode = mode
+        in_dim = d_in + feature_vector_size + (6 * multires_view if multires_view > 0 else 0)
+        widths = [in_dim] + list(dims) + [d_out]
+        if in_dim != expect_in or list(dims) != [256] * 4:
+            raise NotImplementedError(f"HIP path implements {expect_in}->256x4->{d_out}, got {widths}")
+        self.num_layers = len(widths)
+        self.multires_view = multires_view
+        for l in range(self.num_layers - 1):
+            setattr(self, f"lin{l}", _wrap_wn(_wn_linear(widths[l], widths[l + 1], weight_norm)))
+        self.relu, self.sigmoid = nn.ReLU(), nn.Sigmoid()
+
+    def _standalone(self, points, normals, view_dirs, feature_vectors):
+        owner = self.__dict__.get("_neat_owner")
+        if owner is None or owner() is None:
+            raise RuntimeError("this head is not attached to a VolSDFNetwork (the HIP kernels pack all three networks)")
+        if torch.is_grad_enabled() and (normals.requires_grad or feature_vectors.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("stand-alone head calls are forward-only; training goes through "
+                                      "VolSDFNetwork.forward (fused main pass with full backward). Wrap in torch.no_grad().")
+        return ops.heads_forward(owner().handle(), points, normals, view_dirs, feature_vectors)
+
+
+class RenderingNetwork(_Head):
+    """[p, PE4(view), normal, feature] -> 4x256 ReLU -> sigmoid rgb   (rend_a :199-255)."""
+
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0):
+        super().__init__(feature_vector_size, mode, d_in, d_out, dims, weight_norm, multires_view, expect_in=289)
+        if d_out != 3 or multires_view != 4:
+            raise NotImplementedError("rendering head: d_out=3, multires_view=4")
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        return self._standalone(points, normals, view_dirs, feature_vectors)[0]
+
+
+class AttractionFieldNetwork(_Head):
+    """[p, view, normal, feature] -> 4x256 ReLU -> 6 ; y = p + offsets.reshape(2,3)   (rend_a :139-197)."""
+
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0):
+        super().__init__(feature_vector_size, mode, d_in, d_out, dims, weight_norm, multires_view, expect_in=265)
+        if d_out != 6 or multires_view != 0:
+            raise NotImplementedError("attraction head: d_out=6, no view encoding")
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        return self._standalone(points, normals, view_dirs, feature_vectors)[1]
+
+
+class VolSDFNetwork(_HipModule):
+    def __init__(self, conf):
+        super().__init__()
+        if isinstance(conf, dict) and not hasattr(conf, "get_config"):
+            conf = from_dict(conf)
+        self.feature_vector_size = conf.get_int("feature_vector_size")
+        self.scene_bounding_sphere = conf.get_float("scene_bounding_sphere", default=1.0)
+        self.white_bkgd = conf.get_bool("white_bkgd", default=False)
+        self.register_buffer("bg_color", torch.tensor(conf.get_list("bg_color", default=[1.0, 1.0, 1.0])).float(),
+                             persistent=False)
+        self.implicit_network = ImplicitNetwork(self.feature_vector_size,
+                                                0.0 if self.white_bkgd else self.scene_bounding_sphere,
+                                                **conf.get_config("implicit_network"))
+        self.rendering_network = RenderingNetwork(self.feature_vector_size, **conf.get_config("rendering_network"))
+        self.attraction_network = AttractionFieldNetwork(self.feature_vector_size, **conf.get_config("attraction_network"))
+        self.density = LaplaceDensity(**conf.get_config("density"))
+        self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config("ray_sampler"))
+        # global junction MLP on learnable latents (rend_a :272-303)
+        cj = conf.get_config("global_junctions", default=ConfTree())
+        hidden, depth = cj.get_int("dim_hidden", default=256), cj.get_int("num_layers", default=2)
+        self.latents = nn.Parameter(torch.empty(cj.get_int("num_junctions", default=1024), hidden))
+        nn.init.normal_(self.latents, mean=0.0, std=1)
+        stack = []
+        for i in range(depth + 1):
+            stack.append(nn.Linear(hidden, hidden if i != depth else 3))
+            if i != depth:
+                stack.append(nn.ReLU())
+        self.ffn = nn.Sequential(*stack)
+        self.dbscan_enabled = conf.get_bool("dbscan_enabled", default=True)
+        self.use_median = conf.get_bool("use_median", default=False)
+        self.junction_eikonal = conf.get_bool("junction_eikonal", default=False)
+        self.use_l3d = conf.get_bool("use_l3d", default=False)
+        import weakref
+        for head in (self.rendering_network, self.attraction_network):
+            head.__dict__["_neat_owner"] = weakref.ref(self)
+        self.z_vals_override = None       # bench/tests: given depth samples [R,S] bypass the sampler
+
+    # ---- HIP plumbing ----------------------------------------------------------------------------
+    def handle(self):
+        h = self._handle()
+        h.set_layers(0, _triples(self.implicit_network, 9))
+        h.set_layers(9, _triples(self.rendering_network, 5))
+        h.set_layers(14, _triples(self.attraction_network, 5))
+        self.implicit_network.__dict__["_neat_handle"] = h      # share the pack cache with the sub-module API
+        return h
+
+    def _sphere(self):
+        return 0.0 if self.white_bkgd else self.scene_bounding_sphere
+
+    def _render(self, cam_loc, ray_dirs, z_vals, want_normal_map):
+        rgb, lines3d, depth, xyz, weights, sdf, points, nmap = ops.render_rays(
+            self.handle(), cam_loc, ray_dirs, z_vals, self.density.get_beta(), self._sphere(),
+            self.implicit_network.sphere_scale, want_normal_map)
+        if self.white_bkgd:
+            rgb = rgb + (1.0 - weights.sum(-1, keepdim=True)) * self.bg_color.unsqueeze(0)
+        return rgb, lines3d, depth, xyz, weights, sdf, points, nmap
+
+    # ---- reference helpers -------------------------------------------------------------------------
+    def project2D(self, K, R, T, points3d):
+        shape = points3d.shape
+        assert shape[-1] == 3
+        cam = (K @ (R @ points3d.reshape(-1, 3).t() + T)).t()
+        w = cam[:, -1:]
+        w = w + torch.where(w.abs() < 1e-8, torch.full_like(w, 1e-8), torch.zeros_like(w)) * torch.where(
+            w >= 0, torch.ones_like(w), -torch.ones_like(w))
+        return (cam / w).reshape(*shape)[..., :2]
+
+    def cluster_dbscan(self, points, eps=0.01, min_samples=2):
+        from sklearn.cluster import DBSCAN
+        labels = DBSCAN(eps=eps, min_samples=min_samples).fit(points).labels_
+        centres = [points[labels == i].mean(axis=0) for i in range(labels.max() + 1)]
+        return torch.tensor(np.array(centres).reshape(-1, 3)).float().to(self.latents.device)
+
+    def volume_rendering(self, z_vals, sdf):
+        return ops.volume_weights(z_vals, sdf, self.density.get_beta())
+
+    def _rays(self, input, key="uv"):
+        dirs, cam = rend_util.get_camera_params(input[key], input["pose"], input["intrinsics"])
+        n = dirs.shape[1]
+        return dirs.reshape(-1, 3), cam.unsqueeze(1).repeat(1, n, 1).reshape(-1, 3)
+
+    def _z_vals(self, ray_dirs, cam_loc):
+        if self.z_vals_override is not None:
+            z = self.z_vals_override
+            idx = torch.randint(z.shape[-1], (z.shape[0],)).to(z.device)
+            return z, z.gather(1, idx.unsqueeze(-1))
+        return self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self)
+
+    def render_rgb(self, input):
+        assert not self.training
+        ray_dirs, cam_loc = self._rays(input)
+        z_vals, _ = self._z_vals(ray_dirs, cam_loc)
+        return self._render(cam_loc, ray_dirs, z_vals, False)[0]
+
+    def forward(self, input):
+        intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
+        ray_dirs, cam_loc = self._rays(input)
+        n_rays = ray_dirs.shape[0]
+        z_vals, z_eik = self._z_vals(ray_dirs, cam_loc)
+        rgb, lines3d, depth, xyz, weights, sdf_s, points, nmap = self._render(cam_loc, ray_dirs, z_vals, not self.training)
+        output = {"points": points, "rgb_values": rgb, "sdf": sdf_s, "depth": depth, "xyz": xyz}
+
+        # ---- attraction field / junctions (rend_a :424-513); R-sized, stays in torch -------------------
+        points3d = xyz
+        p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
+        w2c = pose[0].inverse()[:3]
+        Rm, T = w2c[:, :3], w2c[:, 3:]
+        K3 = intrinsics[0, :3, :3]
+        eye = torch.eye(3, device=K3.device)
+        lines2d = self.project2D(K3, Rm, T, lines3d.detach())
+        lines2d_calib = self.project2D(eye, Rm, T, lines3d)
+        l_dirs, l_orig = self._rays(input, "uv_proj")
+        den = (l_dirs * p3_grad).sum(-1)
+        den = den + torch.where(den >= 0, torch.full_like(den, 1e-6), torch.full_like(den, -1e-6))
+        t = (((points3d - l_orig) * p3_grad).sum(-1) / den).detach()
+        l3d = l_orig + l_dirs * t.unsqueeze(-1)
+        with torch.no_grad():
+            a, b = l3d - lines3d[:, 0], l3d - lines3d[:, 1]
+            l3d_score = torch.linalg.cross(a, b).norm(dim=-1) / (lines3d[:, 0] - lines3d[:, 1]).norm(dim=-1)
+        if self.training:
+            from scipy.optimize import linear_sum_assignment
+            if self.dbscan_enabled:
+                cand3d = self.cluster_dbscan(lines3d.detach().cpu().numpy().reshape(-1, 3), eps=0.01, min_samples=2)
+            elif self.use_l3d:
+                thr = max(l3d_score.median(), 0.01)
+                keep = l3d_score < thr
+                cand3d = torch.cat([lines3d[keep].detach().reshape(-1, 3), l3d[keep]], 0)
+            else:
+                cand3d = lines3d.detach().reshape(-1, 3)
+            cand2d = self.project2D(K3, Rm, T, cand3d)
+            cand2d_calib = self.project2D(eye, Rm, T, cand3d)
+            gt2d = input["wireframe"][0].vertices.to(cand2d.device)
+            cost = ((cand2d[None] - gt2d[:, None]) ** 2).sum(-1).sqrt()
+            rows, cols = linear_sum_assignment(cost.detach().cpu())          # host round trip, as the reference (:473)
+            rows, cols = torch.as_tensor(rows, device=cost.device), torch.as_tensor(cols, device=cost.device)
+            matched = cost[rows, cols]
+            if self.use_median:
+                median = matched.detach().median()
+                if torch.isnan(median):
+                    median = torch.tensor(10, dtype=torch.float32, device=cost.device)
+                good = matched < median
+                output["median"] = median
+            else:
+                good = matched < 10
+            j3d_global = self.ffn(self.latents)
+            output["j2d_local"] = cand2d[cols][good]
+            output["j3d_local"] = cand3d[cols][good]
+            output["j3d_global"] = j3d_global
+            output["j2d_global"] = self.project2D(K3, Rm, T, j3d_global)
+            output["j2d_local_calib"] = cand2d_calib[cols][good]
+            output["j2d_global_calib"] = self.project2D(eye, Rm, T, j3d_global)
+        output["l3d"] = l3d
+        output["points3d"] = points3d
+        output["lines3d"] = lines3d
+        output["lines2d_calib"] = lines2d_calib
+        output["lines2d"] = lines2d
+        output["sdf"] = p3_sdf.flatten()
+        output["wireframe-gt"] = input["wireframe"]
+        output["K"] = K3
+
+        if self.training:      # eikonal points: uniform in the bounding cube + one near-surface sample per ray (:515-527)
+            r = self.scene_bounding_sphere
+            eik = torch.empty(n_rays, 3).uniform_(-r, r).to(ray_dirs.device)
+            near = cam_loc + z_eik * ray_dirs
+            eik = torch.cat([eik, near], 0)
+            if self.junction_eikonal:
+                eik = torch.cat([eik, output["j3d_global"].detach()], 0)
+            output["grad_theta"] = self.implicit_network.gradient(eik)
+        else:
+            output["normal_map"] = nmap
+        return output

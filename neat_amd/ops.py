@@ -1,0 +1,246 @@
+"""torch ops over libneat_hip.so: autograd Functions whose forward/backward are the HIP kernels.
+
+PyTorch is plumbing here (device memory, current stream, autograd graph); all P-sized arithmetic
+happens in neat_amd/csrc.  Every op requires CUDA float32 tensors and raises if the library is absent.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+# layer order of the C ABI (include/neat_hip.h)
+NET_LAYOUT = (("implicit_network", 9), ("rendering_network", 5), ("attraction_network", 5))
+LAYER_OUT = [256, 256, 256, 217, 256, 256, 256, 256, 257, 256, 256, 256, 256, 3, 256, 256, 256, 256, 6]
+LAYER_IN = [39, 256, 256, 256, 256, 256, 256, 256, 256, 289, 256, 256, 256, 256, 265, 256, 256, 256, 256]
+N_SDF = 9
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise RuntimeError("neat_amd ops need CUDA float32 tensors (no CPU path): got %s on %s" % (t.dtype, t.device))
+    return t.contiguous()
+
+
+class NetHandle:
+    """The 19 weight-normed layers of one model (heads may be absent) + a cache of the packed weights."""
+
+    def __init__(self):
+        self.layers = [None] * _lib.NUM_LAYERS      # (weight_v, weight_g, bias) Parameters
+        self._key = None
+        self._packed = None
+        self._netp = None
+
+    def set_layers(self, first, triples):
+        for i, t in enumerate(triples):
+            self.layers[first + i] = t
+
+    def tensors(self, first=0, count=_lib.NUM_LAYERS):
+        out = []
+        for l in range(first, first + count):
+            if self.layers[l] is None:
+                raise RuntimeError(f"layer {l} is not attached to this NetHandle")
+            out.extend(self.layers[l])
+        return out
+
+    def has_heads(self):
+        return all(l is not None for l in self.layers)
+
+    def packed(self):
+        """Returns (packed weights tensor, NetParams).  Re-packs (2 kernel launches) whenever a parameter changed."""
+        present = [t for l in self.layers if l is not None for t in l]
+        key = tuple((t.data_ptr(), t._version) for t in present)
+        if key != self._key:
+            lib = _lib.lib()
+            netp = _lib.NetParams()
+            dev = None
+            for l, tr in enumerate(self.layers):
+                if tr is None:
+                    continue
+                v, g, b = (x.detach() for x in tr)
+                if tuple(v.shape) != (LAYER_OUT[l], LAYER_IN[l]) or g.numel() != LAYER_OUT[l] or b.numel() != LAYER_OUT[l]:
+                    raise RuntimeError(f"layer {l}: unsupported shape {tuple(v.shape)} (the HIP path implements the "
+                                       "architecture of the shipped confs: 8x256 SDF MLP, PE-6/PE-4, 4x256 heads)")
+                for t in (v, g, b):
+                    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                        raise RuntimeError("parameters must be contiguous CUDA float32 (call model.cuda())")
+                netp.v[l], netp.g[l], netp.b[l] = v.data_ptr(), g.data_ptr(), b.data_ptr()
+                dev = v.device
+            packed = torch.empty(lib.neat_packed_floats(), device=dev, dtype=torch.float32)
+            _lib.check(lib.neat_pack_weights(ctypes.byref(netp), _p(packed), _stream()), "neat_pack_weights")
+            self._key, self._packed, self._netp = key, packed, netp
+        return self._packed, self._netp
+
+
+def _grad_buffers(handle, first, count, device):
+    """One flat buffer with (dv, dg, db) views per layer -> (NetGrads struct, [views in v,g,b order], flat)."""
+    sizes = []
+    for l in range(first, first + count):
+        sizes += [LAYER_OUT[l] * LAYER_IN[l], LAYER_OUT[l], LAYER_OUT[l]]
+    flat = torch.empty(sum(sizes), device=device, dtype=torch.float32)
+    gr = _lib.NetGrads()
+    views, off = [], 0
+    for i, l in enumerate(range(first, first + count)):
+        v, g, b = handle.layers[l]
+        dv = flat[off:off + sizes[3 * i]].view(v.shape); off += sizes[3 * i]
+        dg = flat[off:off + sizes[3 * i + 1]].view(g.shape); off += sizes[3 * i + 1]
+        db = flat[off:off + sizes[3 * i + 2]].view(b.shape); off += sizes[3 * i + 2]
+        gr.dv[l], gr.dg[l], gr.db[l] = dv.data_ptr(), dg.data_ptr(), db.data_ptr()
+        views += [dv, dg, db]
+    return gr, views, flat
+
+
+class SdfOutputsFn(torch.autograd.Function):
+    """ImplicitNetwork.forward / get_outputs / gradient in one op.
+    returns (forward()[P,257], clamped sdf [P,1], feature [P,256], d sdf/dx [P,3]); differentiable wrt the
+    27 SDF parameters (including the double backward through d sdf/dx); x is treated as a constant."""
+
+    @staticmethod
+    def forward(ctx, handle, x, radius, scale, *params):
+        lib = _lib.lib()
+        ctx.set_materialize_grads(False)
+        x = _f32c(x.detach())
+        P = x.shape[0]
+        packed, netp = handle.packed()
+        ws = torch.empty(lib.neat_sdf_ws_floats(P, 1), device=x.device, dtype=torch.float32)
+        out = torch.empty(P, 257, device=x.device)
+        sdf = torch.empty(P, 1, device=x.device)
+        feat = torch.empty(P, 256, device=x.device)
+        grad = torch.empty(P, 3, device=x.device)
+        _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 1, float(radius), float(scale), _p(ws),
+                                        _p(out), _p(sdf), _p(feat), _p(grad), _stream()), "neat_sdf_forward")
+        ctx.handle, ctx.P, ctx.ws, ctx.packed, ctx.netp = handle, P, ws, packed, netp
+        return out, sdf, feat, grad
+
+    @staticmethod
+    def backward(ctx, d_out, d_sdf, d_feat, d_grad):
+        lib = _lib.lib()
+        h = ctx.handle
+        gr, views, _ = _grad_buffers(h, 0, N_SDF, ctx.ws.device)
+        d_out, d_sdf, d_feat, d_grad = (_f32c(t) for t in (d_out, d_sdf, d_feat, d_grad))
+        _lib.check(lib.neat_sdf_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), ctx.P, _p(d_out), _p(d_sdf),
+                                         _p(d_feat), _p(d_grad), ctypes.byref(gr), _stream()), "neat_sdf_backward")
+        ctx.ws = None
+        return (None, None, None, None, *views)
+
+
+def sdf_outputs(handle, x, radius, scale):
+    if x.shape[0] == 0:
+        z = x.new_zeros
+        return z(0, 257), z(0, 1), z(0, 256), z(0, 3)
+    return SdfOutputsFn.apply(handle, x, radius, scale, *handle.tensors(0, N_SDF))
+
+
+def sdf_values(handle, x, radius, scale):
+    """get_sdf_vals without autograd (sampler path): primal chain only, nothing saved."""
+    lib = _lib.lib()
+    x = _f32c(x.detach())
+    P = x.shape[0]
+    sdf = torch.empty(P, 1, device=x.device)
+    if P == 0:
+        return sdf
+    packed, netp = handle.packed()
+    ws = torch.empty(lib.neat_sdf_ws_floats(P, 0), device=x.device, dtype=torch.float32)
+    _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 0, float(radius), float(scale), _p(ws),
+                                    None, _p(sdf), None, None, _stream()), "neat_sdf_forward(values)")
+    return sdf
+
+
+def heads_forward(handle, points, normals, view_dirs, feats):
+    """rgb [P,3] and line endpoints [P,2,3] of the two heads on given inputs (forward only)."""
+    lib = _lib.lib()
+    points, normals, view_dirs, feats = (_f32c(t.detach()) for t in (points, normals, view_dirs, feats))
+    P = points.shape[0]
+    packed, netp = handle.packed()
+    ws = torch.empty(lib.neat_heads_ws_floats(P), device=points.device, dtype=torch.float32)
+    rgb = torch.empty(P, 3, device=points.device)
+    lines = torch.empty(P, 2, 3, device=points.device)
+    _lib.check(lib.neat_heads_forward(_p(packed), ctypes.byref(netp), _p(points), _p(normals), _p(view_dirs), _p(feats), P,
+                                      _p(ws), _p(rgb), _p(lines), _stream()), "neat_heads_forward")
+    return rgb, lines
+
+
+class RenderRaysFn(torch.autograd.Function):
+    """Main pass of VolSDFNetwork.forward (rend_a :392-422): points -> SDF MLP (+normals) -> both heads ->
+    Laplace density -> alpha compositing.  Differentiable wrt all 57 network parameters and beta."""
+
+    @staticmethod
+    def forward(ctx, handle, origins, dirs, z, beta, radius, scale, want_normal_map, *params):
+        lib = _lib.lib()
+        ctx.set_materialize_grads(False)
+        origins, dirs, z = (_f32c(t.detach()) for t in (origins, dirs, z))
+        beta_d = _f32c(beta.detach().reshape(1))
+        R, S = z.shape
+        dev = z.device
+        packed, netp = handle.packed()
+        ws = torch.empty(lib.neat_render_ws_floats(R, S), device=dev, dtype=torch.float32)
+        points = torch.empty(R, S, 3, device=dev)
+        weights = torch.empty(R, S, device=dev)
+        sdf = torch.empty(R, S, device=dev)
+        rgb = torch.empty(R, 3, device=dev)
+        lines3d = torch.empty(R, 2, 3, device=dev)
+        depth = torch.empty(R, device=dev)
+        xyz = torch.empty(R, 3, device=dev)
+        nmap = torch.empty(R, 3, device=dev) if want_normal_map else None
+        _lib.check(lib.neat_render_forward(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, _p(beta_d),
+                                           float(radius), float(scale), _p(ws), _p(points), _p(weights), _p(sdf), _p(rgb),
+                                           _p(lines3d), _p(depth), _p(xyz), _p(nmap), _stream()), "neat_render_forward")
+        ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp = handle, (R, S), ws, packed, netp
+        ctx.dirs, ctx.z, ctx.beta_d, ctx.beta_shape = dirs, z, beta_d, beta.shape
+        if nmap is None:
+            nmap = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(weights, sdf, points, nmap)
+        return rgb, lines3d, depth, xyz, weights, sdf, points, nmap
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_lines3d, d_depth, d_xyz, *_unused):
+        lib = _lib.lib()
+        R, S = ctx.shape
+        h = ctx.handle
+        dev = ctx.ws.device
+        gr, views, _ = _grad_buffers(h, 0, _lib.NUM_LAYERS, dev)
+        d_rgb, d_lines3d, d_depth, d_xyz = (_f32c(t) for t in (d_rgb, d_lines3d, d_depth, d_xyz))
+        dbeta_ray = torch.empty(R, device=dev)
+        _lib.check(lib.neat_render_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), _p(ctx.dirs), _p(ctx.z), R, S,
+                                            _p(ctx.beta_d), _p(d_rgb), _p(d_lines3d), _p(d_depth), _p(d_xyz),
+                                            ctypes.byref(gr), _p(dbeta_ray), _stream()), "neat_render_backward")
+        ctx.ws = None
+        return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, *views)
+
+
+def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False):
+    if not handle.has_heads():
+        raise RuntimeError("render_rays needs the SDF network and both heads attached to the NetHandle")
+    return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, *handle.tensors())
+
+
+def camera_rays(uv, pose, intrinsics):
+    """rend_util.get_camera_params for pose matrices: uv [1,R,2], pose [1,4,4], K [1,3|4,3|4] -> dirs [1,R,3], cam [1,3]."""
+    lib = _lib.lib()
+    if pose.shape[0] != 1 or pose.shape[1:] != (4, 4):
+        raise NotImplementedError("camera_rays: one 4x4 pose per call (the reference forward is single-view; "
+                                  "quaternion poses are not used by the shipped datasets)")
+    uv_c, pose_c, K_c = _f32c(uv.detach()), _f32c(pose.detach()), _f32c(intrinsics.detach())
+    R = uv_c.shape[1]
+    dirs = torch.empty(1, R, 3, device=uv_c.device)
+    _lib.check(lib.neat_camera_rays(_p(uv_c), _p(pose_c), _p(K_c), int(K_c.shape[-1]), R, _p(dirs), _stream()), "neat_camera_rays")
+    return dirs, pose_c[:, :3, 3]
+
+
+def volume_weights(z, sdf, beta):
+    lib = _lib.lib()
+    z, sdf = _f32c(z.detach()), _f32c(sdf.detach().reshape(z.shape))
+    beta_d = _f32c(beta.detach().reshape(1))
+    w = torch.empty_like(z)
+    _lib.check(lib.neat_volume_weights(_p(z), _p(sdf), z.shape[0], z.shape[1], _p(beta_d), _p(w), _stream()), "neat_volume_weights")
+    return w

@@ -1,0 +1,176 @@
+"""Depth samplers with the reference's names (code/model/ray_sampler.py).
+
+ErrorBoundSampler = VolSDF Algorithm 1.  The MLP evaluations (the dominant cost: 128..640 SDF queries per
+ray) run in the HIP SDF kernels via model.implicit_network.get_sdf_vals; the per-ray bookkeeping below is
+R x <=640 sized torch-on-device work (a per-ray HIP kernel is the next step).
+Random draws are made on the CPU generator in the reference's order and moved to the device,
+so a seeded run consumes the RNG stream exactly as the reference does.
+"""
+import math
+
+import torch
+
+
+def _lerp_inverse_cdf(bins, cdf, u):
+    idx = torch.searchsorted(cdf, u, right=True)
+    lo = (idx - 1).clamp_(min=0)
+    hi = idx.clamp_(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = cdf.gather(1, lo), cdf.gather(1, hi)
+    b_lo, b_hi = bins.gather(1, lo), bins.gather(1, hi)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b_lo + (u - c_lo) / span * (b_hi - b_lo)
+
+
+def _pdf_to_cdf(pdf):
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    return torch.cat([torch.zeros_like(pdf[:, :1]), pdf.cumsum(-1)], -1)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """NeRF inverse-CDF sampling (ray_sampler.py:16-59)."""
+    if pytest:
+        raise NotImplementedError("the reference's pytest branch is broken (NameError on np); not reproduced")
+    cdf = _pdf_to_cdf(weights + 1e-5)
+    shape = list(cdf.shape[:-1]) + [N_samples]
+    if det:
+        u = torch.linspace(0.0, 1.0, N_samples).expand(shape)
+    else:
+        u = torch.rand(shape)
+    return _lerp_inverse_cdf(bins, cdf, u.contiguous().to(weights.device))
+
+
+class RaySampler:
+    def __init__(self, near, far):
+        self.near, self.far = near, far
+
+    def get_z_vals(self, ray_dirs, cam_loc, model):
+        raise NotImplementedError
+
+
+class UniformSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, N_important=0, take_sphere_intersection=False, far=-1):
+        super().__init__(near, 2.0 * scene_bounding_sphere if far == -1 else far)
+        self.N_samples = N_samples
+        self.N_important = N_important
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.take_sphere_intersection = take_sphere_intersection
+
+    def get_z_vals(self, ray_dirs, cam_loc, model):
+        dev, R = ray_dirs.device, ray_dirs.shape[0]
+        near = torch.full((R, 1), float(self.near), device=dev)
+        if self.take_sphere_intersection:
+            from . import rend_util
+            far = rend_util.get_sphere_intersections(cam_loc, ray_dirs, r=self.scene_bounding_sphere)[:, 1:]
+        else:
+            far = torch.full((R, 1), float(self.far), device=dev)
+        t = torch.linspace(0.0, 1.0, self.N_samples, device=dev)
+        z = near * (1.0 - t) + far * t
+        if model.training:                                   # stratified jitter inside each bin (:81-89)
+            mid = 0.5 * (z[:, 1:] + z[:, :-1])
+            hi = torch.cat([mid, z[:, -1:]], -1)
+            lo = torch.cat([z[:, :1], mid], -1)
+            z = lo + (hi - lo) * torch.rand(z.shape).to(dev)
+        torch.randint(z.shape[-1], (R,))                     # the reference draws (and discards) an index here (:91)
+        return z
+
+    def get_z_vals_fine(self, z_vals, weights, model):
+        assert self.N_important > 0
+        mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        fine = sample_pdf(mid, weights[..., 1:-1], self.N_important, det=model.training).detach()   # det is inverted vs NeRF
+        return torch.sort(torch.cat([z_vals, fine], -1), -1)[0]
+
+
+class ErrorBoundSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, N_samples_eval, N_samples_extra, eps, beta_iters,
+                 max_total_iters, inverse_sphere_bg=False, N_samples_inverse_sphere=0, add_tiny=0.0):
+        super().__init__(near, 2.0 * scene_bounding_sphere)
+        if inverse_sphere_bg:
+            raise NotImplementedError("inverse_sphere_bg is off in every shipped conf and is not implemented")
+        self.N_samples, self.N_samples_eval, self.N_samples_extra = N_samples, N_samples_eval, N_samples_extra
+        self.eps, self.beta_iters, self.max_total_iters = eps, beta_iters, max_total_iters
+        self.scene_bounding_sphere, self.add_tiny = scene_bounding_sphere, add_tiny
+        self.inverse_sphere_bg = False
+        self.uniform_sampler = UniformSampler(scene_bounding_sphere, near, N_samples_eval)
+        self.last_rounds = 0          # refinement rounds taken by the last call (reported by bench.py)
+
+    # ----- pieces of Algorithm 1 --------------------------------------------------------------
+    @staticmethod
+    def _interval_bound(d, gap):
+        """d* of Theorem 1 per interval (:161-173)."""
+        b, c = d[:, :-1].abs(), d[:, 1:].abs()
+        near_left = gap * gap + b * b <= c * c
+        near_right = gap * gap + c * c <= b * b
+        s = (gap + b + c) / 2.0
+        heron = 2.0 * torch.sqrt(s * (s - gap) * (s - b) * (s - c)) / gap
+        inside = ~near_left & ~near_right & (b + c - gap > 0)
+        out = torch.where(near_left, b, torch.zeros_like(gap))
+        out = torch.where(near_right, c, out)
+        out = torch.where(inside, heron, out)
+        return (d[:, 1:].sign() * d[:, :-1].sign() == 1) * out
+
+    def get_error_bound(self, beta, model, sdf, z_vals, dists, d_star):
+        """max_i of the opacity error bound (:285-293)."""
+        sigma = model.density(sdf.reshape(z_vals.shape), beta=beta)
+        opt_depth = torch.cat([torch.zeros_like(dists[:, :1]), dists * sigma[:, :-1]], -1).cumsum(-1)
+        err = (torch.exp(-d_star / beta) * dists ** 2.0 / (4.0 * beta ** 2)).cumsum(-1)
+        return ((torch.exp(err).clamp(max=1.0e6) - 1.0) * torch.exp(-opt_depth[:, :-1])).max(-1)[0]
+
+    def get_z_vals(self, ray_dirs, cam_loc, model):
+        dev, R = ray_dirs.device, ray_dirs.shape[0]
+        beta0 = model.density.get_beta().detach()
+        z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
+        fresh, order, sdf = z, None, None
+        gap = z[:, 1:] - z[:, :-1]
+        beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (gap ** 2.0).sum(-1))
+        rounds, open_ = 0, True
+        while open_ and rounds < self.max_total_iters:
+            pts = (cam_loc.unsqueeze(1) + fresh.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            with torch.no_grad():
+                new_sdf = model.implicit_network.get_sdf_vals(pts).reshape(R, -1)
+            sdf = new_sdf if order is None else torch.cat([sdf, new_sdf], -1).gather(1, order)
+            gap = z[:, 1:] - z[:, :-1]
+            d_star = self._interval_bound(sdf, gap)
+            # per-ray bisection of beta on [beta0, beta] (:177-185)
+            err = self.get_error_bound(beta0, model, sdf, z, gap, d_star)
+            hi = torch.where(err <= self.eps, beta0.expand_as(beta), beta)
+            lo = beta0.expand(R).clone()
+            for _ in range(self.beta_iters):
+                mid = (lo + hi) / 2.0
+                err = self.get_error_bound(mid.unsqueeze(-1), model, sdf, z, gap, d_star)
+                hi = torch.where(err <= self.eps, mid, hi)
+                lo = torch.where(err > self.eps, mid, lo)
+            beta = hi
+            sigma = model.density(sdf, beta=beta.unsqueeze(-1))
+            gap_inf = torch.cat([gap, torch.full((R, 1), 1e10, device=dev)], -1)
+            energy = gap_inf * sigma
+            trans = torch.exp(-torch.cat([torch.zeros(R, 1, device=dev), energy[:, :-1]], -1).cumsum(-1))
+            weights = (1.0 - torch.exp(-energy)) * trans
+            rounds += 1
+            open_ = bool(beta.max() > beta0)               # batch-global test, one host sync per round (:200)
+            refine = open_ and rounds < self.max_total_iters
+            if refine:      # more samples where the error bound is large (:205-215)
+                n = self.N_samples_eval
+                err = (torch.exp(-d_star / beta.unsqueeze(-1)) * gap ** 2.0 / (4.0 * beta.unsqueeze(-1) ** 2)).cumsum(-1)
+                cdf = _pdf_to_cdf((torch.exp(err).clamp(max=1.0e6) - 1.0) * trans[:, :-1] + self.add_tiny)
+            else:           # final set from the rendering weights (:217-226)
+                n = self.N_samples
+                cdf = _pdf_to_cdf(weights[:, :-1] + 1e-5)
+            if refine or not model.training:
+                u = torch.linspace(0.0, 1.0, n, device=dev).unsqueeze(0).repeat(R, 1)
+            else:
+                u = torch.rand(R, n).to(dev)
+            fresh = _lerp_inverse_cdf(z, cdf, u.contiguous())
+            if refine:
+                z, order = torch.sort(torch.cat([z, fresh], -1), -1)
+        self.last_rounds = rounds
+        ends = torch.tensor([float(self.near), float(self.far)], device=dev).expand(R, 2)
+        if self.N_samples_extra > 0:
+            if model.training:
+                pick = torch.randperm(z.shape[1])[:self.N_samples_extra]
+            else:
+                pick = torch.linspace(0, z.shape[1] - 1, self.N_samples_extra).long()
+            ends = torch.cat([ends, z[:, pick.to(dev)]], -1)
+        z_out = torch.sort(torch.cat([fresh, ends], -1), -1)[0]
+        eik_idx = torch.randint(z_out.shape[-1], (R,)).to(dev)
+        return z_out, z_out.gather(1, eik_idx.unsqueeze(-1))

@@ -1,0 +1,48 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/neat_hip.h declares; the Python binding declares the same set.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "neat_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(neat_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from neat_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    names = header_functions()
+    assert len(names) >= 12
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/neat_hip.h but not exported"
+    assert names == _lib.exported_symbols()
+    assert _lib.lib().neat_abi_version() == 1
+
+
+def test_workspace_queries_are_consistent():
+    from neat_amd import _lib
+    lib = _lib.lib()
+    assert lib.neat_packed_floats() > 19 * 256
+    assert lib.neat_sdf_ws_floats(64, 0) < lib.neat_sdf_ws_floats(64, 1)
+    assert lib.neat_render_ws_floats(8, 8) > lib.neat_sdf_ws_floats(64, 1)
+    # point stride is padded to the 64-point workgroup tile
+    assert lib.neat_sdf_ws_floats(1, 0) == lib.neat_sdf_ws_floats(64, 0)
+    assert lib.neat_sdf_ws_floats(65, 0) == lib.neat_sdf_ws_floats(128, 0)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from neat_amd import networks, synth
+    m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    with pytest.raises(RuntimeError):
+        m.implicit_network.get_sdf_vals(torch.zeros(4, 3))      # no CPU fallback: must fail loudly

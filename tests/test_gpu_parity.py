@@ -1,0 +1,242 @@
+"""Parity of the HIP path (through the C ABI) against (i) golden vectors produced by the reference and
+(ii) the CPU oracle on seeded inputs.  Tolerance: 1e-4 relative to each tensor's scale (north_star: outputs
+within 1e-4 fp32); gradients 2e-3 of each tensor's max (they are sums over up to 10^5 points of fp32 terms).
+Runs on a real MI355X only."""
+import numpy as np
+import pytest
+import torch
+
+from neat_amd import synth
+
+pytestmark = pytest.mark.gpu
+T = torch.tensor
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from neat_amd import _lib
+    _lib.lib()          # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def build_model(dev, variant, seed=42, train=False):
+    from neat_amd import networks
+    m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    m.load_state_dict({k: T(v) for k, v in synth.synth_state_dict(seed, variant).items()}, strict=True)
+    m.to(dev)
+    return m.train() if train else m.eval()
+
+
+def close(a, b, tol=TOL, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    assert np.isfinite(a).all(), f"{what}: non-finite values"
+    err = float(np.abs(a - b).max())
+    lim = tol * max(1.0, float(np.abs(b).max()))
+    assert err <= lim, f"{what}: max abs err {err:.3e} > {lim:.3e}"
+    return err
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_implicit_network_vs_reference_golden(dev, golden, variant):
+    g = golden(f"g2g3_networks_{variant}")
+    m = build_model(dev, variant)
+    x = T(g["x"]).to(dev)
+    with torch.no_grad():
+        close(m.implicit_network(x), g["forward"], what="forward")
+        close(m.implicit_network.get_sdf_vals(x), g["sdf_vals"], what="get_sdf_vals")
+    s, f, gr = m.implicit_network.get_outputs(x)
+    close(s, g["out_sdf"], what="sdf")
+    close(f, g["out_feat"], what="feat")
+    close(gr, g["out_grad"], what="grad (clamped)")
+    close(m.implicit_network.gradient(x), g["grad_raw"], what="gradient (raw)")
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_heads_vs_reference_golden(dev, golden, variant):
+    g = golden(f"g2g3_networks_{variant}")
+    m = build_model(dev, variant)
+    args = [T(g[k]).to(dev) for k in ("x", "out_grad", "view", "out_feat")]
+    with torch.no_grad():
+        close(m.rendering_network(*args), g["rgb"], what="rgb")
+        close(m.attraction_network(*args), g["lines"], what="lines")
+
+
+def test_volume_rendering_and_camera_golden(dev, golden):
+    g = golden("g5_volume_rendering")
+    m = build_model(dev, "rough")
+    close(m.volume_rendering(T(g["z"]).to(dev), T(g["sdf"]).to(dev)), g["weights"], tol=2e-6, what="weights")
+    g = golden("g10_camera")
+    from neat_amd import rend_util
+    for tag, K in (("", "K"), ("_skew", "K_skew")):
+        d, c = rend_util.get_camera_params(T(g["uv"]).to(dev), T(g["pose"]).to(dev), T(g[K]).to(dev))
+        close(d, g["dirs" + tag], tol=1e-6, what="dirs" + tag)
+        close(c, g["cam" + tag], tol=0, what="cam" + tag)
+
+
+def scene_inputs(g, dev):
+    from neat_amd.wireframe import WireframeGraph
+    wf = WireframeGraph(T(g["wf_vertices"]), T(g["wf_vconf"]), T(g["wf_edges"]), T(g["wf_weights"]), 512, 512)
+    inp = {k: T(g[k]).to(dev) for k in ("intrinsics", "pose", "uv", "uv_proj")}
+    inp["wireframe"] = [wf]
+    return inp
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_sampler_vs_reference_golden(dev, golden, variant):
+    from tests.util_replay import RngReplay
+    from neat_amd import rend_util
+    m = build_model(dev, variant)
+    g = golden(f"g6_sampler_eval_{variant}")
+    d, c = rend_util.get_camera_params(T(g["uv"]).to(dev), T(g["pose"]).to(dev), T(g["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(d.shape[0], 3).contiguous()
+    with RngReplay([("randint", None), ("randint", T(g["eik_idx"]))]):
+        z, ze = m.ray_sampler.get_z_vals(d, c, m)
+    close(z, g["z_vals"], tol=2e-4, what="z eval")
+    close(ze, g["z_eik"], tol=2e-4, what="z_eik eval")
+    g = golden(f"g6_sampler_train_{variant}")
+    m.train()
+    with RngReplay([("rand", T(g["t_rand"])), ("randint", None), ("rand", T(g["u_final"])), ("randperm", T(g["perm"])),
+                    ("randint", T(g["eik_idx"]))]):
+        z, ze = m.ray_sampler.get_z_vals(d, c, m)
+    close(z, g["z_vals"], tol=2e-4, what="z train")
+    close(ze, g["z_eik"], tol=2e-4, what="z_eik train")
+
+
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_full_forward_eval_vs_reference_golden(dev, golden, variant):
+    from tests.util_replay import RngReplay
+    g = golden(f"g7_forward_eval_{variant}")
+    m = build_model(dev, variant)
+    with torch.no_grad(), RngReplay([("randint", None), ("randint", T(g["eik_idx"]))]):
+        out = m(scene_inputs(g, dev))
+    for k in ("points", "rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "normal_map"):
+        close(out[k], g["out_" + k], tol=3e-4 if k in ("l3d",) else TOL, what=k)
+    close(out["lines2d"], g["out_lines2d"], tol=1e-4, what="lines2d (pixels, relative to 512)")
+
+
+def test_train_step_vs_reference_golden(dev, golden):
+    """forward + loss + backward on the reference's own recorded random draws: outputs, 11 loss scalars, all 65 grads."""
+    from tests.util_replay import RngReplay
+    from tests.golden.make_golden import GRAD_STRIDE
+    from neat_amd.loss import VolSDFLoss
+    g = golden("g8_train_step_rough")
+    m = build_model(dev, "rough", train=True)
+    draws = [("rand", T(g["t_rand"])), ("randint", None), ("rand", T(g["u_final"])), ("randperm", T(g["perm"])),
+             ("randint", T(g["eik_idx"])), ("uniform_", T(g["eik_uniform"]))]
+    with RngReplay(draws):
+        out = m(scene_inputs(g, dev))
+    for k in ("rgb_values", "depth", "xyz", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+              "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median"):
+        close(out[k], g["out_" + k], what=k)
+    close(out["l3d"], g["out_l3d"], tol=3e-4, what="l3d")
+    lo = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)(out, {"rgb": T(g["gt_rgb"]).to(dev), "lines2d": T(g["gt_lines2d"]).to(dev)})
+    for k in ("loss", "rgb_loss", "eikonal_loss", "line_loss", "l2d_loss", "j3d_loss", "j2d_loss", "j2d_stat"):
+        close(lo[k].float().reshape(()), g["loss_" + k].reshape(()), what="loss " + k)
+    assert int(lo["count"]) == int(g["loss_count"]) and int(lo["jcount"]) == int(g["loss_jcount"])
+    lo["loss"].backward()
+    worst = 0.0
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None, k
+        gr = prm.grad.detach().cpu().reshape(-1).numpy()
+        ref, (nrm, _) = g["grad_" + k], g["gradnorm_" + k]
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = float(np.abs(gr[::GRAD_STRIDE] - ref).max())
+        worst = max(worst, err / scale)
+        assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
+        assert abs(float(np.sqrt((gr.astype(np.float64) ** 2).sum())) - nrm) <= 2e-3 * nrm + 1e-7, k
+    print("worst relative grad error vs reference:", worst)
+
+
+def oracle_train_step(sd, sc, z, eik_idx, eik_uniform):
+    from oracle import neat_oracle as O
+    from neat_amd.wireframe import WireframeGraph
+    p = O.params_from_numpy(sd, requires_grad=True)
+    wf = WireframeGraph(T(sc["wf_vertices"]), T(sc["wf_vconf"]), T(sc["wf_edges"]), T(sc["wf_weights"]), 512, 512)
+    ref = O.full_forward(p, {k: T(sc[k]) for k in ("intrinsics", "pose", "uv", "uv_proj")}, wf.line_segments(), wf.vertices,
+                         training=True, rand={"eik_idx": eik_idx, "eik_uniform": eik_uniform}, z_vals=z)
+    lo = O.neat_loss(ref, T(sc["gt_rgb"]), T(sc["gt_lines2d"]))
+    lo["loss"].backward()
+    return p, ref, lo
+
+
+@pytest.mark.parametrize("R,S,seed", [(96, 128, 1), (33, 50, 2), (1, 7, 3)])
+def test_train_step_given_z_vs_oracle(dev, R, S, seed):
+    """C2-shaped step (depth samples given) at small / ragged sizes (P not a multiple of the 64-point tile, a single ray)."""
+    from neat_amd.loss import VolSDFLoss
+    from tests.util_replay import RngReplay
+    sd = synth.synth_state_dict(seed, "rough")
+    sc = synth.synth_scene(seed=seed, n_rays=R, view=seed)
+    z = T(synth.synth_z_vals(seed, R, S))
+    gen = torch.Generator().manual_seed(seed)
+    eik_idx = torch.randint(S, (R,), generator=gen)
+    eik_uniform = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
+    p, ref, ref_lo = oracle_train_step(sd, sc, z, eik_idx, eik_uniform)
+    from neat_amd import networks
+    m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    m.load_state_dict({k: T(v) for k, v in sd.items()})
+    m.to(dev).train()
+    m.z_vals_override = z.to(dev)
+    g = {k: sc[k] for k in sc}
+    with RngReplay([("randint", eik_idx), ("uniform_", eik_uniform)]):
+        out = m(scene_inputs(g, dev))
+    for k in ("rgb_values", "lines3d", "depth", "xyz", "grad_theta", "lines2d_calib", "sdf"):
+        close(out[k], ref[k], what=k)
+    lo = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)(out, {"rgb": T(sc["gt_rgb"]).to(dev), "lines2d": T(sc["gt_lines2d"]).to(dev)})
+    close(lo["loss"].reshape(()), ref_lo["loss"].reshape(()), what="loss")
+    lo["loss"].backward()
+    for k, prm in m.named_parameters():
+        r = p[k].grad
+        scale = max(float(r.abs().max()), 1e-6)
+        err = float((prm.grad.cpu() - r).abs().max())
+        assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 (1024 rays x 128 samples): size-independent properties instead of an oracle run."""
+    from neat_amd import ops
+    R, S = 1024, 128
+    m = build_model(dev, "rough", seed=5, train=True)
+    sc = synth.synth_scene(seed=5, n_rays=R)
+    from neat_amd import rend_util
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(5, R, S)).to(dev)
+
+    def run(sl, cot_scale=1.0):
+        m.zero_grad()
+        rgb, l3, dep, xyz, w, sdf, pts, _ = m._render(c[sl], d[sl], z[sl], False)
+        ((rgb * cot_rgb[sl]).sum() * cot_scale + (l3 * cot_l[sl]).sum() * cot_scale).backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+        return (rgb.detach(), l3.detach(), dep.detach(), xyz.detach(), w, sdf), grads
+
+    gen = torch.Generator().manual_seed(0)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+    full, g_full = run(slice(0, R))
+    again, g_again = run(slice(0, R))
+    for a, b in zip(full, again):                      # run-to-run determinism (no atomics on the path)
+        assert torch.equal(a, b)
+    assert torch.equal(g_full, g_again)
+    rgb, l3, dep, xyz, w, sdf = full
+    assert torch.isfinite(g_full).all()
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all()               # weights are a sub-probability per ray
+    assert (rgb >= 0).all() and (rgb <= 1 + 1e-5).all()
+    assert (dep >= 0).all() and (dep <= 6 + 1e-4).all()
+    # rays are independent: two halves rendered separately reproduce the whole; their gradients add up
+    lo, g_lo = run(slice(0, R // 2))
+    hi, g_hi = run(slice(R // 2, R))
+    for k in range(4):
+        close(torch.cat([lo[k], hi[k]]), full[k], tol=1e-5, what=f"chunk consistency {k}")
+    scale = float(g_full.abs().max())
+    assert float((g_lo + g_hi - g_full).abs().max()) <= 1e-3 * scale
+    # backward is linear in the cotangent
+    _, g2 = run(slice(0, R), cot_scale=2.0)
+    assert float((g2 - 2 * g_full).abs().max()) <= 1e-4 * scale
