@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Benchmark of the NEAT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1], "C2"): abc-neat-a networks, 1024 rays x 128 depth samples per rank with the
+depth samples GIVEN (sorted stratified U[0,6)), one TRAIN STEP = forward + loss + backward + Adam
+(+ gradient all-reduce for N>1).  value = ray-samples/s over all ranks.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R_RAYS, S_SAMPLES = 1024, 128
+FLOP_PER_RAY_SAMPLE = 9.1254e6        # 4 562 688 MAC per ray-sample per train step
+PEAK_TFLOPS = {"f32": 157.3}          # MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def cpu_baseline(seed):
+    """The CPU oracle (oracle/neat_oracle.py = 'port' of the reference's pure-PyTorch path) timed on this box's host
+    cores on a bounded sample of the same workload: 128 rays x 128 samples, fwd + loss + bwd + Adam."""
+    from neat_amd import synth
+    from neat_amd.wireframe import WireframeGraph
+    from oracle import neat_oracle as O
+    R, S = 128, S_SAMPLES
+    sd = synth.synth_state_dict(seed, "rough")
+    sc = synth.synth_scene(seed=seed, n_rays=R)
+    z = torch.tensor(synth.synth_z_vals(seed, R, S))
+    wf = WireframeGraph(torch.tensor(sc["wf_vertices"]), torch.tensor(sc["wf_vconf"]), torch.tensor(sc["wf_edges"]),
+                        torch.tensor(sc["wf_weights"]), 512, 512)
+    inp = {k: torch.tensor(sc[k]) for k in ("intrinsics", "pose", "uv", "uv_proj")}
+    lines, verts = wf.line_segments(), wf.vertices
+    gt_rgb, gt_l = torch.tensor(sc["gt_rgb"]), torch.tensor(sc["gt_lines2d"])
+
+    def run(threads, iters):
+        torch.set_num_threads(threads)
+        p = O.params_from_numpy(sd, requires_grad=True)
+        opt = torch.optim.Adam(list(p.values()), lr=5e-4)
+        times = []
+        for it in range(iters + 1):
+            t0 = time.perf_counter()
+            rand = {"eik_idx": torch.randint(S, (R,)), "eik_uniform": torch.empty(R, 3).uniform_(-3, 3)}
+            out = O.full_forward(p, inp, lines, verts, training=True, rand=rand, z_vals=z)
+            lo = O.neat_loss(out, gt_rgb, gt_l)
+            opt.zero_grad()
+            lo["loss"].backward()
+            opt.step()
+            if it > 0:
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        return R * S / times[len(times) // 2]
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    before = torch.get_num_threads()
+    v_all = run(cores, 3)
+    v_one = run(1, 1)
+    torch.set_num_threads(before)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": v_all, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch CPU fp32) train step on {R} rays x {S} samples, median of 3 after 1 warm-up, {cores} threads",
+            "value_1thread": v_one, "cpu_model": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    from neat_amd import _lib, dp, synth
+    from neat_amd.train import Trainer, synthetic_batch
+    import torch.distributed as dist
+
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.lib()
+
+    seed = dp.rank_seed(42, rank)
+    torch.manual_seed(seed)
+    sd = {k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()}      # same weights on every rank
+    tr = Trainer(device=dev, state_dict=sd)
+    _, inp, gt = synthetic_batch(seed, R_RAYS, dev, view=rank)
+    tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(seed, R_RAYS, S_SAMPLES)).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(inp, gt)
+    barrier()
+    if not args.no_prof:
+        lib.neat_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, losses = tr.step(inp, gt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline = None
+    kernels = {}
+    if not args.no_prof:
+        for cls, name in ((0, "layer_kernel"), (1, "wgrad_kernel")):
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(lib.neat_prof_collect(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "neat_prof_collect")
+            if n.value:
+                kernels[name] = {"launches": n.value, "total_ms": ms.value, "avg_us": 1e3 * ms.value / n.value,
+                                 "tflops": fl.value / (ms.value * 1e-3) / 1e12, "flop_per_launch": fl.value / n.value}
+        lib.neat_prof_enable(0)
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": PEAK_TFLOPS["f32"],
+                        "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / PEAK_TFLOPS["f32"], "traffic": traffic,
+                        "avg_launch_us": kernels[dom]["avg_us"], "launches": kernels[dom]["launches"],
+                        "kernel_time_share": kernels[dom]["total_ms"] * 1e-3 / elapsed, "all_kernels": kernels}
+
+    if rank == 0:
+        samples = world * R_RAYS * S_SAMPLES * args.steps
+        value = samples / elapsed
+        line = {
+            "metric": "ray-samples/s (train step) on ABC-neat-a", "value": value, "unit": "ray-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: abc-neat-a networks, 1024 rays x 128 samples per GPU, depth samples given, "
+                                   "train step = forward + loss + backward + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
+                       "rays_per_gpu": R_RAYS, "samples_per_ray": S_SAMPLES, "global_rays": world * R_RAYS,
+                       "parallelism": f"dp{world}", "weights": "synthetic 'rough' (seed 42)"},
+            "rays_per_s": world * R_RAYS * args.steps / elapsed,
+            "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,
+            "step_frac_of_f32_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (PEAK_TFLOPS["f32"] * world),
+            "loss": float(losses["loss"]),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(42)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,13 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
 /* ---- a9 alone: volume_rendering :540-554 given sdf [R,S] -> weights [R,S] (used by tests) -------- */
 int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream);
 
+/* ---- measurement support (bench.py): when enabled, every launch of the two GEMM-class kernels is bracketed by
+ * HIP events on the caller's stream.  class 0 = layer_kernel (all MLP chains), class 1 = wgrad_kernel.
+ * neat_prof_collect synchronises on the recorded events and returns the summed kernel time, the summed
+ * ALGORITHMIC flops (2*N*K*P with the true layer dims) and the launch count since neat_prof_enable(1). */
+int neat_prof_enable(int on);
+int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

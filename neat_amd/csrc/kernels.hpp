@@ -688,9 +688,10 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
 #pragma unroll
   for (int c = 0; c < 6; ++c) if (a.d_lines3d) dl[c] = a.d_lines3d[r * 6 + c];
   const float ddepth = a.d_depth ? a.d_depth[r] : 0.0f;
-  // pass 1: total of w^_j w_j (needed for the suffix sums) while walking forward
+  // pass 1 (forward over the ray): transmittance needs the exclusive prefix of E.  Park T_i and w^_i w_i in the
+  // output rows (same thread reads them back in pass 2, so no hazard).
   const int nchunk = (a.S + 63) / 64;
-  float carry = 0.0f, total = 0.0f;
+  float carry = 0.0f;
   for (int ch = 0; ch < nchunk; ++ch) {
     const int i = ch * 64 + lane;
     const bool ok = i < a.S;
@@ -708,12 +709,13 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       wh += drgb[c] * a.rgb_fm[(size_t)c * a.ldp + p] + dxyz[c] * a.x_fm[(size_t)c * a.ldp + p];
-    total += wave_sum(ok ? wh * w : 0.0f);
+    if (ok) { a.dsdf_row[p] = T; a.dlin_fm[p] = wh; }
   }
-  // pass 2: forward again with a running prefix of w^ w ; suffix_i = total - prefix_incl_i
-  carry = 0.0f;
-  float pref = 0.0f, dbeta = 0.0f;
-  for (int ch = 0; ch < nchunk; ++ch) {
+  // pass 2 (backward over the ray): suffix_i = sum_{j>i} w^_j w_j by a reverse exclusive scan -- exactly the
+  // reverse cumsum autograd performs; in particular it is exactly 0 for the last sample, whose 1e10 interval
+  // would otherwise amplify any rounding residue.
+  float carry_rev = 0.0f, dbeta = 0.0f;
+  for (int ch = nchunk - 1; ch >= 0; --ch) {
     const int i = ch * 64 + lane;
     const bool ok = i < a.S;
     const int p = r * a.S + (ok ? i : a.S - 1);
@@ -722,26 +724,25 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
     const float s = a.sdf[p];
     const float sigma = laplace_sigma(s, beta);
     const float e = ok ? delta * sigma : 0.0f;
-    const float incl = wave_incl_scan(e, lane);
-    float excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 0.0f;
-    const float T = expf(-(carry + excl));
+    const float T = ok ? a.dsdf_row[p] : 0.0f;
+    const float wh = ok ? a.dlin_fm[p] : 0.0f;
     const float em = expf(-e);
     const float w = ok ? (1.0f - em) * T : 0.0f;
-    carry += __shfl(incl, 63);
-    float wh = ddepth * fabsf(zi) * dn;
     float rgbv[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      rgbv[c] = a.rgb_fm[(size_t)c * a.ldp + p];
-      wh += drgb[c] * rgbv[c] + dxyz[c] * a.x_fm[(size_t)c * a.ldp + p];
+    for (int c = 0; c < 3; ++c) rgbv[c] = a.rgb_fm[(size_t)c * a.ldp + p];
+    float rs = wh * w;                                   // reverse inclusive scan over lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float t = __shfl_down(rs, off);
+      if (lane + off < 64) rs += t;
     }
-    const float ww = ok ? wh * w : 0.0f;
-    const float inclw = wave_incl_scan(ww, lane);
-    const float suffix = total - (pref + inclw);           // sum_{j>i} w^_j w_j
-    pref += __shfl(inclw, 63);
+    float excl = __shfl_down(rs, 1);
+    if (lane == 63) excl = 0.0f;
+    const float suffix = carry_rev + excl;               // sum_{j>i} w^_j w_j
+    carry_rev += __shfl(rs, 0);
     if (ok) {
-      const float dE = wh * em * T - suffix;               // d w_i/d E_i = e^-E_i T_i ; d w_j/d E_i = -w_j (j>i)
+      const float dE = wh * em * T - suffix;             // d w_i/d E_i = e^-E_i T_i ; d w_j/d E_i = -w_j (j>i)
       const float dsig = dE * delta;
       const float sg = (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f);
       const float q = expf(-fabsf(s) / beta);

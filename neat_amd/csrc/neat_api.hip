@@ -4,6 +4,7 @@
 #include "../../include/neat_hip.h"
 #include <math.h>
 #include <stdio.h>
+#include <vector>
 
 using namespace neat;
 
@@ -72,6 +73,30 @@ NetPtrs to_ptrs(const neat_net_params* net) {
 // ------------------------------------------------------------------------------------------------
 #define NEAT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+// ------------------------------------------------------------------------------------------------
+// optional in-stream kernel timing (bench.py): HIP events around every launch of the two GEMM-class kernels
+// ------------------------------------------------------------------------------------------------
+struct ProfSlot { hipEvent_t e0, e1; double flops; int cls; };
+struct Prof {
+  bool on = false;
+  std::vector<ProfSlot> pool;
+  size_t used = 0;
+} g_prof;
+
+inline ProfSlot* prof_begin(hipStream_t st, int cls, double flops) {
+  if (!g_prof.on) return nullptr;
+  if (g_prof.used == g_prof.pool.size()) {
+    ProfSlot s{};
+    if (hipEventCreate(&s.e0) != hipSuccess || hipEventCreate(&s.e1) != hipSuccess) return nullptr;
+    g_prof.pool.push_back(s);
+  }
+  ProfSlot* s = &g_prof.pool[g_prof.used++];
+  s->flops = flops; s->cls = cls;
+  hipEventRecord(s->e0, st);
+  return s;
+}
+inline void prof_end(hipStream_t st, ProfSlot* s) { if (s) hipEventRecord(s->e1, st); }
+
 template <int EPI> hipError_t launch_layer_t(hipStream_t st, const LayerArgs& a, int ntiles_p) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -122,7 +147,10 @@ hipError_t layer(const Ctx& c, int pid, int epi, const float* in0, int rows0, co
   a.aux0 = aux0; a.aux1 = aux1;
   if (rows0 + rows1 != d.K || N > d.N) return hipErrorInvalidValue;
   // tile stride inside the pack is Kpad/2*64 per 32 rows, independent of how many tiles we compute
-  return launch_layer(c.st, epi, a, c.ldp / BM);
+  ProfSlot* ps = prof_begin(c.st, 0, 2.0 * N * d.K * (double)c.P);      // algorithmic flops: true N, K and point count
+  hipError_t e = launch_layer(c.st, epi, a, c.ldp / BM);
+  prof_end(c.st, ps);
+  return e;
 }
 
 inline dim3 grid1(int n, int b = 256) { return dim3((n + b - 1) / b); }
@@ -230,7 +258,14 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WgradPair* pa
   a.chunk = chunk; a.partial = w.partial; a.Nld = WLDN; a.Kld = WLDK;
   const int ntile = (N + 127) / 128;
   a.ktiles = (Kt + 127) / 128;
+  double wflops = 0.0;
+  for (int q = 0; q < npairs; ++q) {
+    const int kb = pairs[q].rowsB[0] + pairs[q].rowsB[1] + pairs[q].rowsB[2];
+    wflops += 2.0 * pairs[q].rowsA * kb * (double)c.P;
+  }
+  ProfSlot* ps = prof_begin(c.st, 1, wflops);
   hipLaunchKernelGGL(wgrad_kernel, dim3(ntile * a.ktiles, splits), dim3(WG), 0, c.st, a);
+  prof_end(c.st, ps);
   WreduceArgs r{};
   r.partial = w.partial; r.splits = splits; r.Nld = WLDN; r.Kld = WLDK;
   r.O = kO[layer_id]; r.I = kI[layer_id];
@@ -396,6 +431,30 @@ __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const flo
 extern "C" {
 
 int neat_abi_version(void) { return 1; }
+
+int neat_prof_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  return 0;
+}
+
+int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches) {
+  double ms = 0.0, fl = 0.0;
+  int n = 0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    ProfSlot& s = g_prof.pool[i];
+    if (s.cls != cls) continue;
+    hipError_t e = hipEventSynchronize(s.e1);
+    if (e != hipSuccess) return (int)e;
+    float t = 0.0f;
+    if ((e = hipEventElapsedTime(&t, s.e0, s.e1)) != hipSuccess) return (int)e;
+    ms += t; fl += s.flops; ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  return 0;
+}
 
 size_t neat_packed_floats(void) { return pack_layout().total; }
 

@@ -207,12 +207,20 @@ def main():
         net.eval()
 
         # ------------- G7 full forward, eval, R=64
+        rec = {}
+        inner = net.ray_sampler.get_z_vals
+
+        def recording(*a, _inner=inner, _rec=rec, **k):
+            _rec["z"], _rec["z_eik"] = _inner(*a, **k)
+            return _rec["z"], _rec["z_eik"]
+        net.ray_sampler.get_z_vals = recording
         with RngTape() as tp:
             out = net(inp)
+        net.ray_sampler.get_z_vals = inner
         eik_idx = [t for n, t in tp.tape if n == "randint"][-1]
         keys = ["points", "rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "lines2d",
                 "sdf", "normal_map"]
-        save(f"g7_forward_eval_{variant}", eik_idx=np_(eik_idx), **{k: sc[k] for k in
+        save(f"g7_forward_eval_{variant}", eik_idx=np_(eik_idx), z_vals=np_(rec["z"]), **{k: sc[k] for k in
              ("uv", "uv_proj", "pose", "intrinsics", "wf_vertices", "wf_vconf", "wf_edges", "wf_weights")},
              **{"out_" + k: np_(out[k]) for k in keys})
 
