@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 R_RAYS, S_SAMPLES = 1024, 128
 FLOP_PER_RAY_SAMPLE = 9.1254e6        # 4 562 688 MAC per ray-sample per train step
+CPU_BASELINE_THREADS = 16
 PEAK_TFLOPS = {"f32": 157.3}          # MI355X_MICROARCH.md: dense f32-input MFMA peak
 
 
@@ -58,11 +59,12 @@ def cpu_baseline(seed):
         times.sort()
         return R * S / times[len(times) // 2]
 
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    cores = min(avail, CPU_BASELINE_THREADS)      # a 16 K-point batch does not scale past a few tens of threads
     before = torch.get_num_threads()
     v_all = run(cores, 3)
     v_one = run(1, 1)
@@ -78,7 +80,7 @@ def cpu_baseline(seed):
         pass
     return {"value": v_all, "unit": "ray-samples/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch CPU fp32) train step on {R} rays x {S} samples, median of 3 after 1 warm-up, {cores} threads",
-            "value_1thread": v_one, "cpu_model": model}
+            "value_1thread": v_one, "cpu_model": model, "host_cpus": avail}
 
 
 def main():
@@ -94,6 +96,7 @@ def main():
     from neat_amd.train import Trainer, synthetic_batch
     import torch.distributed as dist
 
+    t_start = time.perf_counter()
     rank, world, local = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -115,8 +118,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+    note("model built, starting warm-up")
+    for i in range(args.warmup):
         tr.step(inp, gt)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
     barrier()
     if not args.no_prof:
         lib.neat_prof_enable(1)
@@ -125,6 +135,7 @@ def main():
         _, losses = tr.step(inp, gt)
     barrier()
     elapsed = time.perf_counter() - t0
+    note(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -165,11 +176,13 @@ def main():
             "rays_per_s": world * R_RAYS * args.steps / elapsed,
             "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,
             "step_frac_of_f32_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (PEAK_TFLOPS["f32"] * world),
-            "loss": float(losses["loss"]),
+            "loss": float(losses["loss"].detach()),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
+            note("timing the CPU oracle (cpu_baseline)")
             line["cpu_baseline"] = cpu_baseline(42)
+            note("cpu_baseline done")
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -300,21 +300,41 @@ struct WreduceArgs {
 };
 
 __global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (o >= a.O) return;
-  constexpr int MAXC = 5;                 // up to 320 input columns
+  // one workgroup per output row: wave w sums splits w, w+4, ... (independent loads, unrolled), LDS combine,
+  // then wave 0 applies the weight-norm backward.
+  constexpr int MAXC = 5;                 // up to 320 input columns (+ bias column handled by lane 0 of each wave)
+  __shared__ float red[4][MAXC * 64 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o = blockIdx.x;
+  float acc[MAXC], bacc = 0.0f;
+  int jcol[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = lane + 64 * c;          // source column
+    acc[c] = 0.0f;
+    jcol[c] = (i < a.I) ? ((i < a.perm_split) ? i + (a.I - a.perm_split) : i - a.perm_split) : -1;   // packed column
+  }
+  const size_t row_off = (size_t)o * a.Kld, split_stride = (size_t)a.Nld * a.Kld;
+  for (int sp = wave; sp < a.splits; sp += 4) {
+    const float* src = a.partial + sp * split_stride + row_off;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) if (jcol[c] >= 0) acc[c] += src[jcol[c]];
+    if (lane == 0 && a.bias_col >= 0) bacc += src[a.bias_col];
+  }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) red[wave][c * 64 + lane] = acc[c];
+  if (lane == 0) red[wave][MAXC * 64] = bacc;
+  __syncthreads();
+  if (wave != 0) return;
   float dw[MAXC], vv[MAXC];
   float dot = 0.0f, nrm2 = 0.0f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
-    const int i = lane + 64 * c;          // source column
+    const int i = lane + 64 * c;
     dw[c] = 0.0f; vv[c] = 0.0f;
     if (i < a.I) {
-      const int j = (i < a.perm_split) ? i + (a.I - a.perm_split) : i - a.perm_split;   // packed column
-      float s = 0.0f;
-      for (int sp = 0; sp < a.splits; ++sp) s += a.partial[((size_t)sp * a.Nld + o) * a.Kld + j];
-      dw[c] = s * a.scale;
+      const int k = c * 64 + lane;
+      dw[c] = (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * a.scale;
       vv[c] = a.v[(size_t)o * a.I + i];
       dot += dw[c] * vv[c];
       nrm2 += vv[c] * vv[c];
@@ -332,11 +352,7 @@ __global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
   }
   if (lane == 0) {
     a.dg[o] = dot * inv;
-    if (a.db && a.bias_col >= 0) {
-      float s = 0.0f;
-      for (int sp = 0; sp < a.splits; ++sp) s += a.partial[((size_t)sp * a.Nld + o) * a.Kld + a.bias_col];
-      a.db[o] = s;
-    }
+    if (a.db && a.bias_col >= 0) a.db[o] = red[0][MAXC * 64] + red[1][MAXC * 64] + red[2][MAXC * 64] + red[3][MAXC * 64];
   }
 }
 

@@ -274,7 +274,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WgradPair* pa
   r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
   r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
   r.bias_col = Kt - 1;
-  hipLaunchKernelGGL(wreduce_wnorm_kernel, dim3((r.O + 3) / 4), dim3(WG), 0, c.st, r);
+  hipLaunchKernelGGL(wreduce_wnorm_kernel, dim3(r.O), dim3(WG), 0, c.st, r);
   return hipGetLastError();
 }
 

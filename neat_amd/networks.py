@@ -269,6 +269,11 @@ class VolSDFNetwork(_HipModule):
         z_vals, z_eik = self._z_vals(ray_dirs, cam_loc)
         rgb, lines3d, depth, xyz, weights, sdf_s, points, nmap = self._render(cam_loc, ray_dirs, z_vals, not self.training)
         output = {"points": points, "rgb_values": rgb, "sdf": sdf_s, "depth": depth, "xyz": xyz}
+        grad_theta = None
+        if self.training and not self.junction_eikonal:
+            # Eikonal pass (rend_a :515-527), queued here so the GPU has work while the host runs the Hungarian
+            # matching below.  No random draw happens in between, so the CPU RNG stream order is the reference's.
+            grad_theta = self._eikonal(n_rays, cam_loc, ray_dirs, z_eik, None)
 
         # ---- attraction field / junctions (rend_a :424-513); R-sized, stays in torch -------------------
         points3d = xyz
@@ -328,14 +333,19 @@ class VolSDFNetwork(_HipModule):
         output["wireframe-gt"] = input["wireframe"]
         output["K"] = K3
 
-        if self.training:      # eikonal points: uniform in the bounding cube + one near-surface sample per ray (:515-527)
-            r = self.scene_bounding_sphere
-            eik = torch.empty(n_rays, 3).uniform_(-r, r).to(ray_dirs.device)
-            near = cam_loc + z_eik * ray_dirs
-            eik = torch.cat([eik, near], 0)
-            if self.junction_eikonal:
-                eik = torch.cat([eik, output["j3d_global"].detach()], 0)
-            output["grad_theta"] = self.implicit_network.gradient(eik)
+        if self.training:
+            if grad_theta is None:
+                grad_theta = self._eikonal(n_rays, cam_loc, ray_dirs, z_eik, output["j3d_global"].detach())
+            output["grad_theta"] = grad_theta
         else:
             output["normal_map"] = nmap
         return output
+
+    def _eikonal(self, n_rays, cam_loc, ray_dirs, z_eik, junctions):
+        """Eikonal points: uniform in the bounding cube + one near-surface sample per ray (rend_a :515-527)."""
+        r = self.scene_bounding_sphere
+        eik = torch.empty(n_rays, 3).uniform_(-r, r).to(ray_dirs.device)
+        eik = torch.cat([eik, cam_loc + z_eik * ray_dirs], 0)
+        if junctions is not None:
+            eik = torch.cat([eik, junctions], 0)
+        return self.implicit_network.gradient(eik)

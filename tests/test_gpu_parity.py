@@ -88,7 +88,8 @@ def close_sampler(z, ref, what):
     assert err.shape == ref.shape
     frac = float((err > 2e-4).mean())
     assert frac <= 0.005, f"{what}: {frac:.4%} of samples differ by more than 2e-4"
-    assert float(err.max()) <= 6.0 / 127 + 1e-3, f"{what}: max err {err.max():.3e} exceeds one coarse bin"
+    # a flipped sample moves by one bin of the *current* grid: <= 2 * 6/127 with stratified jitter (training)
+    assert float(err.max()) <= 2 * 6.0 / 127 + 1e-3, f"{what}: max err {err.max():.3e} exceeds one coarse bin"
 
 
 def scene_inputs(g, dev):
