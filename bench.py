@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 R_RAYS, S_SAMPLES = 1024, 128
 FLOP_PER_RAY_SAMPLE = 9.1254e6        # 4 562 688 MAC per ray-sample per train step
 CPU_BASELINE_THREADS = 16
-PEAK_TFLOPS = {"f32": 157.3}          # MI355X_MICROARCH.md: dense f32-input MFMA peak
+DEFAULT_PRECISION = "fp32"
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks          # MI355X_MICROARCH.md: dense f32-input MFMA peak
 
 
 def cpu_baseline(seed):
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=DEFAULT_PRECISION,
+                    help="GEMM build: fp32 = exact-f32 MFMA (parity build); bf16 = bf16 MFMA, fp32 accumulate (BASELINE config 2)")
     args = ap.parse_args()
 
     from neat_amd import _lib, dp, synth
@@ -112,6 +115,8 @@ def main():
     tr = Trainer(device=dev, state_dict=sd)
     _, inp, gt = synthetic_batch(seed, R_RAYS, dev, view=rank)
     tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(seed, R_RAYS, S_SAMPLES)).to(dev)
+    tr.model.set_precision(args.precision)
+    peak = PEAK_TFLOPS[args.precision]
 
     def barrier():
         if world > 1:
@@ -157,8 +162,8 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": PEAK_TFLOPS["f32"],
-                        "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / PEAK_TFLOPS["f32"], "traffic": traffic,
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": peak,
+                        "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak, "traffic": traffic,
                         "avg_launch_us": kernels[dom]["avg_us"], "launches": kernels[dom]["launches"],
                         "kernel_time_share": kernels[dom]["total_ms"] * 1e-3 / elapsed, "all_kernels": kernels}
 
@@ -168,14 +173,15 @@ def main():
         line = {
             "metric": "ray-samples/s (train step) on ABC-neat-a", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "C2: abc-neat-a networks, 1024 rays x 128 samples per GPU, depth samples given, "
                                    "train step = forward + loss + backward + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
                        "rays_per_gpu": R_RAYS, "samples_per_ray": S_SAMPLES, "global_rays": world * R_RAYS,
                        "parallelism": f"dp{world}", "weights": "synthetic 'rough' (seed 42)"},
             "rays_per_s": world * R_RAYS * args.steps / elapsed,
             "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,
-            "step_frac_of_f32_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (PEAK_TFLOPS["f32"] * world),
+            "step_frac_of_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (peak * world),
             "loss": float(losses["loss"].detach()),
             "roofline": roofline,
         }

@@ -37,12 +37,19 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);
+int neat_abi_version(void);      /* 2 */
+
+/* `precision` selects the build of the GEMM-class kernels:
+ *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
+ *   NEAT_BF16 (1): bf16 MFMA with fp32 accumulate, bf16 hidden activations -- throughput build
+ * Packed weights, workspaces and forward/backward calls of one pass must use the same value. */
+#define NEAT_F32 0
+#define NEAT_BF16 1
 
 /* ---- a15: weight norm + packing (replaces the per-call `_weight_norm` pre-hook) -------------------
  * Computes W = g * v/|v| for all 19 layers once per step and stores W and W^T in MFMA-fragment order. */
-size_t neat_packed_floats(void);
-int neat_pack_weights(const neat_net_params* net, float* packed, void* stream);
+size_t neat_packed_floats(int precision);
+int neat_pack_weights(const neat_net_params* net, float* packed, int precision, void* stream);
 
 /* ---- a1: pixel -> unit ray directions (utils/rend_util.py:55-81 get_camera_params, :95-108 lift) --
  * uv [R,2], pose [4,4] cam-to-world, K row stride `kstride` (3 or 4).  dirs [R,3].  Origin = pose[:3,3]. */
@@ -54,23 +61,23 @@ int neat_camera_rays(const float* uv, const float* pose, const float* K, int kst
  *                         gradient :98-109 when radius <= 0), activations saved in `ws` for backward.
  * radius > 0 enables the bounding-sphere clamp min(sdf, scale*(radius-|x|)).
  * Any of out257 / sdf / feat / grad may be NULL.  x is row-major [P,3]. */
-size_t neat_sdf_ws_floats(int P, int mode);
-int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode,
+size_t neat_sdf_ws_floats(int P, int mode, int precision);
+int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
                      float radius, float scale, float* ws,
                      float* out257, float* sdf, float* feat, float* grad, void* stream);
 /* Backward of mode-1 forward (autograd incl. the double backward through d sdf/dx, which the reference
  * gets from create_graph=True at :121-127).  Cotangents are row-major and may be NULL (= zero):
  * d_out257 [P,257] (of forward()), d_sdf [P] (of the clamped sdf), d_feat [P,256], d_grad [P,3].
  * Writes grads->dv/dg/db[0..8]. */
-int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P,
+int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P, int precision,
                       const float* d_out257, const float* d_sdf, const float* d_feat, const float* d_grad,
                       const neat_net_grads* grads, void* stream);
 
 /* ---- a6+a7: the two heads on given inputs (RenderingNetwork.forward :235-255,
  * AttractionFieldNetwork.forward :175-197), row-major inputs; rgb [P,3], lines [P,2,3]. */
-size_t neat_heads_ws_floats(int P);
+size_t neat_heads_ws_floats(int P, int precision);
 int neat_heads_forward(const float* packed, const neat_net_params* net, const float* points, const float* normals,
-                       const float* view_dirs, const float* feats, int P, float* ws,
+                       const float* view_dirs, const float* feats, int P, int precision, float* ws,
                        float* rgb, float* lines, void* stream);
 
 /* ---- a5-a10 fused main pass: VolSDFNetwork.forward :392-422 (+ :530-536 normal_map in eval) -------
@@ -78,16 +85,16 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
  * |density.beta| + beta_min (model/density.py:28-30) -- a pointer so that no host sync is needed.
  * Outputs (row-major, NULL to skip where noted): points [R,S,3] (opt), weights [R,S] (opt),
  * sdf [R,S] (opt), rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], normal_map [R,3] (opt). */
-size_t neat_render_ws_floats(int R, int S);
+size_t neat_render_ws_floats(int R, int S, int precision);
 int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                        const float* z, int R, int S, const float* beta, float radius, float scale, float* ws,
+                        const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
                         float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                         float* xyz, float* normal_map, void* stream);
 /* Backward of neat_render_forward.  Cotangents d_rgb [R,3], d_lines3d [R,6], d_depth [R], d_xyz [R,3]
  * (NULL = zero).  lines3d uses detached weights exactly as :410.  Writes all 19 layers' grads and the
  * per-ray partial derivative wrt beta, dbeta_ray [R] (sum it, times sign(density.beta)). */
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs,
-                         const float* z, int R, int S, const float* beta,
+                         const float* z, int R, int S, int precision, const float* beta,
                          const float* d_rgb, const float* d_lines3d, const float* d_depth, const float* d_xyz,
                          const neat_net_grads* grads, float* dbeta_ray, void* stream);
 

@@ -6,6 +6,8 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
+ABI_VERSION = 2
+PRECISIONS = {"fp32": 0, "bf16": 1}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libneat_hip.so")
 
@@ -22,22 +24,22 @@ class NetGrads(ctypes.Structure):
 
 _SIGNATURES = {
     "neat_abi_version": (ctypes.c_int, []),
-    "neat_packed_floats": (ctypes.c_size_t, []),
-    "neat_pack_weights": (ctypes.c_int, [ctypes.POINTER(NetParams), c_fp, c_fp]),
+    "neat_packed_floats": (ctypes.c_size_t, [ctypes.c_int]),
+    "neat_pack_weights": (ctypes.c_int, [ctypes.POINTER(NetParams), c_fp, ctypes.c_int, c_fp]),
     "neat_camera_rays": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
-    "neat_sdf_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
-    "neat_sdf_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int,
+    "neat_sdf_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "neat_sdf_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    "neat_sdf_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp,
+    "neat_sdf_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp,
                                          ctypes.POINTER(NetGrads), c_fp]),
-    "neat_heads_ws_floats": (ctypes.c_size_t, [ctypes.c_int]),
-    "neat_heads_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp,
+    "neat_heads_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "neat_heads_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp,
                                           c_fp, c_fp, c_fp]),
-    "neat_render_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
-    "neat_render_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int,
+    "neat_render_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "neat_render_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            c_fp, ctypes.c_float, ctypes.c_float, c_fp,
                                            c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
-    "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int,
+    "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
     "neat_volume_weights": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_prof_enable": (ctypes.c_int, [ctypes.c_int]),

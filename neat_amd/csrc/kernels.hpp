@@ -292,7 +292,8 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
 struct WreduceArgs {
   const float* partial; int splits, Nld, Kld;
   int O, I;                  // layer dims (torch layout [O][I])
-  int perm_split;            // source columns [0,perm_split) sit at the END of the packed input order
+  int s0, s0p, off0, off1;   // packed input order: [source cols off0..off0+s0) | pad to s0p | source cols off1.. )
+  int rot;                   // packed output row n holds source row (n + rot) mod O
   float scale;               // folded input scale (1/sqrt2 for the skip layer)
   const float* v; const float* g;      // weight_v [O][I], weight_g [O]
   float* dv; float* dg; float* db;     // outputs (db may be null -> no bias column)
@@ -312,9 +313,10 @@ __global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
   for (int c = 0; c < MAXC; ++c) {
     const int i = lane + 64 * c;          // source column
     acc[c] = 0.0f;
-    jcol[c] = (i < a.I) ? ((i < a.perm_split) ? i + (a.I - a.perm_split) : i - a.perm_split) : -1;   // packed column
+    jcol[c] = (i < a.I) ? ((i >= a.off0 && i < a.off0 + a.s0) ? i - a.off0 : a.s0p + (i - a.off1)) : -1;   // packed column
   }
-  const size_t row_off = (size_t)o * a.Kld, split_stride = (size_t)a.Nld * a.Kld;
+  const int on = (o - a.rot + a.O) % a.O;                    // packed row of source row o
+  const size_t row_off = (size_t)on * a.Kld, split_stride = (size_t)a.Nld * a.Kld;
   for (int sp = wave; sp < a.splits; sp += 4) {
     const float* src = a.partial + sp * split_stride + row_off;
 #pragma unroll
@@ -380,35 +382,6 @@ __global__ __launch_bounds__(WG) void rowscale_kernel(RowScaleArgs a) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) a.rowscale[row] = a.net.g[l][o] / sqrtf(s);
-}
-
-struct PackDesc { int layer, transpose, N, K, Kpad, NT, perm_split; float scale; int offset; int blk0; };
-constexpr int MAXPACKS = 40;
-struct PackArgs { NetPtrs net; const float* rowscale; int row_off[NLAYERS + 1]; PackDesc d[MAXPACKS]; int npacks; float* out; };
-
-// one workgroup per (pack, 32-row tile): out[off + (nt*KS + s)*64 + lane] = Wm[nt*32+(lane&31)][2s+(lane>>5)]
-__global__ __launch_bounds__(WG) void pack_kernel(PackArgs a) {
-  int pk = 0;
-  while (pk + 1 < a.npacks && (int)blockIdx.x >= a.d[pk + 1].blk0) ++pk;
-  const PackDesc d = a.d[pk];
-  const int nt = blockIdx.x - d.blk0;
-  const int KS = d.Kpad >> 1;
-  const int O = a.net.O[d.layer], I = a.net.I[d.layer];
-  const float* v = a.net.v[d.layer];
-  const float* rs = a.rowscale + a.row_off[d.layer];
-  float* out = a.out + d.offset + (size_t)nt * KS * 64;
-  for (int e = threadIdx.x; e < KS * 64; e += WG) {
-    const int s = e >> 6, ln = e & 63;
-    const int n = nt * 32 + (ln & 31), k = 2 * s + (ln >> 5);
-    float w = 0.0f;
-    if (v && n < d.N && k < d.K) {
-      const int o = d.transpose ? k : n;        // output-feature index in the torch weight
-      const int j = d.transpose ? n : k;        // packed input index
-      const int i = (j < I - d.perm_split) ? j + d.perm_split : j - (I - d.perm_split);
-      if (o < O && i < I) w = v[(size_t)o * I + i] * rs[o] * d.scale;
-    }
-    out[e] = w;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,6 +1,9 @@
 // Host orchestration + C ABI of libneat_hip.so (see include/neat_hip.h).
 // One stream-ordered sequence of kernel launches per entry point; no allocation, no sync.
-#include "kernels.hpp"
+// Two builds of the GEMM-class kernels share the orchestration: precision 0 = exact-f32 MFMA with fp32
+// feature-major activations (parity build), precision 1 = bf16 MFMA (fp32 accumulate) with bf16 octet-major
+// hidden activations (throughput build).  Small arrays are fp32 feature-major in both.
+#include "kernels_bf16.hpp"
 #include "../../include/neat_hip.h"
 #include <math.h>
 #include <stdio.h>
@@ -13,53 +16,64 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // architecture (identical in all shipped confs: confs/abc-neat-a.conf:42-70, dtu.conf, bmvs.conf)
 // ------------------------------------------------------------------------------------------------
-constexpr int L_SDF = 0, L_REND = 9, L_ATTR = 14;
+constexpr int L_REND = 9, L_ATTR = 14;
 const int kO[NLAYERS] = {256, 256, 256, 217, 256, 256, 256, 256, 257, 256, 256, 256, 256, 3, 256, 256, 256, 256, 6};
 const int kI[NLAYERS] = {39, 256, 256, 256, 256, 256, 256, 256, 256, 289, 256, 256, 256, 256, 265, 256, 256, 256, 256};
 constexpr int PE_ROWS = 39, SMALL_R = 33, SMALL_A = 9;
+enum { F32 = 0, BF16 = 1 };
 
+inline int padk(int k, int prec) { return prec ? (k + 15) & ~15 : (k + 7) & ~7; }
 inline int pad8(int k) { return (k + 7) & ~7; }
 inline int tiles32(int n) { return (n + 31) / 32; }
 
 struct PackLayout {
-  PackDesc d[MAXPACKS];
+  PackDesc2 d[MAXPACKS2];
   int npacks, nblocks;
-  int fwd[NLAYERS], tr[NLAYERS];      // pack ids
+  int fwd[NLAYERS], tr[NLAYERS], sdf_row;      // pack ids (sdf_row: lin8 restricted to the sdf output row)
   int row_off[NLAYERS + 1];
   size_t rowscale_off, total;
 };
 
-const PackLayout& pack_layout() {
-  static PackLayout L;
-  static bool init = false;
-  if (init) return L;
+void build_layout(PackLayout& L, int prec) {
   size_t off = 0;
   int np = 0, blk = 0;
   L.row_off[0] = 0;
   for (int l = 0; l < NLAYERS; ++l) L.row_off[l + 1] = L.row_off[l] + kO[l];
+  auto add = [&](int l, int t, int nrows_limit, int rot) {
+    PackDesc2& d = L.d[np];
+    d.layer = l; d.transpose = t; d.bf16 = prec;
+    d.s0 = kI[l]; d.s0p = kI[l]; d.off0 = 0; d.off1 = 0;
+    if (l == L_REND) { d.s0 = 256; d.s0p = 256; d.off0 = SMALL_R; d.off1 = 0; }          // [feature | p, PE4(view), normal]
+    if (l == L_ATTR) { d.s0 = 256; d.s0p = 256; d.off0 = SMALL_A; d.off1 = 0; }          // [feature | p, view, normal]
+    if (l == 4) { d.s0 = 217; d.s0p = prec ? 224 : 217; d.off0 = 0; d.off1 = 217; }       // [h4 | PE]  (skip, rend_a :87-88)
+    d.rot = rot;
+    d.scale = (l == 4) ? (float)(1.0 / sqrt(2.0)) : 1.0f;                                 // /sqrt2 of the skip concat folded in
+    const int kin = d.s0p + (kI[l] - d.s0);
+    d.N = t ? kin : (nrows_limit > 0 ? nrows_limit : kO[l]);
+    d.K = t ? kO[l] : kin;
+    d.Kpad = padk(d.K, prec); d.NT = tiles32(d.N);
+    d.offset = (int)off; d.blk0 = blk;
+    off += prec ? (size_t)d.NT * (d.Kpad / 16) * 64 * 4 : (size_t)d.NT * (d.Kpad / 2) * 64;
+    blk += d.NT;
+    return np++;
+  };
   for (int l = 0; l < NLAYERS; ++l) {
-    const int perm = (l == L_REND) ? SMALL_R : (l == L_ATTR) ? SMALL_A : 0;
-    const float scale = (l == 4) ? (float)(1.0 / sqrt(2.0)) : 1.0f;   // skip concat /sqrt2 (rend_a :87-88) folded in
-    for (int t = 0; t < 2; ++t) {
-      PackDesc& d = L.d[np];
-      d.layer = l; d.transpose = t;
-      d.N = t ? kI[l] : kO[l];
-      d.K = t ? kO[l] : kI[l];
-      d.Kpad = pad8(d.K); d.NT = tiles32(d.N);
-      d.perm_split = perm; d.scale = scale;
-      d.offset = (int)off; d.blk0 = blk;
-      off += (size_t)d.NT * (d.Kpad / 2) * 64;
-      blk += d.NT;
-      (t ? L.tr : L.fwd)[l] = np;
-      ++np;
-    }
+    const int rot = (l == 8 && prec) ? 1 : 0;         // bf16: lin8 rows reordered to [feature(256) | sdf] (octet aligned)
+    L.fwd[l] = add(l, 0, 0, rot);
+    L.tr[l] = add(l, 1, 0, rot);
   }
+  L.sdf_row = add(8, 0, 1, 0);
   L.npacks = np; L.nblocks = blk;
   L.rowscale_off = off;
   off += (size_t)((L.row_off[NLAYERS] + 63) & ~63);
   L.total = off;
-  init = true;
-  return L;
+}
+
+const PackLayout& pack_layout(int prec) {
+  static PackLayout L[2];
+  static bool init[2] = {false, false};
+  if (!init[prec]) { build_layout(L[prec], prec); init[prec] = true; }
+  return L[prec];
 }
 
 NetPtrs to_ptrs(const neat_net_params* net) {
@@ -68,9 +82,6 @@ NetPtrs to_ptrs(const neat_net_params* net) {
   return p;
 }
 
-// ------------------------------------------------------------------------------------------------
-// launch helpers
-// ------------------------------------------------------------------------------------------------
 #define NEAT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // ------------------------------------------------------------------------------------------------
@@ -97,7 +108,10 @@ inline ProfSlot* prof_begin(hipStream_t st, int cls, double flops) {
 }
 inline void prof_end(hipStream_t st, ProfSlot* s) { if (s) hipEventRecord(s->e1, st); }
 
-template <int EPI> hipError_t launch_layer_t(hipStream_t st, const LayerArgs& a, int ntiles_p) {
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+template <int EPI> hipError_t launch_layer_f(hipStream_t st, const LayerArgs& a, int ntiles_p) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<EPI>),
@@ -110,45 +124,84 @@ template <int EPI> hipError_t launch_layer_t(hipStream_t st, const LayerArgs& a,
   hipLaunchKernelGGL(layer_kernel<EPI>, dim3(ntiles_p), dim3(WG), lds, st, a);
   return hipGetLastError();
 }
-
-hipError_t launch_layer(hipStream_t st, int epi, const LayerArgs& a, int ntiles_p) {
-  switch (epi) {
-    case EPI_LINEAR: return launch_layer_t<EPI_LINEAR>(st, a, ntiles_p);
-    case EPI_SOFTPLUS: return launch_layer_t<EPI_SOFTPLUS>(st, a, ntiles_p);
-    case EPI_RELU: return launch_layer_t<EPI_RELU>(st, a, ntiles_p);
-    case EPI_SIGMOID: return launch_layer_t<EPI_SIGMOID>(st, a, ntiles_p);
-    case EPI_REV: return launch_layer_t<EPI_REV>(st, a, ntiles_p);
-    case EPI_TAN: return launch_layer_t<EPI_TAN>(st, a, ntiles_p);
-    case EPI_BWD: return launch_layer_t<EPI_BWD>(st, a, ntiles_p);
-    case EPI_BWD_RELU: return launch_layer_t<EPI_BWD_RELU>(st, a, ntiles_p);
+template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a, int ntiles_p) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_h<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
   }
-  return hipErrorInvalidValue;
+  size_t lds = (size_t)(a.Kpad / 8) * BMH * 16;
+  if (a.NT <= 2 && lds < 65536) lds = 65536;
+  hipLaunchKernelGGL(layer_kernel_h<EPI>, dim3(ntiles_p), dim3(WG), lds, st, a);
+  return hipGetLastError();
 }
+#define EPI_SWITCH(FN, st, epi, a, nt)                                         \
+  switch (epi) {                                                              \
+    case EPI_LINEAR: return FN<EPI_LINEAR>(st, a, nt);                        \
+    case EPI_SOFTPLUS: return FN<EPI_SOFTPLUS>(st, a, nt);                    \
+    case EPI_RELU: return FN<EPI_RELU>(st, a, nt);                            \
+    case EPI_SIGMOID: return FN<EPI_SIGMOID>(st, a, nt);                      \
+    case EPI_REV: return FN<EPI_REV>(st, a, nt);                              \
+    case EPI_TAN: return FN<EPI_TAN>(st, a, nt);                              \
+    case EPI_BWD: return FN<EPI_BWD>(st, a, nt);                              \
+    case EPI_BWD_RELU: return FN<EPI_BWD_RELU>(st, a, nt);                    \
+  }                                                                           \
+  return hipErrorInvalidValue;
+hipError_t dispatch_f(hipStream_t st, int epi, const LayerArgs& a, int nt) { EPI_SWITCH(launch_layer_f, st, epi, a, nt) }
+hipError_t dispatch_h(hipStream_t st, int epi, const LayerArgsH& a, int nt) { EPI_SWITCH(launch_layer_h, st, epi, a, nt) }
 
 struct Ctx {
   hipStream_t st;
   const float* packed;
   const neat_net_params* net;
-  int P, ldp;
-  const float* pack(int id) const { return packed + pack_layout().d[id].offset; }
-  const float* rowscale(int l) const { return packed + pack_layout().rowscale_off + pack_layout().row_off[l]; }
+  int P, ldp, prec;
+  const PackLayout& L() const { return pack_layout(prec); }
+  const float* rowscale(int l) const { return packed + L().rowscale_off + L().row_off[l]; }
 };
 
-// out[n][p] = epi(Wm in + bias) with Wm = pack `pid`; N may be < pack N (only the leading rows are computed)
-hipError_t layer(const Ctx& c, int pid, int epi, const float* in0, int rows0, const float* in1, int rows1,
-                 const float* bias, int N, float* out0, float* out1 = nullptr, int n_split = 1 << 30,
-                 const float* aux0 = nullptr, const float* aux1 = nullptr, int accumulate = 0) {
-  const PackDesc& d = pack_layout().d[pid];
-  LayerArgs a;
-  a.in0 = in0; a.in1 = in1; a.rows0 = rows0; a.rows1 = rows1;
-  a.Kpad = d.Kpad; a.Wp = c.pack(pid); a.bias = bias;
-  a.N = N; a.NT = tiles32(N);
-  a.ldp = c.ldp; a.out0 = out0; a.out1 = out1; a.n_split = n_split; a.accumulate = accumulate;
-  a.aux0 = aux0; a.aux1 = aux1;
-  if (rows0 + rows1 != d.K || N > d.N) return hipErrorInvalidValue;
-  // tile stride inside the pack is Kpad/2*64 per 32 rows, independent of how many tiles we compute
-  ProfSlot* ps = prof_begin(c.st, 0, 2.0 * N * d.K * (double)c.P);      // algorithmic flops: true N, K and point count
-  hipError_t e = launch_layer(c.st, epi, a, c.ldp / BM);
+// an array in the workspace: fp32 feature-major, or (big hidden activations in the bf16 build) bf16 octet-major
+struct Arr {
+  void* p = nullptr; int bf16 = 0;
+  float* f() const { return reinterpret_cast<float*>(p); }
+};
+inline Arr F(float* p) { Arr a; a.p = p; a.bf16 = 0; return a; }
+inline Arr F(const float* p) { return F(const_cast<float*>(p)); }
+struct In { Arr a; int rows; };
+inline In in(Arr a, int rows) { return In{a, rows}; }
+const In NOIN = In{Arr{}, 0};
+
+// out[n][p] = epi(Wm in + bias) with Wm = pack `pid`; N <= pack rows (only the leading rows are computed)
+hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bias, int N, Arr out0, Arr out1 = Arr{},
+                 int n_split = 1 << 30, Arr aux0 = Arr{}, Arr aux1 = Arr{}, int accumulate = 0, int bias_rot = 0, int bias_n = 1 << 30) {
+  const PackDesc2& d = c.L().d[pid];
+  const float* wp = c.packed + d.offset;
+  const int k_in = (c.prec && in1.rows > 0 ? pad8(in0.rows) : in0.rows) + in1.rows;
+  if (k_in != d.K || N > d.N) return hipErrorInvalidValue;
+  ProfSlot* ps = prof_begin(c.st, 0, 2.0 * N * (in0.rows + in1.rows) * (double)c.P);      // algorithmic flops: true N, K, P
+  hipError_t e;
+  if (!c.prec) {
+    if (in0.a.bf16 || in1.a.bf16 || out0.bf16 || aux0.bf16 || aux1.bf16) return hipErrorInvalidValue;
+    LayerArgs a;
+    a.in0 = in0.a.f(); a.in1 = in1.a.f(); a.rows0 = in0.rows; a.rows1 = in1.rows;
+    a.Kpad = d.Kpad; a.Wp = wp; a.bias = bias;
+    a.N = N; a.NT = tiles32(N); a.ldp = c.ldp;
+    a.out0 = out0.f(); a.out1 = out1.f(); a.n_split = n_split; a.accumulate = accumulate;
+    a.aux0 = aux0.f(); a.aux1 = aux1.f();
+    e = dispatch_f(c.st, epi, a, c.ldp / BM);
+  } else {
+    LayerArgsH a;
+    a.in[0] = SegH{in0.a.p, in0.rows, in0.a.bf16}; a.in[1] = SegH{in1.a.p, in1.rows, in1.a.bf16};
+    a.Kpad = d.Kpad; a.Wp = reinterpret_cast<const uint4*>(wp);
+    a.bias = bias; a.bias_rot = bias_rot; a.bias_n = bias_n;
+    a.N = N; a.NT = tiles32(N); a.ldp = c.ldp;
+    a.out0 = out0.p; a.out1 = out1.p; a.out0_bf16 = out0.bf16; a.out1_bf16 = out1.bf16;
+    a.n_split = n_split; a.accumulate = accumulate;
+    a.aux0 = reinterpret_cast<const u16*>(aux0.p); a.aux1 = reinterpret_cast<const u16*>(aux1.p);
+    if ((aux0.p && !aux0.bf16) || (aux1.p && !aux1.bf16) || (out1.p && (out1.bf16 != (epi == EPI_TAN)))) return hipErrorInvalidValue;
+    e = dispatch_h(c.st, epi, a, c.ldp / BMH);
+  }
   prof_end(c.st, ps);
   return e;
 }
@@ -156,33 +209,34 @@ hipError_t layer(const Ctx& c, int pid, int epi, const float* in0, int rows0, co
 inline dim3 grid1(int n, int b = 256) { return dim3((n + b - 1) / b); }
 
 // ------------------------------------------------------------------------------------------------
-// workspaces (float offsets; every array is [rows][ldp])
+// workspaces (float offsets; every array is [rows][ldp] floats of space; bf16 arrays use the first half)
 // ------------------------------------------------------------------------------------------------
 struct SdfWs {
-  float *x, *E, *h[9], *out8, *sdf, *mask, *g, *u[8], *e0, *es;      // forward + adjoint
-  float *Eh, *gh, *vh[9], *m[8], *abar8, *ones, *partial;            // backward
+  float *x, *E, *sdfraw, *sdf, *mask, *g, *e0, *es, *Eh, *gh, *abar8, *ones, *partial;   // fp32 feature-major
+  Arr h[9], feat, u[8], vh[9], m[8];                                                   // big (bf16 in the bf16 build)
   size_t total;
 };
 constexpr int WSPLIT = 128;                 // point-splits of the weight-gradient reduction
-constexpr int WLDN = 384, WLDK = 384;       // partial tile leading dims (>= 289+1, multiple of 128)
+constexpr int WLDN = 384, WLDK = 384;       // partial tile leading dims (>= 296+1, multiple of 128)
 
-SdfWs sdf_ws(float* base, int ldp, int mode) {
+SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
   SdfWs w{};
   size_t off = 0;
   auto take = [&](int rows) { float* p = base ? base + off : nullptr; off += (size_t)rows * ldp; return p; };
-  w.x = take(3); w.E = take(PE_ROWS + 1); w.sdf = take(1); w.mask = take(1); w.g = take(3);
+  auto big = [&](int rows) { Arr a; a.p = take(rows); a.bf16 = prec; return a; };
+  w.x = take(3); w.E = take(PE_ROWS + 1); w.sdf = take(1); w.mask = take(1); w.g = take(3); w.sdfraw = take(1);
   if (mode == 0) {
-    float* a = take(256); float* b = take(256);
+    Arr a = big(256), b = big(256);
     for (int l = 1; l <= 8; ++l) w.h[l] = (l & 1) ? a : b;
-    w.out8 = take(1);
   } else {
-    for (int l = 1; l <= 8; ++l) w.h[l] = take(256);
-    w.out8 = take(257);
-    for (int l = 0; l < 8; ++l) w.u[l] = take(256);
+    for (int l = 1; l <= 8; ++l) w.h[l] = big(256);
+    if (prec) w.feat = big(256);
+    else { float* out8 = take(257); w.sdfraw = out8; w.feat = F(out8 + ldp); }      // fp32: lin8 output [sdf | feature] in place
+    for (int l = 0; l < 8; ++l) w.u[l] = big(256);
     w.e0 = take(PE_ROWS); w.es = take(PE_ROWS);
     w.Eh = take(PE_ROWS); w.gh = take(3);
-    for (int l = 1; l <= 8; ++l) w.vh[l] = take(256);
-    for (int l = 0; l < 8; ++l) w.m[l] = take(256);
+    for (int l = 1; l <= 8; ++l) w.vh[l] = big(256);
+    for (int l = 0; l < 8; ++l) w.m[l] = big(256);
     w.abar8 = take(257); w.ones = take(1);
     w.partial = base ? base + off : nullptr;
     off += (size_t)WSPLIT * WLDN * WLDK;
@@ -192,85 +246,110 @@ SdfWs sdf_ws(float* base, int ldp, int mode) {
 }
 
 struct HeadWs {
-  float *small_r, *small_a, *hr[5], *ha[5], *rgb, *lin;             // forward
-  float *zrgb, *dlin, *ar[4], *aa[4], *sc_r, *sc_a;                 // backward
+  float *small_r, *small_a, *rgb, *lin, *zrgb, *dlin, *sc_r, *sc_a;      // fp32
+  Arr hr[5], ha[5], ar[4], aa[4];                                       // big
   size_t total;
 };
-HeadWs head_ws(float* base, int ldp) {
+HeadWs head_ws(float* base, int ldp, int prec) {
   HeadWs w{};
   size_t off = 0;
   auto take = [&](int rows) { float* p = base ? base + off : nullptr; off += (size_t)rows * ldp; return p; };
+  auto big = [&](int rows) { Arr a; a.p = take(rows); a.bf16 = prec; return a; };
   w.small_r = take(SMALL_R); w.small_a = take(SMALL_A);
-  for (int l = 1; l <= 4; ++l) { w.hr[l] = take(256); w.ha[l] = take(256); }
+  for (int l = 1; l <= 4; ++l) { w.hr[l] = big(256); w.ha[l] = big(256); }
   w.rgb = take(3); w.lin = take(6);
   w.zrgb = take(3); w.dlin = take(6);
-  for (int l = 0; l < 4; ++l) { w.ar[l] = take(256); w.aa[l] = take(256); }
+  for (int l = 0; l < 4; ++l) { w.ar[l] = big(256); w.aa[l] = big(256); }
   w.sc_r = take(SMALL_R); w.sc_a = take(SMALL_A);
   w.total = off;
   return w;
 }
 
-inline int round_ldp(int P) { return (P + BM - 1) / BM * BM; }
+inline int round_ldp(int P, int prec) { const int t = prec ? BMH : BM; return (P + t - 1) / t * t; }
 
 // ------------------------------------------------------------------------------------------------
 // SDF network chains
 // ------------------------------------------------------------------------------------------------
-// primal chain  (ImplicitNetwork.forward, rend_a :78-96)
-hipError_t sdf_primal(const Ctx& c, const SdfWs& w, int out_rows) {
-  const PackLayout& L = pack_layout();
+// primal chain  (ImplicitNetwork.forward, rend_a :78-96); full = also the 256 feature rows
+hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full) {
+  const PackLayout& L = c.L();
   hipLaunchKernelGGL(posenc6_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, c.ldp, w.E);
   hipError_t e;
   for (int l = 0; l < 8; ++l) {
-    const float* in0 = l == 0 ? w.E : w.h[l];
-    const int rows0 = l == 0 ? PE_ROWS : (l == 4 ? 217 : 256);
-    const float* in1 = l == 4 ? w.E : nullptr;
-    const int rows1 = l == 4 ? PE_ROWS : 0;
-    if ((e = layer(c, L.fwd[l], EPI_SOFTPLUS, in0, rows0, in1, rows1, c.net->b[l], kO[l], w.h[l + 1])) != hipSuccess) return e;
+    In a = l == 0 ? in(F(w.E), PE_ROWS) : in(w.h[l], l == 4 ? 217 : 256);
+    In b = l == 4 ? in(F(w.E), PE_ROWS) : NOIN;
+    if ((e = layer(c, L.fwd[l], EPI_SOFTPLUS, a, b, c.net->b[l], kO[l], w.h[l + 1])) != hipSuccess) return e;
   }
-  return layer(c, L.fwd[8], EPI_LINEAR, w.h[8], 256, nullptr, 0, c.net->b[8], out_rows, w.out8);
+  if (!full) return layer(c, L.sdf_row, EPI_LINEAR, in(w.h[8], 256), NOIN, c.net->b[8], 1, F(w.sdfraw));
+  if (!c.prec) return layer(c, L.fwd[8], EPI_LINEAR, in(w.h[8], 256), NOIN, c.net->b[8], 257, F(w.sdfraw));
+  // bf16: packed rows [feature(256) | sdf]: features -> octet-major bf16, the sdf row stays fp32
+  return layer(c, L.fwd[8], EPI_LINEAR, in(w.h[8], 256), NOIN, c.net->b[8], 257, w.feat, F(w.sdfraw), 256, Arr{}, Arr{}, 0, 1, 257);
 }
 
 // adjoint chain: u_l = d sdf_raw / d a_l, then e0/es = cotangent of the PE rows (autograd.grad at rend_a :121-127)
 hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w) {
-  const PackLayout& L = pack_layout();
-  hipLaunchKernelGGL(adjoint_seed_kernel, dim3((c.ldp + 255) / 256, 256), dim3(256), 0, c.st,
-                     c.net->v[8], c.rowscale(8), w.h[8], c.ldp, w.u[7]);
+  const PackLayout& L = c.L();
+  if (c.prec)
+    hipLaunchKernelGGL(adjoint_seed_kernel_h, dim3((c.ldp + 255) / 256, 32), dim3(256), 0, c.st, c.net->v[8], c.rowscale(8),
+                       reinterpret_cast<const u16*>(w.h[8].p), c.ldp, reinterpret_cast<u16*>(w.u[7].p));
+  else
+    hipLaunchKernelGGL(adjoint_seed_kernel, dim3((c.ldp + 255) / 256, 256), dim3(256), 0, c.st, c.net->v[8], c.rowscale(8),
+                       w.h[8].f(), c.ldp, w.u[7].f());
   hipError_t e;
   for (int l = 7; l >= 1; --l) {
-    const int rows = kO[l];
-    if (l == 4) e = layer(c, L.tr[l], EPI_REV, w.u[l], rows, nullptr, 0, nullptr, 256, w.u[l - 1], w.es, 217, w.h[l]);
-    else e = layer(c, L.tr[l], EPI_REV, w.u[l], rows, nullptr, 0, nullptr, kI[l], w.u[l - 1], nullptr, 1 << 30, w.h[l]);
+    if (l == 4) {
+      const int split = c.prec ? 224 : 217;
+      e = layer(c, L.tr[l], EPI_REV, in(w.u[l], kO[l]), NOIN, nullptr, split + PE_ROWS, w.u[l - 1], F(w.es), split, w.h[l]);
+    } else {
+      e = layer(c, L.tr[l], EPI_REV, in(w.u[l], kO[l]), NOIN, nullptr, kI[l], w.u[l - 1], Arr{}, 1 << 30, w.h[l]);
+    }
     if (e != hipSuccess) return e;
   }
-  return layer(c, L.tr[0], EPI_LINEAR, w.u[0], 256, nullptr, 0, nullptr, PE_ROWS, w.e0);
+  return layer(c, L.tr[0], EPI_LINEAR, in(w.u[0], 256), NOIN, nullptr, PE_ROWS, F(w.e0));
 }
 
-hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WgradPair* pairs, int npairs, int N, int Kt,
-                 const neat_net_grads* gr) {
+struct WPair { Arr A; int rowsA; int A_rot, A_mod; Arr B[3]; int rowsB[3]; };
+
+hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs, int npairs, int N, const neat_net_grads* gr) {
   if (!gr->dv[layer_id]) return hipSuccess;
-  WgradArgs a{};
-  for (int q = 0; q < npairs; ++q) a.pair[q] = pairs[q];
-  a.npairs = npairs; a.N = N; a.Kt = Kt; a.P = c.P; a.ldp = c.ldp;
-  int splits = WSPLIT;
-  int chunk = ((c.ldp + splits - 1) / splits + WBP - 1) / WBP * WBP;
-  if (chunk < 2 * WBP) chunk = 2 * WBP;
-  splits = (c.P + chunk - 1) / chunk;
-  a.chunk = chunk; a.partial = w.partial; a.Nld = WLDN; a.Kld = WLDK;
-  const int ntile = (N + 127) / 128;
-  a.ktiles = (Kt + 127) / 128;
+  const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
+  // packed column count of the B operand (+1 for the ones row that yields the bias gradient)
+  const int Kt = d.s0p + (kI[layer_id] - d.s0) + 1;
+  const int step = c.prec ? HBP : WBP;
+  int chunk = ((c.ldp + WSPLIT - 1) / WSPLIT + step - 1) / step * step;
+  if (chunk < 2 * step) chunk = 2 * step;
+  const int splits = (c.P + chunk - 1) / chunk;
+  const int ntile = (N + 127) / 128, ktiles = (Kt + 127) / 128;
   double wflops = 0.0;
-  for (int q = 0; q < npairs; ++q) {
-    const int kb = pairs[q].rowsB[0] + pairs[q].rowsB[1] + pairs[q].rowsB[2];
-    wflops += 2.0 * pairs[q].rowsA * kb * (double)c.P;
-  }
+  for (int q = 0; q < npairs; ++q)
+    wflops += 2.0 * pairs[q].rowsA * (pairs[q].rowsB[0] + pairs[q].rowsB[1] + pairs[q].rowsB[2]) * (double)c.P;
   ProfSlot* ps = prof_begin(c.st, 1, wflops);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(ntile * a.ktiles, splits), dim3(WG), 0, c.st, a);
+  if (!c.prec) {
+    WgradArgs a{};
+    for (int q = 0; q < npairs; ++q) {
+      a.pair[q].A = pairs[q].A.f(); a.pair[q].rowsA = pairs[q].rowsA;
+      for (int s = 0; s < 3; ++s) { a.pair[q].B[s] = pairs[q].B[s].f(); a.pair[q].rowsB[s] = pairs[q].rowsB[s]; }
+    }
+    a.npairs = npairs; a.N = N; a.Kt = Kt; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
+    a.partial = w.partial; a.Nld = WLDN; a.Kld = WLDK; a.ktiles = ktiles;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(ntile * ktiles, splits), dim3(WG), 0, c.st, a);
+  } else {
+    WgradArgsH a{};
+    for (int q = 0; q < npairs; ++q) {
+      const WPair& s = pairs[q];
+      a.pair[q].A = SegH{s.A.p, s.rowsA, s.A.bf16}; a.pair[q].A_rot = s.A_rot; a.pair[q].A_mod = s.A_mod;
+      for (int t = 0; t < 3; ++t) a.pair[q].B[t] = SegH{s.B[t].p, s.rowsB[t], s.B[t].bf16};
+      a.pair[q].padB0 = s.B[0].bf16 ? pad8(s.rowsB[0]) : s.rowsB[0];
+    }
+    a.npairs = npairs; a.N = N; a.Kt = Kt; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
+    a.partial = w.partial; a.Nld = WLDN; a.Kld = WLDK; a.ktiles = ktiles;
+    hipLaunchKernelGGL(wgrad_kernel_h, dim3(ntile * ktiles, splits), dim3(WG), 0, c.st, a);
+  }
   prof_end(c.st, ps);
   WreduceArgs r{};
   r.partial = w.partial; r.splits = splits; r.Nld = WLDN; r.Kld = WLDK;
   r.O = kO[layer_id]; r.I = kI[layer_id];
-  r.perm_split = layer_id == L_REND ? SMALL_R : layer_id == L_ATTR ? SMALL_A : 0;
-  r.scale = layer_id == 4 ? (float)(1.0 / sqrt(2.0)) : 1.0f;
+  r.s0 = d.s0; r.s0p = d.s0p; r.off0 = d.off0; r.off1 = d.off1; r.rot = d.rot; r.scale = d.scale;
   r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
   r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
   r.bias_col = Kt - 1;
@@ -280,45 +359,41 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WgradPair* pa
 
 // double backward + backward: w.gh (cotangent of normals, masked) and w.abar8 (cotangent of lin8 output) are set
 hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grads* gr) {
-  const PackLayout& L = pack_layout();
+  const PackLayout& L = c.L();
   hipError_t e;
   hipLaunchKernelGGL(posenc6_tangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
   hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, c.P, c.ldp);
   // tangent chain (forward-mode along g^): vh_{l+1} = tangent of h_{l+1}, m_l = extra cotangent of a_l
   for (int l = 0; l < 8; ++l) {
-    const float* in0 = l == 0 ? w.Eh : w.vh[l];
-    const int rows0 = l == 0 ? PE_ROWS : (l == 4 ? 217 : 256);
-    const float* in1 = l == 4 ? w.Eh : nullptr;
-    const int rows1 = l == 4 ? PE_ROWS : 0;
-    if ((e = layer(c, L.fwd[l], EPI_TAN, in0, rows0, in1, rows1, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30,
-                   w.h[l + 1], w.u[l])) != hipSuccess) return e;
+    In a = l == 0 ? in(F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? 217 : 256);
+    In b = l == 4 ? in(F(w.Eh), PE_ROWS) : NOIN;
+    if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l])) != hipSuccess) return e;
   }
   // reverse chain: a^_{l-1} = (W_l^T a^_l) phi'(a_{l-1}) + m_{l-1}   (in place in m)
-  if ((e = layer(c, L.tr[8], EPI_BWD, w.abar8, 257, nullptr, 0, nullptr, 256, w.m[7], nullptr, 1 << 30, w.h[8], w.m[7])) != hipSuccess) return e;
+  if (!c.prec) e = layer(c, L.tr[8], EPI_BWD, in(F(w.abar8), 257), NOIN, nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
+  else e = layer(c, L.tr[8], EPI_BWD, in(F(w.abar8 + c.ldp), 256), in(F(w.abar8), 1), nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
+  if (e != hipSuccess) return e;
   for (int l = 7; l >= 1; --l) {
     const int N = l == 4 ? 217 : kI[l];
-    if ((e = layer(c, L.tr[l], EPI_BWD, w.m[l], kO[l], nullptr, 0, nullptr, N, w.m[l - 1], nullptr, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
+    if ((e = layer(c, L.tr[l], EPI_BWD, in(w.m[l], kO[l]), NOIN, nullptr, N, w.m[l - 1], Arr{}, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
   }
   // weight gradients: dW_l = a^_l in_l^T + u_l vhat_l^T  (+ bias column from the ones row)
   for (int l = 0; l <= 8; ++l) {
-    WgradPair pr[2] = {};
-    pr[0].A = l == 8 ? w.abar8 : w.m[l]; pr[0].rowsA = kO[l];
-    pr[1].A = l == 8 ? w.ones : w.u[l];  pr[1].rowsA = l == 8 ? 1 : kO[l];
-    int Kt;
+    WPair pr[2] = {};
+    const int rot8 = (l == 8 && c.prec) ? 1 : 0;
+    pr[0].A = l == 8 ? F(w.abar8) : w.m[l]; pr[0].rowsA = kO[l]; pr[0].A_rot = rot8; pr[0].A_mod = rot8 ? 257 : 0;
+    pr[1].A = l == 8 ? F(w.ones) : w.u[l];  pr[1].rowsA = l == 8 ? 1 : kO[l]; pr[1].A_rot = rot8; pr[1].A_mod = rot8 ? 257 : 0;
     if (l == 0) {
-      pr[0].B[0] = w.E; pr[0].rowsB[0] = PE_ROWS; pr[0].B[1] = w.ones; pr[0].rowsB[1] = 1;
-      pr[1].B[0] = w.Eh; pr[1].rowsB[0] = PE_ROWS;
-      Kt = PE_ROWS + 1;
+      pr[0].B[0] = F(w.E); pr[0].rowsB[0] = PE_ROWS; pr[0].B[1] = F(w.ones); pr[0].rowsB[1] = 1;
+      pr[1].B[0] = F(w.Eh); pr[1].rowsB[0] = PE_ROWS;
     } else if (l == 4) {
-      pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 217; pr[0].B[1] = w.E; pr[0].rowsB[1] = PE_ROWS; pr[0].B[2] = w.ones; pr[0].rowsB[2] = 1;
-      pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 217; pr[1].B[1] = w.Eh; pr[1].rowsB[1] = PE_ROWS;
-      Kt = 257;
+      pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 217; pr[0].B[1] = F(w.E); pr[0].rowsB[1] = PE_ROWS; pr[0].B[2] = F(w.ones); pr[0].rowsB[2] = 1;
+      pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 217; pr[1].B[1] = F(w.Eh); pr[1].rowsB[1] = PE_ROWS;
     } else {
-      pr[0].B[0] = w.h[l]; pr[0].rowsB[0] = 256; pr[0].B[1] = w.ones; pr[0].rowsB[1] = 1;
+      pr[0].B[0] = w.h[l]; pr[0].rowsB[0] = 256; pr[0].B[1] = F(w.ones); pr[0].rowsB[1] = 1;
       pr[1].B[0] = w.vh[l]; pr[1].rowsB[0] = 256;
-      Kt = 257;
     }
-    if ((e = wgrad(c, w, l, pr, 2, kO[l], Kt, gr)) != hipSuccess) return e;
+    if ((e = wgrad(c, w, l, pr, 2, kO[l], gr)) != hipSuccess) return e;
   }
   return hipSuccess;
 }
@@ -326,19 +401,19 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
 // ------------------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------------------
-hipError_t heads_forward(const Ctx& c, const HeadWs& h, const float* feat_fm) {
-  const PackLayout& L = pack_layout();
+hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat) {
+  const PackLayout& L = c.L();
   hipError_t e;
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
-    float* const* hh = head ? h.ha : h.hr;
+    const Arr* hh = head ? h.ha : h.hr;
     const float* small = head ? h.small_a : h.small_r;
     const int srows = head ? SMALL_A : SMALL_R;
-    if ((e = layer(c, L.fwd[base], EPI_RELU, feat_fm, 256, small, srows, c.net->b[base], 256, hh[1])) != hipSuccess) return e;
+    if ((e = layer(c, L.fwd[base], EPI_RELU, in(feat, 256), in(F(small), srows), c.net->b[base], 256, hh[1])) != hipSuccess) return e;
     for (int l = 1; l < 4; ++l)
-      if ((e = layer(c, L.fwd[base + l], EPI_RELU, hh[l], 256, nullptr, 0, c.net->b[base + l], 256, hh[l + 1])) != hipSuccess) return e;
-    if (head == 0) e = layer(c, L.fwd[base + 4], EPI_SIGMOID, hh[4], 256, nullptr, 0, c.net->b[base + 4], 3, h.rgb);
-    else e = layer(c, L.fwd[base + 4], EPI_LINEAR, hh[4], 256, nullptr, 0, c.net->b[base + 4], 6, h.lin);
+      if ((e = layer(c, L.fwd[base + l], EPI_RELU, in(hh[l], 256), NOIN, c.net->b[base + l], 256, hh[l + 1])) != hipSuccess) return e;
+    if (head == 0) e = layer(c, L.fwd[base + 4], EPI_SIGMOID, in(hh[4], 256), NOIN, c.net->b[base + 4], 3, F(h.rgb));
+    else e = layer(c, L.fwd[base + 4], EPI_LINEAR, in(hh[4], 256), NOIN, c.net->b[base + 4], 6, F(h.lin));
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -346,41 +421,38 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, const float* feat_fm) {
 
 // zrgb / dlin hold the cotangents of the heads' last linear outputs; accumulates the feature cotangent into
 // abar8 rows 1..256 (render overwrites, attraction adds) and the small-input cotangents into sc_r / sc_a.
-hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const float* feat_fm, const neat_net_grads* gr) {
-  const PackLayout& L = pack_layout();
+hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const neat_net_grads* gr) {
+  const PackLayout& L = c.L();
   hipError_t e;
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
-    float* const* hh = head ? h.ha : h.hr;
-    float* const* ab = head ? h.aa : h.ar;
+    const Arr* hh = head ? h.ha : h.hr;
+    const Arr* ab = head ? h.aa : h.ar;
     const float* top = head ? h.dlin : h.zrgb;
     const int top_rows = head ? 6 : 3;
     const float* small = head ? h.small_a : h.small_r;
     const int srows = head ? SMALL_A : SMALL_R;
-    if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, top, top_rows, nullptr, 0, nullptr, 256, ab[3], nullptr, 1 << 30, hh[4])) != hipSuccess) return e;
+    if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, in(F(top), top_rows), NOIN, nullptr, 256, ab[3], Arr{}, 1 << 30, hh[4])) != hipSuccess) return e;
     for (int l = 3; l >= 1; --l)
-      if ((e = layer(c, L.tr[base + l], EPI_BWD_RELU, ab[l], 256, nullptr, 0, nullptr, 256, ab[l - 1], nullptr, 1 << 30, hh[l])) != hipSuccess) return e;
-    if ((e = layer(c, L.tr[base], EPI_LINEAR, ab[0], 256, nullptr, 0, nullptr, 256 + srows, w.abar8 + c.ldp,
-                   head ? h.sc_a : h.sc_r, 256, nullptr, nullptr, head)) != hipSuccess) return e;
+      if ((e = layer(c, L.tr[base + l], EPI_BWD_RELU, in(ab[l], 256), NOIN, nullptr, 256, ab[l - 1], Arr{}, 1 << 30, hh[l])) != hipSuccess) return e;
+    if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, 256 + srows, F(w.abar8 + c.ldp),
+                   F(head ? h.sc_a : h.sc_r), 256, Arr{}, Arr{}, head)) != hipSuccess) return e;
     for (int l = 0; l <= 4; ++l) {
-      WgradPair pr[1] = {};
-      pr[0].A = l == 4 ? top : ab[l]; pr[0].rowsA = kO[base + l];
-      int Kt;
+      WPair pr[1] = {};
+      pr[0].A = l == 4 ? F(top) : ab[l]; pr[0].rowsA = kO[base + l];
       if (l == 0) {
-        pr[0].B[0] = feat_fm; pr[0].rowsB[0] = 256; pr[0].B[1] = small; pr[0].rowsB[1] = srows; pr[0].B[2] = w.ones; pr[0].rowsB[2] = 1;
-        Kt = 256 + srows + 1;
+        pr[0].B[0] = w.feat; pr[0].rowsB[0] = 256; pr[0].B[1] = F(small); pr[0].rowsB[1] = srows; pr[0].B[2] = F(w.ones); pr[0].rowsB[2] = 1;
       } else {
-        pr[0].B[0] = hh[l]; pr[0].rowsB[0] = 256; pr[0].B[1] = w.ones; pr[0].rowsB[1] = 1;
-        Kt = 257;
+        pr[0].B[0] = hh[l]; pr[0].rowsB[0] = 256; pr[0].B[1] = F(w.ones); pr[0].rowsB[1] = 1;
       }
-      if ((e = wgrad(c, w, base + l, pr, 1, kO[base + l], Kt, gr)) != hipSuccess) return e;
+      if ((e = wgrad(c, w, base + l, pr, 1, kO[base + l], gr)) != hipSuccess) return e;
     }
   }
   return hipSuccess;
 }
 
-__global__ void volume_weights_kernel(const float* __restrict__ z, const float* __restrict__ sdf, int R, int S, const float* __restrict__ beta_ptr,
-                                      float* __restrict__ weights) {
+__global__ void volume_weights_kernel(const float* __restrict__ z, const float* __restrict__ sdf, int R, int S,
+                                      const float* __restrict__ beta_ptr, float* __restrict__ weights) {
   const float beta = *beta_ptr;
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -407,7 +479,7 @@ __global__ void lines_from_offsets_kernel(const float* __restrict__ lin_fm, cons
   for (int c = 0; c < 6; ++c) lines[(size_t)p * 6 + c] = x_fm[(size_t)(c % 3) * ldp + p] + lin_fm[(size_t)c * ldp + p];
 }
 
-// abar8 row 0 <- (1-mask) d_sdf ; rows 1.. <- d_feat ; (+ d_out257)
+// abar8 (source row order) row 0 <- (1-mask) d_sdf ; rows 1.. <- d_feat ; (+ d_out257)
 __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const float* __restrict__ d_sdf,
                                    const float* __restrict__ d_feat, const float* __restrict__ mask, int P, int ldp,
                                    float* __restrict__ abar8) {
@@ -423,6 +495,23 @@ __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const flo
   abar8[(size_t)n * ldp + p] = v;
 }
 
+// row-major copies of the lin8 output for the stand-alone module API
+void export_out8(const Ctx& c, const SdfWs& w, float* out257, float* feat) {
+  const int P = c.P;
+  if (c.prec) {
+    if (out257) {
+      hipLaunchKernelGGL(fm_col_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, out257, 257, 0);
+      hipLaunchKernelGGL(oct_to_rm_kernel, grid1(P), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, out257, 257, 1);
+    }
+    if (feat) hipLaunchKernelGGL(oct_to_rm_kernel, grid1(P), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, feat, 256, 0);
+  } else {
+    if (out257) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, 257, c.ldp, out257, 0);
+    if (feat) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.feat.f(), P, 256, c.ldp, feat, 0);
+  }
+}
+
+bool bad_prec(int p) { return p != F32 && p != BF16; }
+
 }  // namespace
 
 // ================================================================================================
@@ -430,7 +519,7 @@ __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const flo
 // ================================================================================================
 extern "C" {
 
-int neat_abi_version(void) { return 1; }
+int neat_abi_version(void) { return 2; }
 
 int neat_prof_enable(int on) {
   g_prof.on = on != 0;
@@ -456,23 +545,23 @@ int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launc
   return 0;
 }
 
-size_t neat_packed_floats(void) { return pack_layout().total; }
+size_t neat_packed_floats(int precision) { return bad_prec(precision) ? 0 : pack_layout(precision).total; }
 
-int neat_pack_weights(const neat_net_params* net, float* packed, void* stream) {
-  if (!net || !packed) return -1;
+int neat_pack_weights(const neat_net_params* net, float* packed, int precision, void* stream) {
+  if (!net || !packed || bad_prec(precision)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  const PackLayout& L = pack_layout();
+  const PackLayout& L = pack_layout(precision);
   RowScaleArgs ra;
   ra.net = to_ptrs(net);
   ra.rowscale = packed + L.rowscale_off;
   for (int l = 0; l <= NLAYERS; ++l) ra.row_off[l] = L.row_off[l];
   hipLaunchKernelGGL(rowscale_kernel, dim3((L.row_off[NLAYERS] + 3) / 4), dim3(WG), 0, st, ra);
-  PackArgs pa;
+  PackArgs2 pa;
   pa.net = ra.net; pa.rowscale = ra.rowscale;
   for (int l = 0; l <= NLAYERS; ++l) pa.row_off[l] = L.row_off[l];
   for (int i = 0; i < L.npacks; ++i) pa.d[i] = L.d[i];
   pa.npacks = L.npacks; pa.out = packed;
-  hipLaunchKernelGGL(pack_kernel, dim3(L.nblocks), dim3(WG), 0, st, pa);
+  hipLaunchKernelGGL(pack_kernel2, dim3(L.nblocks), dim3(WG), 0, st, pa);
   return (int)hipGetLastError();
 }
 
@@ -482,38 +571,39 @@ int neat_camera_rays(const float* uv, const float* pose, const float* K, int kst
   return (int)hipGetLastError();
 }
 
-size_t neat_sdf_ws_floats(int P, int mode) { return sdf_ws(nullptr, round_ldp(P), mode).total; }
+size_t neat_sdf_ws_floats(int P, int mode, int precision) {
+  return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision).total;
+}
 
-int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode,
+int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
                      float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad,
                      void* stream) {
   if (P <= 0) return 0;
-  if (!packed || !net || !x || !ws) return -1;
-  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P)};
-  SdfWs w = sdf_ws(ws, c.ldp, mode);
+  if (!packed || !net || !x || !ws || bad_prec(precision)) return -1;
+  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  SdfWs w = sdf_ws(ws, c.ldp, mode, precision);
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
   if (mode == 0) {
-    NEAT_CHECK(sdf_primal(c, w, 1));
-    hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.out8, (const float*)nullptr,
+    NEAT_CHECK(sdf_primal(c, w, false));
+    hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, (const float*)nullptr,
                        (const float*)nullptr, P, c.ldp, radius, scale, w.sdf, (float*)nullptr, (float*)nullptr, sdf, (float*)nullptr);
     return (int)hipGetLastError();
   }
-  NEAT_CHECK(sdf_primal(c, w, 257));
+  NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w));
-  hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.out8, w.e0, w.es, P, c.ldp, radius, scale,
+  hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
                      w.sdf, w.g, w.mask, sdf, grad);
-  if (out257) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.out8, P, 257, c.ldp, out257, 0);
-  if (feat) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.out8 + c.ldp, P, 256, c.ldp, feat, 0);
+  export_out8(c, w, out257, feat);
   return (int)hipGetLastError();
 }
 
-int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P,
+int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P, int precision,
                       const float* d_out257, const float* d_sdf, const float* d_feat, const float* d_grad,
                       const neat_net_grads* grads, void* stream) {
   if (P <= 0) return 0;
-  if (!packed || !net || !ws || !grads) return -1;
-  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P)};
-  SdfWs w = sdf_ws(ws, c.ldp, 1);
+  if (!packed || !net || !ws || !grads || bad_prec(precision)) return -1;
+  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
   hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8);
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, (const float*)nullptr, (const float*)nullptr,
                      d_grad, w.mask, P, c.ldp, w.gh);
@@ -521,52 +611,56 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
   return (int)hipGetLastError();
 }
 
-size_t neat_heads_ws_floats(int P) {
-  const int ldp = round_ldp(P);
-  return head_ws(nullptr, ldp).total + (size_t)(3 + 3 + 256) * ldp;
+size_t neat_heads_ws_floats(int P, int precision) {
+  if (bad_prec(precision)) return 0;
+  const int ldp = round_ldp(P, precision);
+  return head_ws(nullptr, ldp, precision).total + (size_t)(3 + 3 + 256) * ldp;
 }
 
 int neat_heads_forward(const float* packed, const neat_net_params* net, const float* points, const float* normals,
-                       const float* view_dirs, const float* feats, int P, float* ws, float* rgb, float* lines, void* stream) {
+                       const float* view_dirs, const float* feats, int P, int precision, float* ws, float* rgb, float* lines,
+                       void* stream) {
   if (P <= 0) return 0;
-  if (!packed || !net || !ws) return -1;
-  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P)};
-  HeadWs h = head_ws(ws, c.ldp);
+  if (!packed || !net || !ws || bad_prec(precision)) return -1;
+  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  HeadWs h = head_ws(ws, c.ldp, precision);
   float* x_fm = ws + h.total; float* g_fm = x_fm + 3 * (size_t)c.ldp; float* f_fm = g_fm + 3 * (size_t)c.ldp;
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, points, P, 3, c.ldp, x_fm);
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, normals, P, 3, c.ldp, g_fm);
-  hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, f_fm);
+  Arr feat;
+  feat.p = f_fm; feat.bf16 = precision;
+  if (precision) hipLaunchKernelGGL(rm_to_oct_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, reinterpret_cast<u16*>(f_fm));
+  else hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, f_fm);
   hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, x_fm, g_fm, view_dirs, P, 1, c.ldp, h.small_r, h.small_a);
-  NEAT_CHECK(heads_forward(c, h, f_fm));
+  NEAT_CHECK(heads_forward(c, h, feat));
   if (rgb) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, h.rgb, P, 3, c.ldp, rgb, 0);
-  if (lines) {   // y = p + offsets.reshape(2,3)   (rend_a :195)
-    hipLaunchKernelGGL(lines_from_offsets_kernel, grid1(P), dim3(256), 0, c.st, h.lin, x_fm, P, c.ldp, lines);
-  }
+  if (lines) hipLaunchKernelGGL(lines_from_offsets_kernel, grid1(P), dim3(256), 0, c.st, h.lin, x_fm, P, c.ldp, lines);   // y = p + offsets (rend_a :195)
   return (int)hipGetLastError();
 }
 
-size_t neat_render_ws_floats(int R, int S) {
-  const int ldp = round_ldp(R * S);
-  return sdf_ws(nullptr, ldp, 1).total + head_ws(nullptr, ldp).total;
+size_t neat_render_ws_floats(int R, int S, int precision) {
+  if (bad_prec(precision)) return 0;
+  const int ldp = round_ldp(R * S, precision);
+  return sdf_ws(nullptr, ldp, 1, precision).total + head_ws(nullptr, ldp, precision).total;
 }
 
 int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                        const float* z, int R, int S, const float* beta, float radius, float scale, float* ws,
+                        const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
                         float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                         float* xyz, float* normal_map, void* stream) {
   if (R <= 0 || S <= 0) return 0;
-  if (!packed || !net || !ws || !origins || !dirs || !z || !rgb || !lines3d || !depth || !xyz) return -1;
+  if (!packed || !net || !ws || !origins || !dirs || !z || !rgb || !lines3d || !depth || !xyz || bad_prec(precision)) return -1;
   const int P = R * S;
-  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P)};
-  SdfWs w = sdf_ws(ws, c.ldp, 1);
-  HeadWs h = head_ws(ws + w.total, c.ldp);
+  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
+  HeadWs h = head_ws(ws + w.total, c.ldp, precision);
   hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points);
-  NEAT_CHECK(sdf_primal(c, w, 257));
+  NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w));
-  hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.out8, w.e0, w.es, P, c.ldp, radius, scale,
+  hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
                      w.sdf, w.g, w.mask, sdf, (float*)nullptr);
   hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, P, S, c.ldp, h.small_r, h.small_a);
-  NEAT_CHECK(heads_forward(c, h, w.out8 + c.ldp));
+  NEAT_CHECK(heads_forward(c, h, w.feat));
   CompositeArgs ca;
   ca.z = z; ca.sdf = w.sdf; ca.dirs = dirs; ca.x_fm = w.x; ca.rgb_fm = h.rgb; ca.lin_fm = h.lin; ca.g_fm = w.g;
   ca.R = R; ca.S = S; ca.ldp = c.ldp; ca.beta_ptr = beta;
@@ -576,23 +670,22 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
 }
 
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs, const float* z,
-                         int R, int S, const float* beta, const float* d_rgb, const float* d_lines3d, const float* d_depth,
-                         const float* d_xyz, const neat_net_grads* grads, float* dbeta_ray, void* stream) {
+                         int R, int S, int precision, const float* beta, const float* d_rgb, const float* d_lines3d,
+                         const float* d_depth, const float* d_xyz, const neat_net_grads* grads, float* dbeta_ray, void* stream) {
   if (R <= 0 || S <= 0) return 0;
-  if (!packed || !net || !ws || !grads) return -1;
+  if (!packed || !net || !ws || !grads || bad_prec(precision)) return -1;
   const int P = R * S;
-  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P)};
-  SdfWs w = sdf_ws(ws, c.ldp, 1);
-  HeadWs h = head_ws(ws + w.total, c.ldp);
+  Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
+  HeadWs h = head_ws(ws + w.total, c.ldp, precision);
   CompositeBwdArgs cb;
   cb.z = z; cb.sdf = w.sdf; cb.dirs = dirs; cb.mask = w.mask; cb.x_fm = w.x; cb.rgb_fm = h.rgb;
   cb.R = R; cb.S = S; cb.ldp = c.ldp; cb.beta_ptr = beta;
   cb.d_rgb = d_rgb; cb.d_lines3d = d_lines3d; cb.d_depth = d_depth; cb.d_xyz = d_xyz;
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
-  // padded columns of the cotangent arrays must be finite zeros (the weight-gradient kernels mask p >= P anyway)
   hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, cb);
-  NEAT_CHECK(heads_backward(c, h, w, w.out8 + c.ldp, grads));
+  NEAT_CHECK(heads_backward(c, h, w, grads));
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp, w.gh);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));
   return (int)hipGetLastError();

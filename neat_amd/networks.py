@@ -51,6 +51,14 @@ class _HipModule(nn.Module):
             self.__dict__["_neat_handle"] = h
         return h
 
+    def set_precision(self, precision):
+        """'fp32' (exact-f32 MFMA, parity build, default) or 'bf16' (bf16 MFMA with fp32 accumulate)."""
+        from . import _lib
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        self._handle().precision = _lib.PRECISIONS[precision]
+        return self
+
 
 class ImplicitNetwork(_HipModule):
     """SDF MLP: PE-6 -> 8 x 256 softplus(100) with a skip into layer 4 -> [sdf, 256 features]  (rend_a :14-137)."""
@@ -204,6 +212,7 @@ class VolSDFNetwork(_HipModule):
         for head in (self.rendering_network, self.attraction_network):
             head.__dict__["_neat_owner"] = weakref.ref(self)
         self.z_vals_override = None       # bench/tests: given depth samples [R,S] bypass the sampler
+        self.set_precision(conf.get_string("hip_precision", default="fp32"))      # new optional key, default = parity build
 
     # ---- HIP plumbing ----------------------------------------------------------------------------
     def handle(self):

@@ -37,6 +37,7 @@ class NetHandle:
 
     def __init__(self):
         self.layers = [None] * _lib.NUM_LAYERS      # (weight_v, weight_g, bias) Parameters
+        self.precision = 0                          # 0 = fp32 (parity build), 1 = bf16 MFMA (throughput build)
         self._key = None
         self._packed = None
         self._netp = None
@@ -59,7 +60,7 @@ class NetHandle:
     def packed(self):
         """Returns (packed weights tensor, NetParams).  Re-packs (2 kernel launches) whenever a parameter changed."""
         present = [t for l in self.layers if l is not None for t in l]
-        key = tuple((t.data_ptr(), t._version) for t in present)
+        key = (self.precision,) + tuple((t.data_ptr(), t._version) for t in present)
         if key != self._key:
             lib = _lib.lib()
             netp = _lib.NetParams()
@@ -76,8 +77,8 @@ class NetHandle:
                         raise RuntimeError("parameters must be contiguous CUDA float32 (call model.cuda())")
                 netp.v[l], netp.g[l], netp.b[l] = v.data_ptr(), g.data_ptr(), b.data_ptr()
                 dev = v.device
-            packed = torch.empty(lib.neat_packed_floats(), device=dev, dtype=torch.float32)
-            _lib.check(lib.neat_pack_weights(ctypes.byref(netp), _p(packed), _stream()), "neat_pack_weights")
+            packed = torch.empty(lib.neat_packed_floats(self.precision), device=dev, dtype=torch.float32)
+            _lib.check(lib.neat_pack_weights(ctypes.byref(netp), _p(packed), self.precision, _stream()), "neat_pack_weights")
             self._key, self._packed, self._netp = key, packed, netp
         return self._packed, self._netp
 
@@ -112,14 +113,15 @@ class SdfOutputsFn(torch.autograd.Function):
         x = _f32c(x.detach())
         P = x.shape[0]
         packed, netp = handle.packed()
-        ws = torch.empty(lib.neat_sdf_ws_floats(P, 1), device=x.device, dtype=torch.float32)
+        prec = handle.precision
+        ws = torch.empty(lib.neat_sdf_ws_floats(P, 1, prec), device=x.device, dtype=torch.float32)
         out = torch.empty(P, 257, device=x.device)
         sdf = torch.empty(P, 1, device=x.device)
         feat = torch.empty(P, 256, device=x.device)
         grad = torch.empty(P, 3, device=x.device)
-        _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 1, float(radius), float(scale), _p(ws),
+        _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 1, prec, float(radius), float(scale), _p(ws),
                                         _p(out), _p(sdf), _p(feat), _p(grad), _stream()), "neat_sdf_forward")
-        ctx.handle, ctx.P, ctx.ws, ctx.packed, ctx.netp = handle, P, ws, packed, netp
+        ctx.handle, ctx.P, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, P, ws, packed, netp, prec
         return out, sdf, feat, grad
 
     @staticmethod
@@ -128,7 +130,7 @@ class SdfOutputsFn(torch.autograd.Function):
         h = ctx.handle
         gr, views, _ = _grad_buffers(h, 0, N_SDF, ctx.ws.device)
         d_out, d_sdf, d_feat, d_grad = (_f32c(t) for t in (d_out, d_sdf, d_feat, d_grad))
-        _lib.check(lib.neat_sdf_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), ctx.P, _p(d_out), _p(d_sdf),
+        _lib.check(lib.neat_sdf_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), ctx.P, ctx.prec, _p(d_out), _p(d_sdf),
                                          _p(d_feat), _p(d_grad), ctypes.byref(gr), _stream()), "neat_sdf_backward")
         ctx.ws = None
         return (None, None, None, None, *views)
@@ -150,8 +152,8 @@ def sdf_values(handle, x, radius, scale):
     if P == 0:
         return sdf
     packed, netp = handle.packed()
-    ws = torch.empty(lib.neat_sdf_ws_floats(P, 0), device=x.device, dtype=torch.float32)
-    _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 0, float(radius), float(scale), _p(ws),
+    ws = torch.empty(lib.neat_sdf_ws_floats(P, 0, handle.precision), device=x.device, dtype=torch.float32)
+    _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 0, handle.precision, float(radius), float(scale), _p(ws),
                                     None, _p(sdf), None, None, _stream()), "neat_sdf_forward(values)")
     return sdf
 
@@ -162,11 +164,11 @@ def heads_forward(handle, points, normals, view_dirs, feats):
     points, normals, view_dirs, feats = (_f32c(t.detach()) for t in (points, normals, view_dirs, feats))
     P = points.shape[0]
     packed, netp = handle.packed()
-    ws = torch.empty(lib.neat_heads_ws_floats(P), device=points.device, dtype=torch.float32)
+    ws = torch.empty(lib.neat_heads_ws_floats(P, handle.precision), device=points.device, dtype=torch.float32)
     rgb = torch.empty(P, 3, device=points.device)
     lines = torch.empty(P, 2, 3, device=points.device)
     _lib.check(lib.neat_heads_forward(_p(packed), ctypes.byref(netp), _p(points), _p(normals), _p(view_dirs), _p(feats), P,
-                                      _p(ws), _p(rgb), _p(lines), _stream()), "neat_heads_forward")
+                                      handle.precision, _p(ws), _p(rgb), _p(lines), _stream()), "neat_heads_forward")
     return rgb, lines
 
 
@@ -183,7 +185,8 @@ class RenderRaysFn(torch.autograd.Function):
         R, S = z.shape
         dev = z.device
         packed, netp = handle.packed()
-        ws = torch.empty(lib.neat_render_ws_floats(R, S), device=dev, dtype=torch.float32)
+        prec = handle.precision
+        ws = torch.empty(lib.neat_render_ws_floats(R, S, prec), device=dev, dtype=torch.float32)
         points = torch.empty(R, S, 3, device=dev)
         weights = torch.empty(R, S, device=dev)
         sdf = torch.empty(R, S, device=dev)
@@ -192,10 +195,10 @@ class RenderRaysFn(torch.autograd.Function):
         depth = torch.empty(R, device=dev)
         xyz = torch.empty(R, 3, device=dev)
         nmap = torch.empty(R, 3, device=dev) if want_normal_map else None
-        _lib.check(lib.neat_render_forward(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, _p(beta_d),
+        _lib.check(lib.neat_render_forward(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, _p(beta_d),
                                            float(radius), float(scale), _p(ws), _p(points), _p(weights), _p(sdf), _p(rgb),
                                            _p(lines3d), _p(depth), _p(xyz), _p(nmap), _stream()), "neat_render_forward")
-        ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp = handle, (R, S), ws, packed, netp
+        ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, (R, S), ws, packed, netp, prec
         ctx.dirs, ctx.z, ctx.beta_d, ctx.beta_shape = dirs, z, beta_d, beta.shape
         if nmap is None:
             nmap = torch.empty(0, device=dev)
@@ -212,7 +215,7 @@ class RenderRaysFn(torch.autograd.Function):
         d_rgb, d_lines3d, d_depth, d_xyz = (_f32c(t) for t in (d_rgb, d_lines3d, d_depth, d_xyz))
         dbeta_ray = torch.empty(R, device=dev)
         _lib.check(lib.neat_render_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), _p(ctx.dirs), _p(ctx.z), R, S,
-                                            _p(ctx.beta_d), _p(d_rgb), _p(d_lines3d), _p(d_depth), _p(d_xyz),
+                                            ctx.prec, _p(ctx.beta_d), _p(d_rgb), _p(d_lines3d), _p(d_depth), _p(d_xyz),
                                             ctypes.byref(gr), _p(dbeta_ray), _stream()), "neat_render_backward")
         ctx.ws = None
         return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, *views)

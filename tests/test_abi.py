@@ -26,18 +26,20 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/neat_hip.h but not exported"
     assert names == _lib.exported_symbols()
-    assert _lib.lib().neat_abi_version() == 1
+    assert _lib.lib().neat_abi_version() == _lib.ABI_VERSION
 
 
 def test_workspace_queries_are_consistent():
     from neat_amd import _lib
     lib = _lib.lib()
-    assert lib.neat_packed_floats() > 19 * 256
-    assert lib.neat_sdf_ws_floats(64, 0) < lib.neat_sdf_ws_floats(64, 1)
-    assert lib.neat_render_ws_floats(8, 8) > lib.neat_sdf_ws_floats(64, 1)
-    # point stride is padded to the 64-point workgroup tile
-    assert lib.neat_sdf_ws_floats(1, 0) == lib.neat_sdf_ws_floats(64, 0)
-    assert lib.neat_sdf_ws_floats(65, 0) == lib.neat_sdf_ws_floats(128, 0)
+    for prec, tile in ((0, 64), (1, 128)):
+        assert lib.neat_packed_floats(prec) > 19 * 256
+        assert lib.neat_sdf_ws_floats(64, 0, prec) < lib.neat_sdf_ws_floats(64, 1, prec)
+        assert lib.neat_render_ws_floats(8, 8, prec) > lib.neat_sdf_ws_floats(64, 1, prec)
+        # point stride is padded to the workgroup's point tile (64 fp32 / 128 bf16)
+        assert lib.neat_sdf_ws_floats(1, 0, prec) == lib.neat_sdf_ws_floats(tile, 0, prec)
+        assert lib.neat_sdf_ws_floats(tile + 1, 0, prec) == lib.neat_sdf_ws_floats(2 * tile, 0, prec)
+    assert lib.neat_packed_floats(7) == 0          # unknown precision is rejected
 
 
 def test_ops_refuse_cpu_tensors():

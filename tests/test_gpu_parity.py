@@ -255,3 +255,80 @@ def test_full_size_properties(dev):
     # backward is linear in the cotangent
     _, g2 = run(slice(0, R), cot_scale=2.0)
     assert float((g2 - 2 * g_full).abs().max()) <= 1e-4 * scale
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# bf16 build (BASELINE config 2: "bf16").  bf16 has an 8-bit mantissa, so it cannot meet the 1e-4 fp32 tolerance --
+# that is what the fp32 build above is for.  Here the bar is bf16-grade agreement with the SAME oracle on the same
+# inputs: rendered outputs within 5e-3 of scale, normals within 3e-2, every gradient tensor within 0.99 cosine of the
+# fp32 truth and the loss within 5e-3; plus the same structural properties (determinism, finiteness).
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,S,seed", [(96, 128, 1), (33, 50, 2)])
+def test_bf16_build_vs_oracle(dev, R, S, seed):
+    from neat_amd.loss import VolSDFLoss
+    from neat_amd import networks
+    from tests.util_replay import RngReplay
+    sd = synth.synth_state_dict(seed, "rough")
+    sc = synth.synth_scene(seed=seed, n_rays=R, view=seed)
+    z = T(synth.synth_z_vals(seed, R, S))
+    gen = torch.Generator().manual_seed(seed)
+    eik_idx = torch.randint(S, (R,), generator=gen)
+    eik_uniform = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
+    p, ref, ref_lo = oracle_train_step(sd, sc, z, eik_idx, eik_uniform)
+    m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    m.load_state_dict({k: T(v) for k, v in sd.items()})
+    m.to(dev).train().set_precision("bf16")
+    m.z_vals_override = z.to(dev)
+    with RngReplay([("randint", eik_idx), ("uniform_", eik_uniform)]):
+        out = m(scene_inputs(sc, dev))
+    for k, tol in (("rgb_values", 5e-3), ("lines3d", 5e-3), ("depth", 5e-3), ("xyz", 5e-3), ("sdf", 1e-2), ("grad_theta", 3e-2)):
+        close(out[k], ref[k], tol=tol, what="bf16 " + k)
+    lo = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)(out, {"rgb": T(sc["gt_rgb"]).to(dev), "lines2d": T(sc["gt_lines2d"]).to(dev)})
+    close(lo["loss"].reshape(()), ref_lo["loss"].reshape(()), tol=5e-3, what="bf16 loss")
+    lo["loss"].backward()
+    for k, prm in m.named_parameters():
+        r = p[k].grad
+        if r is None or r.numel() < 2:
+            continue
+        g = prm.grad.detach().cpu().flatten()
+        assert torch.isfinite(g).all(), k
+        cos = float(g @ r.flatten() / (g.norm() * r.norm() + 1e-30))
+        assert cos > 0.99, (k, cos)
+
+
+def test_bf16_full_size_properties(dev):
+    R, S = 1024, 128
+    m = build_model(dev, "rough", seed=5, train=True).set_precision("bf16")
+    sc = synth.synth_scene(seed=5, n_rays=R)
+    from neat_amd import rend_util
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(5, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(0)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def run(sl):
+        m.zero_grad()
+        rgb, l3, dep, xyz, w, sdf, pts, _ = m._render(c[sl], d[sl], z[sl], False)
+        ((rgb * cot_rgb[sl]).sum() + (l3 * cot_l[sl]).sum()).backward()
+        return (rgb.detach(), l3.detach(), w), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+
+    a, ga = run(slice(0, R))
+    b, gb = run(slice(0, R))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(ga, gb) and torch.isfinite(ga).all()
+    rgb, l3, w = a
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all() and (rgb >= 0).all() and (rgb <= 1 + 1e-5).all()
+    lo, g_lo = run(slice(0, R // 2))
+    hi, g_hi = run(slice(R // 2, R))
+    close(torch.cat([lo[0], hi[0]]), rgb, tol=1e-5, what="bf16 chunk consistency rgb")     # rays are independent
+    assert float((g_lo + g_hi - ga).abs().max()) <= 2e-3 * float(ga.abs().max())
+    # and the bf16 build agrees with the fp32 build on the same 131 072 points
+    m.set_precision("fp32")
+    ref, g_ref = run(slice(0, R))
+    close(rgb, ref[0], tol=5e-3, what="bf16 vs fp32 rgb")
+    close(l3, ref[1], tol=5e-3, what="bf16 vs fp32 lines3d")
+    assert float(ga @ g_ref / (ga.norm() * g_ref.norm())) > 0.995
