@@ -85,18 +85,22 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
  * |density.beta| + beta_min (model/density.py:28-30) -- a pointer so that no host sync is needed.
  * Outputs (row-major, NULL to skip where noted): points [R,S,3] (opt), weights [R,S] (opt),
  * sdf [R,S] (opt), rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], normal_map [R,3] (opt). */
-size_t neat_render_ws_floats(int R, int S, int precision);
+size_t neat_render_ws_floats(int R, int S, int E, int precision);
 int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
                         const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
                         float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
-                        float* xyz, float* normal_map, void* stream);
-/* Backward of neat_render_forward.  Cotangents d_rgb [R,3], d_lines3d [R,6], d_depth [R], d_xyz [R,3]
+                        float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream);
+/* a12 folded in: `eik_points` [E,3] (may be NULL with E = 0) are E extra points appended to the R*S ray samples for
+ * the SDF network only; eik_grad [E,3] receives ImplicitNetwork.gradient (:98-109, no sphere clamp) at those points.
+ * This removes ~66 latency-bound small launches per training step (the 2R eikonal points of :515-527).
+ *
+ * Backward of neat_render_forward.  Cotangents d_rgb [R,3], d_lines3d [R,6], d_depth [R], d_xyz [R,3], d_eik_grad [E,3]
  * (NULL = zero).  lines3d uses detached weights exactly as :410.  Writes all 19 layers' grads and the
  * per-ray partial derivative wrt beta, dbeta_ray [R] (sum it, times sign(density.beta)). */
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs,
-                         const float* z, int R, int S, int precision, const float* beta,
+                         const float* z, int R, int S, int E, int precision, const float* beta,
                          const float* d_rgb, const float* d_lines3d, const float* d_depth, const float* d_xyz,
-                         const neat_net_grads* grads, float* dbeta_ray, void* stream);
+                         const float* d_eik_grad, const neat_net_grads* grads, float* dbeta_ray, void* stream);
 
 /* ---- a9 alone: volume_rendering :540-554 given sdf [R,S] -> weights [R,S] (used by tests) -------- */
 int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream);

@@ -35,12 +35,12 @@ _SIGNATURES = {
     "neat_heads_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "neat_heads_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp,
                                           c_fp, c_fp, c_fp]),
-    "neat_render_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "neat_render_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "neat_render_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            c_fp, ctypes.c_float, ctypes.c_float, c_fp,
-                                           c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+                                           c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                            c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
+                                            ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
     "neat_volume_weights": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "neat_prof_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),

@@ -200,8 +200,8 @@ struct WgradArgs {
   WgradPair pair[2]; int npairs;
   int N, Kt;                 // valid rows / cols (Kt includes the ones column if present)
   int P, ldp, chunk;         // points per grid.y slice (multiple of 32)
-  float* partial;            // [gridDim.y][Nld][Kld]
-  int Nld, Kld, ktiles;
+  float* partial;            // element (split, n, k) at n*row_stride + split*split_stride + k
+  size_t row_stride, split_stride; int ktiles;
 };
 
 constexpr int WBP = 32;      // points per staging step
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
       __syncthreads();
     }
   }
-  float* dst = a.partial + (size_t)blockIdx.y * a.Nld * a.Kld;
+  float* dst = a.partial + (size_t)blockIdx.y * a.split_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < a.N && k < a.Kt) dst[(size_t)n * a.Kld + k] = acc[i][j][r];
+        if (n < a.N && k < a.Kt) dst[(size_t)n * a.row_stride + k] = acc[i][j][r];
       }
     }
 }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
 // Reduce the split partials for one output row, undo the input-column permutation / fold scale, and
 // apply the weight-norm backward:  W = g v/|v|  =>  dg = <dW, v>/|v| ;  dv = g/|v| (dW - <dW,v> v/|v|^2).
 struct WreduceArgs {
-  const float* partial; int splits, Nld, Kld;
+  const float* partial; int splits; size_t row_stride, split_stride;   // (split, n, k) at n*row_stride + split*split_stride + k
   int O, I;                  // layer dims (torch layout [O][I])
   int s0, s0p, off0, off1;   // packed input order: [source cols off0..off0+s0) | pad to s0p | source cols off1.. )
   int rot;                   // packed output row n holds source row (n + rot) mod O
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
     jcol[c] = (i < a.I) ? ((i >= a.off0 && i < a.off0 + a.s0) ? i - a.off0 : a.s0p + (i - a.off1)) : -1;   // packed column
   }
   const int on = (o - a.rot + a.O) % a.O;                    // packed row of source row o
-  const size_t row_off = (size_t)on * a.Kld, split_stride = (size_t)a.Nld * a.Kld;
+  const size_t row_off = (size_t)on * a.row_stride, split_stride = a.split_stride;
+#pragma unroll 4
   for (int sp = wave; sp < a.splits; sp += 4) {
     const float* src = a.partial + sp * split_stride + row_off;
 #pragma unroll
@@ -390,10 +391,15 @@ __global__ __launch_bounds__(WG) void rowscale_kernel(RowScaleArgs a) {
 // x = o + z d for p = r*S + i ; also writes row-major points if requested
 __global__ void points_from_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                         const float* __restrict__ z, int R, int S, int ldp,
-                                        float* __restrict__ x_fm, float* __restrict__ pts_rm) {
+                                        float* __restrict__ x_fm, float* __restrict__ pts_rm,
+                                        const float* __restrict__ extra, int E) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= ldp) return;
   float xv[3] = {0.f, 0.f, 0.f};
+  if (p >= R * S && p < R * S + E) {
+    const int e = p - R * S;
+    xv[0] = extra[e * 3]; xv[1] = extra[e * 3 + 1]; xv[2] = extra[e * 3 + 2];
+  }
   if (p < R * S) {
     const int r = p / S;
     const float zz = z[p];
@@ -479,7 +485,10 @@ __global__ void adjoint_seed_kernel(const float* __restrict__ v8, const float* _
 __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float* __restrict__ out8,
                                     const float* __restrict__ e0, const float* __restrict__ es, int P, int ldp,
                                     float radius, float scale, float* __restrict__ sdf, float* __restrict__ g_fm,
-                                    float* __restrict__ mask, float* __restrict__ sdf_rm, float* __restrict__ g_rm) {
+                                    float* __restrict__ mask, float* __restrict__ sdf_rm, float* __restrict__ g_rm,
+                                    int n_clamp, float* __restrict__ g_extra_rm) {
+  // points [0, n_clamp) get the bounding-sphere clamp (get_outputs); points [n_clamp, P) are eikonal points:
+  // raw network gradient (ImplicitNetwork.gradient), written to g_extra_rm
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= ldp) return;
   float xv[3], gv[3] = {0.f, 0.f, 0.f};
@@ -501,7 +510,7 @@ __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float*
       gv[c] = acc;
     }
   }
-  if (radius > 0.0f) {
+  if (radius > 0.0f && p < n_clamp) {
     const float nr = sqrtf(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
     const float sph = scale * (radius - nr);
     if (sph < s) {
@@ -514,8 +523,13 @@ __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float*
   if (mask) mask[p] = m;
   if (g_fm) { g_fm[p] = gv[0]; g_fm[(size_t)ldp + p] = gv[1]; g_fm[(size_t)2 * ldp + p] = gv[2]; }
   if (p < P) {
-    if (sdf_rm) sdf_rm[p] = s;
-    if (g_rm && e0) { g_rm[p * 3 + 0] = gv[0]; g_rm[p * 3 + 1] = gv[1]; g_rm[p * 3 + 2] = gv[2]; }
+    if (p < n_clamp) {
+      if (sdf_rm) sdf_rm[p] = s;
+      if (g_rm && e0) { g_rm[p * 3 + 0] = gv[0]; g_rm[p * 3 + 1] = gv[1]; g_rm[p * 3 + 2] = gv[2]; }
+    } else if (g_extra_rm) {
+      const int e = p - n_clamp;
+      g_extra_rm[e * 3 + 0] = gv[0]; g_extra_rm[e * 3 + 1] = gv[1]; g_extra_rm[e * 3 + 2] = gv[2];
+    }
   }
 }
 
@@ -552,18 +566,32 @@ __global__ void head_inputs_kernel(const float* __restrict__ x_fm, const float* 
 // cotangent of the normals: g^ = (1-mask) (sc_r[30..32] + sc_a[6..8] + extra) ; also masks the sdf cotangent row
 __global__ void normal_cotangent_kernel(const float* __restrict__ sc_r, const float* __restrict__ sc_a,
                                         const float* __restrict__ extra_rm, const float* __restrict__ mask,
-                                        int P, int ldp, float* __restrict__ gh_fm) {
+                                        int P, int ldp, float* __restrict__ gh_fm,
+                                        int P_main, const float* __restrict__ d_tail_rm) {
+  // points [0, P_main): heads' normal cotangents (+ optional row-major extra), masked where the sphere clamp won;
+  // points [P_main, P): appended eikonal points, cotangent d_tail_rm[p - P_main]
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= ldp) return;
   const float keep = (p < P) ? 1.0f - (mask ? mask[p] : 0.0f) : 0.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     float v = 0.0f;
-    if (sc_r) v += sc_r[(size_t)(30 + c) * ldp + p];
-    if (sc_a) v += sc_a[(size_t)(6 + c) * ldp + p];
-    if (extra_rm && p < P) v += extra_rm[p * 3 + c];
+    if (p < P_main) {
+      if (sc_r) v += sc_r[(size_t)(30 + c) * ldp + p];
+      if (sc_a) v += sc_a[(size_t)(6 + c) * ldp + p];
+      if (extra_rm) v += extra_rm[p * 3 + c];
+    } else if (p < P && d_tail_rm) {
+      v = d_tail_rm[(p - P_main) * 3 + c];
+    }
     gh_fm[(size_t)c * ldp + p] = v * keep;
   }
+}
+
+// zero columns [p_from, ldp) of `rows` feature-major rows
+__global__ void zero_tail_kernel(float* __restrict__ a, int rows, int p_from, int ldp) {
+  const int p = p_from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+  for (int r = 0; r < rows; ++r) a[(size_t)r * ldp + p] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -148,18 +148,34 @@ __device__ __forceinline__ void epilogue_tile_h(const LayerArgsH& a, const f32x1
 template <int NTW>
 __device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][4], const uint4* __restrict__ wp0, int tile_stride,
                                            const uint4* __restrict__ bl, int s_begin, int s_end) {
-  for (int s = s_begin; s < s_end; ++s) {
-    uint4 av[NTW], bv[4];
+  // Weight fragments come from L2 (packed, 1 KiB per wave-load).  One k-step is only 4*NTW MFMAs (~130-260 cycles),
+  // shorter than an L2 round trip, so keep a 4-deep register ring: the load for step s+3 is issued before the MFMAs of
+  // step s.  Ring slots are compile-time indices (the loop advances by 4).
+  uint4 ring[4][NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) av[i] = wp0[(size_t)i * tile_stride + s * 64];
+  for (int u = 0; u < 3; ++u)
+    if (s_begin + u < s_end) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[q] = bl[(2 * s) * BMH + q * 32];
+      for (int i = 0; i < NTW; ++i) ring[u][i] = wp0[(size_t)i * tile_stride + (s_begin + u) * 64];
+    }
+  for (int s = s_begin; s < s_end; s += 4) {
 #pragma unroll
-    for (int i = 0; i < NTW; ++i)
+    for (int u = 0; u < 4; ++u) {
+      if (s + u >= s_end) break;
+      if (s + u + 3 < s_end) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[q]),
-                                                            acc[i][q], 0, 0, 0);
+        for (int i = 0; i < NTW; ++i) ring[(u + 3) & 3][i] = wp0[(size_t)i * tile_stride + (s + u + 3) * 64];
+      }
+      uint4 bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = bl[(2 * (s + u)) * BMH + q * 32];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&ring[u][i]), *reinterpret_cast<bf16x8*>(&bv[q]),
+                                                              acc[i][q], 0, 0, 0);
+    }
   }
 }
 
@@ -171,11 +187,32 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
   const int K8 = a.Kpad >> 3;
   const int oct0 = (a.in[0].rows + 7) >> 3;                         // octets of segment 0 (padded)
   const int oct1 = (a.in[1].rows + 7) >> 3;
-  for (int o = tid >> 7; o < K8; o += 2) {
-    uint4* dst = ldsq + (size_t)o * BMH;
-    if (o < oct0) stage_octet(a.in[0], o, p0, a.ldp, dst, tid);
-    else if (o < oct0 + oct1) stage_octet(a.in[1], o - oct0, p0, a.ldp, dst, tid);
-    else dst[tid & 127] = make_uint4(0u, 0u, 0u, 0u);
+  {
+    // bf16 octet-major segments: the tile image is a straight copy -> global_load_lds DMA, 1 KiB per wave-instruction
+    // (LDS destination = wave-uniform base + lane*16, exactly the [octet][point] tile row).
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    for (int o = wave; o < K8; o += 4) {
+      const SegH& sg = (o < oct0) ? a.in[0] : a.in[1];
+      const int so = (o < oct0) ? o : o - oct0;
+      const bool has = (o < oct0 + oct1) && sg.bf16 && (so * 8 < sg.rows);
+      if (has) {
+        const uint4* src = reinterpret_cast<const uint4*>(sg.p) + (size_t)so * a.ldp + p0 + lane;
+        uint4* dst = ldsq + (size_t)o * BMH;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(src + 64), (lds_ptr)(dst + 64), 16, 0, 0);
+      }
+    }
+    // fp32 feature-major segments (few rows: PE, head inputs, cotangents) and zero padding: convert through registers
+    for (int o = tid >> 7; o < K8; o += 2) {
+      const SegH& sg = (o < oct0) ? a.in[0] : a.in[1];
+      const int so = (o < oct0) ? o : o - oct0;
+      const bool dma = (o < oct0 + oct1) && sg.bf16 && (so * 8 < sg.rows);
+      if (dma) continue;
+      uint4* dst = ldsq + (size_t)o * BMH;
+      if (o < oct0 + oct1 && !sg.bf16) stage_octet(sg, so, p0, a.ldp, dst, tid);
+      else dst[tid & 127] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
   __syncthreads();
   const int KS = a.Kpad >> 4;
@@ -251,7 +288,8 @@ struct WgradPairH {
 struct WgradArgsH {
   WgradPairH pair[2]; int npairs;
   int N, Kt, P, ldp, chunk;      // chunk: points per grid.y slice (multiple of 64)
-  float* partial; int Nld, Kld, ktiles;
+  float* partial; size_t row_stride, split_stride; int ktiles;    // (split, n, k) at n*row_stride + split*split_stride + k
+  int bias_col;                  // wgrad_kernel_h2: partial column receiving the row sums of pair 0's A (or -1)
 };
 
 constexpr int HBP = 64;                 // points per staging step
@@ -386,7 +424,7 @@ __global__ __launch_bounds__(WG) void wgrad_kernel_h(WgradArgsH a) {
       __syncthreads();
     }
   }
-  float* dstp = a.partial + (size_t)blockIdx.y * a.Nld * a.Kld;
+  float* dstp = a.partial + (size_t)blockIdx.y * a.split_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -396,9 +434,196 @@ __global__ __launch_bounds__(WG) void wgrad_kernel_h(WgradArgsH a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < a.N && k < a.Kt) dstp[(size_t)n * a.Kld + k] = acc[i][j][r];
+        if (n < a.N && k < a.Kt) dstp[(size_t)n * a.row_stride + k] = acc[i][j][r];
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient, second generation: ONE workgroup (8 waves) owns a full 256x256 output tile, so every
+// operand element is read from HBM exactly once per launch (the 128x128 version re-read A 3x and B 2x and was
+// HBM-bound at ~800 MB per layer).  The bias gradient (row sums of A) comes from an extra MFMA against an all-ones
+// B fragment -- no ones row in memory, no 257th column tile.  Staging loads for step t+1 are issued right after the
+// LDS image of step t is written, so HBM latency hides under the 32..40 MFMAs of step t.
+// ---------------------------------------------------------------------------------------------
+constexpr int W2T = 512;                       // threads
+__device__ __forceinline__ void w2_issue(const SegH& s, int row0, int p, int ldp, int pend, uint4 (&raw)[8]) {
+  // raw octet loads of an 8-row x 8-point block of a bf16 octet-major segment (transposed later)
+  const bool ok = s.p != nullptr && s.bf16 && row0 < s.rows;
+  const uint4* src = reinterpret_cast<const uint4*>(s.p) + (size_t)(row0 >> 3) * ldp + p;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) raw[t] = (ok && p + t < pend) ? src[t] : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ void w2_transpose(const uint4 (&raw)[8], uint4 (&out)[8]) {
+  unsigned in[8][4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { in[t][0] = raw[t].x; in[t][1] = raw[t].y; in[t][2] = raw[t].z; in[t][3] = raw[t].w; }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    unsigned d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned lo = in[2 * j][f >> 1], hi = in[2 * j + 1][f >> 1];
+      d[j] = (f & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    }
+    out[f] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+}
+// fp32 feature-major rows (possibly spanning B[0..2] / rotated A) -> packed block, row by row
+__device__ __forceinline__ void w2_rows_f32(const WgradPairH& pr, bool isA, int row0, int p, int ldp, int pend, uint4 (&out)[8]) {
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const float* sp = nullptr;
+    int rr = row0 + f;
+    if (isA) {
+      if (pr.A_mod) { const bool in_range = rr < pr.A_mod; rr += pr.A_rot; if (rr >= pr.A_mod) rr -= pr.A_mod; if (!in_range) rr = 1 << 30; }
+      if (!pr.A.bf16 && rr < pr.A.rows) sp = reinterpret_cast<const float*>(pr.A.p);
+    } else {
+      if (rr < pr.padB0) { if (!pr.B[0].bf16 && rr < pr.B[0].rows) sp = reinterpret_cast<const float*>(pr.B[0].p); }
+      else {
+        rr -= pr.padB0;
+        if (rr < pr.B[1].rows) sp = reinterpret_cast<const float*>(pr.B[1].p);
+        else { rr -= pr.B[1].rows; if (rr < pr.B[2].rows) sp = reinterpret_cast<const float*>(pr.B[2].p); }
+      }
+    }
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = (sp && p + t < pend) ? sp[(size_t)rr * ldp + p + t] : 0.0f;
+    out[f] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+  }
+}
+
+__global__ __launch_bounds__(W2T, 2) void wgrad_kernel_h2(WgradArgsH a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char w2lds[];     // As[256][HLD] | Bs[256][HLD]
+  unsigned char* As = w2lds;
+  unsigned char* Bs = w2lds + 256 * HLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = blockIdx.x / a.ktiles, tk = blockIdx.x % a.ktiles;
+  const int n0 = tn * 256, k0 = tk * 256;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 128;
+  bool liveR[2], liveC[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) liveR[i] = n0 + wr + 32 * i < a.N;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) liveC[j] = k0 + wc + 32 * j < a.Kt;
+  const bool do_bias = (tk == 0) && a.bias_col >= 0;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float rsum[8];                                            // bias gradient: row sums of pair 0's A, kept by the A-staging threads
+#pragma unroll
+  for (int f = 0; f < 8; ++f) rsum[f] = 0.0f;
+  const int pbeg = blockIdx.y * a.chunk;
+  const int pend = min(a.P, pbeg + a.chunk);
+  const int nsteps = (pend - pbeg + HBP - 1) / HBP;
+  const bool isA = tid < 256;
+  const int sid = tid & 255;
+  const int boct = sid >> 3, bpg = sid & 7;                 // 32 row octets x 8 point groups
+  const int row0 = (isA ? n0 : k0) + boct * 8;
+  // raw staging ring in LDS, filled by LDS-DMA (no VGPRs held across the MFMA phase): [wave][load t][lane] x 16 B
+  uint4* rawl = reinterpret_cast<uint4*>(w2lds + 2 * 256 * HLD) + (size_t)wave * 8 * 64;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  // all kernarg accesses below use compile-time pair indices (a runtime-indexed a.pair[q] would be copied to scratch)
+#define W2_FAST(pr) (isA ? ((pr).A.bf16 != 0) : ((pr).B[0].bf16 && row0 < (pr).padB0))
+#define W2_SEG(pr) (isA ? (pr).A : (pr).B[0])
+#define W2_ISSUE(pr, pb)                                                                                         \
+  do {                                                                                                           \
+    if (W2_FAST(pr) && W2_SEG(pr).p && row0 < W2_SEG(pr).rows) {                                                 \
+      const uint4* src_ = reinterpret_cast<const uint4*>(W2_SEG(pr).p) + (size_t)(row0 >> 3) * a.ldp + (pb) + bpg * 8; \
+      _Pragma("unroll") for (int t = 0; t < 8; ++t)                                                              \
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(src_ + t), (lds_ptr)(rawl + t * 64), 16, 0, 0);               \
+    }                                                                                                            \
+  } while (0)
+  if (nsteps > 0) W2_ISSUE(a.pair[0], pbeg);
+  __syncthreads();                                          // (the DMA is drained by the barrier's vmcnt(0))
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (q >= a.npairs) break;
+    const WgradPairH& pr = a.pair[q];
+    const bool fast = W2_FAST(pr);
+    const bool okr = fast && W2_SEG(pr).p != nullptr && row0 < W2_SEG(pr).rows;
+    const bool bias_now = do_bias && q == 0 && isA;
+    for (int st = 0; st < nsteps; ++st) {
+      const int pb = pbeg + st * HBP;
+      uint4 blk[8];
+      if (fast) {
+        const int p = pb + bpg * 8;
+        uint4 raw[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) raw[t] = (okr && p + t < pend) ? rawl[t * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        w2_transpose(raw, blk);
+      } else {
+        w2_rows_f32(pr, isA, row0, pb + bpg * 8, a.ldp, pend, blk);
+      }
+      unsigned char* dst = (isA ? As : Bs) + (boct * 8) * HLD + bpg * 16;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) *reinterpret_cast<uint4*>(dst + f * HLD) = blk[f];
+      if (bias_now) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          const unsigned w4[4] = {blk[f].x, blk[f].y, blk[f].z, blk[f].w};
+          float t = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t += bf2f((u16)(w4[j] & 0xFFFF)) + bf2f((u16)(w4[j] >> 16));
+          rsum[f] += t;
+        }
+      }
+      __syncthreads();
+      // next block's HBM latency hides under the MFMAs below
+      if (st + 1 < nsteps) W2_ISSUE(pr, pb + HBP);
+      else if (q == 0 && a.npairs > 1) W2_ISSUE(a.pair[1], pbeg);
+      const unsigned char* ap = As + (wr + (lane & 31)) * HLD + (lane >> 5) * 16;
+      const unsigned char* bp = Bs + (wc + (lane & 31)) * HLD + (lane >> 5) * 16;
+#pragma unroll
+      for (int s = 0; s < HBP / 16; ++s) {
+        uint4 av[2], bv[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const uint4*>(ap + i * 32 * HLD + s * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const uint4*>(bp + j * 32 * HLD + s * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (!liveR[i]) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (liveC[j])
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+#undef W2_ISSUE
+#undef W2_SEG
+#undef W2_FAST
+  float* dstp = a.partial + (size_t)blockIdx.y * a.split_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!liveR[i]) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wc + 32 * j + (lane & 31);
+        if (liveC[j] && k < a.Kt) dstp[(size_t)n * a.row_stride + k] = acc[i][j][r];
+      }
+    }
+  }
+  if (do_bias && isA) {                                     // combine the 8 point-group partials (adjacent lanes) of each row
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      float v = rsum[f];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+      if (bpg == 0 && row0 + f < a.N) dstp[(size_t)(row0 + f) * a.row_stride + a.bias_col] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

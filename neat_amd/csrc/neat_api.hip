@@ -216,8 +216,12 @@ struct SdfWs {
   Arr h[9], feat, u[8], vh[9], m[8];                                                   // big (bf16 in the bf16 build)
   size_t total;
 };
-constexpr int WSPLIT = 128;                 // point-splits of the weight-gradient reduction
-constexpr int WLDN = 384, WLDK = 384;       // partial tile leading dims (>= 296+1, multiple of 128)
+constexpr int WSPLIT = 128;                 // fp32 build: point-splits of the weight-gradient reduction
+constexpr int WLDN = 384, WLDK = 384;       //             partial tile leading dims (>= 296+1, multiple of 128)
+constexpr int W2SPLIT = 256;                // bf16 build (256x256 tiles): splits and leading dims
+constexpr int W2LDN = 288, W2LDK = 320;
+constexpr int W2_LDS_BYTES = 2 * 256 * HLD + 8 * 8 * 64 * 16;      // operand tiles + raw DMA ring
+constexpr size_t WPARTIAL_FLOATS = (size_t)W2SPLIT * W2LDN * W2LDK;   // >= WSPLIT*WLDN*WLDK
 
 SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
   SdfWs w{};
@@ -239,7 +243,7 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
     for (int l = 0; l < 8; ++l) w.m[l] = big(256);
     w.abar8 = take(257); w.ones = take(1);
     w.partial = base ? base + off : nullptr;
-    off += (size_t)WSPLIT * WLDN * WLDK;
+    off += WPARTIAL_FLOATS;
   }
   w.total = off;
   return w;
@@ -310,49 +314,67 @@ hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w) {
 
 struct WPair { Arr A; int rowsA; int A_rot, A_mod; Arr B[3]; int rowsB[3]; };
 
-hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs, int npairs, int N, const neat_net_grads* gr) {
+hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_in, int npairs, int N, const neat_net_grads* gr) {
   if (!gr->dv[layer_id]) return hipSuccess;
   const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
-  // packed column count of the B operand (+1 for the ones row that yields the bias gradient)
-  const int Kt = d.s0p + (kI[layer_id] - d.s0) + 1;
-  const int step = c.prec ? HBP : WBP;
-  int chunk = ((c.ldp + WSPLIT - 1) / WSPLIT + step - 1) / step * step;
-  if (chunk < 2 * step) chunk = 2 * step;
-  const int splits = (c.P + chunk - 1) / chunk;
-  const int ntile = (N + 127) / 128, ktiles = (Kt + 127) / 128;
+  const int K = d.s0p + (kI[layer_id] - d.s0);      // packed column count of the B operand
   double wflops = 0.0;
   for (int q = 0; q < npairs; ++q)
-    wflops += 2.0 * pairs[q].rowsA * (pairs[q].rowsB[0] + pairs[q].rowsB[1] + pairs[q].rowsB[2]) * (double)c.P;
-  ProfSlot* ps = prof_begin(c.st, 1, wflops);
+    wflops += 2.0 * pairs_in[q].rowsA * (pairs_in[q].rowsB[0] + pairs_in[q].rowsB[1] + pairs_in[q].rowsB[2]) * (double)c.P;
+  WreduceArgs r{};
+  int splits;
   if (!c.prec) {
+    // fp32: 128x128 tiles; the bias gradient is the column of the `ones` row appended to pair 0's B
+    WPair pairs[2] = {pairs_in[0], npairs > 1 ? pairs_in[1] : WPair{}};
+    for (int s = 0; s < 3; ++s)
+      if (pairs[0].rowsB[s] == 0) { pairs[0].B[s] = F(w.ones); pairs[0].rowsB[s] = 1; break; }
+    const int Kt = K + 1;
+    int chunk = ((c.ldp + WSPLIT - 1) / WSPLIT + WBP - 1) / WBP * WBP;
+    if (chunk < 2 * WBP) chunk = 2 * WBP;
+    splits = (c.P + chunk - 1) / chunk;
+    const int ntile = (N + 127) / 128, ktiles = (Kt + 127) / 128;
     WgradArgs a{};
     for (int q = 0; q < npairs; ++q) {
       a.pair[q].A = pairs[q].A.f(); a.pair[q].rowsA = pairs[q].rowsA;
       for (int s = 0; s < 3; ++s) { a.pair[q].B[s] = pairs[q].B[s].f(); a.pair[q].rowsB[s] = pairs[q].rowsB[s]; }
     }
     a.npairs = npairs; a.N = N; a.Kt = Kt; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-    a.partial = w.partial; a.Nld = WLDN; a.Kld = WLDK; a.ktiles = ktiles;
+    a.partial = w.partial; a.row_stride = (size_t)splits * WLDK; a.split_stride = WLDK; a.ktiles = ktiles;
+    ProfSlot* ps = prof_begin(c.st, 1, wflops);
     hipLaunchKernelGGL(wgrad_kernel, dim3(ntile * ktiles, splits), dim3(WG), 0, c.st, a);
+    prof_end(c.st, ps);
+    r.row_stride = (size_t)splits * WLDK; r.split_stride = WLDK;
   } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h2), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + HBP - 1) / HBP * HBP;
+    if (chunk < 2 * HBP) chunk = 2 * HBP;
+    splits = (c.P + chunk - 1) / chunk;
+    const int ntile = (N + 255) / 256, ktiles = (K + 255) / 256;
     WgradArgsH a{};
     for (int q = 0; q < npairs; ++q) {
-      const WPair& s = pairs[q];
+      const WPair& s = pairs_in[q];
       a.pair[q].A = SegH{s.A.p, s.rowsA, s.A.bf16}; a.pair[q].A_rot = s.A_rot; a.pair[q].A_mod = s.A_mod;
       for (int t = 0; t < 3; ++t) a.pair[q].B[t] = SegH{s.B[t].p, s.rowsB[t], s.B[t].bf16};
       a.pair[q].padB0 = s.B[0].bf16 ? pad8(s.rowsB[0]) : s.rowsB[0];
     }
-    a.npairs = npairs; a.N = N; a.Kt = Kt; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-    a.partial = w.partial; a.Nld = WLDN; a.Kld = WLDK; a.ktiles = ktiles;
-    hipLaunchKernelGGL(wgrad_kernel_h, dim3(ntile * ktiles, splits), dim3(WG), 0, c.st, a);
+    a.npairs = npairs; a.N = N; a.Kt = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
+    a.partial = w.partial; a.row_stride = (size_t)splits * W2LDK; a.split_stride = W2LDK; a.ktiles = ktiles; a.bias_col = K;
+    ProfSlot* ps = prof_begin(c.st, 1, wflops);
+    hipLaunchKernelGGL(wgrad_kernel_h2, dim3(ntile * ktiles, splits), dim3(W2T), W2_LDS_BYTES, c.st, a);
+    prof_end(c.st, ps);
+    r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
   }
-  prof_end(c.st, ps);
-  WreduceArgs r{};
-  r.partial = w.partial; r.splits = splits; r.Nld = WLDN; r.Kld = WLDK;
+  r.partial = w.partial; r.splits = splits;
   r.O = kO[layer_id]; r.I = kI[layer_id];
   r.s0 = d.s0; r.s0p = d.s0p; r.off0 = d.off0; r.off1 = d.off1; r.rot = d.rot; r.scale = d.scale;
   r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
   r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
-  r.bias_col = Kt - 1;
+  r.bias_col = K;
   hipLaunchKernelGGL(wreduce_wnorm_kernel, dim3(r.O), dim3(WG), 0, c.st, r);
   return hipGetLastError();
 }
@@ -384,13 +406,13 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     pr[0].A = l == 8 ? F(w.abar8) : w.m[l]; pr[0].rowsA = kO[l]; pr[0].A_rot = rot8; pr[0].A_mod = rot8 ? 257 : 0;
     pr[1].A = l == 8 ? F(w.ones) : w.u[l];  pr[1].rowsA = l == 8 ? 1 : kO[l]; pr[1].A_rot = rot8; pr[1].A_mod = rot8 ? 257 : 0;
     if (l == 0) {
-      pr[0].B[0] = F(w.E); pr[0].rowsB[0] = PE_ROWS; pr[0].B[1] = F(w.ones); pr[0].rowsB[1] = 1;
+      pr[0].B[0] = F(w.E); pr[0].rowsB[0] = PE_ROWS;
       pr[1].B[0] = F(w.Eh); pr[1].rowsB[0] = PE_ROWS;
     } else if (l == 4) {
-      pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 217; pr[0].B[1] = F(w.E); pr[0].rowsB[1] = PE_ROWS; pr[0].B[2] = F(w.ones); pr[0].rowsB[2] = 1;
+      pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 217; pr[0].B[1] = F(w.E); pr[0].rowsB[1] = PE_ROWS;
       pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 217; pr[1].B[1] = F(w.Eh); pr[1].rowsB[1] = PE_ROWS;
     } else {
-      pr[0].B[0] = w.h[l]; pr[0].rowsB[0] = 256; pr[0].B[1] = F(w.ones); pr[0].rowsB[1] = 1;
+      pr[0].B[0] = w.h[l]; pr[0].rowsB[0] = 256;
       pr[1].B[0] = w.vh[l]; pr[1].rowsB[0] = 256;
     }
     if ((e = wgrad(c, w, l, pr, 2, kO[l], gr)) != hipSuccess) return e;
@@ -441,9 +463,9 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
       WPair pr[1] = {};
       pr[0].A = l == 4 ? F(top) : ab[l]; pr[0].rowsA = kO[base + l];
       if (l == 0) {
-        pr[0].B[0] = w.feat; pr[0].rowsB[0] = 256; pr[0].B[1] = F(small); pr[0].rowsB[1] = srows; pr[0].B[2] = F(w.ones); pr[0].rowsB[2] = 1;
+        pr[0].B[0] = w.feat; pr[0].rowsB[0] = 256; pr[0].B[1] = F(small); pr[0].rowsB[1] = srows;
       } else {
-        pr[0].B[0] = hh[l]; pr[0].rowsB[0] = 256; pr[0].B[1] = F(w.ones); pr[0].rowsB[1] = 1;
+        pr[0].B[0] = hh[l]; pr[0].rowsB[0] = 256;
       }
       if ((e = wgrad(c, w, base + l, pr, 1, kO[base + l], gr)) != hipSuccess) return e;
     }
@@ -586,13 +608,14 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
   if (mode == 0) {
     NEAT_CHECK(sdf_primal(c, w, false));
     hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, (const float*)nullptr,
-                       (const float*)nullptr, P, c.ldp, radius, scale, w.sdf, (float*)nullptr, (float*)nullptr, sdf, (float*)nullptr);
+                       (const float*)nullptr, P, c.ldp, radius, scale, w.sdf, (float*)nullptr, (float*)nullptr, sdf, (float*)nullptr,
+                       P, (float*)nullptr);
     return (int)hipGetLastError();
   }
   NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w));
   hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
-                     w.sdf, w.g, w.mask, sdf, grad);
+                     w.sdf, w.g, w.mask, sdf, grad, P, (float*)nullptr);
   export_out8(c, w, out257, feat);
   return (int)hipGetLastError();
 }
@@ -606,7 +629,7 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
   SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
   hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8);
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, (const float*)nullptr, (const float*)nullptr,
-                     d_grad, w.mask, P, c.ldp, w.gh);
+                     d_grad, w.mask, P, c.ldp, w.gh, P, (const float*)nullptr);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));
   return (int)hipGetLastError();
 }
@@ -638,28 +661,30 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
   return (int)hipGetLastError();
 }
 
-size_t neat_render_ws_floats(int R, int S, int precision) {
+size_t neat_render_ws_floats(int R, int S, int E, int precision) {
   if (bad_prec(precision)) return 0;
-  const int ldp = round_ldp(R * S, precision);
+  const int ldp = round_ldp(R * S + E, precision);
   return sdf_ws(nullptr, ldp, 1, precision).total + head_ws(nullptr, ldp, precision).total;
 }
 
 int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
                         const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
                         float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
-                        float* xyz, float* normal_map, void* stream) {
+                        float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream) {
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !origins || !dirs || !z || !rgb || !lines3d || !depth || !xyz || bad_prec(precision)) return -1;
-  const int P = R * S;
+  if (E < 0 || (E > 0 && (!eik_points || !eik_grad))) return -1;
+  const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
   HeadWs h = head_ws(ws + w.total, c.ldp, precision);
-  hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points);
+  hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points, eik_points, E);
   NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w));
   hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
-                     w.sdf, w.g, w.mask, sdf, (float*)nullptr);
-  hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, P, S, c.ldp, h.small_r, h.small_a);
+                     w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
+  // the heads run over every column of the tile grid; only the first R*S columns are consumed
+  hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, Pm, S, c.ldp, h.small_r, h.small_a);
   NEAT_CHECK(heads_forward(c, h, w.feat));
   CompositeArgs ca;
   ca.z = z; ca.sdf = w.sdf; ca.dirs = dirs; ca.x_fm = w.x; ca.rgb_fm = h.rgb; ca.lin_fm = h.lin; ca.g_fm = w.g;
@@ -670,11 +695,12 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
 }
 
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs, const float* z,
-                         int R, int S, int precision, const float* beta, const float* d_rgb, const float* d_lines3d,
-                         const float* d_depth, const float* d_xyz, const neat_net_grads* grads, float* dbeta_ray, void* stream) {
+                         int R, int S, int E, int precision, const float* beta, const float* d_rgb, const float* d_lines3d,
+                         const float* d_depth, const float* d_xyz, const float* d_eik_grad, const neat_net_grads* grads,
+                         float* dbeta_ray, void* stream) {
   if (R <= 0 || S <= 0) return 0;
-  if (!packed || !net || !ws || !grads || bad_prec(precision)) return -1;
-  const int P = R * S;
+  if (!packed || !net || !ws || !grads || bad_prec(precision) || E < 0) return -1;
+  const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
   HeadWs h = head_ws(ws + w.total, c.ldp, precision);
@@ -685,8 +711,14 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
   hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, cb);
+  if (c.ldp > Pm) {      // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents
+    hipLaunchKernelGGL(zero_tail_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, Pm, c.ldp);
+    hipLaunchKernelGGL(zero_tail_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.dlin, 6, Pm, c.ldp);
+    hipLaunchKernelGGL(zero_tail_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, w.abar8, 1, Pm, c.ldp);
+  }
   NEAT_CHECK(heads_backward(c, h, w, grads));
-  hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp, w.gh);
+  hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
+                     w.gh, Pm, d_eik_grad);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));
   return (int)hipGetLastError();
 }

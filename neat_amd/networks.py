@@ -226,12 +226,14 @@ class VolSDFNetwork(_HipModule):
     def _sphere(self):
         return 0.0 if self.white_bkgd else self.scene_bounding_sphere
 
-    def _render(self, cam_loc, ray_dirs, z_vals, want_normal_map):
-        rgb, lines3d, depth, xyz, weights, sdf, points, nmap = ops.render_rays(
+    def _render(self, cam_loc, ray_dirs, z_vals, want_normal_map, eik_points=None, with_eik=False):
+        rgb, lines3d, depth, xyz, eik_grad, weights, sdf, points, nmap = ops.render_rays(
             self.handle(), cam_loc, ray_dirs, z_vals, self.density.get_beta(), self._sphere(),
-            self.implicit_network.sphere_scale, want_normal_map)
+            self.implicit_network.sphere_scale, want_normal_map, eik_points)
         if self.white_bkgd:
             rgb = rgb + (1.0 - weights.sum(-1, keepdim=True)) * self.bg_color.unsqueeze(0)
+        if with_eik:
+            return rgb, lines3d, depth, xyz, weights, sdf, points, nmap, eik_grad
         return rgb, lines3d, depth, xyz, weights, sdf, points, nmap
 
     # ---- reference helpers -------------------------------------------------------------------------
@@ -276,13 +278,17 @@ class VolSDFNetwork(_HipModule):
         ray_dirs, cam_loc = self._rays(input)
         n_rays = ray_dirs.shape[0]
         z_vals, z_eik = self._z_vals(ray_dirs, cam_loc)
-        rgb, lines3d, depth, xyz, weights, sdf_s, points, nmap = self._render(cam_loc, ray_dirs, z_vals, not self.training)
-        output = {"points": points, "rgb_values": rgb, "sdf": sdf_s, "depth": depth, "xyz": xyz}
         grad_theta = None
         if self.training and not self.junction_eikonal:
-            # Eikonal pass (rend_a :515-527), queued here so the GPU has work while the host runs the Hungarian
-            # matching below.  No random draw happens in between, so the CPU RNG stream order is the reference's.
-            grad_theta = self._eikonal(n_rays, cam_loc, ray_dirs, z_eik, None)
+            # Eikonal points (rend_a :515-527) ride along with the main pass through the SDF network: no separate
+            # latency-bound small launches.  The reference draws them after the junction block, but no random draw
+            # happens in between, so the CPU RNG stream order is unchanged.
+            eik = self._eikonal_points(n_rays, cam_loc, ray_dirs, z_eik, None)
+            rgb, lines3d, depth, xyz, weights, sdf_s, points, nmap, grad_theta = self._render(
+                cam_loc, ray_dirs, z_vals, False, eik, with_eik=True)
+        else:
+            rgb, lines3d, depth, xyz, weights, sdf_s, points, nmap = self._render(cam_loc, ray_dirs, z_vals, not self.training)
+        output = {"points": points, "rgb_values": rgb, "sdf": sdf_s, "depth": depth, "xyz": xyz}
 
         # ---- attraction field / junctions (rend_a :424-513); R-sized, stays in torch -------------------
         points3d = xyz
@@ -350,11 +356,14 @@ class VolSDFNetwork(_HipModule):
             output["normal_map"] = nmap
         return output
 
-    def _eikonal(self, n_rays, cam_loc, ray_dirs, z_eik, junctions):
+    def _eikonal_points(self, n_rays, cam_loc, ray_dirs, z_eik, junctions):
         """Eikonal points: uniform in the bounding cube + one near-surface sample per ray (rend_a :515-527)."""
         r = self.scene_bounding_sphere
         eik = torch.empty(n_rays, 3).uniform_(-r, r).to(ray_dirs.device)
         eik = torch.cat([eik, cam_loc + z_eik * ray_dirs], 0)
         if junctions is not None:
             eik = torch.cat([eik, junctions], 0)
-        return self.implicit_network.gradient(eik)
+        return eik
+
+    def _eikonal(self, n_rays, cam_loc, ray_dirs, z_eik, junctions):
+        return self.implicit_network.gradient(self._eikonal_points(n_rays, cam_loc, ray_dirs, z_eik, junctions))

@@ -85,19 +85,19 @@ class NetHandle:
 
 def _grad_buffers(handle, first, count, device):
     """One flat buffer with (dv, dg, db) views per layer -> (NetGrads struct, [views in v,g,b order], flat)."""
-    sizes = []
+    sizes, shapes = [], []
     for l in range(first, first + count):
-        sizes += [LAYER_OUT[l] * LAYER_IN[l], LAYER_OUT[l], LAYER_OUT[l]]
-    flat = torch.empty(sum(sizes), device=device, dtype=torch.float32)
-    gr = _lib.NetGrads()
-    views, off = [], 0
-    for i, l in enumerate(range(first, first + count)):
         v, g, b = handle.layers[l]
-        dv = flat[off:off + sizes[3 * i]].view(v.shape); off += sizes[3 * i]
-        dg = flat[off:off + sizes[3 * i + 1]].view(g.shape); off += sizes[3 * i + 1]
-        db = flat[off:off + sizes[3 * i + 2]].view(b.shape); off += sizes[3 * i + 2]
-        gr.dv[l], gr.dg[l], gr.db[l] = dv.data_ptr(), dg.data_ptr(), db.data_ptr()
-        views += [dv, dg, db]
+        sizes += [LAYER_OUT[l] * LAYER_IN[l], LAYER_OUT[l], LAYER_OUT[l]]
+        shapes += [v.shape, g.shape, b.shape]
+    flat = torch.empty(sum(sizes), device=device, dtype=torch.float32)
+    views = [t.view(sh) for t, sh in zip(flat.split(sizes), shapes)]
+    gr = _lib.NetGrads()
+    base, off = flat.data_ptr(), 0
+    for i, l in enumerate(range(first, first + count)):
+        gr.dv[l] = base + 4 * off; off += sizes[3 * i]
+        gr.dg[l] = base + 4 * off; off += sizes[3 * i + 1]
+        gr.db[l] = base + 4 * off; off += sizes[3 * i + 2]
     return gr, views, flat
 
 
@@ -174,19 +174,22 @@ def heads_forward(handle, points, normals, view_dirs, feats):
 
 class RenderRaysFn(torch.autograd.Function):
     """Main pass of VolSDFNetwork.forward (rend_a :392-422): points -> SDF MLP (+normals) -> both heads ->
-    Laplace density -> alpha compositing.  Differentiable wrt all 57 network parameters and beta."""
+    Laplace density -> alpha compositing; optionally E extra points ride along through the SDF network only and
+    return its raw gradient (the eikonal term, :515-527).  Differentiable wrt all 57 network parameters and beta."""
 
     @staticmethod
-    def forward(ctx, handle, origins, dirs, z, beta, radius, scale, want_normal_map, *params):
+    def forward(ctx, handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, *params):
         lib = _lib.lib()
         ctx.set_materialize_grads(False)
         origins, dirs, z = (_f32c(t.detach()) for t in (origins, dirs, z))
         beta_d = _f32c(beta.detach().reshape(1))
         R, S = z.shape
         dev = z.device
+        eik = _f32c(eik_points.detach()) if eik_points is not None else None
+        E = 0 if eik is None else eik.shape[0]
         packed, netp = handle.packed()
         prec = handle.precision
-        ws = torch.empty(lib.neat_render_ws_floats(R, S, prec), device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.neat_render_ws_floats(R, S, E, prec), device=dev, dtype=torch.float32)
         points = torch.empty(R, S, 3, device=dev)
         weights = torch.empty(R, S, device=dev)
         sdf = torch.empty(R, S, device=dev)
@@ -195,36 +198,40 @@ class RenderRaysFn(torch.autograd.Function):
         depth = torch.empty(R, device=dev)
         xyz = torch.empty(R, 3, device=dev)
         nmap = torch.empty(R, 3, device=dev) if want_normal_map else None
+        eik_grad = torch.empty(E, 3, device=dev)
         _lib.check(lib.neat_render_forward(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, _p(beta_d),
                                            float(radius), float(scale), _p(ws), _p(points), _p(weights), _p(sdf), _p(rgb),
-                                           _p(lines3d), _p(depth), _p(xyz), _p(nmap), _stream()), "neat_render_forward")
-        ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, (R, S), ws, packed, netp, prec
+                                           _p(lines3d), _p(depth), _p(xyz), _p(nmap), _p(eik) if E else None, E,
+                                           _p(eik_grad) if E else None, _stream()), "neat_render_forward")
+        ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, (R, S, E), ws, packed, netp, prec
         ctx.dirs, ctx.z, ctx.beta_d, ctx.beta_shape = dirs, z, beta_d, beta.shape
         if nmap is None:
             nmap = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(weights, sdf, points, nmap)
-        return rgb, lines3d, depth, xyz, weights, sdf, points, nmap
+        return rgb, lines3d, depth, xyz, eik_grad, weights, sdf, points, nmap
 
     @staticmethod
-    def backward(ctx, d_rgb, d_lines3d, d_depth, d_xyz, *_unused):
+    def backward(ctx, d_rgb, d_lines3d, d_depth, d_xyz, d_eik, *_unused):
         lib = _lib.lib()
-        R, S = ctx.shape
+        R, S, E = ctx.shape
         h = ctx.handle
         dev = ctx.ws.device
         gr, views, _ = _grad_buffers(h, 0, _lib.NUM_LAYERS, dev)
-        d_rgb, d_lines3d, d_depth, d_xyz = (_f32c(t) for t in (d_rgb, d_lines3d, d_depth, d_xyz))
+        d_rgb, d_lines3d, d_depth, d_xyz, d_eik = (_f32c(t) for t in (d_rgb, d_lines3d, d_depth, d_xyz, d_eik))
         dbeta_ray = torch.empty(R, device=dev)
-        _lib.check(lib.neat_render_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), _p(ctx.dirs), _p(ctx.z), R, S,
+        _lib.check(lib.neat_render_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), _p(ctx.dirs), _p(ctx.z), R, S, E,
                                             ctx.prec, _p(ctx.beta_d), _p(d_rgb), _p(d_lines3d), _p(d_depth), _p(d_xyz),
-                                            ctypes.byref(gr), _p(dbeta_ray), _stream()), "neat_render_backward")
+                                            _p(d_eik) if E else None, ctypes.byref(gr), _p(dbeta_ray), _stream()),
+                   "neat_render_backward")
         ctx.ws = None
-        return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, *views)
+        return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, None, *views)
 
 
-def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False):
+def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False, eik_points=None):
+    """-> rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], eik_grad [E,3], weights, sdf, points, normal_map"""
     if not handle.has_heads():
         raise RuntimeError("render_rays needs the SDF network and both heads attached to the NetHandle")
-    return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, *handle.tensors())
+    return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, *handle.tensors())
 
 
 def camera_rays(uv, pose, intrinsics):

@@ -35,7 +35,8 @@ def test_workspace_queries_are_consistent():
     for prec, tile in ((0, 64), (1, 128)):
         assert lib.neat_packed_floats(prec) > 19 * 256
         assert lib.neat_sdf_ws_floats(64, 0, prec) < lib.neat_sdf_ws_floats(64, 1, prec)
-        assert lib.neat_render_ws_floats(8, 8, prec) > lib.neat_sdf_ws_floats(64, 1, prec)
+        assert lib.neat_render_ws_floats(8, 8, 0, prec) > lib.neat_sdf_ws_floats(64, 1, prec)
+        assert lib.neat_render_ws_floats(8, 8, 0, prec) == lib.neat_render_ws_floats(8, 7, 8, prec)     # E extra points share the tile grid
         # point stride is padded to the workgroup's point tile (64 fp32 / 128 bf16)
         assert lib.neat_sdf_ws_floats(1, 0, prec) == lib.neat_sdf_ws_floats(tile, 0, prec)
         assert lib.neat_sdf_ws_floats(tile + 1, 0, prec) == lib.neat_sdf_ws_floats(2 * tile, 0, prec)
