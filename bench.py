@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--pt", type=int, default=0, help="(tuning) bf16 layer-kernel point tile: 2 = 64 points, 4 = 128 points")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=DEFAULT_PRECISION,
                     help="GEMM build: fp32 = exact-f32 MFMA (parity build); bf16 = bf16 MFMA, fp32 accumulate (BASELINE config 2)")
     args = ap.parse_args()
@@ -108,6 +109,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.lib()
+    if args.pt:
+        _lib.check(lib.neat_set_tuning(0, args.pt), "neat_set_tuning")
 
     seed = dp.rank_seed(42, rank)
     torch.manual_seed(seed)

@@ -109,6 +109,7 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  * HIP events on the caller's stream.  class 0 = layer_kernel (all MLP chains), class 1 = wgrad_kernel.
  * neat_prof_collect synchronises on the recorded events and returns the summed kernel time, the summed
  * ALGORITHMIC flops (2*N*K*P with the true layer dims) and the launch count since neat_prof_enable(1). */
+int neat_set_tuning(int key, int value);   /* key 0: bf16 layer-kernel point tile, value 2 (64 points, default) or 4 (128) */
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches);
 

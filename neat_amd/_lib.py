@@ -42,6 +42,7 @@ _SIGNATURES = {
     "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
     "neat_volume_weights": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
+    "neat_set_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "neat_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "neat_prof_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int)]),

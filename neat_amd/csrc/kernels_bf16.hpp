@@ -17,7 +17,7 @@ namespace neat {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-constexpr int BMH = 128;         // points per workgroup tile (bf16 build)
+constexpr int BMH = 128;         // point-stride granule of the bf16 build (ldp is a multiple of this)
 
 __device__ __forceinline__ u16 f2bf(float f) {            // round to nearest even (finite inputs)
   unsigned u = __float_as_uint(f);
@@ -57,10 +57,10 @@ __device__ __forceinline__ float seg_read_f32(const SegH& s, int row, int p, int
 }
 
 // stage one 8-row octet x 128 points of a segment into the LDS tile (dst = &tile[octet][0][0])
+template <int BMT>
 __device__ __forceinline__ void stage_octet(const SegH& s, int oct, int p0, int ldp, uint4* dst, int tid) {
-  // 256 threads: 128 points, two threads per point are not needed -> threads 0..127 copy, the rest take the next octet
-  // (caller strides octets by 2)
-  const int p = tid & 127;
+  // BMT points per octet row; 256/BMT octet rows are staged per pass (caller strides octets accordingly)
+  const int p = tid & (BMT - 1);
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
   if (s.bf16) {
     if (oct * 8 < s.rows) v = reinterpret_cast<const uint4*>(s.p)[(size_t)oct * ldp + p0 + p];
@@ -145,9 +145,10 @@ __device__ __forceinline__ void epilogue_tile_h(const LayerArgsH& a, const f32x1
   }
 }
 
-template <int NTW>
-__device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][4], const uint4* __restrict__ wp0, int tile_stride,
+template <int NTW, int PT>
+__device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][PT], const uint4* __restrict__ wp0, int tile_stride,
                                            const uint4* __restrict__ bl, int s_begin, int s_end) {
+  constexpr int BMT = 32 * PT;
   // Weight fragments come from L2 (packed, 1 KiB per wave-load).  One k-step is only 4*NTW MFMAs (~130-260 cycles),
   // shorter than an L2 round trip, so keep a 4-deep register ring: the load for step s+3 is issued before the MFMAs of
   // step s.  Ring slots are compile-time indices (the loop advances by 4).
@@ -166,24 +167,25 @@ __device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][4], const uint4* __r
 #pragma unroll
         for (int i = 0; i < NTW; ++i) ring[(u + 3) & 3][i] = wp0[(size_t)i * tile_stride + (s + u + 3) * 64];
       }
-      uint4 bv[4];
+      uint4 bv[PT];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bv[q] = bl[(2 * (s + u)) * BMH + q * 32];
+      for (int q = 0; q < PT; ++q) bv[q] = bl[(2 * (s + u)) * BMT + q * 32];
 #pragma unroll
       for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < PT; ++q)
           acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&ring[u][i]), *reinterpret_cast<bf16x8*>(&bv[q]),
                                                               acc[i][q], 0, 0, 0);
     }
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
-  extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];     // [Kpad/8][BMH] octets (16 B each); reused for split-K reduce
+template <int EPI, int PT>
+__global__ __launch_bounds__(WG, (PT == 4 ? 2 : 3)) void layer_kernel_h(LayerArgsH a) {
+  constexpr int BMT = 32 * PT;                                       // points per workgroup: 128 (PT=4) or 64 (PT=2)
+  extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];     // [Kpad/8][BMT] octets (16 B each); reused for split-K reduce
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p0 = blockIdx.x * BMH;
+  const int p0 = blockIdx.x * BMT;
   const int K8 = a.Kpad >> 3;
   const int oct0 = (a.in[0].rows + 7) >> 3;                         // octets of segment 0 (padded)
   const int oct1 = (a.in[1].rows + 7) >> 3;
@@ -198,26 +200,28 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
       const bool has = (o < oct0 + oct1) && sg.bf16 && (so * 8 < sg.rows);
       if (has) {
         const uint4* src = reinterpret_cast<const uint4*>(sg.p) + (size_t)so * a.ldp + p0 + lane;
-        uint4* dst = ldsq + (size_t)o * BMH;
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr)(src + 64), (lds_ptr)(dst + 64), 16, 0, 0);
+        uint4* dst = ldsq + (size_t)o * BMT;
+#pragma unroll
+        for (int hh = 0; hh < BMT / 64; ++hh)
+          __builtin_amdgcn_global_load_lds((gbl_ptr)(src + 64 * hh), (lds_ptr)(dst + 64 * hh), 16, 0, 0);
       }
     }
     // fp32 feature-major segments (few rows: PE, head inputs, cotangents) and zero padding: convert through registers
-    for (int o = tid >> 7; o < K8; o += 2) {
+    constexpr int OPP = 256 / BMT;                                    // octet rows per pass
+    for (int o = tid / BMT; o < K8; o += OPP) {
       const SegH& sg = (o < oct0) ? a.in[0] : a.in[1];
       const int so = (o < oct0) ? o : o - oct0;
       const bool dma = (o < oct0 + oct1) && sg.bf16 && (so * 8 < sg.rows);
       if (dma) continue;
-      uint4* dst = ldsq + (size_t)o * BMH;
-      if (o < oct0 + oct1 && !sg.bf16) stage_octet(sg, so, p0, a.ldp, dst, tid);
-      else dst[tid & 127] = make_uint4(0u, 0u, 0u, 0u);
+      uint4* dst = ldsq + (size_t)o * BMT;
+      if (o < oct0 + oct1 && !sg.bf16) stage_octet<BMT>(sg, so, p0, a.ldp, dst, tid);
+      else dst[tid & (BMT - 1)] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
   __syncthreads();
   const int KS = a.Kpad >> 4;
-  const uint4* bl = ldsq + (size_t)(lane >> 5) * BMH + (lane & 31);
-  f32x16 acc[2][4];
+  const uint4* bl = ldsq + (size_t)(lane >> 5) * BMT + (lane & 31);
+  f32x16 acc[2][PT];
   if (a.NT > 2) {
     const int tstride = 4 * KS * 64;
     for (int round = 0; round * 8 < a.NT; ++round) {                // wave w owns tiles 8r+w, 8r+w+4
@@ -227,17 +231,17 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < PT; ++q)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
       const uint4* wp0 = a.Wp + (size_t)t0 * KS * 64 + lane;
-      if (ntw == 2) mma_rows_h<2>(acc, wp0, tstride, bl, 0, KS);
-      else mma_rows_h<1>(acc, wp0, tstride, bl, 0, KS);
+      if (ntw == 2) mma_rows_h<2, PT>(acc, wp0, tstride, bl, 0, KS);
+      else mma_rows_h<1, PT>(acc, wp0, tstride, bl, 0, KS);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         if (i < ntw) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) epilogue_tile_h<EPI>(a, acc[i][q], t0 + 4 * i, q, lane, p0);
+          for (int q = 0; q < PT; ++q) epilogue_tile_h<EPI>(a, acc[i][q], t0 + 4 * i, q, lane, p0);
         }
     }
   } else {
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < PT; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
     const int ksplit = 4 / a.NT;
@@ -253,22 +257,22 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
     const int per = (KS + ksplit - 1) / ksplit;
     const int sb = kpart * per, se = min(KS, sb + per);
     const uint4* wp0 = a.Wp + (size_t)tile * KS * 64 + lane;
-    if (sb < se) mma_rows_h<1>(acc, wp0, 0, bl, sb, se);
+    if (sb < se) mma_rows_h<1, PT>(acc, wp0, 0, bl, sb, se);
     __syncthreads();
-    float* red = reinterpret_cast<float*>(ldsq);                    // [4 waves][4 ptiles][16][64] = 64 KB
+    float* red = reinterpret_cast<float*>(ldsq);                    // [4 waves][PT ptiles][16][64]
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < PT; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wave * 4 + q) * 16 + r) * 64 + lane] = acc[0][q][r];
+      for (int r = 0; r < 16; ++r) red[((wave * PT + q) * 16 + r) * 64 + lane] = acc[0][q][r];
     __syncthreads();
     if (kpart == 0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < PT; ++q) {
         f32x16 sum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = 0.0f;
-          for (int kp = 0; kp < ksplit; ++kp) v += red[(((kp * a.NT + tile) * 4 + q) * 16 + r) * 64 + lane];
+          for (int kp = 0; kp < ksplit; ++kp) v += red[(((kp * a.NT + tile) * PT + q) * 16 + r) * 64 + lane];
           sum[r] = v;
         }
         epilogue_tile_h<EPI>(a, sum, tile, q, lane, p0);

@@ -124,18 +124,25 @@ template <int EPI> hipError_t launch_layer_f(hipStream_t st, const LayerArgs& a,
   hipLaunchKernelGGL(layer_kernel<EPI>, dim3(ntiles_p), dim3(WG), lds, st, a);
   return hipGetLastError();
 }
-template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a, int ntiles_p) {
+int g_pt_bf16 = 2;          // 32-point column tiles per workgroup in the bf16 layer kernel: 2 (64 pts, higher occupancy) or 4
+
+template <int EPI, int PT> hipError_t launch_layer_h_pt(hipStream_t st, const LayerArgsH& a) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_h<EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_h<EPI, PT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  size_t lds = (size_t)(a.Kpad / 8) * BMH * 16;
-  if (a.NT <= 2 && lds < 65536) lds = 65536;
-  hipLaunchKernelGGL(layer_kernel_h<EPI>, dim3(ntiles_p), dim3(WG), lds, st, a);
+  constexpr int BMT = 32 * PT;
+  size_t lds = (size_t)(a.Kpad / 8) * BMT * 16;
+  const size_t red = (size_t)4 * PT * 16 * 64 * 4;
+  if (a.NT <= 2 && lds < red) lds = red;
+  hipLaunchKernelGGL((layer_kernel_h<EPI, PT>), dim3(a.ldp / BMT), dim3(WG), lds, st, a);
   return hipGetLastError();
+}
+template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a, int) {
+  return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4>(st, a) : launch_layer_h_pt<EPI, 2>(st, a);
 }
 #define EPI_SWITCH(FN, st, epi, a, nt)                                         \
   switch (epi) {                                                              \
@@ -542,6 +549,11 @@ bool bad_prec(int p) { return p != F32 && p != BF16; }
 extern "C" {
 
 int neat_abi_version(void) { return 2; }
+
+int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
+  if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
+  return -1;
+}
 
 int neat_prof_enable(int on) {
   g_prof.on = on != 0;
