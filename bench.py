@@ -152,7 +152,7 @@ def main():
     roofline = None
     kernels = {}
     if not args.no_prof:
-        for cls, name in ((0, "layer_kernel"), (1, "wgrad_kernel")):
+        for cls, name in ((0, "layer_kernel"), (1, "wgrad_kernel"), (2, "sdf_fused_kernel")):
             ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
             _lib.check(lib.neat_prof_collect(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "neat_prof_collect")
             if n.value:

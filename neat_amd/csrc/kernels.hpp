@@ -287,6 +287,24 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// stage 1 of the split reduction: sum groups of consecutive splits, fully parallel and bandwidth-bound
+//   out[n][g][k] = sum_{s in group g} partial[n][s][k]        (both with row stride = (#splits) * Kld)
+__global__ void wpartial_group_sum_kernel(const float* __restrict__ partial, int splits, int Kld4, int groups, int per,
+                                          int rows, float* __restrict__ out) {
+  const int k4 = blockIdx.x * blockDim.x + threadIdx.x;     // float4 column
+  const int g = blockIdx.y, n = blockIdx.z;
+  if (k4 >= Kld4 || n >= rows) return;
+  const float4* src = reinterpret_cast<const float4*>(partial) + ((size_t)n * splits + (size_t)g * per) * Kld4 + k4;
+  const int cnt = min(per, splits - g * per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int s = 0; s < cnt; ++s) {
+    const float4 v = src[(size_t)s * Kld4];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[((size_t)n * groups + g) * Kld4 + k4] = acc;
+}
+
 // Reduce the split partials for one output row, undo the input-column permutation / fold scale, and
 // apply the weight-norm backward:  W = g v/|v|  =>  dg = <dW, v>/|v| ;  dv = g/|v| (dW - <dW,v> v/|v|^2).
 struct WreduceArgs {

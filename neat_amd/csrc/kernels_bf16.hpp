@@ -19,13 +19,19 @@ typedef unsigned short u16;
 
 constexpr int BMH = 128;         // point-stride granule of the bf16 build (ldp is a multiple of this)
 
-__device__ __forceinline__ u16 f2bf(float f) {            // round to nearest even (finite inputs)
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// float -> bf16 round-to-nearest-even through the compiler's native conversion (v_cvt_pk_bf16_f32 on gfx950: one
+// instruction per PAIR; the hand-rolled add/shift form cost ~5 VALU per value and made the epilogues issue-bound)
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(unsigned, r);
 }
+__device__ __forceinline__ u16 f2bf(float f) { return (u16)(pack2(f, 0.0f) & 0xFFFFu); }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 // branch-free activation math for the bf16 build (hardware exp/log; absolute error ~1e-7, far below bf16 resolution)
 __device__ __forceinline__ float softplus100_fast(float a) {
@@ -50,6 +56,8 @@ struct LayerArgsH {
   void* out0; void* out1;     // out1 receives rows >= n_split (row - n_split)
   int out0_bf16, out1_bf16, n_split, accumulate;
   const u16* aux0; const u16* aux1;     // bf16 octet-major, same row indexing as out0
+  const float* padfill; int padfill_rows;   // rows [N, N+padfill_rows) of out0 receive these fp32 rows (skip layer: the
+                                            // first 7 PE rows ride in the padding of the 217-row h4 octets); out1 gets 0
 };
 
 __device__ __forceinline__ float seg_read_f32(const SegH& s, int row, int p, int ldp) {
@@ -76,69 +84,87 @@ __device__ __forceinline__ void stage_octet(const SegH& s, int oct, int p0, int 
   dst[p] = v;
 }
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_tile_h(const LayerArgsH& a, const f32x16& acc, int nt, int pt, int lane, int p0) {
-  const int p = p0 + pt * 32 + (lane & 31);
+template <int EPI, int PT>
+__device__ __forceinline__ void epilogue_rows_h(const LayerArgsH& a, const f32x16 (&acc)[PT], int nt, int lane, int p0) {
+  // one 32-row output tile x PT point tiles.  Row-dependent state (validity, bias) is built once per 4-row quad and
+  // reused over the point tiles, which keeps the number of live compare masks small (they used to spill by the hundred).
   const int hi = lane >> 5;
+  const int Npad = (a.N + 7) & ~7;
+  const int split_pad = (a.n_split + 7) & ~7;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n0 = nt * 32 + 8 * q + 4 * hi;               // 4 consecutive rows n0..n0+3
-    if (n0 >= ((a.N + 7) & ~7)) continue;                  // rows inside the last valid octet are still written (as zeros)
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
-    const size_t oidx = ((size_t)(n0 >> 3) * a.ldp + p) * 8 + (n0 & 7);     // bf16 element index of row n0 (octet-major)
-    float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_REV || EPI == EPI_TAN || EPI == EPI_BWD || EPI == EPI_BWD_RELU) {
-      const uint2 r = *reinterpret_cast<const uint2*>(a.aux0 + oidx);
-      x0[0] = bf2f((u16)(r.x & 0xFFFF)); x0[1] = bf2f((u16)(r.x >> 16)); x0[2] = bf2f((u16)(r.y & 0xFFFF)); x0[3] = bf2f((u16)(r.y >> 16));
-    }
-    if (EPI == EPI_TAN || EPI == EPI_BWD) {
-      const uint2 r = *reinterpret_cast<const uint2*>(a.aux1 + oidx);
-      x1[0] = bf2f((u16)(r.x & 0xFFFF)); x1[1] = bf2f((u16)(r.x >> 16)); x1[2] = bf2f((u16)(r.y & 0xFFFF)); x1[3] = bf2f((u16)(r.y >> 16));
-    }
-    float o0[4], o1[4];
+    if (n0 >= Npad) continue;                              // rows inside the last valid octet are still written (as zeros)
+    float b[4];
+    bool valid[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = n0 + e;
-      float b = 0.0f;
-      if (a.bias && n < a.N) { int bi = n + a.bias_rot; if (bi >= a.bias_n) bi -= a.bias_n; b = a.bias[bi]; }
-      float r0 = 0.0f, r1 = 0.0f;
-      if (EPI == EPI_LINEAR) r0 = v[e] + b;
-      else if (EPI == EPI_SOFTPLUS) r0 = softplus100_fast(v[e] + b);
-      else if (EPI == EPI_RELU) r0 = fmaxf(v[e] + b, 0.0f);
-      else if (EPI == EPI_SIGMOID) r0 = 1.0f / (1.0f + __expf(-(v[e] + b)));
-      else if (EPI == EPI_REV) r0 = (n < a.n_split) ? v[e] * dphi_fast(x0[e]) : v[e];
-      else if (EPI == EPI_TAN) { const float s = dphi_fast(x0[e]); r0 = v[e] * s; r1 = v[e] * x1[e] * (100.0f * (1.0f - s)); }
-      else if (EPI == EPI_BWD) r0 = v[e] * dphi_fast(x0[e]) + x1[e];
-      else if (EPI == EPI_BWD_RELU) r0 = x0[e] > 0.0f ? v[e] : 0.0f;
-      if (n >= a.N) { r0 = 0.0f; r1 = 0.0f; }             // padded rows of the last octet stay finite zeros
-      o0[e] = r0; o1[e] = r1;
+      valid[e] = n < a.N;
+      b[e] = 0.0f;
+      if (a.bias && valid[e]) { int bi = n + a.bias_rot; if (bi >= a.bias_n) bi -= a.bias_n; b[e] = a.bias[bi]; }
     }
-    if (n0 < a.n_split) {
-      if (a.out0_bf16) {
-        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out0) + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
-      } else {
-        float* o = reinterpret_cast<float*>(a.out0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + e;
-          if (n < a.N && n < a.n_split) {
-            const size_t idx = (size_t)n * a.ldp + p;
-            o[idx] = a.accumulate ? o[idx] + o0[e] : o0[e];
+    for (int pt = 0; pt < PT; ++pt) {
+      const int p = p0 + pt * 32 + (lane & 31);
+      // bf16 element index of row n0 (octet-major); arrays are < 2^31 elements, keep the address math 32-bit
+      const unsigned oidx = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)p) * 8u + (unsigned)(n0 & 7);
+      float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_REV || EPI == EPI_TAN || EPI == EPI_BWD || EPI == EPI_BWD_RELU) {
+        const uint2 r = *reinterpret_cast<const uint2*>(a.aux0 + oidx);
+        x0[0] = bf_lo(r.x); x0[1] = bf_hi(r.x); x0[2] = bf_lo(r.y); x0[3] = bf_hi(r.y);
+      }
+      if (EPI == EPI_TAN || EPI == EPI_BWD) {
+        const uint2 r = *reinterpret_cast<const uint2*>(a.aux1 + oidx);
+        x1[0] = bf_lo(r.x); x1[1] = bf_hi(r.x); x1[2] = bf_lo(r.y); x1[3] = bf_hi(r.y);
+      }
+      float o0[4], o1[4], ox[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + e;
+        const float v = acc[pt][4 * q + e];
+        float r0 = 0.0f, r1 = 0.0f;
+        if (EPI == EPI_LINEAR) r0 = v + b[e];
+        else if (EPI == EPI_SOFTPLUS) r0 = softplus100_fast(v + b[e]);
+        else if (EPI == EPI_RELU) r0 = fmaxf(v + b[e], 0.0f);
+        else if (EPI == EPI_SIGMOID) r0 = 1.0f / (1.0f + __expf(-(v + b[e])));
+        else if (EPI == EPI_REV) r0 = (n < a.n_split) ? v * dphi_fast(x0[e]) : v;
+        else if (EPI == EPI_TAN) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
+        else if (EPI == EPI_BWD) r0 = v * dphi_fast(x0[e]) + x1[e];
+        else if (EPI == EPI_BWD_RELU) r0 = x0[e] > 0.0f ? v : 0.0f;
+        if (!valid[e]) {                                     // padded rows of the last octet: finite zeros, or the pad-fill rows
+          r0 = (a.padfill && n < a.N + a.padfill_rows) ? a.padfill[(unsigned)(n - a.N) * (unsigned)a.ldp + (unsigned)p] : 0.0f;
+          r1 = 0.0f;
+        }
+        ox[e] = r0;                                          // value for out1 when this row lies beyond n_split
+        if (EPI == EPI_REV && a.out0_bf16 && n >= a.n_split) r0 = 0.0f;    // ... and out0's octet stays clean (finite zeros)
+        o0[e] = r0; o1[e] = r1;
+      }
+      if (n0 < split_pad) {                                  // (bf16 out0: finish the octet that contains the split row)
+        if (a.out0_bf16) {
+          *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out0) + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
+        } else {
+          float* o = reinterpret_cast<float*>(a.out0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + e;
+            if (valid[e] && n < a.n_split) {
+              const unsigned idx = (unsigned)n * (unsigned)a.ldp + (unsigned)p;
+              o[idx] = a.accumulate ? o[idx] + o0[e] : o0[e];
+            }
           }
         }
+        if (EPI == EPI_TAN)
+          *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out1) + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
       }
-      if (EPI == EPI_TAN)
-        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out1) + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
-    }
-    if (EPI == EPI_LINEAR || EPI == EPI_REV) {             // split outputs: rows >= n_split go to out1 (fp32 feature-major)
-      if (n0 + 3 >= a.n_split && a.out1) {
-        float* o = reinterpret_cast<float*>(a.out1);
+      if (EPI == EPI_LINEAR || EPI == EPI_REV) {             // split outputs: rows >= n_split go to out1 (fp32 feature-major)
+        if (n0 + 3 >= a.n_split && a.out1) {
+          float* o = reinterpret_cast<float*>(a.out1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + e;
-          if (n >= a.n_split && n < a.N) o[(size_t)(n - a.n_split) * a.ldp + p] = o0[e];
+          for (int e = 0; e < 4; ++e) {
+            const int n = n0 + e;
+            if (n >= a.n_split && valid[e]) o[(unsigned)(n - a.n_split) * (unsigned)a.ldp + (unsigned)p] = ox[e];
+          }
         }
       }
     }
@@ -148,25 +174,25 @@ __device__ __forceinline__ void epilogue_tile_h(const LayerArgsH& a, const f32x1
 template <int NTW, int PT>
 __device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][PT], const uint4* __restrict__ wp0, int tile_stride,
                                            const uint4* __restrict__ bl, int s_begin, int s_end) {
-  constexpr int BMT = 32 * PT;
-  // Weight fragments come from L2 (packed, 1 KiB per wave-load).  One k-step is only 4*NTW MFMAs (~130-260 cycles),
+  // Weight fragments come from L2 (packed, 1 KiB per wave-load).  One k-step is only PT*NTW MFMAs (~130-260 cycles),
   // shorter than an L2 round trip, so keep a 4-deep register ring: the load for step s+3 is issued before the MFMAs of
-  // step s.  Ring slots are compile-time indices (the loop advances by 4).
+  // step s.  The loop is BRANCH-FREE (trip count a multiple of 4, prefetch index clamped at the tail): with guards the
+  // compiler joins control flow with s_waitcnt vmcnt(0) and the ring degenerates into load->wait->use.
+  constexpr int BMT = 32 * PT;
   uint4 ring[4][NTW];
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
-    if (s_begin + u < s_end) {
+  for (int u = 0; u < 3; ++u) {
+    const int sp = min(s_begin + u, s_end - 1);
 #pragma unroll
-      for (int i = 0; i < NTW; ++i) ring[u][i] = wp0[(size_t)i * tile_stride + (s_begin + u) * 64];
-    }
+    for (int i = 0; i < NTW; ++i) ring[u][i] = wp0[(size_t)i * tile_stride + sp * 64];
+  }
   for (int s = s_begin; s < s_end; s += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (s + u >= s_end) break;
-      if (s + u + 3 < s_end) {
+      const int sp = min(s + u + 3, s_end - 1);
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) ring[(u + 3) & 3][i] = wp0[(size_t)i * tile_stride + (s + u + 3) * 64];
-      }
+      for (int i = 0; i < NTW; ++i) ring[(u + 3) & 3][i] = wp0[(size_t)i * tile_stride + sp * 64];
+      __builtin_amdgcn_sched_barrier(0);      // pin the prefetch HERE: the scheduler otherwise sinks it next to its use 3 steps later
       uint4 bv[PT];
 #pragma unroll
       for (int q = 0; q < PT; ++q) bv[q] = bl[(2 * (s + u)) * BMT + q * 32];
@@ -181,7 +207,7 @@ __device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][PT], const uint4* __
 }
 
 template <int EPI, int PT>
-__global__ __launch_bounds__(WG, (PT == 4 ? 2 : 3)) void layer_kernel_h(LayerArgsH a) {
+__global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
   constexpr int BMT = 32 * PT;                                       // points per workgroup: 128 (PT=4) or 64 (PT=2)
   extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];     // [Kpad/8][BMT] octets (16 B each); reused for split-K reduce
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -239,10 +265,7 @@ __global__ __launch_bounds__(WG, (PT == 4 ? 2 : 3)) void layer_kernel_h(LayerArg
       else mma_rows_h<1, PT>(acc, wp0, tstride, bl, 0, KS);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        if (i < ntw) {
-#pragma unroll
-          for (int q = 0; q < PT; ++q) epilogue_tile_h<EPI>(a, acc[i][q], t0 + 4 * i, q, lane, p0);
-        }
+        if (i < ntw) epilogue_rows_h<EPI, PT>(a, acc[i], t0 + 4 * i, lane, p0);
     }
   } else {
     // narrow outputs (N <= 64): split K over the waves, reduce through LDS
@@ -254,7 +277,7 @@ __global__ __launch_bounds__(WG, (PT == 4 ? 2 : 3)) void layer_kernel_h(LayerArg
         for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
     const int ksplit = 4 / a.NT;
     const int tile = wave % a.NT, kpart = wave / a.NT;
-    const int per = (KS + ksplit - 1) / ksplit;
+    const int per = ((KS / 4 + ksplit - 1) / ksplit) * 4;            // k-steps per wave, a multiple of 4 (KS is one too)
     const int sb = kpart * per, se = min(KS, sb + per);
     const uint4* wp0 = a.Wp + (size_t)tile * KS * 64 + lane;
     if (sb < se) mma_rows_h<1, PT>(acc, wp0, 0, bl, sb, se);
@@ -266,17 +289,210 @@ __global__ __launch_bounds__(WG, (PT == 4 ? 2 : 3)) void layer_kernel_h(LayerArg
       for (int r = 0; r < 16; ++r) red[((wave * PT + q) * 16 + r) * 64 + lane] = acc[0][q][r];
     __syncthreads();
     if (kpart == 0) {
+      f32x16 sum[PT];
 #pragma unroll
-      for (int q = 0; q < PT; ++q) {
-        f32x16 sum;
+      for (int q = 0; q < PT; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = 0.0f;
           for (int kp = 0; kp < ksplit; ++kp) v += red[(((kp * a.NT + tile) * PT + q) * 16 + r) * 64 + lane];
-          sum[r] = v;
+          sum[q][r] = v;
         }
-        epilogue_tile_h<EPI>(a, sum, tile, q, lane, p0);
+      epilogue_rows_h<EPI, PT>(a, sum, tile, lane, p0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused SDF primal chain (ImplicitNetwork.forward, rend_a :78-96, + get_sdf_vals' clamp :131-137):
+// PE-6 -> lin0..lin8 for a tile of 32*PT points in ONE launch.  The activation tile lives in LDS (octet-major
+// bf16) and is updated in place layer after layer; weights stream from L2 through the register ring of mma_rows_h.
+//   values mode : only the clamped sdf leaves the chip (the sampler's 128..640 queries per ray: no HBM round trips)
+//   save mode   : every post-activation h_l, the PE rows and the lin8 output are also written for the backward pass
+// ---------------------------------------------------------------------------------------------
+struct FusedArgs {
+  const float* x_fm; int P, ldp;
+  const uint4* Wp[9]; int KS[9]; const float* bias[9];
+  int save, values_only;
+  u16* h[9];                  // h[1..8], octet-major (save mode)
+  float* E;                   // [39][ldp] fp32 (save mode)
+  u16* feat; float* sdfraw;   // lin8 outputs (save mode): 256 feature rows (octet-major) + raw sdf row
+  float* sdf_out;             // values mode: clamped sdf, row-major [P]
+  float radius, scale;
+  int bias8_rot, bias8_n;     // lin8 rows are packed [feature | sdf]
+};
+
+template <int PT, bool VALUES>
+__global__ __launch_bounds__(WG, 2) void sdf_fused_kernel_h(FusedArgs a) {
+  constexpr int BMT = 32 * PT;
+  extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];        // tile [32][BMT] | PE octets [8][BMT] (K padded to 64)
+  uint4* tile = ldsq;
+  uint4* pe = ldsq + 32 * BMT;
+  u16* tile16 = reinterpret_cast<u16*>(tile);
+  u16* pe16 = reinterpret_cast<u16*>(pe);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p0 = blockIdx.x * BMT;
+  // ---- positional encoding (embedder.py:12-36) into the PE octets (rows 39..63 zero)
+  for (int idx = tid; idx < 64 * BMT; idx += WG) {
+    const int j = idx / BMT, p = idx % BMT;
+    float v = 0.0f;
+    if (j < 39) {
+      const int c = j < 3 ? j : (j - 3) % 3;
+      const float xc = a.x_fm[(size_t)c * a.ldp + p0 + p];
+      if (j < 3) v = xc;
+      else {
+        const int k = (j - 3) / 6, is_cos = ((j - 3) % 6) >= 3;
+        const float f = (float)(1 << k);
+        v = is_cos ? __cosf(xc * f) : __sinf(xc * f);      // hardware sin/cos: |arg| <= 96, abs error ~1e-6 << bf16 resolution
       }
+      if (!VALUES && a.save) a.E[(size_t)j * a.ldp + p0 + p] = v;
+    }
+    pe16[((size_t)(j >> 3) * BMT + p) * 8 + (j & 7)] = f2bf(v);
+  }
+  __syncthreads();
+  f32x16 acc[2][PT];
+  const int hi = lane >> 5;
+  // kernarg tables are read through compile-time indices only (a runtime-indexed by-value array would be copied to scratch)
+#define FUSED_SEL(T, field, l, out)                                                                   \
+  T out = a.field[0];                                                                                \
+  _Pragma("unroll") for (int k_ = 1; k_ < 9; ++k_) if ((l) == k_) out = a.field[k_];
+  // ---- hidden layers lin0..lin7
+#pragma unroll 1
+  for (int l = 0; l < 8; ++l) {
+    const int N = (l == 3) ? 217 : 256;
+    const int NT = (N + 31) >> 5;
+    FUSED_SEL(int, KS, l, KS)
+    FUSED_SEL(const uint4*, Wp, l, Wl)
+    FUSED_SEL(const float*, bias, l, bias)
+    FUSED_SEL(u16*, h, l + 1, hsel)
+    const uint4* bl = (l == 0 ? pe : tile) + (size_t)hi * BMT + (lane & 31);
+    const int t0 = wave;
+    const int ntw = (t0 + 4 < NT) ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < PT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
+    const uint4* wp0 = Wl + (size_t)t0 * KS * 64 + lane;
+    if (ntw == 2) mma_rows_h<2, PT>(acc, wp0, 4 * KS * 64, bl, 0, KS);
+    else mma_rows_h<1, PT>(acc, wp0, 4 * KS * 64, bl, 0, KS);
+    __syncthreads();                                               // everyone has read the tile: update it in place
+    u16* hout = (!VALUES && a.save) ? hsel : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= ntw) continue;
+      const int nt = t0 + 4 * i;
+#pragma unroll
+      for (int q = 0; q < PT; ++q) {
+        const int p = q * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = nt * 32 + 8 * g + 4 * hi;
+          if (n0 >= N) continue;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? softplus100_fast(acc[i][q][4 * g + e] + bias[n0 + e]) : 0.0f;
+          const size_t li = ((size_t)(n0 >> 3) * BMT + p) * 8 + (n0 & 7);
+          if (n0 + 3 < N) {
+            const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+            *reinterpret_cast<uint2*>(tile16 + li) = pk;
+            if (hout && l != 3) *reinterpret_cast<uint2*>(hout + ((size_t)(n0 >> 3) * a.ldp + p0 + p) * 8 + (n0 & 7)) = pk;
+          } else {                                                   // lin3: the quad holding row 216 (rows 217.. belong to the PE copy)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n0 + e < N) tile16[li + e] = f2bf(o[e]);
+          }
+        }
+      }
+    }
+    if (l == 3) {
+      __syncthreads();
+      // skip connection (rend_a :87-88): rows 217..255 of lin4's input are the 39 PE rows (the 1/sqrt2 is folded into W4)
+      for (int idx = tid; idx < 39 * BMT; idx += WG) {
+        const int j = idx / BMT, p = idx % BMT, row = 217 + j;
+        tile16[((size_t)(row >> 3) * BMT + p) * 8 + (row & 7)] = pe16[((size_t)(j >> 3) * BMT + p) * 8 + (j & 7)];
+      }
+      if (hout) {                                                    // h4 as the unfused consumers expect it: 217 rows + PE[0..6] in the pad
+        __syncthreads();
+        for (int idx = tid; idx < 28 * BMT; idx += WG) {
+          const int o8 = idx / BMT, p = idx % BMT;
+          reinterpret_cast<uint4*>(hout)[(size_t)o8 * a.ldp + p0 + p] = tile[(size_t)o8 * BMT + p];
+        }
+      }
+    }
+    __syncthreads();
+  }
+#undef FUSED_SEL
+  // ---- lin8
+  const uint4* bl = tile + (size_t)hi * BMT + (lane & 31);
+  const int KS = a.KS[8];
+  if (!VALUES) {
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {                      // tiles 0..7 = features, tile 8 = [sdf, 31 x padding]
+      const int t0 = round * 8 + wave;
+      const int ntw = (round == 0) ? 2 : (t0 < 9 ? 1 : 0);
+      if (ntw == 0) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < PT; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
+      const uint4* wp0 = a.Wp[8] + (size_t)t0 * KS * 64 + lane;
+      if (ntw == 2) mma_rows_h<2, PT>(acc, wp0, 4 * KS * 64, bl, 0, KS);
+      else mma_rows_h<1, PT>(acc, wp0, 4 * KS * 64, bl, 0, KS);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (i >= ntw) continue;
+        const int nt = t0 + 4 * i;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+          const int p = p0 + q * 32 + (lane & 31);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n0 = nt * 32 + 8 * g + 4 * hi;
+            if (n0 >= 257) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              int bi = n0 + e + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
+              o[e] = (n0 + e < 257) ? acc[i][q][4 * g + e] + a.bias[8][bi] : 0.0f;
+            }
+            if (n0 < 256) *reinterpret_cast<uint2*>(a.feat + ((size_t)(n0 >> 3) * a.ldp + p) * 8 + (n0 & 7)) = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+            else a.sdfraw[p] = o[0];
+          }
+        }
+      }
+    }
+  } else {
+    // values mode: lin8 restricted to the sdf row (pack with one 32-row tile): split K over the 4 waves
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < PT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
+    const int per = ((KS / 4 + 3) / 4) * 4;
+    const int sb = wave * per, se = min(KS, sb + per);
+    if (sb < se) mma_rows_h<1, PT>(acc, a.Wp[8] + lane, 0, bl, sb, se);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsq);                    // [4 waves][PT][64]: only accumulator register 0 of lanes 0..31 matters
+    if (hi == 0) {
+#pragma unroll
+      for (int q = 0; q < PT; ++q) red[(wave * PT + q) * 32 + lane] = acc[0][q][0];
+    }
+    __syncthreads();
+    if (tid < BMT) {
+      const int q = tid >> 5, ln = tid & 31;
+      float s = a.bias[8][0];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[(w * PT + q) * 32 + ln];
+      const int p = p0 + tid;
+      if (a.radius > 0.0f) {
+        const float x0 = a.x_fm[p], x1 = a.x_fm[(size_t)a.ldp + p], x2 = a.x_fm[(size_t)2 * a.ldp + p];
+        s = fminf(s, a.scale * (a.radius - sqrtf(x0 * x0 + x1 * x1 + x2 * x2)));
+      }
+      if (p < a.P) a.sdf_out[p] = s;
     }
   }
 }
@@ -573,7 +789,7 @@ __global__ __launch_bounds__(W2T, 2) void wgrad_kernel_h2(WgradArgsH a) {
           const unsigned w4[4] = {blk[f].x, blk[f].y, blk[f].z, blk[f].w};
           float t = 0.0f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t += bf2f((u16)(w4[j] & 0xFFFF)) + bf2f((u16)(w4[j] >> 16));
+          for (int j = 0; j < 4; ++j) t += bf_lo(w4[j]) + bf_hi(w4[j]);
           rsum[f] += t;
         }
       }
@@ -698,7 +914,7 @@ __global__ void adjoint_seed_kernel_h(const float* __restrict__ v8, const float*
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float w0 = v8[oct * 8 + 2 * j] * rs8[0], w1 = v8[oct * 8 + 2 * j + 1] * rs8[0];
-    o[j] = pack2(w0 * dphi_fast(bf2f((u16)(hw[j] & 0xFFFF))), w1 * dphi_fast(bf2f((u16)(hw[j] >> 16))));
+    o[j] = pack2(w0 * dphi_fast(bf_lo(hw[j])), w1 * dphi_fast(bf_hi(hw[j])));
   }
   *reinterpret_cast<uint4*>(u7 + idx) = make_uint4(o[0], o[1], o[2], o[3]);
 }

@@ -7,6 +7,7 @@
 #include "../../include/neat_hip.h"
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 using namespace neat;
@@ -22,7 +23,7 @@ const int kI[NLAYERS] = {39, 256, 256, 256, 256, 256, 256, 256, 256, 289, 256, 2
 constexpr int PE_ROWS = 39, SMALL_R = 33, SMALL_A = 9;
 enum { F32 = 0, BF16 = 1 };
 
-inline int padk(int k, int prec) { return prec ? (k + 15) & ~15 : (k + 7) & ~7; }
+inline int padk(int k, int prec) { return prec ? (k + 63) & ~63 : (k + 7) & ~7; }   // bf16: k-steps of 16, unrolled by 4
 inline int pad8(int k) { return (k + 7) & ~7; }
 inline int tiles32(int n) { return (n + 31) / 32; }
 
@@ -45,7 +46,7 @@ void build_layout(PackLayout& L, int prec) {
     d.s0 = kI[l]; d.s0p = kI[l]; d.off0 = 0; d.off1 = 0;
     if (l == L_REND) { d.s0 = 256; d.s0p = 256; d.off0 = SMALL_R; d.off1 = 0; }          // [feature | p, PE4(view), normal]
     if (l == L_ATTR) { d.s0 = 256; d.s0p = 256; d.off0 = SMALL_A; d.off1 = 0; }          // [feature | p, view, normal]
-    if (l == 4) { d.s0 = 217; d.s0p = prec ? 224 : 217; d.off0 = 0; d.off1 = 217; }       // [h4 | PE]  (skip, rend_a :87-88)
+    if (l == 4) { d.s0 = 217; d.s0p = 217; d.off0 = 0; d.off1 = 217; }                     // [h4 | PE]  (skip, rend_a :87-88)
     d.rot = rot;
     d.scale = (l == 4) ? (float)(1.0 / sqrt(2.0)) : 1.0f;                                 // /sqrt2 of the skip concat folded in
     const int kin = d.s0p + (kI[l] - d.s0);
@@ -80,6 +81,15 @@ NetPtrs to_ptrs(const neat_net_params* net) {
   NetPtrs p;
   for (int l = 0; l < NLAYERS; ++l) { p.v[l] = net->v[l]; p.g[l] = net->g[l]; p.b[l] = net->b[l]; p.O[l] = kO[l]; p.I[l] = kI[l]; }
   return p;
+}
+
+// NEAT_DEBUG=1: synchronise after every GEMM-class launch and log it (fault localisation only)
+inline bool dbg() { static int v = -1; if (v < 0) { const char* e = getenv("NEAT_DEBUG"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
+inline void dbg_sync(hipStream_t st, const char* what, int a, int b, int c2) {
+  if (!dbg()) return;
+  hipError_t e = hipStreamSynchronize(st);
+  fprintf(stderr, "[neat] %s %d %d %d -> %s\n", what, a, b, c2, hipGetErrorString(e));
+  fflush(stderr);
 }
 
 #define NEAT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -181,7 +191,8 @@ const In NOIN = In{Arr{}, 0};
 
 // out[n][p] = epi(Wm in + bias) with Wm = pack `pid`; N <= pack rows (only the leading rows are computed)
 hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bias, int N, Arr out0, Arr out1 = Arr{},
-                 int n_split = 1 << 30, Arr aux0 = Arr{}, Arr aux1 = Arr{}, int accumulate = 0, int bias_rot = 0, int bias_n = 1 << 30) {
+                 int n_split = 1 << 30, Arr aux0 = Arr{}, Arr aux1 = Arr{}, int accumulate = 0, int bias_rot = 0, int bias_n = 1 << 30,
+                 const float* padfill = nullptr, int padfill_rows = 0) {
   const PackDesc2& d = c.L().d[pid];
   const float* wp = c.packed + d.offset;
   const int k_in = (c.prec && in1.rows > 0 ? pad8(in0.rows) : in0.rows) + in1.rows;
@@ -206,10 +217,12 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
     a.out0 = out0.p; a.out1 = out1.p; a.out0_bf16 = out0.bf16; a.out1_bf16 = out1.bf16;
     a.n_split = n_split; a.accumulate = accumulate;
     a.aux0 = reinterpret_cast<const u16*>(aux0.p); a.aux1 = reinterpret_cast<const u16*>(aux1.p);
+    a.padfill = padfill; a.padfill_rows = padfill_rows;
     if ((aux0.p && !aux0.bf16) || (aux1.p && !aux1.bf16) || (out1.p && (out1.bf16 != (epi == EPI_TAN)))) return hipErrorInvalidValue;
     e = dispatch_h(c.st, epi, a, c.ldp / BMH);
   }
   prof_end(c.st, ps);
+  dbg_sync(c.st, "layer pid/epi/N", pid, epi, N);
   return e;
 }
 
@@ -228,7 +241,9 @@ constexpr int WLDN = 384, WLDK = 384;       //             partial tile leading 
 constexpr int W2SPLIT = 256;                // bf16 build (256x256 tiles): splits and leading dims
 constexpr int W2LDN = 288, W2LDK = 320;
 constexpr int W2_LDS_BYTES = 2 * 256 * HLD + 8 * 8 * 64 * 16;      // operand tiles + raw DMA ring
-constexpr size_t WPARTIAL_FLOATS = (size_t)W2SPLIT * W2LDN * W2LDK;   // >= WSPLIT*WLDN*WLDK
+constexpr int WGROUPS = 8;                  // stage-1 groups of the split reduction
+constexpr size_t WSTAGE_FLOATS = (size_t)WGROUPS * WLDN * WLDK;
+constexpr size_t WPARTIAL_FLOATS = (size_t)W2SPLIT * W2LDN * W2LDK + WSTAGE_FLOATS;   // >= WSPLIT*WLDN*WLDK + stage
 
 SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
   SdfWs w{};
@@ -281,9 +296,35 @@ inline int round_ldp(int P, int prec) { const int t = prec ? BMH : BM; return (P
 // ------------------------------------------------------------------------------------------------
 // SDF network chains
 // ------------------------------------------------------------------------------------------------
-// primal chain  (ImplicitNetwork.forward, rend_a :78-96); full = also the 256 feature rows
-hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full) {
+// primal chain  (ImplicitNetwork.forward, rend_a :78-96); full = also the 256 feature rows and everything backward needs
+// sdf_out (values mode only): clamped sdf, row-major
+hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.f, float scale = 0.f, float* sdf_out = nullptr) {
   const PackLayout& L = c.L();
+  if (c.prec) {
+    // bf16 build: ONE fused launch, activation tile resident in LDS
+    FusedArgs a{};
+    a.x_fm = w.x; a.P = c.P; a.ldp = c.ldp;
+    for (int l = 0; l < 9; ++l) {
+      const PackDesc2& d = L.d[(l == 8 && !full) ? L.sdf_row : L.fwd[l]];
+      a.Wp[l] = reinterpret_cast<const uint4*>(c.packed + d.offset);
+      a.KS[l] = d.Kpad >> 4;
+      a.bias[l] = c.net->b[l];
+      a.h[l] = l ? reinterpret_cast<u16*>(w.h[l].p) : nullptr;
+    }
+    a.save = full; a.values_only = !full;
+    a.E = w.E; a.feat = reinterpret_cast<u16*>(w.feat.p); a.sdfraw = w.sdfraw; a.sdf_out = sdf_out;
+    a.radius = radius; a.scale = scale; a.bias8_rot = 1; a.bias8_n = 257;
+    constexpr int PT = 2;
+    const size_t lds = (size_t)(32 + 8) * (32 * PT) * 16;
+    double fl = 0.0;
+    for (int l = 0; l < 8; ++l) fl += 2.0 * kO[l] * kI[l] * (double)c.P;
+    fl += 2.0 * (full ? 257 : 1) * 256 * (double)c.P;
+    ProfSlot* ps = prof_begin(c.st, 2, fl);
+    if (full) hipLaunchKernelGGL((sdf_fused_kernel_h<PT, false>), dim3(c.ldp / (32 * PT)), dim3(WG), lds, c.st, a);
+    else hipLaunchKernelGGL((sdf_fused_kernel_h<PT, true>), dim3(c.ldp / (32 * PT)), dim3(WG), lds, c.st, a);
+    prof_end(c.st, ps);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(posenc6_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, c.ldp, w.E);
   hipError_t e;
   for (int l = 0; l < 8; ++l) {
@@ -292,9 +333,7 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full) {
     if ((e = layer(c, L.fwd[l], EPI_SOFTPLUS, a, b, c.net->b[l], kO[l], w.h[l + 1])) != hipSuccess) return e;
   }
   if (!full) return layer(c, L.sdf_row, EPI_LINEAR, in(w.h[8], 256), NOIN, c.net->b[8], 1, F(w.sdfraw));
-  if (!c.prec) return layer(c, L.fwd[8], EPI_LINEAR, in(w.h[8], 256), NOIN, c.net->b[8], 257, F(w.sdfraw));
-  // bf16: packed rows [feature(256) | sdf]: features -> octet-major bf16, the sdf row stays fp32
-  return layer(c, L.fwd[8], EPI_LINEAR, in(w.h[8], 256), NOIN, c.net->b[8], 257, w.feat, F(w.sdfraw), 256, Arr{}, Arr{}, 0, 1, 257);
+  return layer(c, L.fwd[8], EPI_LINEAR, in(w.h[8], 256), NOIN, c.net->b[8], 257, F(w.sdfraw));
 }
 
 // adjoint chain: u_l = d sdf_raw / d a_l, then e0/es = cotangent of the PE rows (autograd.grad at rend_a :121-127)
@@ -309,8 +348,7 @@ hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w) {
   hipError_t e;
   for (int l = 7; l >= 1; --l) {
     if (l == 4) {
-      const int split = c.prec ? 224 : 217;
-      e = layer(c, L.tr[l], EPI_REV, in(w.u[l], kO[l]), NOIN, nullptr, split + PE_ROWS, w.u[l - 1], F(w.es), split, w.h[l]);
+      e = layer(c, L.tr[l], EPI_REV, in(w.u[l], kO[l]), NOIN, nullptr, 256, w.u[l - 1], F(w.es), 217, w.h[l]);
     } else {
       e = layer(c, L.tr[l], EPI_REV, in(w.u[l], kO[l]), NOIN, nullptr, kI[l], w.u[l - 1], Arr{}, 1 << 30, w.h[l]);
     }
@@ -377,12 +415,23 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
   }
   r.partial = w.partial; r.splits = splits;
+  if (splits > 2 * WGROUPS) {
+    // two-stage, deterministic: bandwidth-bound group sums first, then the per-row finish on 8 partials
+    const int Kld = (int)r.split_stride, per = (splits + WGROUPS - 1) / WGROUPS;
+    float* stage = w.partial + (WPARTIAL_FLOATS - WSTAGE_FLOATS);
+    hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld / 4 + 127) / 128, WGROUPS, N), dim3(128), 0, c.st,
+                       w.partial, splits, Kld / 4, WGROUPS, per, N, stage);
+    r.partial = stage; r.splits = (splits + per - 1) / per;
+    r.row_stride = (size_t)WGROUPS * Kld; r.split_stride = Kld;
+  }
   r.O = kO[layer_id]; r.I = kI[layer_id];
   r.s0 = d.s0; r.s0p = d.s0p; r.off0 = d.off0; r.off1 = d.off1; r.rot = d.rot; r.scale = d.scale;
   r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
   r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
   r.bias_col = K;
+  dbg_sync(c.st, "wgrad layer/N/K", layer_id, N, K);
   hipLaunchKernelGGL(wreduce_wnorm_kernel, dim3(r.O), dim3(WG), 0, c.st, r);
+  dbg_sync(c.st, "wreduce layer/splits", layer_id, splits, 0);
   return hipGetLastError();
 }
 
@@ -393,10 +442,14 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   hipLaunchKernelGGL(posenc6_tangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
   hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, c.P, c.ldp);
   // tangent chain (forward-mode along g^): vh_{l+1} = tangent of h_{l+1}, m_l = extra cotangent of a_l
+  // bf16 build: the 217-row arrays of the skip layer carry the first 7 PE rows in the padding of their last octet, so
+  // lin4's input is [h4 | PE0..6] (224 rows, octet aligned) + PE7..38 (32 rows) = 256 columns
   for (int l = 0; l < 8; ++l) {
-    In a = l == 0 ? in(F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? 217 : 256);
-    In b = l == 4 ? in(F(w.Eh), PE_ROWS) : NOIN;
-    if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l])) != hipSuccess) return e;
+    In a = l == 0 ? in(F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? (c.prec ? 224 : 217) : 256);
+    In b = l == 4 ? (c.prec ? in(F(w.Eh + 7 * (size_t)c.ldp), 32) : in(F(w.Eh), PE_ROWS)) : NOIN;
+    const bool fill = c.prec && l == 3;
+    if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l], 0, 0, 1 << 30,
+                   fill ? w.Eh : nullptr, fill ? 7 : 0)) != hipSuccess) return e;
   }
   // reverse chain: a^_{l-1} = (W_l^T a^_l) phi'(a_{l-1}) + m_{l-1}   (in place in m)
   if (!c.prec) e = layer(c, L.tr[8], EPI_BWD, in(F(w.abar8), 257), NOIN, nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
@@ -416,8 +469,13 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       pr[0].B[0] = F(w.E); pr[0].rowsB[0] = PE_ROWS;
       pr[1].B[0] = F(w.Eh); pr[1].rowsB[0] = PE_ROWS;
     } else if (l == 4) {
-      pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 217; pr[0].B[1] = F(w.E); pr[0].rowsB[1] = PE_ROWS;
-      pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 217; pr[1].B[1] = F(w.Eh); pr[1].rowsB[1] = PE_ROWS;
+      if (c.prec) {
+        pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 224; pr[0].B[1] = F(w.E + 7 * (size_t)c.ldp); pr[0].rowsB[1] = 32;
+        pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 224; pr[1].B[1] = F(w.Eh + 7 * (size_t)c.ldp); pr[1].rowsB[1] = 32;
+      } else {
+        pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 217; pr[0].B[1] = F(w.E); pr[0].rowsB[1] = PE_ROWS;
+        pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 217; pr[1].B[1] = F(w.Eh); pr[1].rowsB[1] = PE_ROWS;
+      }
     } else {
       pr[0].B[0] = w.h[l]; pr[0].rowsB[0] = 256;
       pr[1].B[0] = w.vh[l]; pr[1].rowsB[0] = 256;
@@ -617,6 +675,10 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   SdfWs w = sdf_ws(ws, c.ldp, mode, precision);
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
+  if (mode == 0 && precision) {
+    NEAT_CHECK(sdf_primal(c, w, false, radius, scale, sdf));      // fused: PE -> 9 layers -> clamp, one launch
+    return (int)hipGetLastError();
+  }
   if (mode == 0) {
     NEAT_CHECK(sdf_primal(c, w, false));
     hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, (const float*)nullptr,

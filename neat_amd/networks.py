@@ -215,6 +215,11 @@ class VolSDFNetwork(_HipModule):
         self.set_precision(conf.get_string("hip_precision", default="fp32"))      # new optional key, default = parity build
 
     # ---- HIP plumbing ----------------------------------------------------------------------------
+    def set_precision(self, precision):
+        super().set_precision(precision)
+        self.handle()                  # the SDF sub-module shares this handle (and therefore the precision)
+        return self
+
     def handle(self):
         h = self._handle()
         h.set_layers(0, _triples(self.implicit_network, 9))
