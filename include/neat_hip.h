@@ -102,6 +102,25 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
                          const float* d_rgb, const float* d_lines3d, const float* d_depth, const float* d_xyz,
                          const float* d_eik_grad, const neat_net_grads* grads, float* dbeta_ray, void* stream);
 
+/* ---- a3: ErrorBoundSampler bookkeeping (model/ray_sampler.py:130-293), one wavefront per ray --------------------
+ * One round of Algorithm 1 = neat_sdf_forward(mode 0) on the new samples, then:
+ *  neat_sampler_bound    : merge the sdf values (order from the previous round, :152-157), d* per interval (:161-173),
+ *                          per-ray bisection of beta on [beta0, beta_in] (:177-185, get_error_bound :285-293);
+ *                          *flag |= 1 if any ray still has beta > beta0 (the batch-global test of :200 -- the host
+ *                          reads the flag once per round, as the reference syncs once per round).
+ *  neat_sampler_resample : pdf (error-bound opacity :205-215 if refine, rendering weights + 1e-5 :217-226 otherwise),
+ *                          CDF, inverse-CDF sampling at u (:237-249); refine also emits the sorted union with the old
+ *                          grid and its gather order (:254).  u has N entries per ray (u_stride = N) or is shared (0).
+ *  neat_sampler_finish   : [final samples | near | far | picked grid points] sorted (:259-272) and the eikonal depth.
+ * All tensors row-major; n, N <= 1024. */
+int neat_sampler_bound(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
+                       const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out,
+                       int* flag, void* stream);
+int neat_sampler_resample(const float* z, const float* sdf, int n, int R, const float* beta, int refine, float add_tiny,
+                          const float* u, int u_stride, int N, float* samples, float* z_merged, int* order, void* stream);
+int neat_sampler_finish(const float* samples, int N, const float* z, int n, const int* pick, int n_extra, float near, float far,
+                        int R, const int* eik_idx, float* z_vals, float* z_eik, void* stream);
+
 /* ---- a9 alone: volume_rendering :540-554 given sdf [R,S] -> weights [R,S] (used by tests) -------- */
 int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream);
 

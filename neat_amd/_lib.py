@@ -41,6 +41,12 @@ _SIGNATURES = {
                                            c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
+    "neat_sampler_bound": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp,
+                                          ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "neat_sampler_resample": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_float,
+                                             c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "neat_sampler_finish": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_volume_weights": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_set_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "neat_prof_enable": (ctypes.c_int, [ctypes.c_int]),

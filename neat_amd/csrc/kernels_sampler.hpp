@@ -1,0 +1,219 @@
+// Per-ray kernels for the ErrorBoundSampler (VolSDF Algorithm 1; reference: code/model/ray_sampler.py:130-293).
+// One wavefront per ray, the ray's samples (<= SMAX) live in LDS; prefix sums are wave scans with a cross-chunk
+// carry.  The batch-global convergence test of the reference (`beta.max() > beta0`, :200) is a device flag that
+// the host reads once per round -- the same single sync the reference has.
+#pragma once
+#include "kernels.hpp"
+
+namespace neat {
+
+constexpr int SMAX = 1024;      // max samples per ray inside the sampler (reference: 128 * max_total_iters = 640)
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// d* of Theorem 1 per interval (:161-173)
+__device__ __forceinline__ float interval_bound(float a, float d0, float d1) {
+  const float b = fabsf(d0), c = fabsf(d1);
+  const bool c1 = a * a + b * b <= c * c;
+  const bool c2 = a * a + c * c <= b * b;
+  float ds = 0.0f;
+  if (c1) ds = b;
+  if (c2) ds = c;
+  const float s = (a + b + c) / 2.0f;
+  const float area = s * (s - a) * (s - b) * (s - c);
+  if (!c1 && !c2 && (b + c - a > 0.0f)) ds = 2.0f * sqrtf(area) / a;
+  const float sg0 = (d0 > 0.f) ? 1.f : ((d0 < 0.f) ? -1.f : 0.f), sg1 = (d1 > 0.f) ? 1.f : ((d1 < 0.f) ? -1.f : 0.f);
+  return (sg1 * sg0 == 1.0f) ? ds : 0.0f;
+}
+
+// max_i of the opacity error bound for one beta (get_error_bound, :285-293); arrays in LDS, m = n-1 intervals
+__device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
+  float carryE = 0.0f, carryS = 0.0f, best = -INFINITY;
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + lane;
+    const bool ok = j < m;
+    float e = 0.0f, s = 0.0f;
+    if (ok) {
+      const float d = dist[j];
+      e = d * laplace_sigma(sdf[j], beta);
+      s = expf(-dstar[j] / beta) * (d * d) / (4.0f * beta * beta);
+    }
+    const float inclE = wave_incl_scan(e, lane), inclS = wave_incl_scan(s, lane);
+    float exclE = __shfl_up(inclE, 1);
+    if (lane == 0) exclE = 0.0f;
+    if (ok) best = fmaxf(best, (fminf(expf(carryS + inclS), 1.0e6f) - 1.0f) * expf(-(carryE + exclE)));
+    carryE += __shfl(inclE, 63);
+    carryS += __shfl(inclS, 63);
+  }
+  return wave_max(best);
+}
+
+struct SamplerBoundArgs {
+  const float* z; int n, R;                  // [R,n] sorted depths
+  const float* sdf_old; const float* sdf_new; const int* order; int n_old;   // merged sdf = gather(cat[old,new], order); order==null: sdf_new is [R,n]
+  const float* beta_in; const float* beta0;  // [R], device scalar
+  float eps; int iters;
+  float* sdf_out; float* beta_out; int* flag;   // merged sdf [R,n], new beta [R], flag |= (beta > beta0)
+};
+
+__global__ __launch_bounds__(64) void sampler_bound_kernel(SamplerBoundArgs a) {
+  __shared__ float ssdf[SMAX], sdist[SMAX], sdstar[SMAX];
+  const int r = blockIdx.x, lane = threadIdx.x, n = a.n;
+  const float* z = a.z + (size_t)r * n;
+  for (int j = lane; j < n; j += 64) {
+    float v;
+    if (a.order) {
+      const int o = a.order[(size_t)r * n + j];
+      v = o < a.n_old ? a.sdf_old[(size_t)r * a.n_old + o] : a.sdf_new[(size_t)r * (n - a.n_old) + (o - a.n_old)];
+    } else {
+      v = a.sdf_new[(size_t)r * n + j];
+    }
+    ssdf[j] = v;
+    a.sdf_out[(size_t)r * n + j] = v;
+  }
+  __syncthreads();
+  const int m = n - 1;
+  for (int j = lane; j < m; j += 64) {
+    const float d = z[j + 1] - z[j];
+    sdist[j] = d;
+    sdstar[j] = interval_bound(d, ssdf[j], ssdf[j + 1]);
+  }
+  __syncthreads();
+  const float beta0 = *a.beta0;
+  float hi = a.beta_in[r];
+  if (error_bound(ssdf, sdist, sdstar, m, beta0, lane) <= a.eps) hi = beta0;      // (:177-178)
+  float lo = beta0;
+  for (int it = 0; it < a.iters; ++it) {                                           // bisection (:179-185)
+    const float mid = (lo + hi) / 2.0f;
+    const float err = error_bound(ssdf, sdist, sdstar, m, mid, lane);
+    if (err <= a.eps) hi = mid;
+    if (err > a.eps) lo = mid;
+  }
+  if (lane == 0) {
+    a.beta_out[r] = hi;
+    if (hi > beta0) atomicOr(a.flag, 1);
+  }
+}
+
+struct SamplerResampleArgs {
+  const float* z; const float* sdf; int n, R;   // [R,n]
+  const float* beta;                            // [R]
+  int refine; float add_tiny;                   // refine: error-bound pdf + merge; else: weights pdf (final set)
+  const float* u; int u_stride; int N;          // u [N] (stride 0) or [R,N]
+  float* samples;                               // [R,N]
+  float* z_merged; int* order;                  // refine: [R,n+N] sorted union and its source index into cat[z, samples]
+};
+
+__global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArgs a) {
+  __shared__ float sz[SMAX], scdf[SMAX], ssmp[SMAX];
+  __shared__ float ssdf[SMAX];
+  const int r = blockIdx.x, lane = threadIdx.x, n = a.n, m = n - 1;
+  const float beta = a.beta[r];
+  for (int j = lane; j < n; j += 64) { sz[j] = a.z[(size_t)r * n + j]; ssdf[j] = a.sdf[(size_t)r * n + j]; }
+  __syncthreads();
+  // pdf over the n-1 intervals -> scdf[1..n-1] (unnormalised), total in `sum`
+  float carryE = 0.0f, carryS = 0.0f, sum = 0.0f;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int j = c0 + lane;
+    const bool ok = j < n;
+    float e = 0.0f, s = 0.0f;
+    if (ok) {
+      const float d = (j < m) ? sz[j + 1] - sz[j] : 1e10f;
+      e = d * laplace_sigma(ssdf[j], beta);
+      if (j < m) s = expf(-interval_bound(d, ssdf[j], ssdf[j + 1]) / beta) * (d * d) / (4.0f * beta * beta);
+    }
+    const float inclE = wave_incl_scan(e, lane), inclS = wave_incl_scan(s, lane);
+    float exclE = __shfl_up(inclE, 1);
+    if (lane == 0) exclE = 0.0f;
+    const float T = expf(-(carryE + exclE));
+    float pdf = 0.0f;
+    if (j < m) {
+      if (a.refine) pdf = (fminf(expf(carryS + inclS), 1.0e6f) - 1.0f) * T + a.add_tiny;      // (:205-211)
+      else pdf = (1.0f - expf(-e)) * T + 1e-5f;                                                  // (:220-222)
+      scdf[j + 1] = pdf;
+    }
+    sum += wave_sum(pdf);
+    carryE += __shfl(inclE, 63);
+    carryS += __shfl(inclS, 63);
+  }
+  __syncthreads();
+  // normalise, then inclusive cumsum -> cdf[0..n-1] with cdf[0] = 0
+  float carry = 0.0f;
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + lane;
+    const float p = (j < m) ? scdf[j + 1] / sum : 0.0f;
+    const float incl = wave_incl_scan(p, lane);
+    if (j < m) scdf[j + 1] = carry + incl;
+    carry += __shfl(incl, 63);
+  }
+  if (lane == 0) scdf[0] = 0.0f;
+  __syncthreads();
+  // inverse CDF (:237-249): searchsorted(right) + lerp with the 1e-5 denominator guard
+  for (int k = lane; k < a.N; k += 64) {
+    const float u = a.u[(size_t)r * a.u_stride + k];
+    int lo = 0, hi = n;                          // first index with cdf[idx] > u
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (scdf[mid] > u) hi = mid; else lo = mid + 1; }
+    const int below = max(lo - 1, 0), above = min(lo, n - 1);
+    float den = scdf[above] - scdf[below];
+    if (den < 1e-5f) den = 1.0f;
+    const float t = (u - scdf[below]) / den;
+    const float smp = sz[below] + t * (sz[above] - sz[below]);
+    ssmp[k] = smp;
+    a.samples[(size_t)r * a.N + k] = smp;
+  }
+  if (!a.refine) return;
+  __syncthreads();
+  // sorted union of z (sorted) and the new samples (sorted: u is increasing): rank by binary search, old first on ties
+  const int tot = n + a.N;
+  for (int j = lane; j < n; j += 64) {
+    const float v = sz[j];
+    int lo = 0, hi = a.N;                        // #samples < v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ssmp[mid] < v) lo = mid + 1; else hi = mid; }
+    a.z_merged[(size_t)r * tot + j + lo] = v;
+    a.order[(size_t)r * tot + j + lo] = j;
+  }
+  for (int k = lane; k < a.N; k += 64) {
+    const float v = ssmp[k];
+    int lo = 0, hi = n;                          // #z <= v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sz[mid] <= v) lo = mid + 1; else hi = mid; }
+    a.z_merged[(size_t)r * tot + k + lo] = v;
+    a.order[(size_t)r * tot + k + lo] = n + k;
+  }
+}
+
+struct SamplerFinishArgs {
+  const float* samples; int N;        // [R,N] final samples
+  const float* z; int n;              // [R,n] sampler grid
+  const int* pick; int n_extra;       // indices into the grid (shared by all rays), (:263-268)
+  float near, far; int R;
+  const int* eik_idx;                 // [R] index into the output row (:275-276)
+  float* z_vals; float* z_eik;        // [R, N+2+n_extra] sorted, [R]
+};
+
+__global__ __launch_bounds__(64) void sampler_finish_kernel(SamplerFinishArgs a) {
+  __shared__ float v[SMAX];
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int M = a.N + 2 + a.n_extra;
+  for (int k = lane; k < M; k += 64) {
+    float x;
+    if (k < a.N) x = a.samples[(size_t)r * a.N + k];
+    else if (k == a.N) x = a.near;
+    else if (k == a.N + 1) x = a.far;
+    else x = a.z[(size_t)r * a.n + a.pick[k - a.N - 2]];
+    v[k] = x;
+  }
+  __syncthreads();
+  for (int k = lane; k < M; k += 64) {          // rank sort (M ~ 100): ties broken by position
+    const float x = v[k];
+    int rank = 0;
+    for (int j = 0; j < M; ++j) rank += (v[j] < x) || (v[j] == x && j < k);
+    a.z_vals[(size_t)r * M + rank] = x;
+    if (rank == a.eik_idx[r]) a.z_eik[r] = x;
+  }
+}
+
+}  // namespace neat

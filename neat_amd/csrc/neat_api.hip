@@ -4,6 +4,7 @@
 // feature-major activations (parity build), precision 1 = bf16 MFMA (fp32 accumulate) with bf16 octet-major
 // hidden activations (throughput build).  Small arrays are fp32 feature-major in both.
 #include "kernels_bf16.hpp"
+#include "kernels_sampler.hpp"
 #include "../../include/neat_hip.h"
 #include <math.h>
 #include <stdio.h>
@@ -794,6 +795,34 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
                      w.gh, Pm, d_eik_grad);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_bound(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
+                       const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out,
+                       int* flag, void* stream) {
+  if (R <= 0) return 0;
+  if (n < 2 || n > SMAX || !z || !sdf_new || !beta_in || !beta0 || !sdf_out || !beta_out || !flag) return -1;
+  SamplerBoundArgs a{z, n, R, sdf_old, sdf_new, order, n_old, beta_in, beta0, eps, iters, sdf_out, beta_out, flag};
+  hipLaunchKernelGGL(sampler_bound_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_resample(const float* z, const float* sdf, int n, int R, const float* beta, int refine, float add_tiny,
+                          const float* u, int u_stride, int N, float* samples, float* z_merged, int* order, void* stream) {
+  if (R <= 0) return 0;
+  if (n < 2 || n > SMAX || N < 1 || N > SMAX || !z || !sdf || !beta || !u || !samples || (refine && (!z_merged || !order))) return -1;
+  SamplerResampleArgs a{z, sdf, n, R, beta, refine, add_tiny, u, u_stride, N, samples, z_merged, order};
+  hipLaunchKernelGGL(sampler_resample_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_finish(const float* samples, int N, const float* z, int n, const int* pick, int n_extra, float near, float far,
+                        int R, const int* eik_idx, float* z_vals, float* z_eik, void* stream) {
+  if (R <= 0) return 0;
+  if (N + 2 + n_extra > SMAX || !samples || !z || (n_extra > 0 && !pick) || !eik_idx || !z_vals || !z_eik) return -1;
+  SamplerFinishArgs a{samples, N, z, n, pick, n_extra, near, far, R, eik_idx, z_vals, z_eik};
+  hipLaunchKernelGGL(sampler_finish_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -254,3 +254,53 @@ def volume_weights(z, sdf, beta):
     w = torch.empty_like(z)
     _lib.check(lib.neat_volume_weights(_p(z), _p(sdf), z.shape[0], z.shape[1], _p(beta_d), _p(w), _stream()), "neat_volume_weights")
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a3: per-ray sampler kernels (ErrorBoundSampler bookkeeping)
+# ---------------------------------------------------------------------------------------------------------------
+def sampler_bound(z, sdf_old, sdf_new, order, beta_in, beta0, eps, iters, flag):
+    """-> (merged sdf [R,n], new per-ray beta [R]); flag (int32[1]) |= any(beta > beta0)."""
+    lib = _lib.lib()
+    z = _f32c(z)
+    R, n = z.shape
+    sdf_new = _f32c(sdf_new)
+    n_old = 0
+    if order is not None:
+        sdf_old = _f32c(sdf_old)
+        n_old = sdf_old.shape[1]
+        order = order.contiguous()
+    sdf_out = torch.empty(R, n, device=z.device)
+    beta_out = torch.empty(R, device=z.device)
+    _lib.check(lib.neat_sampler_bound(_p(z), n, R, _p(sdf_old) if order is not None else None, _p(sdf_new),
+                                      _p(order), n_old, _p(_f32c(beta_in)), _p(_f32c(beta0.reshape(1))), float(eps), int(iters),
+                                      _p(sdf_out), _p(beta_out), _p(flag), _stream()), "neat_sampler_bound")
+    return sdf_out, beta_out
+
+
+def sampler_resample(z, sdf, beta, u, refine, add_tiny=0.0):
+    """-> samples [R,N] (and, when refining, the sorted union [R,n+N] with its int32 gather order)."""
+    lib = _lib.lib()
+    z, sdf, beta, u = _f32c(z), _f32c(sdf), _f32c(beta), _f32c(u)
+    R, n = z.shape
+    N = u.shape[-1]
+    stride = N if u.dim() == 2 else 0
+    samples = torch.empty(R, N, device=z.device)
+    zm = torch.empty(R, n + N, device=z.device) if refine else None
+    order = torch.empty(R, n + N, device=z.device, dtype=torch.int32) if refine else None
+    _lib.check(lib.neat_sampler_resample(_p(z), _p(sdf), n, R, _p(beta), int(bool(refine)), float(add_tiny), _p(u), stride, N,
+                                         _p(samples), _p(zm), _p(order), _stream()), "neat_sampler_resample")
+    return samples, zm, order
+
+
+def sampler_finish(samples, z, pick, near, far, eik_idx):
+    """-> z_vals [R, N+2+len(pick)] sorted, z_eik [R,1]."""
+    lib = _lib.lib()
+    samples, z = _f32c(samples), _f32c(z)
+    R, N = samples.shape
+    n_extra = 0 if pick is None else pick.numel()
+    out = torch.empty(R, N + 2 + n_extra, device=z.device)
+    zeik = torch.empty(R, 1, device=z.device)
+    _lib.check(lib.neat_sampler_finish(_p(samples), N, _p(z), z.shape[1], _p(pick), n_extra, float(near), float(far), R,
+                                       _p(eik_idx), _p(out), _p(zeik), _stream()), "neat_sampler_finish")
+    return out, zeik

@@ -117,6 +117,48 @@ class ErrorBoundSampler(RaySampler):
         return ((torch.exp(err).clamp(max=1.0e6) - 1.0) * torch.exp(-opt_depth[:, :-1])).max(-1)[0]
 
     def get_z_vals(self, ray_dirs, cam_loc, model):
+        """Algorithm 1 with the per-ray work in HIP (neat_sampler_* kernels, one wavefront per ray) and the MLP queries in
+        the SDF kernels.  Control flow, the one host sync per round and the CPU random draws follow the reference."""
+        from . import ops
+        dev, R = ray_dirs.device, ray_dirs.shape[0]
+        beta0 = model.density.get_beta().detach()
+        z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
+        fresh, order, sdf = z, None, None
+        gap = z[:, 1:] - z[:, :-1]
+        beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (gap ** 2.0).sum(-1))
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        rounds, open_ = 0, True
+        while open_ and rounds < self.max_total_iters:
+            pts = (cam_loc.unsqueeze(1) + fresh.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+            with torch.no_grad():
+                new_sdf = model.implicit_network.get_sdf_vals(pts).reshape(R, -1)
+            flag.zero_()
+            sdf, beta = ops.sampler_bound(z, sdf, new_sdf, order, beta, beta0, self.eps, self.beta_iters, flag)
+            rounds += 1
+            open_ = bool(flag.item())                       # batch-global `beta.max() > beta0`, one host sync per round (:200)
+            refine = open_ and rounds < self.max_total_iters
+            n = self.N_samples_eval if refine else self.N_samples
+            if refine or not model.training:
+                u = torch.linspace(0.0, 1.0, n, device=dev)
+            else:
+                u = torch.rand(R, n).to(dev)
+            fresh, zm, order = ops.sampler_resample(z, sdf, beta, u, refine, self.add_tiny)
+            if refine:
+                z = zm
+        self.last_rounds = rounds
+        pick = None
+        if self.N_samples_extra > 0:
+            if model.training:
+                pick = torch.randperm(z.shape[1])[:self.N_samples_extra]
+            else:
+                pick = torch.linspace(0, z.shape[1] - 1, self.N_samples_extra).long()
+            pick = pick.to(torch.int32).to(dev)
+        n_out = self.N_samples + 2 + (self.N_samples_extra if self.N_samples_extra > 0 else 0)
+        eik_idx = torch.randint(n_out, (R,)).to(torch.int32).to(dev)
+        return ops.sampler_finish(fresh, z, pick, self.near, self.far, eik_idx)
+
+    # ---- torch-on-device formulation of the same algorithm (kept for cross-checking the kernels in the gpu tests) ----
+    def get_z_vals_torch(self, ray_dirs, cam_loc, model):
         dev, R = ray_dirs.device, ray_dirs.shape[0]
         beta0 = model.density.get_beta().detach()
         z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)

@@ -332,3 +332,51 @@ def test_bf16_full_size_properties(dev):
     close(rgb, ref[0], tol=5e-3, what="bf16 vs fp32 rgb")
     close(l3, ref[1], tol=5e-3, what="bf16 vs fp32 lines3d")
     assert float(ga @ g_ref / (ga.norm() * g_ref.norm())) > 0.995
+
+
+@pytest.mark.parametrize("variant,train", [("rough", False), ("rough", True), ("init", False)])
+def test_sampler_kernels_match_torch_formulation(dev, golden, variant, train):
+    """The per-ray HIP sampler kernels against the same algorithm written with torch device ops (same SDF kernels
+    underneath), on 64 rays: same round count, samples equal up to the CDF-knot caveat."""
+    from tests.util_replay import RngReplay
+    from neat_amd import rend_util
+    m = build_model(dev, variant, train=train)
+    g = golden(f"g6_sampler_{'train' if train else 'eval'}_{variant}")
+    d, c = rend_util.get_camera_params(T(g["uv"]).to(dev), T(g["pose"]).to(dev), T(g["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(d.shape[0], 3).contiguous()
+    if train:
+        draws = [("rand", T(g["t_rand"])), ("randint", None), ("rand", T(g["u_final"])), ("randperm", T(g["perm"])),
+                 ("randint", T(g["eik_idx"]))]
+    else:
+        draws = [("randint", None), ("randint", T(g["eik_idx"]))]
+    with RngReplay(list(draws)):
+        z1, e1 = m.ray_sampler.get_z_vals(d, c, m)
+    r1 = m.ray_sampler.last_rounds
+    with RngReplay(list(draws)):
+        z2, e2 = m.ray_sampler.get_z_vals_torch(d, c, m)
+    assert r1 == m.ray_sampler.last_rounds
+    close_sampler(z1, z2.cpu().numpy(), what="kernel vs torch sampler")
+    assert (z1[:, 1:] >= z1[:, :-1]).all()                      # sortedness
+    assert float(z1.min()) >= 0.0 and float(z1.max()) <= 6.0 + 1e-5
+
+
+def test_hierarchical_sampler_on_device(dev, golden):
+    """a2 + a13 (BASELINE config 5: 64 coarse + 64 fine): UniformSampler / sample_pdf / get_z_vals_fine on the device
+    against the reference's golden vectors (det = linspace u, and recorded random u)."""
+    from neat_amd.ray_sampler import UniformSampler
+    from tests.util_replay import RngReplay
+    g = golden("g9_hierarchical")
+    us = UniformSampler(3.0, 0.0, 64, N_important=64)
+
+    class M:
+        training = False
+    with RngReplay([("randint", None)]):
+        zc = us.get_z_vals(torch.zeros(16, 3, device=dev), torch.zeros(16, 3, device=dev), M)
+    close(zc, g["z_coarse"], tol=0, what="coarse")
+    w = T(g["weights"]).to(dev)
+    M.training = True
+    close(us.get_z_vals_fine(zc, w, M), g["z_fine_det"], tol=2e-6, what="fine det")
+    M.training = False
+    with RngReplay([("rand", T(g["u_rand"]))]):
+        close(us.get_z_vals_fine(zc, w, M), g["z_fine_rand"], tol=2e-6, what="fine rand")
