@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 R_RAYS, S_SAMPLES = 1024, 128
 FLOP_PER_RAY_SAMPLE = 9.1254e6        # 4 562 688 MAC per ray-sample per train step
 CPU_BASELINE_THREADS = 16
-DEFAULT_PRECISION = "fp32"
+DEFAULT_PRECISION = "bf16"      # BASELINE.json configs[1]: "8x256 SDF MLP, bf16, 1x MI355X"; --precision fp32 = parity build
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks          # MI355X_MICROARCH.md: dense f32-input MFMA peak
 
 
@@ -153,22 +154,34 @@ def main():
     kernels = {}
     if not args.no_prof:
         for cls, name in ((0, "layer_kernel"), (1, "wgrad_kernel"), (2, "sdf_fused_kernel")):
-            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-            _lib.check(lib.neat_prof_collect(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "neat_prof_collect")
+            ms, fl, n, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+            _lib.check(lib.neat_prof_collect(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n), ctypes.byref(by)),
+                       "neat_prof_collect")
             if n.value:
+                sec = ms.value * 1e-3
                 kernels[name] = {"launches": n.value, "total_ms": ms.value, "avg_us": 1e3 * ms.value / n.value,
-                                 "tflops": fl.value / (ms.value * 1e-3) / 1e12, "flop_per_launch": fl.value / n.value}
+                                 "tflops": fl.value / sec / 1e12, "flop_per_launch": fl.value / n.value,
+                                 "gbytes_per_s": by.value / sec / 1e9, "bytes_per_launch": by.value / n.value,
+                                 "flop_per_byte": fl.value / max(by.value, 1.0)}
         lib.neat_prof_enable(0)
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+            k = kernels[dom]
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": peak,
-                        "unit": "TFLOP/s", "frac": kernels[dom]["tflops"] / peak, "traffic": traffic,
-                        "avg_launch_us": kernels[dom]["avg_us"], "launches": kernels[dom]["launches"],
-                        "kernel_time_share": kernels[dom]["total_ms"] * 1e-3 / elapsed, "all_kernels": kernels}
+                traffic = json.load(open(tpath)).get(args.precision, {}).get(dom, {}).get("hbm_bytes_per_launch")
+            # which roof bounds the dominant kernel: its algorithmic intensity against the machine balance peak/HBM
+            hbm_bound = k["flop_per_byte"] < peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+            if hbm_bound:
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbytes_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": k["gbytes_per_s"] / PEAK_HBM_GBS, "traffic": traffic}
+            else:
+                roofline = {"bound": "mfma", "kernel": dom, "achieved": k["tflops"], "peak": peak, "unit": "TFLOP/s",
+                            "frac": k["tflops"] / peak, "traffic": traffic}
+            roofline.update({"avg_launch_us": k["avg_us"], "launches": k["launches"], "flop_per_byte": k["flop_per_byte"],
+                             "mfma_tflops": k["tflops"], "mfma_frac": k["tflops"] / peak,
+                             "kernel_time_share": k["total_ms"] * 1e-3 / elapsed, "all_kernels": kernels})
 
     if rank == 0:
         samples = world * R_RAYS * S_SAMPLES * args.steps

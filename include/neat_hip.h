@@ -128,10 +128,11 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  * HIP events on the caller's stream.  class 0 = layer_kernel (all MLP chains), class 1 = wgrad_kernel,
  * class 2 = sdf_fused_kernel (bf16 build: PE + lin0..lin8 of the SDF network in one launch).
  * neat_prof_collect synchronises on the recorded events and returns the summed kernel time, the summed
- * ALGORITHMIC flops (2*N*K*P with the true layer dims) and the launch count since neat_prof_enable(1). */
+ * ALGORITHMIC flops (2*N*K*P with the true layer dims), the summed ALGORITHMIC HBM bytes (each operand/result row once,
+ * weights once) and the launch count since neat_prof_enable(1). */
 int neat_set_tuning(int key, int value);   /* key 0: bf16 layer-kernel point tile, value 2 (64 points, default) or 4 (128) */
 int neat_prof_enable(int on);
-int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches);
+int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);
 
 #ifdef __cplusplus
 }

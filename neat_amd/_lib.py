@@ -51,7 +51,7 @@ _SIGNATURES = {
     "neat_set_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "neat_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "neat_prof_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
-                                         ctypes.POINTER(ctypes.c_int)]),
+                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

@@ -98,14 +98,14 @@ inline void dbg_sync(hipStream_t st, const char* what, int a, int b, int c2) {
 // ------------------------------------------------------------------------------------------------
 // optional in-stream kernel timing (bench.py): HIP events around every launch of the two GEMM-class kernels
 // ------------------------------------------------------------------------------------------------
-struct ProfSlot { hipEvent_t e0, e1; double flops; int cls; };
+struct ProfSlot { hipEvent_t e0, e1; double flops, bytes; int cls; };
 struct Prof {
   bool on = false;
   std::vector<ProfSlot> pool;
   size_t used = 0;
 } g_prof;
 
-inline ProfSlot* prof_begin(hipStream_t st, int cls, double flops) {
+inline ProfSlot* prof_begin(hipStream_t st, int cls, double flops, double bytes = 0.0) {
   if (!g_prof.on) return nullptr;
   if (g_prof.used == g_prof.pool.size()) {
     ProfSlot s{};
@@ -113,7 +113,7 @@ inline ProfSlot* prof_begin(hipStream_t st, int cls, double flops) {
     g_prof.pool.push_back(s);
   }
   ProfSlot* s = &g_prof.pool[g_prof.used++];
-  s->flops = flops; s->cls = cls;
+  s->flops = flops; s->bytes = bytes; s->cls = cls;
   hipEventRecord(s->e0, st);
   return s;
 }
@@ -198,7 +198,20 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
   const float* wp = c.packed + d.offset;
   const int k_in = (c.prec && in1.rows > 0 ? pad8(in0.rows) : in0.rows) + in1.rows;
   if (k_in != d.K || N > d.N) return hipErrorInvalidValue;
-  ProfSlot* ps = prof_begin(c.st, 0, 2.0 * N * (in0.rows + in1.rows) * (double)c.P);      // algorithmic flops: true N, K, P
+  // algorithmic flops (true N, K, P) and algorithmic HBM bytes (every operand row once, weights once)
+  double bytes = 0.0;
+  {
+    const double P = (double)c.P;
+    auto esz = [](const Arr& a) { return a.bf16 ? 2.0 : 4.0; };
+    bytes += in0.rows * P * esz(in0.a) + in1.rows * P * esz(in1.a);
+    const int n0rows = N < n_split ? N : n_split;
+    bytes += n0rows * P * esz(out0) * (accumulate ? 2.0 : 1.0);
+    if (out1.p) bytes += (epi == EPI_TAN ? N : (N > n_split ? N - n_split : 0)) * P * esz(out1);
+    if (aux0.p) bytes += n0rows * P * esz(aux0);
+    if (aux1.p) bytes += n0rows * P * esz(aux1);
+    bytes += (double)N * (in0.rows + in1.rows) * (c.prec ? 2.0 : 4.0);
+  }
+  ProfSlot* ps = prof_begin(c.st, 0, 2.0 * N * (in0.rows + in1.rows) * (double)c.P, bytes);
   hipError_t e;
   if (!c.prec) {
     if (in0.a.bf16 || in1.a.bf16 || out0.bf16 || aux0.bf16 || aux1.bf16) return hipErrorInvalidValue;
@@ -320,7 +333,8 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
     double fl = 0.0;
     for (int l = 0; l < 8; ++l) fl += 2.0 * kO[l] * kI[l] * (double)c.P;
     fl += 2.0 * (full ? 257 : 1) * 256 * (double)c.P;
-    ProfSlot* ps = prof_begin(c.st, 2, fl);
+    const double fbytes = (double)c.P * (12.0 + (full ? (39 * 4.0 + (7 * 256 + 224 + 256) * 2.0 + 4.0) : 4.0)) + 2.0 * 589000.0;
+    ProfSlot* ps = prof_begin(c.st, 2, fl, fbytes);
     if (full) hipLaunchKernelGGL((sdf_fused_kernel_h<PT, false>), dim3(c.ldp / (32 * PT)), dim3(WG), lds, c.st, a);
     else hipLaunchKernelGGL((sdf_fused_kernel_h<PT, true>), dim3(c.ldp / (32 * PT)), dim3(WG), lds, c.st, a);
     prof_end(c.st, ps);
@@ -367,6 +381,11 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
   double wflops = 0.0;
   for (int q = 0; q < npairs; ++q)
     wflops += 2.0 * pairs_in[q].rowsA * (pairs_in[q].rowsB[0] + pairs_in[q].rowsB[1] + pairs_in[q].rowsB[2]) * (double)c.P;
+  double wbytes = 0.0;
+  for (int q = 0; q < npairs; ++q) {
+    wbytes += pairs_in[q].rowsA * (double)c.P * (pairs_in[q].A.bf16 ? 2.0 : 4.0);
+    for (int t = 0; t < 3; ++t) wbytes += pairs_in[q].rowsB[t] * (double)c.P * (pairs_in[q].B[t].bf16 ? 2.0 : 4.0);
+  }
   WreduceArgs r{};
   int splits;
   if (!c.prec) {
@@ -386,7 +405,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     }
     a.npairs = npairs; a.N = N; a.Kt = Kt; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
     a.partial = w.partial; a.row_stride = (size_t)splits * WLDK; a.split_stride = WLDK; a.ktiles = ktiles;
-    ProfSlot* ps = prof_begin(c.st, 1, wflops);
+    ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * Kt * 4.0);
     hipLaunchKernelGGL(wgrad_kernel, dim3(ntile * ktiles, splits), dim3(WG), 0, c.st, a);
     prof_end(c.st, ps);
     r.row_stride = (size_t)splits * WLDK; r.split_stride = WLDK;
@@ -410,7 +429,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     }
     a.npairs = npairs; a.N = N; a.Kt = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
     a.partial = w.partial; a.row_stride = (size_t)splits * W2LDK; a.split_stride = W2LDK; a.ktiles = ktiles; a.bias_col = K;
-    ProfSlot* ps = prof_begin(c.st, 1, wflops);
+    ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * (K + 1) * 4.0);
     hipLaunchKernelGGL(wgrad_kernel_h2, dim3(ntile * ktiles, splits), dim3(W2T), W2_LDS_BYTES, c.st, a);
     prof_end(c.st, ps);
     r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
@@ -620,8 +639,8 @@ int neat_prof_enable(int on) {
   return 0;
 }
 
-int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches) {
-  double ms = 0.0, fl = 0.0;
+int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes) {
+  double ms = 0.0, fl = 0.0, by = 0.0;
   int n = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     ProfSlot& s = g_prof.pool[i];
@@ -630,11 +649,12 @@ int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launc
     if (e != hipSuccess) return (int)e;
     float t = 0.0f;
     if ((e = hipEventElapsedTime(&t, s.e0, s.e1)) != hipSuccess) return (int)e;
-    ms += t; fl += s.flops; ++n;
+    ms += t; fl += s.flops; by += s.bytes; ++n;
   }
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = n;
+  if (total_bytes) *total_bytes = by;
   return 0;
 }
 
