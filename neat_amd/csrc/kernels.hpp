@@ -213,7 +213,8 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tn = blockIdx.x / a.ktiles, tk = blockIdx.x % a.ktiles;
   const int n0 = tn * 128, k0 = tk * 128;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably wave-uniform: the live[][] tests below become
+  const int wr = (wave_u >> 1) * 64, wc = (wave_u & 1) * 64;     // scalar branches instead of exec-mask branches per MFMA
   // which 32x32 sub-tiles of this wave hold any valid output
   bool live[2][2];
 #pragma unroll

@@ -84,7 +84,7 @@ __device__ __forceinline__ void stage_octet(const SegH& s, int oct, int p0, int 
   dst[p] = v;
 }
 
-template <int EPI, int PT>
+template <int EPI, int PT, bool OBF>      // OBF: out0 is bf16 octet-major (compile-time: sheds the fp32 / split / accumulate code)
 __device__ __forceinline__ void epilogue_rows_h(const LayerArgsH& a, const f32x16 (&acc)[PT], int nt, int lane, int p0) {
   // one 32-row output tile x PT point tiles.  Row-dependent state (validity, bias) is built once per 4-row quad and
   // reused over the point tiles, which keeps the number of live compare masks small (they used to spill by the hundred).
@@ -137,11 +137,11 @@ __device__ __forceinline__ void epilogue_rows_h(const LayerArgsH& a, const f32x1
           r1 = 0.0f;
         }
         ox[e] = r0;                                          // value for out1 when this row lies beyond n_split
-        if (EPI == EPI_REV && a.out0_bf16 && n >= a.n_split) r0 = 0.0f;    // ... and out0's octet stays clean (finite zeros)
+        if (EPI == EPI_REV && OBF && n >= a.n_split) r0 = 0.0f;    // ... and out0's octet stays clean (finite zeros)
         o0[e] = r0; o1[e] = r1;
       }
       if (n0 < split_pad) {                                  // (bf16 out0: finish the octet that contains the split row)
-        if (a.out0_bf16) {
+        if (OBF) {
           *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out0) + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
         } else {
           float* o = reinterpret_cast<float*>(a.out0);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void epilogue_rows_h(const LayerArgsH& a, const f32x1
         if (EPI == EPI_TAN)
           *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(a.out1) + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
       }
-      if (EPI == EPI_LINEAR || EPI == EPI_REV) {             // split outputs: rows >= n_split go to out1 (fp32 feature-major)
+      if ((EPI == EPI_LINEAR || EPI == EPI_REV) && (EPI == EPI_REV || !OBF || true)) {   // split outputs: rows >= n_split go to out1 (fp32 feature-major)
         if (n0 + 3 >= a.n_split && a.out1) {
           float* o = reinterpret_cast<float*>(a.out1);
 #pragma unroll
@@ -206,7 +206,7 @@ __device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][PT], const uint4* __
   }
 }
 
-template <int EPI, int PT>
+template <int EPI, int PT, bool OBF>
 __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
   constexpr int BMT = 32 * PT;                                       // points per workgroup: 128 (PT=4) or 64 (PT=2)
   extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];     // [Kpad/8][BMT] octets (16 B each); reused for split-K reduce
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
       else mma_rows_h<1, PT>(acc, wp0, tstride, bl, 0, KS);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        if (i < ntw) epilogue_rows_h<EPI, PT>(a, acc[i], t0 + 4 * i, lane, p0);
+        if (i < ntw) epilogue_rows_h<EPI, PT, OBF>(a, acc[i], t0 + 4 * i, lane, p0);
     }
   } else {
     // narrow outputs (N <= 64): split K over the waves, reduce through LDS
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
           for (int kp = 0; kp < ksplit; ++kp) v += red[(((kp * a.NT + tile) * PT + q) * 16 + r) * 64 + lane];
           sum[q][r] = v;
         }
-      epilogue_rows_h<EPI, PT>(a, sum, tile, lane, p0);
+      epilogue_rows_h<EPI, PT, OBF>(a, sum, tile, lane, p0);
     }
   }
 }
@@ -515,152 +515,8 @@ struct WgradArgsH {
 constexpr int HBP = 64;                 // points per staging step
 constexpr int HLD = HBP * 2 + 16;       // LDS row stride in bytes (128 B data + 16 B pad -> conflict-free b128 reads)
 
-// rows [row0, row0+8) x points [p, p+8) of a segment -> 8 uint4 (out[f] = 8 consecutive points of row row0+f)
-__device__ __forceinline__ void load_block_T(const SegH& s, int row0, int p, int ldp, int pend, uint4 (&out)[8]) {
-  if (s.p == nullptr || row0 >= s.rows) {
-#pragma unroll
-    for (int f = 0; f < 8; ++f) out[f] = make_uint4(0u, 0u, 0u, 0u);
-    return;
-  }
-  if (s.bf16) {
-    unsigned in[8][4];
-    const uint4* src = reinterpret_cast<const uint4*>(s.p) + (size_t)(row0 >> 3) * ldp + p;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const uint4 v = (p + t < pend) ? src[t] : make_uint4(0u, 0u, 0u, 0u);
-      in[t][0] = v.x; in[t][1] = v.y; in[t][2] = v.z; in[t][3] = v.w;
-    }
-    // 8x8 transpose of 16-bit elements inside the lane: out[f].dword[j] = { in[2j].feat f , in[2j+1].feat f }
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      unsigned d[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned lo = in[2 * j][f >> 1], hi = in[2 * j + 1][f >> 1];
-        d[j] = (f & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-      }
-      out[f] = make_uint4(d[0], d[1], d[2], d[3]);
-    }
-    // rows beyond the segment inside its last octet are zero by construction of the producers
-  } else {
-    const float* base = reinterpret_cast<const float*>(s.p);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      const int row = row0 + f;
-      float v[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = (row < s.rows && p + t < pend) ? base[(size_t)row * ldp + p + t] : 0.0f;
-      out[f] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-    }
-  }
-}
-
-__global__ __launch_bounds__(WG) void wgrad_kernel_h(WgradArgsH a) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[128 * HLD];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[128 * HLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tn = blockIdx.x / a.ktiles, tk = blockIdx.x % a.ktiles;
-  const int n0 = tn * 128, k0 = tk * 128;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-  bool live[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) live[i][j] = (n0 + wr + 32 * i < a.N) && (k0 + wc + 32 * j < a.Kt);
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const int pbeg = blockIdx.y * a.chunk;
-  const int pend = min(a.P, pbeg + a.chunk);
-  // staging role: threads 0..127 -> A blocks, 128..255 -> B blocks; block = (row octet 0..15, point group 0..7)
-  const int sid = tid & 127;
-  const int boct = sid >> 3, bpg = sid & 7;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if (q >= a.npairs) break;
-    const WgradPairH& pr = a.pair[q];
-    for (int pb = pbeg; pb < pend; pb += HBP) {
-      uint4 blk[8];
-      const int p = pb + bpg * 8;
-      if (tid < 128) {
-        const int row = n0 + boct * 8;
-        if (pr.A.bf16 || pr.A_mod == 0) {
-          load_block_T(pr.A, row, p, a.ldp, pend, blk);
-        } else {
-#pragma unroll
-          for (int f = 0; f < 8; ++f) {
-            int rr = row + f + pr.A_rot;
-            if (rr >= pr.A_mod) rr -= pr.A_mod;
-            const bool okr = (row + f < pr.A_mod) && rr < pr.A.rows;
-            float v[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-              v[t] = (okr && p + t < pend) ? reinterpret_cast<const float*>(pr.A.p)[(size_t)rr * a.ldp + p + t] : 0.0f;
-            blk[f] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-          }
-        }
-      } else {
-        const int col = k0 + boct * 8;               // packed column of this 8-row block
-        if (pr.B[0].bf16 && col < pr.padB0) {
-          load_block_T(pr.B[0], col, p, a.ldp, pend, blk);
-        } else {                                     // fp32 segments, possibly straddling two of them: row by row
-#pragma unroll
-          for (int f = 0; f < 8; ++f) {
-            int cc = col + f;
-            const float* sp = nullptr;
-            if (cc < pr.padB0) { if (!pr.B[0].bf16 && cc < pr.B[0].rows) sp = reinterpret_cast<const float*>(pr.B[0].p); }
-            else {
-              cc -= pr.padB0;
-              if (cc < pr.B[1].rows) sp = reinterpret_cast<const float*>(pr.B[1].p);
-              else { cc -= pr.B[1].rows; if (cc < pr.B[2].rows) sp = reinterpret_cast<const float*>(pr.B[2].p); }
-            }
-            float v[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-              v[t] = (sp && p + t < pend) ? sp[(size_t)cc * a.ldp + p + t] : 0.0f;
-            blk[f] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-          }
-        }
-      }
-      unsigned char* dst = (tid < 128 ? As : Bs) + (boct * 8) * HLD + bpg * 16;
-#pragma unroll
-      for (int f = 0; f < 8; ++f) *reinterpret_cast<uint4*>(dst + f * HLD) = blk[f];
-      __syncthreads();
-      const unsigned char* ap = As + (wr + (lane & 31)) * HLD + (lane >> 5) * 16;
-      const unsigned char* bp = Bs + (wc + (lane & 31)) * HLD + (lane >> 5) * 16;
-#pragma unroll
-      for (int s = 0; s < HBP / 16; ++s) {
-        uint4 a0 = *reinterpret_cast<const uint4*>(ap + s * 32), a1 = *reinterpret_cast<const uint4*>(ap + 32 * HLD + s * 32);
-        uint4 b0 = *reinterpret_cast<const uint4*>(bp + s * 32), b1 = *reinterpret_cast<const uint4*>(bp + 32 * HLD + s * 32);
-        if (live[0][0]) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a0), *reinterpret_cast<bf16x8*>(&b0), acc[0][0], 0, 0, 0);
-        if (live[0][1]) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a0), *reinterpret_cast<bf16x8*>(&b1), acc[0][1], 0, 0, 0);
-        if (live[1][0]) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a1), *reinterpret_cast<bf16x8*>(&b0), acc[1][0], 0, 0, 0);
-        if (live[1][1]) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&a1), *reinterpret_cast<bf16x8*>(&b1), acc[1][1], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-  }
-  float* dstp = a.partial + (size_t)blockIdx.y * a.split_stride;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (!live[i][j]) continue;
-      const int k = k0 + wc + 32 * j + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < a.N && k < a.Kt) dstp[(size_t)n * a.row_stride + k] = acc[i][j][r];
-      }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// bf16 weight gradient, second generation: ONE workgroup (8 waves) owns a full 256x256 output tile, so every
+// bf16 weight gradient: ONE workgroup (8 waves) owns a full 256x256 output tile, so every
 // operand element is read from HBM exactly once per launch (the 128x128 version re-read A 3x and B 2x and was
 // HBM-bound at ~800 MB per layer).  The bias gradient (row sums of A) comes from an extra MFMA against an all-ones
 // B fragment -- no ones row in memory, no 257th column tile.  Staging loads for step t+1 are issued right after the

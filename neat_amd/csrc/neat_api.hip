@@ -137,10 +137,10 @@ template <int EPI> hipError_t launch_layer_f(hipStream_t st, const LayerArgs& a,
 }
 int g_pt_bf16 = 2;          // 32-point column tiles per workgroup in the bf16 layer kernel: 2 (64 pts, higher occupancy) or 4
 
-template <int EPI, int PT> hipError_t launch_layer_h_pt(hipStream_t st, const LayerArgsH& a) {
+template <int EPI, int PT, bool OBF> hipError_t launch_layer_h_pt(hipStream_t st, const LayerArgsH& a) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_h<EPI, PT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_h<EPI, PT, OBF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -149,11 +149,13 @@ template <int EPI, int PT> hipError_t launch_layer_h_pt(hipStream_t st, const La
   size_t lds = (size_t)(a.Kpad / 8) * BMT * 16;
   const size_t red = (size_t)4 * PT * 16 * 64 * 4;
   if (a.NT <= 2 && lds < red) lds = red;
-  hipLaunchKernelGGL((layer_kernel_h<EPI, PT>), dim3(a.ldp / BMT), dim3(WG), lds, st, a);
+  hipLaunchKernelGGL((layer_kernel_h<EPI, PT, OBF>), dim3(a.ldp / BMT), dim3(WG), lds, st, a);
   return hipGetLastError();
 }
 template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a, int) {
-  return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4>(st, a) : launch_layer_h_pt<EPI, 2>(st, a);
+  // the 128-point tile (PT = 4) is kept as a tuning option for the bf16-output variants only
+  if (a.out0_bf16) return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4, true>(st, a) : launch_layer_h_pt<EPI, 2, true>(st, a);
+  return launch_layer_h_pt<EPI, 2, false>(st, a);
 }
 #define EPI_SWITCH(FN, st, epi, a, nt)                                         \
   switch (epi) {                                                              \

