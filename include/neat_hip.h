@@ -121,6 +121,13 @@ int neat_sampler_resample(const float* z, const float* sdf, int n, int R, const 
 int neat_sampler_finish(const float* samples, int N, const float* z, int n, const int* pick, int n_extra, float near, float far,
                         int R, const int* eik_idx, float* z_vals, float* z_eik, void* stream);
 
+/* ---- 8f-1 (next row): dataset attraction field, replacement for the un-vendored hawp.base._C.encodels ------------
+ * (datasets/blender_hawp_dataset.py:96, scene_hawp_dataset.py:95).  lines [N,4] = (x1,y1,x2,y2) in pixels;
+ * lmap [6,H,W] = closest point - pixel (0:2), endpoint 1 - pixel (2:4), endpoint 2 - pixel (4:6), all (x,y);
+ * label [H,W] int32 = index of the nearest segment (the reference's labels_onehot.max(dim=0)[1]).
+ * PARITY UNPINNED: hawp is an empty submodule here; semantics are those the call sites rely on. */
+int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream);
+
 /* ---- a9 alone: volume_rendering :540-554 given sdf [R,S] -> weights [R,S] (used by tests) -------- */
 int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream);
 

@@ -47,6 +47,7 @@ _SIGNATURES = {
                                              c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_sampler_finish": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_volume_weights": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_set_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "neat_prof_enable": (ctypes.c_int, [ctypes.c_int]),

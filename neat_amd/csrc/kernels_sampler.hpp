@@ -216,4 +216,45 @@ __global__ __launch_bounds__(64) void sampler_finish_kernel(SamplerFinishArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dataset-side attraction field: replacement for the un-vendored `hawp.base._C.encodels`
+// (call sites: datasets/blender_hawp_dataset.py:96, scene_hawp_dataset.py:95).  Per pixel: the nearest of the N
+// 2-D segments (distance to the segment, projection clamped to its ends); outputs, as the call sites consume them,
+//   lmap[0:2] = closest point - pixel, lmap[2:4] = endpoint 1 - pixel, lmap[4:6] = endpoint 2 - pixel  (x, y order)
+//   label     = index of that segment (the reference takes argmax over a one-hot [N,H,W] map).
+// Ties go to the lower index.  Segments are cached in LDS in chunks; one thread per pixel.
+// ---------------------------------------------------------------------------------------------
+__global__ void encode_lines_kernel(const float* __restrict__ lines, int N, int H, int W, float* __restrict__ lmap,
+                                    int* __restrict__ label) {
+  __shared__ float sl[256 * 4];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = idx < H * W;
+  const float px = (float)(idx % W), py = (float)(idx / W);
+  float best = INFINITY, bx = 0.f, by = 0.f, e1x = 0.f, e1y = 0.f, e2x = 0.f, e2y = 0.f;
+  int bi = 0;
+  for (int c0 = 0; c0 < N; c0 += 256) {
+    const int cn = min(256, N - c0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cn * 4; t += blockDim.x) sl[t] = lines[(size_t)c0 * 4 + t];
+    __syncthreads();
+    if (!ok) continue;
+    for (int j = 0; j < cn; ++j) {
+      const float x1 = sl[4 * j], y1 = sl[4 * j + 1], x2 = sl[4 * j + 2], y2 = sl[4 * j + 3];
+      const float dx = x2 - x1, dy = y2 - y1;
+      const float len2 = dx * dx + dy * dy;
+      float t = len2 > 0.0f ? ((px - x1) * dx + (py - y1) * dy) / len2 : 0.0f;
+      t = fminf(fmaxf(t, 0.0f), 1.0f);
+      const float qx = x1 + t * dx, qy = y1 + t * dy;
+      const float d2 = (qx - px) * (qx - px) + (qy - py) * (qy - py);
+      if (d2 < best) { best = d2; bi = c0 + j; bx = qx - px; by = qy - py; e1x = x1 - px; e1y = y1 - py; e2x = x2 - px; e2y = y2 - py; }
+    }
+  }
+  if (!ok) return;
+  const size_t hw = (size_t)H * W;
+  lmap[idx] = bx; lmap[hw + idx] = by;
+  lmap[2 * hw + idx] = e1x; lmap[3 * hw + idx] = e1y;
+  lmap[4 * hw + idx] = e2x; lmap[5 * hw + idx] = e2y;
+  label[idx] = bi;
+}
+
 }  // namespace neat

@@ -848,6 +848,12 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
   return (int)hipGetLastError();
 }
 
+int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || !lines || !lmap || !label) return -1;
+  hipLaunchKernelGGL(encode_lines_kernel, grid1(H * W), dim3(256), 0, (hipStream_t)stream, lines, N, H, W, lmap, label);
+  return (int)hipGetLastError();
+}
+
 int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream) {
   if (R <= 0 || S <= 0) return 0;
   hipLaunchKernelGGL(volume_weights_kernel, dim3((R + 3) / 4), dim3(WG), 0, (hipStream_t)stream, z, sdf, R, S, beta, weights);

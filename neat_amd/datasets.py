@@ -1,0 +1,147 @@
+"""Dataset side of the hot path: per-pixel 2-D attraction field and the ABC/Blender dataset class with the
+reference's constructor and sample layout (code/datasets/blender_hawp_dataset.py).  The per-pixel nearest-segment search
+that the reference delegates to the un-vendored CUDA op `hawp.base._C.encodels` is a HIP kernel here
+(`neat_encode_lines`); images are read with PIL (imageio / skimage / cv2 are not needed).
+
+PARITY UNPINNED at the encodels boundary: the hawp submodule is empty in the reference tree, so its exact tie-breaking
+cannot be checked; the semantics implemented are the ones the call sites depend on (see include/neat_hip.h) and are
+tested against a brute-force numpy oracle (oracle/attraction_oracle.py)."""
+import ctypes
+import json
+import os
+from glob import glob
+
+import numpy as np
+import torch
+
+from . import _lib
+from .wireframe import WireframeGraph
+
+
+def encode_lines(lines, height, width):
+    """lines [N,4] (x1,y1,x2,y2) on the GPU -> lmap [6,H,W] float32, labels [H,W] int64."""
+    lib = _lib.lib()
+    if not lines.is_cuda:
+        raise RuntimeError("encode_lines needs CUDA tensors (no CPU path)")
+    lines = lines.detach().float().contiguous()
+    lmap = torch.empty(6, height, width, device=lines.device)
+    label = torch.empty(height, width, device=lines.device, dtype=torch.int32)
+    _lib.check(lib.neat_encode_lines(ctypes.c_void_p(lines.data_ptr()), lines.shape[0], height, width,
+                                     ctypes.c_void_p(lmap.data_ptr()), ctypes.c_void_p(label.data_ptr()),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "neat_encode_lines")
+    return lmap, label.long()
+
+
+def _unit(v):
+    return v / (torch.sqrt(v[0] * v[0] + v[1] * v[1]) + 1e-6)
+
+
+def compute_point_line_attraction(lines, img_res, distance=10.0):
+    """Support mask, nearest-segment label and foot point per pixel (blender_hawp_dataset.py:93-146).
+    A pixel supports its nearest segment when it is within `distance` px; the reference's two angle tests on the
+    endpoints rotated into the foot-point frame are kept for fidelity, but its clamps (:125-128) make them always pass."""
+    H, W = img_res
+    lmap, labels = encode_lines(lines[:, :4].cuda(), H, W)
+    dist = torch.sqrt(lmap[0] ** 2 + lmap[1] ** 2)
+    md = _unit(lmap[:2]).reshape(2, -1)
+    st, ed = lmap[2:4].reshape(2, -1), lmap[4:6].reshape(2, -1)
+    # rotate both endpoint vectors by R^T, R = [[md_x, -md_y], [md_y, md_x]]
+    st_r = torch.stack([md[0] * st[0] + md[1] * st[1], -md[1] * st[0] + md[0] * st[1]])
+    ed_r = torch.stack([md[0] * ed[0] + md[1] * ed[1], -md[1] * ed[0] + md[0] * ed[1]])
+    swap = (st_r[1] < 0) & (ed_r[1] > 0)
+    pos = torch.where(swap, ed_r, st_r)
+    neg = torch.where(swap, st_r, ed_r)
+    pos = torch.stack([pos[0].clamp(min=1e-9), pos[1].clamp(min=1e-9)])
+    neg = torch.stack([neg[0].clamp(min=1e-9), neg[1].clamp(max=-1e-9)])
+    mask = (dist <= distance).reshape(-1)
+    mask &= torch.atan2(pos[1], pos[0]) > 0
+    mask &= torch.atan2(neg[1], neg[0]) < 0
+    ys, xs = torch.meshgrid(torch.arange(H, device=lmap.device), torch.arange(W, device=lmap.device), indexing="ij")
+    foot = torch.stack([lmap[0] + xs, lmap[1] + ys], -1).reshape(-1, 2)
+    foot = torch.where(mask[:, None], foot, torch.zeros_like(foot))
+    return mask.cpu(), labels.reshape(-1).cpu(), foot.float()
+
+
+def load_rgb(path):
+    """[3,H,W] float32 in [0,1] (rend_util.load_rgb without imageio/skimage)."""
+    from PIL import Image
+    img = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+    return img.transpose(2, 0, 1)
+
+
+class BlenderDataset(torch.utils.data.Dataset):
+    """ABC / Blender scenes: images/*.png, cameras.npz (intrinsics, extrinsics), <line_detector>/*.json wireframes."""
+
+    def __init__(self, data_dir, img_res, reverse_coordinate=False, line_detector="hawp", distance_threshold=10.0,
+                 data_root="../data"):
+        self.instance_dir = os.path.join(data_root, data_dir)
+        assert os.path.exists(self.instance_dir), "Data directory is empty"
+        self.img_res = list(img_res)
+        self.total_pixels = img_res[0] * img_res[1]
+        self.sampling_idx = None
+        self.distance = distance_threshold
+        self.score_threshold = 0.05
+        paths = []
+        for ext in ("*.png", "*.jpg", "*.JPEG", "*.JPG"):
+            paths += glob(os.path.join(self.instance_dir, "images", ext))
+        paths = [p for p in sorted(paths) if "mask" not in p]
+        cams = np.load(os.path.join(self.instance_dir, "cameras.npz"))
+        intr, pose = torch.from_numpy(cams["intrinsics"]).float(), torch.from_numpy(cams["extrinsics"]).float()
+        self.rgb_images, self.wireframes, self.lines = [], [], []
+        keep = []
+        for i, path in enumerate(paths):
+            wf = WireframeGraph.load_json(os.path.join(self.instance_dir, line_detector,
+                                                       os.path.splitext(os.path.basename(path))[0] + ".json"))
+            if wf.vertices.shape[0] == 0 or wf.edges.shape[0] == 0 or wf.line_segments(self.score_threshold).shape[0] == 0:
+                continue
+            assert wf.frame_height == img_res[0] and wf.frame_width == img_res[1]
+            keep.append(i)
+            self.rgb_images.append(torch.from_numpy(load_rgb(path).reshape(3, -1).transpose(1, 0).copy()).float())
+            self.wireframes.append(wf)
+            self.lines.append(wf.line_segments(self.score_threshold))
+        self.intrinsics_all, self.pose_all = intr[keep], pose[keep]
+        self.n_images = len(keep)
+        sign = [1, -1, -1, 1] if reverse_coordinate else [1, 1, 1, 1]
+        self.normalization = torch.diag(torch.tensor(sign)).float()
+        self.masks, self.labels, self.att_points = [], [], []
+        for lines in self.lines:          # precompute the support regions of the 2-D attraction fields (HIP kernel)
+            m, l, a = compute_point_line_attraction(lines, self.img_res, self.distance)
+            self.masks.append(m)
+            self.labels.append(l)
+            self.att_points.append(a.cpu())
+
+    def __len__(self):
+        return self.n_images
+
+    def __getitem__(self, idx):
+        H, W = self.img_res
+        ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        uv = torch.stack([xs, ys], -1).reshape(-1, 2).float()
+        lines, mask, labels = self.lines[idx], self.masks[idx], self.labels[idx]
+        sample = {"uv": uv, "uv_proj": self.att_points[idx], "juncs2d": self.wireframes[idx].vertices,
+                  "intrinsics": self.intrinsics_all[idx], "pose": self.pose_all[idx], "wireframe": self.wireframes[idx],
+                  "mask": mask, "labels": labels, "lines": lines[labels], "lines_uniq": lines}
+        gt = {"rgb": self.rgb_images[idx]}
+        if self.sampling_idx is not None:      # rays only inside the line support, with replacement (:186-198)
+            pool = mask.nonzero().flatten()
+            pick = np.random.choice(pool, len(self.sampling_idx))
+            gt["rgb"] = self.rgb_images[idx][pick, :]
+            gt["lines2d"] = lines[labels[pick]]
+            sample.update(lines=lines[labels[pick]], labels=labels[pick], uv=uv[pick, :], uv_proj=self.att_points[idx][pick])
+        return idx, sample, gt
+
+    def collate_fn(self, batch_list):
+        parsed = []
+        for entry in zip(*batch_list):
+            if isinstance(entry[0], dict):
+                parsed.append({k: torch.stack([o[k] for o in entry]) if isinstance(entry[0][k], torch.Tensor)
+                               else [o[k] for o in entry] for k in entry[0]})
+            else:
+                parsed.append(torch.LongTensor(entry))
+        return tuple(parsed)
+
+    def change_sampling_idx(self, sampling_size):
+        self.sampling_idx = None if sampling_size == -1 else torch.randperm(self.total_pixels)[:sampling_size]
+
+    def get_scale_mat(self):
+        return np.eye(4)
