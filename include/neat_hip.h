@@ -128,6 +128,15 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
  * PARITY UNPINNED: hawp is an empty submodule here; semantics are those the call sites rely on. */
 int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream);
 
+/* ---- 8f-2 (next row): device-side rectangular assignment = scipy.optimize.linear_sum_assignment as called at
+ * model/networks/neat_wfr_rend_a.py:473 and model/networks/loss_wfr.py:108 (same algorithm, float64 duals, same tie
+ * rule => same assignment), without the host round trip.  cost [nr,nc] float32 row-major; row_mask [nr] bytes or NULL
+ * (rows with 0 do not take part: replaces the reference's `[good]` compaction); outputs row_ind/col_ind
+ * [min(nr,nc)] int64 sorted by row and padded with -1, *n_match = number of pairs (-1 if a cost is not finite). */
+size_t neat_lsap_ws_bytes(int nr, int nc);
+int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, long long* row_ind, long long* col_ind,
+              int* n_match, void* ws, void* stream);
+
 /* ---- a9 alone: volume_rendering :540-554 given sdf [R,S] -> weights [R,S] (used by tests) -------- */
 int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream);
 

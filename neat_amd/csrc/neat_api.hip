@@ -5,6 +5,7 @@
 // hidden activations (throughput build).  Small arrays are fp32 feature-major in both.
 #include "kernels_bf16.hpp"
 #include "kernels_sampler.hpp"
+#include "kernels_junction.hpp"
 #include "../../include/neat_hip.h"
 #include <math.h>
 #include <stdio.h>
@@ -851,6 +852,22 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
 int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || !lines || !lmap || !label) return -1;
   hipLaunchKernelGGL(encode_lines_kernel, grid1(H * W), dim3(256), 0, (hipStream_t)stream, lines, N, H, W, lmap, label);
+  return (int)hipGetLastError();
+}
+
+size_t neat_lsap_ws_bytes(int nr, int nc) {
+  const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
+  return (mn + 2 * mx) * sizeof(double) + ((size_t)nr + 5 * mx + 2 * mn) * sizeof(int);
+}
+
+int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, long long* row_ind, long long* col_ind,
+              int* n_match, void* ws, void* stream) {
+  if (nr < 0 || nc < 0 || !n_match) return -1;
+  if (nr == 0 || nc == 0) return (int)hipMemsetAsync(n_match, 0, sizeof(int), (hipStream_t)stream);
+  if (!cost || !row_ind || !col_ind || !ws) return -1;
+  const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
+  LsapArgs a{cost, nr, nc, row_mask, row_ind, col_ind, n_match, (double*)ws, (int*)((double*)ws + mn + 2 * mx)};
+  hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(LSAP_WG), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

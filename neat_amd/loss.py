@@ -1,5 +1,6 @@
 """VolSDFLoss with the reference's constructor and output keys (code/model/networks/loss_wfr.py:16-139).
-R-sized reductions; torch ops on the device.  The Hungarian assignment runs on the host as in the reference."""
+R-sized reductions; torch ops on the device.  The Hungarian assignment runs on the device too (`neat_lsap`), so the
+loss makes no host round trip; the reference calls scipy on the host (loss_wfr.py:108)."""
 import torch
 from torch import nn
 
@@ -8,7 +9,7 @@ from .general import get_class
 
 def _symmetric_line_l1(pred, gt, weight, threshold=100):
     """Endpoint-order-invariant L1 between 2-D segments [N,4], gated at `threshold` px (loss_wfr.py:34-45)."""
-    flipped = gt[:, [2, 3, 0, 1]]
+    flipped = torch.cat([gt[:, 2:4], gt[:, 0:2]], -1)
     with torch.no_grad():
         straight = ((pred - gt) ** 2).sum(-1, keepdim=True) < ((pred - flipped) ** 2).sum(-1, keepdim=True)
     per_line = (pred - torch.where(straight, gt, flipped)).abs().mean(-1)
@@ -23,6 +24,27 @@ class VolSDFLoss(nn.Module):
         self.junction_3d_weight, self.junction_2d_weight = junction_3d_weight, junction_2d_weight
         self.rgb_loss = get_class(rgb_loss)(reduction="mean")
         self.steps = 0
+
+    def _defer_nan_check(self, line_loss):
+        """The reference drops into pdb on a NaN line loss (loss_wfr.py:66-67).  Reading the flag here would drain the
+        GPU every step; it is copied to pinned memory asynchronously and looked at on the next call instead."""
+        if not line_loss.is_cuda:
+            if torch.isnan(line_loss):
+                raise FloatingPointError("line loss is NaN (the reference drops into pdb here, loss_wfr.py:66-67)")
+            return
+        flag = torch.empty(1, dtype=torch.bool).pin_memory()
+        flag.copy_(torch.isnan(line_loss.detach()).reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (flag, ev, self.steps)
+
+    def _check_deferred(self):
+        pending, self._pending = getattr(self, "_pending", None), None
+        if pending is not None:
+            flag, ev, step = pending
+            ev.synchronize()
+            if bool(flag[0]):
+                raise FloatingPointError(f"line loss was NaN at step {step} (the reference drops into pdb, loss_wfr.py:66-67)")
 
     def get_rgb_loss(self, rgb_values, rgb_gt):
         return self.rgb_loss(rgb_values, rgb_gt.reshape(-1, 3))
@@ -43,32 +65,40 @@ class VolSDFLoss(nn.Module):
         close = per_line < 100
         # bring the GT segments into calibrated (K^-1) coordinates for the differentiable term (:59-65)
         ends = seg_gt.reshape(-1, 2)
-        ends_h = (model_outputs["K"].inverse() @ torch.cat([ends, torch.ones_like(ends[:, :1])], -1).t()).t()
+        ends_h = (torch.linalg.inv_ex(model_outputs["K"]).inverse @ torch.cat([ends, torch.ones_like(ends[:, :1])], -1).t()).t()
         seg_gt_calib = (ends_h[:, :2] / ends_h[:, 2, None]).reshape(-1, 4)
         line_loss, _ = self.get_line_loss(model_outputs["lines2d_calib"].reshape(-1, 4), seg_gt_calib,
                                           seg_w * close.reshape(-1, 1))
-        if torch.isnan(line_loss):
-            raise FloatingPointError("line loss is NaN (the reference drops into pdb here, loss_wfr.py:66-67)")
+        self._check_deferred()
+        self._defer_nan_check(line_loss)
         rgb_loss = self.get_rgb_loss(model_outputs["rgb_values"], ground_truth["rgb"].to(dev))
-        zero = torch.tensor(0.0, device=dev)
+        zero = torch.zeros((), device=dev)
         eikonal = self.get_eikonal_loss(model_outputs["grad_theta"]) if "grad_theta" in model_outputs else zero
         loss = rgb_loss + self.eikonal_weight * eikonal + self.line_weight * line_loss
         out = {"rgb_loss": rgb_loss, "eikonal_loss": eikonal, "line_loss": line_loss, "l2d_loss": l2d_uncalib,
                "count": close.sum(), "j3d_loss": zero, "j2d_loss": zero, "j2d_stat": zero, "jcount": zero}
-        if model_outputs["j3d_local"].shape[0] > 0:
-            from scipy.optimize import linear_sum_assignment
-            loc3, glo3 = model_outputs["j3d_local"], model_outputs["j3d_global"]
-            loc2c, glo2c = model_outputs["j2d_local_calib"], model_outputs["j2d_global_calib"]
+        padded = getattr(model_outputs, "padded", None)
+        if padded is not None:           # neat_amd model: matched junctions padded + mask, no data-dependent shape
+            loc3, loc2c, loc2, good = padded["j3d_local"], padded["j2d_local_calib"], padded["j2d_local"], model_outputs.good
+        else:                            # plain dict (e.g. the reference model's outputs): already compact
+            loc3, loc2c, loc2, good = (model_outputs["j3d_local"], model_outputs["j2d_local_calib"],
+                                       model_outputs["j2d_local"], None)
+        if loc3.shape[0] > 0:
+            from . import ops
+            glo3, glo2c = model_outputs["j3d_global"], model_outputs["j2d_global_calib"]
             with torch.no_grad():
                 pair_cost = torch.cdist(loc3, glo3, p=1) + 0.1 * torch.cdist(loc2c, glo2c, p=1)
-            ri, ci = linear_sum_assignment(pair_cost.detach().cpu().numpy())
-            ri, ci = torch.as_tensor(ri, device=dev), torch.as_tensor(ci, device=dev)
-            j3 = (loc3[ri] - glo3[ci]).abs().sum(-1).mean()
-            j2 = (loc2c[ri] - glo2c[ci]).abs().sum(-1).mean()
+            # Hungarian on the device over the rows that passed the gate (reference: scipy on the host, :108)
+            ri, ci, n_match = ops.linear_sum_assignment(pair_cost, good)
+            valid = ri >= 0
+            ri, ci = ri.clamp_min(0), ci.clamp_min(0)
+            denom = n_match.clamp_min(1).to(loc3.dtype)
+            pair_mean = lambda a, b: ((a[ri] - b[ci]).abs().sum(-1) * valid).sum() / denom[0]
+            j3, j2 = pair_mean(loc3, glo3), pair_mean(loc2c, glo2c)
             with torch.no_grad():
-                j2_px = (model_outputs["j2d_local"][ri] - model_outputs["j2d_global"][ci]).abs().sum(-1).mean()
+                j2_px = pair_mean(loc2, model_outputs["j2d_global"])
             loss = loss + self.junction_3d_weight * j3 + self.junction_2d_weight * j2
-            out.update(j3d_loss=j3, j2d_loss=j2, j2d_stat=j2_px, jcount=(pair_cost[ri, ci] < 10).sum())
+            out.update(j3d_loss=j3, j2d_loss=j2, j2d_stat=j2_px, jcount=((pair_cost[ri, ci] < 10) & valid).sum())
         out["loss"] = loss
         if "median" in model_outputs:
             out["median"] = model_outputs["median"]

@@ -176,6 +176,52 @@ class AttractionFieldNetwork(_Head):
         return self._standalone(points, normals, view_dirs, feature_vectors)[1]
 
 
+def _to_device_async(t, device):
+    """CPU-drawn randoms (the reference's RNG stream) -> device without stalling the host behind queued GPU work."""
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+def _device_copy(obj, attr, device):
+    """Device-resident copy of a per-view CPU tensor attribute, made once (a pageable H2D copy stalls the host)."""
+    cache = obj.__dict__.setdefault("_device_cache", {})
+    src = getattr(obj, attr)
+    hit = cache.get((attr, str(device)))
+    if hit is None or hit[0] is not src:
+        hit = (src, src.to(device))
+        cache[(attr, str(device))] = hit
+    return hit[1]
+
+
+class JunctionOutputs(dict):
+    """Model output dict whose `j2d_local`, `j3d_local`, `j2d_local_calib` entries (the matched local junctions that
+    pass the gate, rend_a :478-489) are compacted lazily: `padded[k]` [K,.] + `good` [K] live on the device, and
+    `out[k]` = `padded[k][good]` is only materialised (one host sync for the data-dependent shape) when read."""
+
+    def __init__(self, base, good, padded):
+        super().__init__(base)
+        self.good, self.padded = good, padded
+
+    def __missing__(self, key):
+        if key in self.padded:
+            self[key] = self.padded[key][self.good]
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.padded
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self.padded if not dict.__contains__(self, k)]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
 class VolSDFNetwork(_HipModule):
     def __init__(self, conf):
         super().__init__()
@@ -268,7 +314,7 @@ class VolSDFNetwork(_HipModule):
     def _z_vals(self, ray_dirs, cam_loc):
         if self.z_vals_override is not None:
             z = self.z_vals_override
-            idx = torch.randint(z.shape[-1], (z.shape[0],)).to(z.device)
+            idx = _to_device_async(torch.randint(z.shape[-1], (z.shape[0],)), z.device)
             return z, z.gather(1, idx.unsqueeze(-1))
         return self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self)
 
@@ -298,7 +344,7 @@ class VolSDFNetwork(_HipModule):
         # ---- attraction field / junctions (rend_a :424-513); R-sized, stays in torch -------------------
         points3d = xyz
         p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
-        w2c = pose[0].inverse()[:3]
+        w2c = torch.linalg.inv_ex(pose[0]).inverse[:3]       # inv_ex: no host-side singularity check, no sync
         Rm, T = w2c[:, :3], w2c[:, 3:]
         K3 = intrinsics[0, :3, :3]
         eye = torch.eye(3, device=K3.device)
@@ -313,36 +359,35 @@ class VolSDFNetwork(_HipModule):
             a, b = l3d - lines3d[:, 0], l3d - lines3d[:, 1]
             l3d_score = torch.linalg.cross(a, b).norm(dim=-1) / (lines3d[:, 0] - lines3d[:, 1]).norm(dim=-1)
         if self.training:
-            from scipy.optimize import linear_sum_assignment
             if self.dbscan_enabled:
                 cand3d = self.cluster_dbscan(lines3d.detach().cpu().numpy().reshape(-1, 3), eps=0.01, min_samples=2)
             elif self.use_l3d:
-                thr = max(l3d_score.median(), 0.01)
-                keep = l3d_score < thr
+                thr = l3d_score.median().clamp_min(0.01)
+                keep = l3d_score < thr          # data-dependent shape: one host sync, as the reference (:465-468)
                 cand3d = torch.cat([lines3d[keep].detach().reshape(-1, 3), l3d[keep]], 0)
             else:
                 cand3d = lines3d.detach().reshape(-1, 3)
             cand2d = self.project2D(K3, Rm, T, cand3d)
             cand2d_calib = self.project2D(eye, Rm, T, cand3d)
-            gt2d = input["wireframe"][0].vertices.to(cand2d.device)
+            gt2d = _device_copy(input["wireframe"][0], "vertices", cand2d.device)
             cost = ((cand2d[None] - gt2d[:, None]) ** 2).sum(-1).sqrt()
-            rows, cols = linear_sum_assignment(cost.detach().cpu())          # host round trip, as the reference (:473)
-            rows, cols = torch.as_tensor(rows, device=cost.device), torch.as_tensor(cols, device=cost.device)
+            # Hungarian matching on the device (reference: scipy on the host, :473); every gt junction / candidate of the
+            # smaller side is matched, so the pair count min(V, C) is static and nothing has to come back to the host
+            rows, cols, _ = ops.linear_sum_assignment(cost)
             matched = cost[rows, cols]
             if self.use_median:
-                median = matched.detach().median()
-                if torch.isnan(median):
-                    median = torch.tensor(10, dtype=torch.float32, device=cost.device)
+                median = matched.detach().median() if matched.numel() > 0 else matched.new_tensor(10.0)
                 good = matched < median
                 output["median"] = median
             else:
                 good = matched < 10
             j3d_global = self.ffn(self.latents)
-            output["j2d_local"] = cand2d[cols][good]
-            output["j3d_local"] = cand3d[cols][good]
+            # the reference compacts with `[good]` (:478-489), a data-dependent shape; here the matched candidates stay
+            # padded + mask (what neat_amd.loss reads) and the compact tensors are built only if somebody asks for them
+            output = JunctionOutputs(output, good, {"j2d_local": cand2d[cols], "j3d_local": cand3d[cols],
+                                                    "j2d_local_calib": cand2d_calib[cols]})
             output["j3d_global"] = j3d_global
             output["j2d_global"] = self.project2D(K3, Rm, T, j3d_global)
-            output["j2d_local_calib"] = cand2d_calib[cols][good]
             output["j2d_global_calib"] = self.project2D(eye, Rm, T, j3d_global)
         output["l3d"] = l3d
         output["points3d"] = points3d
@@ -364,7 +409,7 @@ class VolSDFNetwork(_HipModule):
     def _eikonal_points(self, n_rays, cam_loc, ray_dirs, z_eik, junctions):
         """Eikonal points: uniform in the bounding cube + one near-surface sample per ray (rend_a :515-527)."""
         r = self.scene_bounding_sphere
-        eik = torch.empty(n_rays, 3).uniform_(-r, r).to(ray_dirs.device)
+        eik = _to_device_async(torch.empty(n_rays, 3).uniform_(-r, r), ray_dirs.device)
         eik = torch.cat([eik, cam_loc + z_eik * ray_dirs], 0)
         if junctions is not None:
             eik = torch.cat([eik, junctions], 0)

@@ -304,3 +304,20 @@ def sampler_finish(samples, z, pick, near, far, eik_idx):
     _lib.check(lib.neat_sampler_finish(_p(samples), N, _p(z), z.shape[1], _p(pick), n_extra, float(near), float(far), R,
                                        _p(eik_idx), _p(out), _p(zeik), _stream()), "neat_sampler_finish")
     return out, zeik
+
+
+def linear_sum_assignment(cost, row_mask=None):
+    """scipy.optimize.linear_sum_assignment on the device, no host round trip (neat_lsap).
+    cost [nr,nc] float32; row_mask [nr] bool: rows that take part (None = all).
+    -> row_ind, col_ind int64 [min(nr,nc)] sorted by row and padded with -1, n_match int32 [1] (on the device)."""
+    lib = _lib.lib()
+    cost = _f32c(cost.detach())
+    nr, nc = cost.shape
+    k = min(nr, nc)
+    rows = torch.empty(k, device=cost.device, dtype=torch.int64)
+    cols = torch.empty(k, device=cost.device, dtype=torch.int64)
+    n_match = torch.empty(1, device=cost.device, dtype=torch.int32)
+    mask = None if row_mask is None else row_mask.to(torch.uint8).contiguous()
+    ws = torch.empty(max(int(lib.neat_lsap_ws_bytes(nr, nc)), 8), device=cost.device, dtype=torch.uint8)
+    _lib.check(lib.neat_lsap(_p(cost), nr, nc, _p(mask), _p(rows), _p(cols), _p(n_match), _p(ws), _stream()), "neat_lsap")
+    return rows, cols, n_match
