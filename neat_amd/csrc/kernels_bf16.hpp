@@ -304,6 +304,145 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel_h(LayerArgsH a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// layer_kernel_ws: weight-stationary streaming version of the hidden 256 -> 256 layers of every chain (all arrays bf16
+// octet-major, K = 256, N <= 256).  layer_kernel_h re-fetches its 128 KiB weight matrix from L2 for every 64-point
+// workgroup through a 4 KiB-per-wave window and is bound by that latency; here
+//  * one persistent workgroup (8 waves) per CU; wave w keeps rows 32w..32w+31 of W as 16 MFMA A fragments in 64 VGPRs
+//    for the whole launch -- no weight traffic in the loop;
+//  * points stream through an LDS ring of 32-point stages filled by LDS-DMA (issued from inline asm, see
+//    wgrad_kernel_h3): the input tile [32 octets][32 points][16 B] is shared by the waves (B fragments by ds_read_b128),
+//    the epilogue operands (h for phi', u / m) are DMA'd per wave for its own 32 rows and read back in accumulator
+//    layout by ds_read_b64 -- no VGPR-destination global load inside the loop, so the counted waits stay exact;
+//  * D = NS-1 stages in flight across raw s_barriers; outputs leave as 8-byte stores straight from the accumulators.
+// Stores share the vector-memory counter with the DMA and may retire out of order with it: waiting for
+// "at most (later DMA instructions) outstanding" is sufficient whatever the stores do (DMAs retire in order).
+// ---------------------------------------------------------------------------------------------
+constexpr int WST = 512, WSP = 32;
+constexpr int WS_TILE = 32 * WSP * 16;                   // 16 KiB: [32 octets][32 points][16 B]
+struct LayerArgsWS {
+  const u16* in; const uint4* Wp; const float* bias;
+  const u16* aux0; const u16* aux1;
+  u16* out0; u16* out1;
+  int N, in_octs, ldp, ntiles, per_wg;                   // 32-point tiles in total / per workgroup (contiguous)
+};
+template <int EPI> struct WsCfg {
+  static constexpr int NAUX = (EPI == EPI_TAN || EPI == EPI_BWD) ? 2 : ((EPI == EPI_REV || EPI == EPI_BWD_RELU) ? 1 : 0);
+  static constexpr int NS = NAUX == 2 ? 3 : 4;           // ring depth: 3 x 48 KiB or 4 x (16|32) KiB
+  static constexpr int STAGE = WS_TILE * (1 + NAUX);
+  static constexpr int G = 2 * (1 + NAUX);               // DMA instructions per stage per wave
+  static constexpr int LDS = NS * STAGE;
+};
+
+__device__ __forceinline__ void ws_wait_barrier(int n) {     // n = DMA instructions of this wave allowed to stay in flight
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
+  typedef WsCfg<EPI> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wslds[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t_begin = blockIdx.x * a.per_wg;
+  const int T = min(a.per_wg, a.ntiles - t_begin);
+  if (T <= 0) return;
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr)wslds;
+  // DMA: per stage this wave moves octets 4w..4w+3 of the input and of each epilogue operand (2 instructions each:
+  // 2 octets x 32 points); LDS image [octet][point] x 16 B is lane-linear per instruction
+  const unsigned dma_off = (unsigned)(4 * wave) * (WSP * 16);
+  auto dma = [&](const u16* base, int tile, unsigned dst, int max_oct) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // octets past the end of a 217-row array would be uninitialised memory (x zero weight = NaN): re-read a valid one
+      const int oct = min(4 * wave + 2 * i + (lane >> 5), max_oct);
+      const u16* s2 = base + ((size_t)oct * a.ldp + (size_t)tile * WSP + (lane & 31)) * 8;
+      const unsigned d2 = __builtin_amdgcn_readfirstlane(dst + i * (2 * WSP * 16));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
+    }
+  };
+  auto issue = [&](int tau) {
+    const unsigned slot = lds_base + (unsigned)(tau % C::NS) * C::STAGE + dma_off;
+    const int tile = t_begin + tau;
+    dma(a.in, tile, slot, a.in_octs - 1);
+    if (C::NAUX >= 1) dma(a.aux0, tile, slot + WS_TILE, 31);
+    if (C::NAUX >= 2) dma(a.aux1, tile, slot + 2 * WS_TILE, 31);
+  };
+#pragma unroll
+  for (int t = 0; t < C::NS - 1; ++t)
+    if (t < T) issue(t);
+
+  // stationary operands: this wave's 32 x 256 slice of W (A fragments) and its bias values in accumulator layout
+  const bool live = wave * 32 < a.N;
+  uint4 wreg[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) wreg[ks] = live ? a.Wp[((size_t)wave * 16 + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+  float bias[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    bias[r] = (EPI == EPI_RELU && a.bias && n < a.N) ? a.bias[n] : 0.0f;
+  }
+  const unsigned bfrag = (unsigned)((lane >> 5) * WSP + (lane & 31)) * 16;        // + ks * 2 * WSP * 16
+  const unsigned efrag = dma_off + (unsigned)(lane & 31) * 16 + (unsigned)(lane >> 5) * 8;   // + q * WSP * 16
+  const int Npad = (a.N + 7) & ~7;
+
+  for (int tau = 0; tau < T; ++tau) {
+    const int ahead = min(C::NS - 2, T - 1 - tau);
+    ws_wait_barrier(ahead * C::G);
+    if (tau + C::NS - 1 < T) issue(tau + C::NS - 1);
+    const unsigned char* slot = wslds + (tau % C::NS) * C::STAGE;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const uint4 bv = *reinterpret_cast<const uint4*>(slot + bfrag + ks * (2 * WSP * 16));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
+    }
+    if (!live) continue;
+    const int p = (t_begin + tau) * WSP + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n0 = wave * 32 + 8 * q + 4 * (lane >> 5);
+      if (n0 >= Npad) continue;
+      float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {0.f, 0.f, 0.f, 0.f};
+      if (C::NAUX >= 1) {
+        const uint2 r = *reinterpret_cast<const uint2*>(slot + WS_TILE + efrag + q * (WSP * 16));
+        x0[0] = bf_lo(r.x); x0[1] = bf_hi(r.x); x0[2] = bf_lo(r.y); x0[3] = bf_hi(r.y);
+      }
+      if (C::NAUX >= 2) {
+        const uint2 r = *reinterpret_cast<const uint2*>(slot + 2 * WS_TILE + efrag + q * (WSP * 16));
+        x1[0] = bf_lo(r.x); x1[1] = bf_hi(r.x); x1[2] = bf_lo(r.y); x1[3] = bf_hi(r.y);
+      }
+      float o0[4], o1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = acc[4 * q + e];
+        float r0 = 0.0f, r1 = 0.0f;
+        if (EPI == EPI_RELU) r0 = fmaxf(v + bias[4 * q + e], 0.0f);
+        else if (EPI == EPI_REV) r0 = v * dphi_fast(x0[e]);
+        else if (EPI == EPI_TAN) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
+        else if (EPI == EPI_BWD) r0 = v * dphi_fast(x0[e]) + x1[e];
+        else if (EPI == EPI_BWD_RELU) r0 = x0[e] > 0.0f ? v : 0.0f;
+        if (n0 + e >= a.N) { r0 = 0.0f; r1 = 0.0f; }       // padded rows of the last octet: finite zeros
+        o0[e] = r0; o1[e] = r1;
+      }
+      const unsigned oidx = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)p) * 8u + (unsigned)(n0 & 7);
+      *reinterpret_cast<uint2*>(a.out0 + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
+      if (EPI == EPI_TAN) *reinterpret_cast<uint2*>(a.out1 + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused SDF primal chain (ImplicitNetwork.forward, rend_a :78-96, + get_sdf_vals' clamp :131-137):
 // PE-6 -> lin0..lin8 for a tile of 32*PT points in ONE launch.  The activation tile lives in LDS (octet-major
 // bf16) and is updated in place layer after layer; weights stream from L2 through the register ring of mma_rows_h.
@@ -698,6 +837,175 @@ __global__ __launch_bounds__(W2T, 2) void wgrad_kernel_h2(WgradArgsH a) {
       float v = rsum[f];
       v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
       if (bpg == 0 && row0 + f < a.N) dstp[(size_t)(row0 + f) * a.row_stride + a.bias_col] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad_kernel_h3: the all-bf16 256x256 case (hidden layers: both operands octet-major, K = 256, N <= 256).
+// No register staging, no second LDS image, no v_perm transposes:
+//  * LDS-DMA (`global_load_lds`, 16 B/lane) copies 32-point stages straight from HBM into a 4-deep ring; the per-lane
+//    SOURCE address interleaves four feature octets, so the ring holds [32-feature quad][point][32 features] (64 B per
+//    point and quad) -- the image `ds_read_b64_tr_b16` needs;
+//  * `ds_read_b64_tr_b16` (gfx950 transpose read) delivers, per lane, 4 consecutive points of one feature = half an
+//    MFMA A/B fragment of v_mfma_f32_32x32x16_bf16 (reduction index = points).  A 32-lane group touches 256 contiguous
+//    bytes: conflict free;
+//  * three stages (96 KB per CU) stay in flight across raw `s_barrier`s with counted `s_waitcnt vmcnt(N)`
+//    (`__syncthreads()` would drain the DMA queue); nothing else in the loop uses the vector-memory counter.
+// Bias gradient = row sums of pair 0's A, taken from the A fragments on the VALU by the waves of column half 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int W3T = 512, W3P = 32, W3NS = 4;
+constexpr int W3_STAGE = 2 * 256 * W3P * 2;          // bytes per stage: A | B, each 8 quads x 32 points x 64 B
+constexpr int W3_LDS_BYTES = W3NS * W3_STAGE;
+struct WgradArgsH3 {
+  const unsigned short* A[2]; const unsigned short* B[2]; int rowsA[2];
+  int npairs, N, P, ldp, chunk;
+  float* partial; size_t row_stride, split_stride; int bias_col;
+};
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char w3lds[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef __attribute__((address_space(3))) v4s16* lds_v4;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 128;
+  const int pbeg = blockIdx.y * a.chunk;
+  const int pend = min(a.P, pbeg + a.chunk);
+  const int nsteps = (pend - pbeg + W3P - 1) / W3P;
+  const int T = nsteps * a.npairs;
+  bool liveR[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) liveR[i] = wr + 32 * i < a.N;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float rsum[2] = {0.0f, 0.0f};
+
+  // DMA role of this wave: operand (A: waves 0-3, B: 4-7), quads 2(w&3), 2(w&3)+1, two 16-point halves each
+  const int dop = wave >> 2, dq0 = 2 * (wave & 3);
+  const int dl_oct = lane & 3, dl_pt = lane >> 2;
+  // The DMA is issued from inline asm so that hipcc's waitcnt pass does not know about it: otherwise it puts
+  // `s_waitcnt vmcnt(0)` in front of every ds_read that follows an LDS-DMA and the ring never holds more than one stage.
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr)w3lds;
+  auto issue = [&](int tau) {
+    const int q = tau >= nsteps ? 1 : 0;
+    const int st = tau - q * nsteps;
+    const unsigned short* base = dop ? (q ? a.B[1] : a.B[0]) : (q ? a.A[1] : a.A[0]);
+    const int rows = dop ? 256 : (q ? a.rowsA[1] : a.rowsA[0]);
+    const int maxoct = (rows + 7) / 8 - 1;
+    const unsigned slot = lds_base + (tau % W3NS) * W3_STAGE + dop * (W3_STAGE / 2);
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+      const int oct = min(4 * (dq0 + hq) + dl_oct, maxoct);       // rows past the array: re-read a valid octet (dropped later)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = pbeg + st * W3P + 16 * i + dl_pt;
+        const uint4* src = reinterpret_cast<const uint4*>(base) + (size_t)oct * a.ldp + p;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (dq0 + hq) * 2048 + i * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      }
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < W3NS - 1; ++t)
+    if (t < T) issue(t);
+
+  // fragment read offsets: lane -> (16-feature half G&1, k-block G>>1, point i>>2, feature quad i&3)
+  const int G = lane >> 4, li = lane & 15;
+  const int frag_off = ((8 * (G >> 1) + (li >> 2)) * 64) + (G & 1) * 32 + (li & 3) * 8;
+  const bool do_bias = a.bias_col >= 0 && wc == 0;
+
+  for (int tau = 0; tau < T; ++tau) {
+    // stage tau has landed when at most the 2 x 4 newer DMA instructions of this wave are outstanding; the barrier
+    // then publishes every wave's part and retires the reads of stage tau-1 (whose slot is refilled next)
+    if (tau + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (tau + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tau + W3NS - 1 < T) issue(tau + W3NS - 1);
+    const unsigned char* slot = w3lds + (tau % W3NS) * W3_STAGE;
+    const int st = tau >= nsteps ? tau - nsteps : tau;
+    const int pb = pbeg + st * W3P;
+    const bool tail = pb + W3P > pend;
+    const bool bias_now = do_bias && tau < nsteps;
+#pragma unroll
+    for (int s2 = 0; s2 < W3P / 16; ++s2) {
+      uint4 av[2], bv[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* ap = slot + ((wr >> 5) + i) * 2048 + s2 * 1024 + frag_off;
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ap));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ap + 256));
+        av[i] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned char* bp = slot + W3_STAGE / 2 + ((wc >> 5) + j) * 2048 + s2 * 1024 + frag_off;
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(bp));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(bp + 256));
+        bv[j] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
+      }
+      if (tail) {          // last stage of the last slice: points >= P hold whatever the padding holds -> zero them
+        const int p0 = pb + 16 * s2 + 8 * (G >> 1);
+        auto mask4 = [&](uint4& v) {
+          unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool k0 = p0 + 2 * e < pend, k1 = p0 + 2 * e + 1 < pend;
+            w4[e] = (k0 ? (w4[e] & 0x0000FFFFu) : 0u) | (k1 ? (w4[e] & 0xFFFF0000u) : 0u);
+          }
+          v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mask4(av[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mask4(bv[j]);
+      }
+      if (bias_now) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned w4[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+          float t = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t += bf_lo(w4[e]) + bf_hi(w4[e]);
+          rsum[i] += t;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!liveR[i]) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  float* dstp = a.partial + (size_t)blockIdx.y * a.split_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!liveR[i]) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dstp[(size_t)n * a.row_stride + wc + 32 * j + (lane & 31)] = acc[i][j][r];
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v = rsum[i];
+      v += __shfl_xor(v, 32);
+      const int n = wr + 32 * i + (lane & 31);
+      if (lane < 32 && n < a.N) dstp[(size_t)n * a.row_stride + a.bias_col] = v;
     }
   }
 }

@@ -136,6 +136,7 @@ template <int EPI> hipError_t launch_layer_f(hipStream_t st, const LayerArgs& a,
   hipLaunchKernelGGL(layer_kernel<EPI>, dim3(ntiles_p), dim3(WG), lds, st, a);
   return hipGetLastError();
 }
+int g_wgrad_h3 = 1;         // bf16 weight gradient of the all-bf16 256x256 layers: 1 = tr16/4-stage DMA kernel, 0 = wgrad_kernel_h2
 int g_pt_bf16 = 2;          // 32-point column tiles per workgroup in the bf16 layer kernel: 2 (64 pts, higher occupancy) or 4
 
 template <int EPI, int PT, bool OBF> hipError_t launch_layer_h_pt(hipStream_t st, const LayerArgsH& a) {
@@ -157,6 +158,51 @@ template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a
   // the 128-point tile (PT = 4) is kept as a tuning option for the bf16-output variants only
   if (a.out0_bf16) return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4, true>(st, a) : launch_layer_h_pt<EPI, 2, true>(st, a);
   return launch_layer_h_pt<EPI, 2, false>(st, a);
+}
+int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
+int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
+template <int EPI> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_ws<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI>::LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  LayerArgsWS a = a0;
+  a.ntiles = a.ldp / WSP;
+  a.per_wg = (a.ntiles + g_ws_grid - 1) / g_ws_grid;
+  const int grid = (a.ntiles + a.per_wg - 1) / a.per_wg;
+  hipLaunchKernelGGL((layer_kernel_ws<EPI>), dim3(grid), dim3(WST), WsCfg<EPI>::LDS, st, a);
+  return hipGetLastError();
+}
+// the weight-stationary kernel covers: one bf16 octet-major input of up to 256 rows (K = 256 packed columns), bf16
+// outputs without split / accumulate / pad-fill, and the epilogues of the hidden layers
+inline bool ws_eligible(int epi, const LayerArgsH& a) {
+  if (!g_layer_ws) return false;
+  if (!(epi == EPI_RELU || epi == EPI_REV || epi == EPI_TAN || epi == EPI_BWD || epi == EPI_BWD_RELU)) return false;
+  if (a.Kpad != 256 || !a.in[0].bf16 || a.in[0].rows < 193 || a.in[0].rows > 256 || a.in[1].rows != 0) return false;
+  if (a.in[0].rows != 256 && (a.in[0].rows + 7) / 8 * 8 != 224) return false;       // 217-row arrays occupy 28 octets only
+  if (!a.out0_bf16 || a.N > 256 || a.N < 193 || a.n_split < a.N || a.accumulate || a.padfill) return false;
+  if (epi == EPI_TAN && (!a.out1 || !a.out1_bf16)) return false;
+  if (epi != EPI_TAN && a.out1) return false;
+  if (a.bias && (epi != EPI_RELU || a.bias_rot != 0)) return false;
+  return true;
+}
+hipError_t dispatch_ws(hipStream_t st, int epi, const LayerArgsH& h) {
+  LayerArgsWS a{};
+  a.in = reinterpret_cast<const u16*>(h.in[0].p); a.Wp = h.Wp; a.bias = h.bias;
+  a.aux0 = h.aux0; a.aux1 = h.aux1;
+  a.out0 = reinterpret_cast<u16*>(h.out0); a.out1 = reinterpret_cast<u16*>(h.out1);
+  a.N = h.N; a.in_octs = (h.in[0].rows + 7) / 8; a.ldp = h.ldp;
+  switch (epi) {
+    case EPI_RELU: return launch_layer_ws<EPI_RELU>(st, a);
+    case EPI_REV: return launch_layer_ws<EPI_REV>(st, a);
+    case EPI_TAN: return launch_layer_ws<EPI_TAN>(st, a);
+    case EPI_BWD: return launch_layer_ws<EPI_BWD>(st, a);
+    case EPI_BWD_RELU: return launch_layer_ws<EPI_BWD_RELU>(st, a);
+  }
+  return hipErrorInvalidValue;
 }
 #define EPI_SWITCH(FN, st, epi, a, nt)                                         \
   switch (epi) {                                                              \
@@ -236,7 +282,7 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
     a.aux0 = reinterpret_cast<const u16*>(aux0.p); a.aux1 = reinterpret_cast<const u16*>(aux1.p);
     a.padfill = padfill; a.padfill_rows = padfill_rows;
     if ((aux0.p && !aux0.bf16) || (aux1.p && !aux1.bf16) || (out1.p && (out1.bf16 != (epi == EPI_TAN)))) return hipErrorInvalidValue;
-    e = dispatch_h(c.st, epi, a, c.ldp / BMH);
+    e = ws_eligible(epi, a) ? dispatch_ws(c.st, epi, a) : dispatch_h(c.st, epi, a, c.ldp / BMH);
   }
   prof_end(c.st, ps);
   dbg_sync(c.st, "layer pid/epi/N", pid, epi, N);
@@ -419,6 +465,34 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       if (e != hipSuccess) return e;
       attr_set = true;
     }
+    bool h3 = g_wgrad_h3 && K == 256 && N <= 256;
+    for (int q = 0; q < npairs && h3; ++q) {
+      const WPair& s = pairs_in[q];
+      h3 = s.A.bf16 && s.B[0].bf16 && s.rowsB[0] == 256 && s.rowsB[1] == 0 && s.rowsB[2] == 0 && s.A_mod == 0 && s.rowsA <= 256;
+    }
+    if (h3) {
+      static bool attr3_set = false;
+      if (!attr3_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr3_set = true;
+      }
+      int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + W3P - 1) / W3P * W3P;
+      if (chunk < 2 * W3P) chunk = 2 * W3P;
+      splits = (c.P + chunk - 1) / chunk;
+      WgradArgsH3 a{};
+      for (int q = 0; q < npairs; ++q) {
+        a.A[q] = reinterpret_cast<const unsigned short*>(pairs_in[q].A.p);
+        a.B[q] = reinterpret_cast<const unsigned short*>(pairs_in[q].B[0].p);
+        a.rowsA[q] = pairs_in[q].rowsA;
+      }
+      a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
+      a.partial = w.partial; a.row_stride = (size_t)splits * W2LDK; a.split_stride = W2LDK; a.bias_col = K;
+      ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * (K + 1) * 4.0);
+      hipLaunchKernelGGL(wgrad_kernel_h3, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
+      prof_end(c.st, ps);
+      r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
+    } else {
     int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + HBP - 1) / HBP * HBP;
     if (chunk < 2 * HBP) chunk = 2 * HBP;
     splits = (c.P + chunk - 1) / chunk;
@@ -436,6 +510,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     hipLaunchKernelGGL(wgrad_kernel_h2, dim3(ntile * ktiles, splits), dim3(W2T), W2_LDS_BYTES, c.st, a);
     prof_end(c.st, ps);
     r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
+    }
   }
   r.partial = w.partial; r.splits = splits;
   if (splits > 2 * WGROUPS) {
@@ -633,6 +708,9 @@ int neat_abi_version(void) { return 2; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
   if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
+  if (key == 1 && (value == 0 || value == 1)) { g_wgrad_h3 = value; return 0; }
+  if (key == 2 && (value == 0 || value == 1)) { g_layer_ws = value; return 0; }
+  if (key == 3 && value >= 1 && value <= 4096) { g_ws_grid = value; return 0; }
   return -1;
 }
 

@@ -334,6 +334,74 @@ def test_bf16_full_size_properties(dev):
     assert float(ga @ g_ref / (ga.norm() * g_ref.norm())) > 0.995
 
 
+@pytest.mark.parametrize("R,S", [(1024, 128), (37, 50), (3, 7)])
+def test_bf16_layer_kernels_agree(dev, R, S):
+    """layer_kernel_ws (weight-stationary, LDS-DMA ring) against layer_kernel_h on the same inputs: the same bf16 products
+    accumulated in fp32 in the same k order, so outputs and gradients must agree to fp32 rounding of the epilogue."""
+    from neat_amd import _lib, rend_util
+    m = build_model(dev, "rough", seed=4, train=True).set_precision("bf16")
+    sc = synth.synth_scene(seed=4, n_rays=R)
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(4, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(2)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def run(ws):
+        _lib.check(_lib.lib().neat_set_tuning(2, ws), "neat_set_tuning")
+        m.zero_grad()
+        rgb, l3, *_ = m._render(c, d, z, False)
+        ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        return rgb.detach().clone(), l3.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        r0, l0, g0 = run(0)
+        r1, l1, g1 = run(1)
+    finally:
+        _lib.lib().neat_set_tuning(2, 1)
+    close(r1, r0, tol=1e-6, what="ws rgb")
+    close(l1, l0, tol=1e-6, what="ws lines3d")
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        err = float((g1[k] - g0[k]).abs().max())
+        assert err <= 1e-4 * float(g0[k].abs().max()) + 1e-12, (k, err, float(g0[k].abs().max()))
+
+
+@pytest.mark.parametrize("R,S", [(1024, 128), (37, 50), (3, 7)])
+def test_bf16_wgrad_kernels_agree(dev, R, S):
+    """wgrad_kernel_h3 (LDS-DMA ring + ds_read_b64_tr_b16) against wgrad_kernel_h2 (register transposes) on identical
+    bf16 operands: per parameter tensor the two differ only by fp32 summation order.  Covers a ragged tail (P % 32 != 0)."""
+    from neat_amd import _lib, rend_util
+    m = build_model(dev, "rough", seed=3, train=True).set_precision("bf16")
+    sc = synth.synth_scene(seed=3, n_rays=R)
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(3, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(1)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def grads(h3):
+        _lib.check(_lib.lib().neat_set_tuning(1, h3), "neat_set_tuning")
+        m.zero_grad()
+        rgb, l3, *_ = m._render(c, d, z, False)
+        ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        g2, g3 = grads(0), grads(1)
+    finally:
+        _lib.lib().neat_set_tuning(1, 1)
+    assert len(g3) >= 57
+    for k in g2:
+        assert torch.isfinite(g3[k]).all(), k
+        err = float((g3[k] - g2[k]).abs().max())
+        assert err <= 2e-5 * float(g2[k].abs().max()) + 1e-12, (k, err, float(g2[k].abs().max()))
+
+
 @pytest.mark.parametrize("variant,train", [("rough", False), ("rough", True), ("init", False)])
 def test_sampler_kernels_match_torch_formulation(dev, golden, variant, train):
     """The per-ray HIP sampler kernels against the same algorithm written with torch device ops (same SDF kernels
