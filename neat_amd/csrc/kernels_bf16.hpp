@@ -841,6 +841,26 @@ __global__ __launch_bounds__(W2T, 2) void wgrad_kernel_h2(WgradArgsH a) {
   }
 }
 
+// fp32 feature-major rows -> bf16 octet-major copies (zero-padded to whole octets) of the few small operands (PE rows,
+// head inputs, narrow cotangents), so that the streaming kernels see nothing but octet-major bf16
+struct OctPackJob { const float* src; int rows; u16* dst; };
+struct OctPackArgs { OctPackJob job[4]; int njobs, ldp; };
+__global__ void oct_pack_kernel(OctPackArgs a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.ldp) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j >= a.njobs) break;
+    const OctPackJob jb = a.job[j];
+    for (int o = 0; o * 8 < jb.rows; ++o) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (o * 8 + e < jb.rows) ? jb.src[(size_t)(o * 8 + e) * a.ldp + p] : 0.0f;
+      reinterpret_cast<uint4*>(jb.dst)[(size_t)o * a.ldp + p] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // wgrad_kernel_h3: the all-bf16 256x256 case (hidden layers: both operands octet-major, K = 256, N <= 256).
 // No register staging, no second LDS image, no v_perm transposes:
@@ -859,8 +879,10 @@ constexpr int W3_STAGE = 2 * 256 * W3P * 2;          // bytes per stage: A | B, 
 constexpr int W3_LDS_BYTES = W3NS * W3_STAGE;
 struct WgradArgsH3 {
   const unsigned short* A[2]; const unsigned short* B[2]; int rowsA[2];
-  int npairs, N, P, ldp, chunk;
-  float* partial; size_t row_stride, split_stride; int bias_col;
+  const unsigned short* B2[2];       // octets >= splitB of the B operand come from B2 (skip layer: [h4 | PE]); 32 = none
+  int splitB, octsB;                 // octets of B in total (K = packed columns <= 256)
+  int npairs, N, K, P, ldp, chunk;
+  float* partial; size_t row_stride, split_stride; int col_off, bias_col;   // partial column of B column 0 / of the bias (-1: none)
 };
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
@@ -875,9 +897,11 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   const int pend = min(a.P, pbeg + a.chunk);
   const int nsteps = (pend - pbeg + W3P - 1) / W3P;
   const int T = nsteps * a.npairs;
-  bool liveR[2];
+  bool liveR[2], liveC[4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) liveR[i] = wr + 32 * i < a.N;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) liveC[j] = wc + 32 * j < a.K;
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -897,16 +921,18 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
     const int q = tau >= nsteps ? 1 : 0;
     const int st = tau - q * nsteps;
     const unsigned short* base = dop ? (q ? a.B[1] : a.B[0]) : (q ? a.A[1] : a.A[0]);
-    const int rows = dop ? 256 : (q ? a.rowsA[1] : a.rowsA[0]);
-    const int maxoct = (rows + 7) / 8 - 1;
+    const unsigned short* base2 = q ? a.B2[1] : a.B2[0];
+    const int maxoct = dop ? a.octsB - 1 : ((q ? a.rowsA[1] : a.rowsA[0]) + 7) / 8 - 1;
     const unsigned slot = lds_base + (tau % W3NS) * W3_STAGE + dop * (W3_STAGE / 2);
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {
       const int oct = min(4 * (dq0 + hq) + dl_oct, maxoct);       // rows past the array: re-read a valid octet (dropped later)
+      const bool second = dop && oct >= a.splitB;
+      const uint4* seg = reinterpret_cast<const uint4*>(second ? base2 : base) + (size_t)(second ? oct - a.splitB : oct) * a.ldp;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int p = pbeg + st * W3P + 16 * i + dl_pt;
-        const uint4* src = reinterpret_cast<const uint4*>(base) + (size_t)oct * a.ldp + p;
+        const uint4* src = seg + p;
         const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (dq0 + hq) * 2048 + i * 1024);
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -983,7 +1009,8 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
         if (!liveR[i]) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
+          if (liveC[j])
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -996,7 +1023,10 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       const int n = wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (n >= a.N) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dstp[(size_t)n * a.row_stride + wc + 32 * j + (lane & 31)] = acc[i][j][r];
+      for (int j = 0; j < 4; ++j) {
+        const int k = wc + 32 * j + (lane & 31);
+        if (liveC[j] && k < a.K) dstp[(size_t)n * a.row_stride + a.col_off + k] = acc[i][j][r];
+      }
     }
   }
   if (do_bias) {

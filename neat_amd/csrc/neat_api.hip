@@ -296,6 +296,7 @@ inline dim3 grid1(int n, int b = 256) { return dim3((n + b - 1) / b); }
 // ------------------------------------------------------------------------------------------------
 struct SdfWs {
   float *x, *E, *sdfraw, *sdf, *mask, *g, *e0, *es, *Eh, *gh, *abar8, *ones, *partial;   // fp32 feature-major
+  Arr Ebf, Ebf4, Ehbf, Ehbf4;     // bf16 build: octet-major copies of the PE rows 0..38 / 7..38 and of their tangents
   Arr h[9], feat, u[8], vh[9], m[8];                                                   // big (bf16 in the bf16 build)
   size_t total;
 };
@@ -327,6 +328,7 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
     for (int l = 1; l <= 8; ++l) w.vh[l] = big(256);
     for (int l = 0; l < 8; ++l) w.m[l] = big(256);
     w.abar8 = take(257); w.ones = take(1);
+    if (prec) { w.Ebf = big(20); w.Ebf4 = big(16); w.Ehbf = big(20); w.Ehbf4 = big(16); }
     w.partial = base ? base + off : nullptr;
     off += WPARTIAL_FLOATS;
   }
@@ -337,6 +339,7 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
 struct HeadWs {
   float *small_r, *small_a, *rgb, *lin, *zrgb, *dlin, *sc_r, *sc_a;      // fp32
   Arr hr[5], ha[5], ar[4], aa[4];                                       // big
+  Arr smallbf_r, smallbf_a, topbf_r, topbf_a;                           // bf16 build: octet-major copies of small_* / zrgb / dlin
   size_t total;
 };
 HeadWs head_ws(float* base, int ldp, int prec) {
@@ -350,6 +353,7 @@ HeadWs head_ws(float* base, int ldp, int prec) {
   w.zrgb = take(3); w.dlin = take(6);
   for (int l = 0; l < 4; ++l) { w.ar[l] = big(256); w.aa[l] = big(256); }
   w.sc_r = take(SMALL_R); w.sc_a = take(SMALL_A);
+  if (prec) { w.smallbf_r = big(20); w.smallbf_a = big(8); w.topbf_r = big(4); w.topbf_a = big(4); }
   w.total = off;
   return w;
 }
@@ -423,6 +427,15 @@ hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w) {
 
 struct WPair { Arr A; int rowsA; int A_rot, A_mod; Arr B[3]; int rowsB[3]; };
 
+struct PackJob { const float* src; int rows; Arr dst; };
+void oct_pack(const Ctx& c, std::initializer_list<PackJob> jobs) {
+  OctPackArgs a{};
+  for (const PackJob& j : jobs) a.job[a.njobs++] = OctPackJob{j.src, j.rows, reinterpret_cast<u16*>(j.dst.p)};
+  a.ldp = c.ldp;
+  hipLaunchKernelGGL(oct_pack_kernel, dim3((c.ldp + 255) / 256), dim3(256), 0, c.st, a);
+}
+inline bool oct_operands(const Ctx& c) { return c.prec && g_wgrad_h3; }
+
 hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_in, int npairs, int N, const neat_net_grads* gr) {
   if (!gr->dv[layer_id]) return hipSuccess;
   const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
@@ -465,11 +478,18 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       if (e != hipSuccess) return e;
       attr_set = true;
     }
-    bool h3 = g_wgrad_h3 && K == 256 && N <= 256;
+    // all-bf16 octet-major operands: the streaming tr16 kernel.  Shapes: K <= 256 in one launch (B may continue in a
+    // second array at an octet boundary: skip layer), or [256 | few rows] as two launches into disjoint partial columns
+    bool h3 = g_wgrad_h3 && N <= 256;
     for (int q = 0; q < npairs && h3; ++q) {
       const WPair& s = pairs_in[q];
-      h3 = s.A.bf16 && s.B[0].bf16 && s.rowsB[0] == 256 && s.rowsB[1] == 0 && s.rowsB[2] == 0 && s.A_mod == 0 && s.rowsA <= 256;
+      h3 = s.A.bf16 && s.A_mod == 0 && s.rowsA <= 256 && s.B[0].bf16 && s.rowsB[2] == 0 &&
+           (s.rowsB[1] == 0 || (s.B[1].bf16 && s.rowsB[0] % 8 == 0)) &&
+           s.rowsB[0] == pairs_in[0].rowsB[0] && s.rowsB[1] == pairs_in[0].rowsB[1];
     }
+    const int r0 = pairs_in[0].rowsB[0], r1 = pairs_in[0].rowsB[1];
+    const bool two = K > 256;
+    if (two && (r0 != 256 || r1 == 0 || r1 > 256)) h3 = false;
     if (h3) {
       static bool attr3_set = false;
       if (!attr3_set) {
@@ -480,16 +500,28 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + W3P - 1) / W3P * W3P;
       if (chunk < 2 * W3P) chunk = 2 * W3P;
       splits = (c.P + chunk - 1) / chunk;
-      WgradArgsH3 a{};
-      for (int q = 0; q < npairs; ++q) {
-        a.A[q] = reinterpret_cast<const unsigned short*>(pairs_in[q].A.p);
-        a.B[q] = reinterpret_cast<const unsigned short*>(pairs_in[q].B[0].p);
-        a.rowsA[q] = pairs_in[q].rowsA;
-      }
-      a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-      a.partial = w.partial; a.row_stride = (size_t)splits * W2LDK; a.split_stride = W2LDK; a.bias_col = K;
       ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * (K + 1) * 4.0);
-      hipLaunchKernelGGL(wgrad_kernel_h3, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
+      for (int part = 0; part < (two ? 2 : 1); ++part) {
+        WgradArgsH3 a{};
+        for (int q = 0; q < npairs; ++q) {
+          const WPair& s = pairs_in[q];
+          a.A[q] = reinterpret_cast<const unsigned short*>(s.A.p);
+          a.B[q] = reinterpret_cast<const unsigned short*>(part ? s.B[1].p : s.B[0].p);
+          a.B2[q] = reinterpret_cast<const unsigned short*>(s.B[1].p);
+          a.rowsA[q] = s.rowsA;
+        }
+        if (part == 0) {
+          a.K = two ? 256 : K;
+          a.splitB = (!two && r1 > 0) ? r0 / 8 : 32;
+          a.col_off = 0; a.bias_col = K;
+        } else {
+          a.K = r1; a.splitB = 32; a.col_off = 256; a.bias_col = -1;
+        }
+        a.octsB = (a.K + 7) / 8;
+        a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
+        a.partial = w.partial; a.row_stride = (size_t)splits * W2LDK; a.split_stride = W2LDK;
+        hipLaunchKernelGGL(wgrad_kernel_h3, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
+      }
       prof_end(c.st, ps);
       r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
     } else {
@@ -558,18 +590,20 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     if ((e = layer(c, L.tr[l], EPI_BWD, in(w.m[l], kO[l]), NOIN, nullptr, N, w.m[l - 1], Arr{}, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
   }
   // weight gradients: dW_l = a^_l in_l^T + u_l vhat_l^T  (+ bias column from the ones row)
+  const bool oct = oct_operands(c);
+  if (oct) oct_pack(c, {{w.E, PE_ROWS, w.Ebf}, {w.E + 7 * (size_t)c.ldp, 32, w.Ebf4}, {w.Eh, PE_ROWS, w.Ehbf}, {w.Eh + 7 * (size_t)c.ldp, 32, w.Ehbf4}});
   for (int l = 0; l <= 8; ++l) {
     WPair pr[2] = {};
     const int rot8 = (l == 8 && c.prec) ? 1 : 0;
     pr[0].A = l == 8 ? F(w.abar8) : w.m[l]; pr[0].rowsA = kO[l]; pr[0].A_rot = rot8; pr[0].A_mod = rot8 ? 257 : 0;
     pr[1].A = l == 8 ? F(w.ones) : w.u[l];  pr[1].rowsA = l == 8 ? 1 : kO[l]; pr[1].A_rot = rot8; pr[1].A_mod = rot8 ? 257 : 0;
     if (l == 0) {
-      pr[0].B[0] = F(w.E); pr[0].rowsB[0] = PE_ROWS;
-      pr[1].B[0] = F(w.Eh); pr[1].rowsB[0] = PE_ROWS;
+      pr[0].B[0] = oct ? w.Ebf : F(w.E); pr[0].rowsB[0] = PE_ROWS;
+      pr[1].B[0] = oct ? w.Ehbf : F(w.Eh); pr[1].rowsB[0] = PE_ROWS;
     } else if (l == 4) {
       if (c.prec) {
-        pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 224; pr[0].B[1] = F(w.E + 7 * (size_t)c.ldp); pr[0].rowsB[1] = 32;
-        pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 224; pr[1].B[1] = F(w.Eh + 7 * (size_t)c.ldp); pr[1].rowsB[1] = 32;
+        pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 224; pr[0].B[1] = oct ? w.Ebf4 : F(w.E + 7 * (size_t)c.ldp); pr[0].rowsB[1] = 32;
+        pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 224; pr[1].B[1] = oct ? w.Ehbf4 : F(w.Eh + 7 * (size_t)c.ldp); pr[1].rowsB[1] = 32;
       } else {
         pr[0].B[0] = w.h[4]; pr[0].rowsB[0] = 217; pr[0].B[1] = F(w.E); pr[0].rowsB[1] = PE_ROWS;
         pr[1].B[0] = w.vh[4]; pr[1].rowsB[0] = 217; pr[1].B[1] = F(w.Eh); pr[1].rowsB[1] = PE_ROWS;
@@ -609,6 +643,8 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat) {
 hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const neat_net_grads* gr) {
   const PackLayout& L = c.L();
   hipError_t e;
+  const bool oct = oct_operands(c);
+  if (oct) oct_pack(c, {{h.small_r, SMALL_R, h.smallbf_r}, {h.small_a, SMALL_A, h.smallbf_a}, {h.zrgb, 3, h.topbf_r}, {h.dlin, 6, h.topbf_a}});
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
     const Arr* hh = head ? h.ha : h.hr;
@@ -624,9 +660,10 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
                    F(head ? h.sc_a : h.sc_r), 256, Arr{}, Arr{}, head)) != hipSuccess) return e;
     for (int l = 0; l <= 4; ++l) {
       WPair pr[1] = {};
-      pr[0].A = l == 4 ? F(top) : ab[l]; pr[0].rowsA = kO[base + l];
+      pr[0].A = l == 4 ? (oct ? (head ? h.topbf_a : h.topbf_r) : F(top)) : ab[l]; pr[0].rowsA = kO[base + l];
       if (l == 0) {
-        pr[0].B[0] = w.feat; pr[0].rowsB[0] = 256; pr[0].B[1] = F(small); pr[0].rowsB[1] = srows;
+        pr[0].B[0] = w.feat; pr[0].rowsB[0] = 256;
+        pr[0].B[1] = oct ? (head ? h.smallbf_a : h.smallbf_r) : F(small); pr[0].rowsB[1] = srows;
       } else {
         pr[0].B[0] = hh[l]; pr[0].rowsB[0] = 256;
       }
