@@ -35,8 +35,11 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 
 
 // branch-free activation math for the bf16 build (hardware exp/log; absolute error ~1e-7, far below bf16 resolution)
 __device__ __forceinline__ float softplus100_fast(float a) {
-  const float t = 100.0f * a;
-  return (fmaxf(t, 0.0f) + __logf(1.0f + __expf(-fabsf(t)))) * 0.01f;
+  // base-2 form on the raw v_exp_f32 / v_log_f32 (8 VALU ops; `__logf` expands to ~15 with its denormal and ln2 fix-ups):
+  // softplus_100(a) = ln2/100 * (max(u,0) + log2(1 + 2^-|u|)),  u = 100 a log2(e);  the log argument lies in [1, 2]
+  const float u = a * 144.26950408889634f;
+  const float y = __builtin_amdgcn_exp2f(-fabsf(u));
+  return (fmaxf(u, 0.0f) + __builtin_amdgcn_logf(1.0f + y)) * 0.0069314718055994531f;
 }
 __device__ __forceinline__ float dphi_fast(float h) { return 1.0f - __expf(-100.0f * h); }
 
@@ -633,6 +636,237 @@ __global__ __launch_bounds__(WG, 2) void sdf_fused_kernel_h(FusedArgs a) {
       }
       if (p < a.P) a.sdf_out[p] = s;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sdf_fused_ws_kernel: the fused primal chain, weight-stationary.  sdf_fused_kernel_h streams every layer's weights
+// from L2 for each 64-point workgroup (9 x 128 KiB per 64 points, latency bound, ~200 TF/s); here one persistent
+// 8-wave workgroup per CU walks batches of 32*NT points layer by layer:
+//  * wave w owns output rows 32w..32w+31 of every hidden layer and holds that 32 x 256 slice of W_l as 16 A fragments
+//    in VGPRs; the slice of layer l+1 is prefetched into a second register set while layer l computes (lin0's small
+//    slice and the sdf-row fragments of lin8 stay resident for the whole launch);
+//  * activations ping-pong between two LDS buffers [32 octets][points][16 B]: one barrier per layer, no in-place
+//    hazards; biases of all layers sit in LDS;
+//  * save mode streams h_1..h_8, PE and the lin8 outputs to HBM with 8-byte stores straight from the accumulators;
+//    values mode (sampler) writes nothing but the clamped sdf.
+// ---------------------------------------------------------------------------------------------
+constexpr int FWT = 512;
+template <int NT> struct FwsCfg {
+  static constexpr int BP = 32 * NT;
+  static constexpr int XBYTES = 32 * BP * 16;            // one activation buffer
+  static constexpr int PEBYTES = 8 * BP * 16;            // PE octets (K padded to 64); reused for the sdf partial sums
+  static constexpr int BIAS_FLOATS = 9 * 256 + 8;
+  static constexpr int LDS = 2 * XBYTES + PEBYTES + BIAS_FLOATS * 4;
+};
+
+template <int NT, bool VALUES>
+__global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int nbatch, int per_wg) {
+  typedef FwsCfg<NT> C;
+  constexpr int BP = C::BP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fws[];
+  unsigned char* XA = fws;
+  unsigned char* XB = fws + C::XBYTES;
+  unsigned char* PE = fws + 2 * C::XBYTES;
+  float* biasl = reinterpret_cast<float*>(fws + 2 * C::XBYTES + C::PEBYTES);     // [l][256]; lin8 in packed row order
+  u16* pe16 = reinterpret_cast<u16*>(PE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const bool save = !VALUES && a.save;
+
+  // biases -> LDS (lin3 has 217 rows; lin8: packed row n <- bias[(n + rot) mod 257], the sdf row's bias at [8][256])
+  for (int idx = tid; idx < 8 * 256; idx += FWT) {
+    const int l = idx >> 8, n = idx & 255;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (l == k && n < (k == 3 ? 217 : 256)) v = a.bias[k][n];
+    biasl[idx] = v;
+  }
+  for (int n = tid; n < 257; n += FWT) {
+    int bi = n + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
+    biasl[8 * 256 + n] = VALUES ? (n == 0 ? a.bias[8][0] : 0.0f) : a.bias[8][bi];
+  }
+  // resident fragments: lin0 (K = 64: 4 k-steps) and this wave's two k-steps of the sdf row of lin8
+  uint4 w0[4], ws8[2];
+  auto load_small = [&](bool first) {      // lin0 slice (before a batch) / sdf-row k-steps (one layer ahead of lin8)
+    unsigned voff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(voff));
+    if (first) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) w0[ks] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[0]) + voff + (wave * 4 + ks) * 1024);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        ws8[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[8]) + voff + (((VALUES ? 0 : 8) * 16 + 2 * wave + j) * 1024));
+    }
+  };
+  load_small(true);
+  uint4 wA[16], wB[16];
+  auto load_w = [&](uint4 (&w)[16], const uint4* Wl, bool on) {
+    // The per-lane offset is laundered through an empty asm: otherwise the 128 fragment addresses of the 8 layers are
+    // loop-invariant, get hoisted out of the batch loop and spilled (2 VGPRs each).  SGPR base + this offset + immediate.
+    unsigned voff = (unsigned)(wave * 16 * 64 + lane) * 16u;
+    asm volatile("" : "+v"(voff));
+    const char* base = reinterpret_cast<const char*>(Wl);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      w[ks] = on ? *reinterpret_cast<const uint4*>(base + voff + ks * 1024) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  load_w(wA, a.Wp[1], true);
+
+  const int b_begin = blockIdx.x * per_wg, b_end = min(nbatch, b_begin + per_wg);
+  for (int b = b_begin; b < b_end; ++b) {
+    const int p0 = b * BP;
+    const int nt = min(NT, (a.ldp - p0) / 32);           // whole 32-point tiles inside the padded point range
+    // ---- positional encoding (embedder.py:12-36) into the PE octets (rows 39..63 zero)
+    for (int idx = tid; idx < 64 * BP; idx += FWT) {
+      const int j = idx / BP, p = idx % BP;
+      float v = 0.0f;
+      if (j < 39 && p < nt * 32) {
+        const int c = j < 3 ? j : (j - 3) % 3;
+        const float xc = a.x_fm[(size_t)c * a.ldp + p0 + p];
+        if (j < 3) v = xc;
+        else {
+          const int k = (j - 3) / 6, is_cos = ((j - 3) % 6) >= 3;
+          const float f = (float)(1 << k);
+          v = is_cos ? __cosf(xc * f) : __sinf(xc * f);
+        }
+        if (save) a.E[(size_t)j * a.ldp + p0 + p] = v;
+      }
+      pe16[((size_t)(j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
+    }
+    __syncthreads();
+
+    // one hidden layer: dst[rows of this wave] = softplus(W src + b), optionally streamed to HBM
+    auto hidden = [&](const uint4* w, int KS, const unsigned char* src, unsigned char* dst, int l, int N, u16* hout) {
+      const float* bl = biasl + l * 256;
+#pragma unroll 1
+      for (int t = 0; t < nt; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const unsigned char* bp = src + ((size_t)hi * BP + t * 32 + (lane & 31)) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          if (ks < KS) {
+            const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&w[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
+          }
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // at most 4 B fragments in flight: the weights own the registers
+        }
+        if (wave * 32 >= N) continue;
+        const int pl = t * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = wave * 32 + 8 * g + 4 * hi;
+          if (n0 >= N) continue;
+          const float4 bb = *reinterpret_cast<const float4*>(bl + n0);
+          const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? softplus100_fast(acc[4 * g + e] + bq[e]) : 0.0f;
+          u16* lp = reinterpret_cast<u16*>(dst) + ((n0 >> 3) * BP + pl) * 8 + (n0 & 7);
+          if (n0 + 3 < N) {
+            const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+            *reinterpret_cast<uint2*>(lp) = pk;
+            if (hout) {                                    // 32-bit byte offset (arrays < 4 GiB) off the layer's base pointer
+              const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
+              *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + go) = pk;
+            }
+          } else {                                         // lin3: the quad holding row 216 (rows 217.. receive the PE copy)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n0 + e < N) lp[e] = f2bf(o[e]);
+          }
+        }
+      }
+      __syncthreads();
+    };
+
+    // lin0: PE -> XA (w0 resident); lin1 (wA) ... lin8 (wB); the slice two layers ahead loads while a layer computes
+    hidden(w0, 4, PE, XA, 0, 256, save ? a.h[1] : nullptr);
+    load_w(wB, a.Wp[2], true);
+    hidden(wA, 16, XA, XB, 1, 256, save ? a.h[2] : nullptr);
+    load_w(wA, a.Wp[3], wave * 32 < 217);
+    hidden(wB, 16, XB, XA, 2, 256, save ? a.h[3] : nullptr);
+    load_w(wB, a.Wp[4], true);
+    hidden(wA, 16, XA, XB, 3, 217, nullptr);
+    // skip connection (rend_a :87-88): rows 217..255 of lin4's input are the 39 PE rows (1/sqrt2 folded into W4)
+    {
+      u16* xb16 = reinterpret_cast<u16*>(XB);
+      for (int idx = tid; idx < 39 * BP; idx += FWT) {
+        const int j = idx / BP, p = idx % BP, row = 217 + j;
+        xb16[((size_t)(row >> 3) * BP + p) * 8 + (row & 7)] = pe16[((size_t)(j >> 3) * BP + p) * 8 + (j & 7)];
+      }
+      __syncthreads();
+      if (save) {                                          // h4 as the unfused consumers expect it: 217 rows + PE[0..6] in the pad
+        for (int idx = tid; idx < 28 * nt * 32; idx += FWT) {
+          const int o8 = idx / (nt * 32), p = idx % (nt * 32);
+          reinterpret_cast<uint4*>(a.h[4])[(size_t)o8 * a.ldp + p0 + p] = reinterpret_cast<const uint4*>(XB)[(size_t)o8 * BP + p];
+        }
+      }
+    }
+    load_w(wA, a.Wp[5], true);
+    hidden(wB, 16, XB, XA, 4, 256, save ? a.h[5] : nullptr);
+    load_w(wB, a.Wp[6], true);
+    hidden(wA, 16, XA, XB, 5, 256, save ? a.h[6] : nullptr);
+    load_w(wA, a.Wp[7], true);
+    hidden(wB, 16, XB, XA, 6, 256, save ? a.h[7] : nullptr);
+    if (!VALUES) load_w(wB, a.Wp[8], true);
+    load_small(false);
+    hidden(wA, 16, XA, XB, 7, 256, save ? a.h[8] : nullptr);
+    if (b + 1 < b_end) { load_w(wA, a.Wp[1], true); load_small(true); }     // next batch's lin1 and lin0 slices
+
+    // ---- lin8: 256 feature rows (save mode) + the sdf row, split over the waves' k-steps and reduced through LDS
+    float* red = reinterpret_cast<float*>(PE);             // [8 waves][BP]
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+      const unsigned char* bp = XB + ((size_t)hi * BP + t * 32 + (lane & 31)) * 16;
+      f32x16 accs;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)(2 * wave + j) * 2 * BP * 16);
+        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&ws8[j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
+      }
+      if (hi == 0) red[wave * BP + t * 32 + lane] = accs[0];
+      if (!VALUES) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wB[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        const int pl = t * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = wave * 32 + 8 * g + 4 * hi;
+          const float4 bb = *reinterpret_cast<const float4*>(biasl + 8 * 256 + n0);
+          const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
+          *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.feat) + go) =
+              make_uint2(pack2(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y), pack2(acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w));
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < nt * 32) {
+      float sv = biasl[8 * 256 + (VALUES ? 0 : 256)];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sv += red[w * BP + tid];
+      const int p = p0 + tid;
+      if (VALUES) {
+        if (a.radius > 0.0f) {
+          const float x0 = a.x_fm[p], x1 = a.x_fm[(size_t)a.ldp + p], x2 = a.x_fm[(size_t)2 * a.ldp + p];
+          sv = fminf(sv, a.scale * (a.radius - sqrtf(x0 * x0 + x1 * x1 + x2 * x2)));
+        }
+        if (p < a.P) a.sdf_out[p] = sv;
+      } else {
+        a.sdfraw[p] = sv;
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -159,6 +159,8 @@ template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a
   if (a.out0_bf16) return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4, true>(st, a) : launch_layer_h_pt<EPI, 2, true>(st, a);
   return launch_layer_h_pt<EPI, 2, false>(st, a);
 }
+int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persistent kernel, 0 = sdf_fused_kernel_h
+int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
 template <int EPI> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
@@ -388,6 +390,31 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
     fl += 2.0 * (full ? 257 : 1) * 256 * (double)c.P;
     const double fbytes = (double)c.P * (12.0 + (full ? (39 * 4.0 + (7 * 256 + 224 + 256) * 2.0 + 4.0) : 4.0)) + 2.0 * 589000.0;
     ProfSlot* ps = prof_begin(c.st, 2, fl, fbytes);
+    if (g_fused_ws) {
+      // weight-stationary persistent kernel: batches of 128 points (64 when that balances the CUs better)
+      auto go = [&](auto kern, int BP, int lds_bytes) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        const int nbatch = (c.ldp + BP - 1) / BP;
+        const int per_wg = (nbatch + g_ws_grid - 1) / g_ws_grid;
+        hipLaunchKernelGGL(kern, dim3((nbatch + per_wg - 1) / per_wg), dim3(FWT), lds_bytes, c.st, a, nbatch, per_wg);
+        return hipGetLastError();
+      };
+      // batch = 32*NT points: larger batches re-read the weights from L2 less often, but 1040 batches of 128 points only
+      // fill 208 of 256 CUs at the C2 size; pick the NT with the best (CU balance) / (weight traffic) trade-off
+      auto cost = [&](int BP) {
+        const int nb = (c.ldp + BP - 1) / BP, per = (nb + g_ws_grid - 1) / g_ws_grid;
+        return (double)per * (BP + 48.0);            // rounds x (per-point work + per-batch weight streaming, in point units)
+      };
+      int nt_sel = g_fused_nt;
+      if (nt_sel == 0) { nt_sel = 2; for (int n = 3; n <= 4; ++n) if (cost(32 * n) < cost(32 * nt_sel)) nt_sel = n; }
+      hipError_t e;
+      if (nt_sel == 4) e = full ? go(&sdf_fused_ws_kernel<4, false>, 128, FwsCfg<4>::LDS) : go(&sdf_fused_ws_kernel<4, true>, 128, FwsCfg<4>::LDS);
+      else if (nt_sel == 3) e = full ? go(&sdf_fused_ws_kernel<3, false>, 96, FwsCfg<3>::LDS) : go(&sdf_fused_ws_kernel<3, true>, 96, FwsCfg<3>::LDS);
+      else e = full ? go(&sdf_fused_ws_kernel<2, false>, 64, FwsCfg<2>::LDS) : go(&sdf_fused_ws_kernel<2, true>, 64, FwsCfg<2>::LDS);
+      prof_end(c.st, ps);
+      return e;
+    }
     if (full) hipLaunchKernelGGL((sdf_fused_kernel_h<PT, false>), dim3(c.ldp / (32 * PT)), dim3(WG), lds, c.st, a);
     else hipLaunchKernelGGL((sdf_fused_kernel_h<PT, true>), dim3(c.ldp / (32 * PT)), dim3(WG), lds, c.st, a);
     prof_end(c.st, ps);
@@ -748,6 +775,8 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 1 && (value == 0 || value == 1)) { g_wgrad_h3 = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { g_layer_ws = value; return 0; }
   if (key == 3 && value >= 1 && value <= 4096) { g_ws_grid = value; return 0; }
+  if (key == 4 && (value == 0 || value == 1)) { g_fused_ws = value; return 0; }
+  if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   return -1;
 }
 
