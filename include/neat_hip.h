@@ -128,6 +128,14 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
  * PARITY UNPINNED: hawp is an empty submodule here; semantics are those the call sites rely on. */
 int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream);
 
+/* ---- a16: Adam step over one flat fp32 parameter buffer = torch.optim.Adam(lr) as the reference trainer builds it
+ * (training/volsdf_train.py:177; no weight decay, no amsgrad).  The parameters and both moments are flat [n]; the
+ * gradients stay where autograd left them: grads[s] (device pointer, or NULL = no gradient this step: that segment is
+ * skipped like torch does) covers elements [seg_offsets[s], seg_offsets[s+1]); seg_steps[s] = 1-based count of the steps
+ * that segment has taken including this one (torch counts steps per tensor) -- host arrays, nseg <= 96. */
+int neat_adam_step(float* params, const float* const* grads, const long long* seg_offsets, const int* seg_steps, int nseg,
+                   float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, void* stream);
+
 /* ---- 8f-2 (next row): device-side rectangular assignment = scipy.optimize.linear_sum_assignment as called at
  * model/networks/neat_wfr_rend_a.py:473 and model/networks/loss_wfr.py:108 (same algorithm, float64 duals, same tie
  * rule => same assignment), without the host round trip.  cost [nr,nc] float32 row-major; row_mask [nr] bytes or NULL

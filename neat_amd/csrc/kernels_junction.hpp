@@ -167,4 +167,43 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
   if (tid == 0) *a.n_match = N;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Adam over ONE flat parameter buffer (a16: torch.optim.Adam as the reference trainer uses it, volsdf_train.py:177,
+// defaults amsgrad=False, weight_decay=0, maximize=False) -- one launch for the 1 219 274 parameters instead of torch's
+// multi-tensor kernels over 65 tensors.  Arithmetic in torch's order:
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g g ; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// ---------------------------------------------------------------------------------------------
+constexpr int ADAM_MAXSEG = 96;
+struct AdamSegs {                 // gradient of segment s covers [off[s], off[s+1]); per-segment bias corrections (torch counts steps per tensor)
+  const float* g[ADAM_MAXSEG]; long long off[ADAM_MAXSEG + 1]; float lr_over_bc1[ADAM_MAXSEG], inv_sqrt_bc2[ADAM_MAXSEG]; int nseg;
+};
+
+__global__ void adam_flat_kernel(float* __restrict__ p, AdamSegs segs, float* __restrict__ m, float* __restrict__ v,
+                                 long long n, float beta1, float beta2, float eps) {
+  __shared__ long long s_off[ADAM_MAXSEG + 1];
+  __shared__ const float* s_g[ADAM_MAXSEG];
+  __shared__ float s_a1[ADAM_MAXSEG], s_a2[ADAM_MAXSEG];
+  for (int t = threadIdx.x; t <= segs.nseg; t += blockDim.x) {
+    long long o = segs.off[0]; const float* gp = segs.g[0];      // compile-time kernarg indices only (a runtime index = scratch copy)
+    float a1 = segs.lr_over_bc1[0], a2 = segs.inv_sqrt_bc2[0];
+#pragma unroll
+    for (int k = 1; k <= ADAM_MAXSEG; ++k)
+      if (k == t) { o = segs.off[k]; if (k < ADAM_MAXSEG) { gp = segs.g[k]; a1 = segs.lr_over_bc1[k]; a2 = segs.inv_sqrt_bc2[k]; } }
+    s_off[t] = o;
+    if (t < segs.nseg) { s_g[t] = gp; s_a1[t] = a1; s_a2[t] = a2; }
+  }
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = segs.nseg - 1;            // segment of element i: last s with off[s] <= i
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid - 1; }
+  const float* gp = s_g[lo];
+  if (!gp) return;                           // parameter without a gradient this step: untouched, as torch.optim.Adam
+  const float g = gp[i - s_off[lo]];
+  const float mm = beta1 * m[i] + (1.0f - beta1) * g;
+  const float vv = beta2 * v[i] + (1.0f - beta2) * g * g;
+  m[i] = mm; v[i] = vv;
+  p[i] -= s_a1[lo] * (mm / (sqrtf(vv) * s_a2[lo] + eps));
+}
+
 }  // namespace neat

@@ -999,6 +999,28 @@ int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int*
   return (int)hipGetLastError();
 }
 
+int neat_adam_step(float* params, const float* const* grads, const long long* seg_offsets, const int* seg_steps, int nseg,
+                   float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, void* stream) {
+  if (nseg <= 0) return 0;
+  if (!params || !grads || !seg_offsets || !seg_steps || !exp_avg || !exp_avg_sq || nseg > ADAM_MAXSEG) return -1;
+  AdamSegs segs{};
+  for (int s = 0; s < nseg; ++s) {
+    segs.g[s] = grads[s]; segs.off[s] = seg_offsets[s];
+    if (grads[s]) {
+      if (seg_steps[s] < 1) return -1;
+      const double bc1 = 1.0 - pow((double)beta1, (double)seg_steps[s]), bc2 = 1.0 - pow((double)beta2, (double)seg_steps[s]);
+      segs.lr_over_bc1[s] = (float)((double)lr / bc1); segs.inv_sqrt_bc2[s] = (float)(1.0 / sqrt(bc2));
+    }
+  }
+  segs.off[nseg] = seg_offsets[nseg];
+  segs.nseg = nseg;
+  const long long n = seg_offsets[nseg];
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
+                     exp_avg_sq, n, beta1, beta2, eps);
+  return (int)hipGetLastError();
+}
+
 size_t neat_lsap_ws_bytes(int nr, int nc) {
   const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
   return (mn + 2 * mx) * sizeof(double) + ((size_t)nr + 5 * mx + 2 * mn) * sizeof(int);

@@ -53,12 +53,17 @@ class FlatGradBucket:
         if self.flat is None or self.flat.device != p0.device:
             self.flat = torch.zeros(self.numel, device=p0.device, dtype=torch.float32)
 
-    def all_reduce_mean(self):
-        """grad_i <- mean over ranks of grad_i (a parameter with no gradient on this rank contributes zeros)."""
+    def all_reduce_mean(self, flat_grad=None):
+        """grad_i <- mean over ranks of grad_i (a parameter with no gradient on this rank contributes zeros).
+        `flat_grad`: the gradients already live in this flat buffer (neat_amd.optim.FlatAdam) -> reduced in place."""
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
-        self._ensure()
         world = dist.get_world_size(self.group)
+        if flat_grad is not None:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad.mul_(1.0 / world)
+            return
+        self._ensure()
         off = 0
         views = []
         for p in self.params:

@@ -1,0 +1,82 @@
+"""Adam over one flat parameter buffer.  Same arithmetic, hyper-parameters and `state_dict()` layout as
+`torch.optim.Adam` (the reference trainer's optimizer, training/volsdf_train.py:177), but the parameters and both
+moments live in three flat fp32 buffers and a step is ONE HIP launch (`neat_adam_step`) instead of multi-tensor kernels
+over 65 tensors.  Gradients stay wherever autograd put them: the kernel reads them through a pointer table passed as a
+kernel argument (so `zero_grad(set_to_none=True)` keeps its meaning and costs nothing)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MAX_SEGMENTS = 96
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False))
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam keeps one flat buffer: pass one parameter group")
+        self._params = self.param_groups[0]["params"]
+        dev = self._params[0].device
+        if dev.type != "cuda" or any(p.dtype != torch.float32 or p.device != dev for p in self._params):
+            raise RuntimeError("FlatAdam needs float32 CUDA parameters on one device (no CPU path)")
+        if len(self._params) > MAX_SEGMENTS:
+            raise ValueError(f"FlatAdam handles up to {MAX_SEGMENTS} parameter tensors")
+        sizes = [p.numel() for p in self._params]
+        self.numel = sum(sizes)
+        self._offsets = (ctypes.c_longlong * (len(sizes) + 1))()
+        for i, n in enumerate(sizes):
+            self._offsets[i + 1] = self._offsets[i] + n
+        self.flat_param = torch.empty(self.numel, device=dev)
+        self.exp_avg = torch.zeros(self.numel, device=dev)
+        self.exp_avg_sq = torch.zeros(self.numel, device=dev)
+        self._steps = (ctypes.c_int * len(sizes))()
+        for i, p in enumerate(self._params):
+            off, n = self._offsets[i], sizes[i]
+            view = self.flat_param[off:off + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view                      # the module's parameters now alias the flat buffer
+            self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.exp_avg[off:off + n].view(p.shape),
+                             "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape)}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        group = self.param_groups[0]
+        ptrs = (ctypes.c_void_p * len(self._params))()
+        keep = []                                  # non-contiguous / non-fp32 gradients are normalised first (not the usual case)
+        for i, p in enumerate(self._params):
+            g = p.grad
+            if g is None:
+                continue
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+                keep.append(g)
+            ptrs[i] = g.data_ptr()
+            self._steps[i] += 1
+        b1, b2 = group["betas"]
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().neat_adam_step(P(self.flat_param), ptrs, self._offsets, self._steps, len(self._params), P(self.exp_avg),
+                                             P(self.exp_avg_sq), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "neat_adam_step")
+        # the parameters changed behind autograd's back: bump their version counters (packed-weight caches key on them)
+        torch._C._increment_version(self._params)
+        for i, p in enumerate(self._params):
+            self.state[p]["step"] = torch.tensor(float(self._steps[i]))
+        return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for i, p in enumerate(self._params):
+            st = self.state[p]
+            off, n = self._offsets[i], p.numel()
+            for key, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                view = flat[off:off + n].view(p.shape)
+                view.copy_(st[key])
+                st[key] = view
+            self._steps[i] = int(float(st["step"]))

@@ -16,9 +16,10 @@ class Trainer:
             self.model.load_state_dict(state_dict)
         self.model.to(self.device).train()
         self.loss = VolSDFLoss(**(loss_conf or synth.ABC_NEAT_A_LOSS_CONF))
-        try:
-            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, fused=self.device.type == "cuda")
-        except (RuntimeError, TypeError):
+        if self.device.type == "cuda":
+            from .optim import FlatAdam
+            self.optimizer = FlatAdam(self.model.parameters(), lr=lr)      # torch.optim.Adam semantics, one HIP launch
+        else:
             self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.1 ** (1.0 / decay_steps))
         self.bucket = FlatGradBucket(self.model.parameters())

@@ -484,3 +484,35 @@ def test_dtu_style_conf_trains(dev):
         opt.step()
         losses.append(float(lo["loss"].detach()))
     assert losses[-1] != losses[0]
+
+
+def test_flat_adam_matches_torch_adam(dev):
+    """neat_adam_step (one launch over the flat buffer) against torch.optim.Adam on the same gradients, incl. a parameter
+    that gets no gradient in some steps, the lr scheduler, and the state_dict round trip."""
+    from neat_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(256, 39), (256, 1), (256,), (217, 256), (), (64, 256), (3,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=5e-4)
+    our = FlatAdam(our_p, lr=5e-4)
+    rs = torch.optim.lr_scheduler.ExponentialLR(ref, 0.9)
+    os_ = torch.optim.lr_scheduler.ExponentialLR(our, 0.9)
+    for it in range(12):
+        ref.zero_grad(set_to_none=True); our.zero_grad(set_to_none=True)
+        for k, (a, b) in enumerate(zip(ref_p, our_p)):
+            if k == 4 and it % 3 == 0:
+                continue                                    # no gradient this step
+            g = torch.randn(a.shape, device=dev) * (10.0 ** (k - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        v0 = our_p[0]._version
+        ref.step(); our.step(); rs.step(); os_.step()
+        assert our_p[0]._version > v0
+        if it == 5:                                         # checkpoint round trip in torch's format
+            sd = our.state_dict()
+            our2_p = [torch.nn.Parameter(p.detach().clone()) for p in our_p]
+            our2 = FlatAdam(our2_p, lr=5e-4)
+            our2.load_state_dict(sd)
+            assert list(our2._steps) == list(our._steps) and torch.equal(our2.exp_avg, our.exp_avg)
+    for a, b in zip(ref_p, our_p):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
