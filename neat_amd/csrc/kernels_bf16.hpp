@@ -324,15 +324,23 @@ constexpr int WST = 512, WSP = 32;
 constexpr int WS_TILE = 32 * WSP * 16;                   // 16 KiB: [32 octets][32 points][16 B]
 struct LayerArgsWS {
   const u16* in; const uint4* Wp; const float* bias;
+  const float* srow; const float* wrow; const float* wrow_scale;     // EPI_BWD8: per-point scalar, per-row weight and its scale
   const u16* aux0; const u16* aux1;
   u16* out0; u16* out1;
   int N, in_octs, ldp, ntiles, per_wg;                   // 32-point tiles in total / per workgroup (contiguous)
+  int kstride;                                           // k-steps per row tile in the pack (16, or 17 when a 257th column follows)
 };
+// epilogues that exist only in the weight-stationary kernel
+constexpr int EPI_LINACC = 8;      // out0 = acc + aux0                      (feature cotangent: second head adds to the first)
+constexpr int EPI_BWD8 = 9;        // out0 = (acc + wrow[n] s[p]) phi'(aux0) + aux1   (first layer of the reverse chain: the
+                                   // sdf row of lin8 enters as a rank-1 term, s = cotangent of the raw sdf, fp32 per point)
 template <int EPI> struct WsCfg {
-  static constexpr int NAUX = (EPI == EPI_TAN || EPI == EPI_BWD) ? 2 : ((EPI == EPI_REV || EPI == EPI_BWD_RELU) ? 1 : 0);
+  static constexpr int NAUX = (EPI == EPI_TAN || EPI == EPI_BWD || EPI == EPI_BWD8) ? 2
+                              : ((EPI == EPI_REV || EPI == EPI_BWD_RELU || EPI == EPI_LINACC) ? 1 : 0);
+  static constexpr int HAS_S = EPI == EPI_BWD8 ? 1 : 0;
   static constexpr int NS = NAUX == 2 ? 3 : 4;           // ring depth: 3 x 48 KiB or 4 x (16|32) KiB
-  static constexpr int STAGE = WS_TILE * (1 + NAUX);
-  static constexpr int G = 2 * (1 + NAUX);               // DMA instructions per stage per wave
+  static constexpr int STAGE = WS_TILE * (1 + NAUX) + HAS_S * 8 * 256;
+  static constexpr int G = 2 * (1 + NAUX) + HAS_S;       // DMA instructions per stage per wave
   static constexpr int LDS = NS * STAGE;
 };
 
@@ -342,6 +350,7 @@ __device__ __forceinline__ void ws_wait_barrier(int n) {     // n = DMA instruct
     case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
   }
 }
@@ -372,26 +381,37 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     }
   };
   auto issue = [&](int tau) {
-    const unsigned slot = lds_base + (unsigned)(tau % C::NS) * C::STAGE + dma_off;
+    const unsigned stage = lds_base + (unsigned)(tau % C::NS) * C::STAGE;
+    const unsigned slot = stage + dma_off;
     const int tile = t_begin + tau;
     dma(a.in, tile, slot, a.in_octs - 1);
     if (C::NAUX >= 1) dma(a.aux0, tile, slot + WS_TILE, 31);
     if (C::NAUX >= 2) dma(a.aux1, tile, slot + 2 * WS_TILE, 31);
+    if (C::HAS_S) {          // this wave's private copy of the 32 per-point scalars (both half-waves fetch the same 128 B)
+      const float* s2 = a.srow + (size_t)tile * WSP + (lane & 31);
+      const unsigned d2 = __builtin_amdgcn_readfirstlane(stage + WS_TILE * (1 + C::NAUX) + wave * 256);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
+    }
   };
 #pragma unroll
   for (int t = 0; t < C::NS - 1; ++t)
     if (t < T) issue(t);
 
-  // stationary operands: this wave's 32 x 256 slice of W (A fragments) and its bias values in accumulator layout
+  // stationary operands: this wave's 32 x 256 slice of W (A fragments) and its per-row constants in accumulator layout
   const bool live = wave * 32 < a.N;
   uint4 wreg[16];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) wreg[ks] = live ? a.Wp[((size_t)wave * 16 + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
-  float bias[16];
+  for (int ks = 0; ks < 16; ++ks) wreg[ks] = live ? a.Wp[((size_t)wave * a.kstride + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+  float bias[16];             // EPI_RELU / EPI_LINEAR: bias ; EPI_BWD8: the sdf row of lin8 (effective weight)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    bias[r] = (EPI == EPI_RELU && a.bias && n < a.N) ? a.bias[n] : 0.0f;
+    float b = 0.0f;
+    if ((EPI == EPI_RELU || EPI == EPI_LINEAR) && a.bias && n < a.N) b = a.bias[n];
+    if (EPI == EPI_BWD8 && n < a.N) b = a.wrow[n] * a.wrow_scale[0];
+    bias[r] = b;
   }
   const unsigned bfrag = (unsigned)((lane >> 5) * WSP + (lane & 31)) * 16;        // + ks * 2 * WSP * 16
   const unsigned efrag = dma_off + (unsigned)(lane & 31) * 16 + (unsigned)(lane >> 5) * 8;   // + q * WSP * 16
@@ -412,6 +432,8 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     }
     if (!live) continue;
     const int p = (t_begin + tau) * WSP + (lane & 31);
+    float sp = 0.0f;
+    if (C::HAS_S) sp = *reinterpret_cast<const float*>(slot + WS_TILE * (1 + C::NAUX) + wave * 256 + (lane & 31) * 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n0 = wave * 32 + 8 * q + 4 * (lane >> 5);
@@ -431,9 +453,12 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
         const float v = acc[4 * q + e];
         float r0 = 0.0f, r1 = 0.0f;
         if (EPI == EPI_RELU) r0 = fmaxf(v + bias[4 * q + e], 0.0f);
+        else if (EPI == EPI_LINEAR) r0 = v + bias[4 * q + e];
+        else if (EPI == EPI_LINACC) r0 = v + x0[e];
         else if (EPI == EPI_REV) r0 = v * dphi_fast(x0[e]);
         else if (EPI == EPI_TAN) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
         else if (EPI == EPI_BWD) r0 = v * dphi_fast(x0[e]) + x1[e];
+        else if (EPI == EPI_BWD8) r0 = (v + bias[4 * q + e] * sp) * dphi_fast(x0[e]) + x1[e];
         else if (EPI == EPI_BWD_RELU) r0 = x0[e] > 0.0f ? v : 0.0f;
         if (n0 + e >= a.N) { r0 = 0.0f; r1 = 0.0f; }       // padded rows of the last octet: finite zeros
         o0[e] = r0; o1[e] = r1;
@@ -442,6 +467,41 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
       *reinterpret_cast<uint2*>(a.out0 + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
       if (EPI == EPI_TAN) *reinterpret_cast<uint2*>(a.out1 + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
     }
+  }
+}
+
+// out[split][k] = sum over the split's points of  s[p] B0[k][p] + B1[k][p]  (k < 256) and out[split][256] = sum s[p]:
+// the lin8 row of the weight gradient that belongs to the raw sdf (cotangent s, fp32 per point) -- the feature rows go
+// through wgrad_kernel_h3; same point chunks, same partial layout, so the reduction kernels see one more row.
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ s, const u16* __restrict__ B0, const u16* __restrict__ B1,
+                                                     int P, int ldp, int chunk, float* __restrict__ out, size_t split_stride) {
+  __shared__ float red[8][264];
+  const int tid = threadIdx.x, oct = tid & 31, pg = tid >> 5;          // 32 octets x 8 point lanes
+  const int pbeg = blockIdx.x * chunk, pend = min(P, pbeg + chunk);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.0f;
+  const uint4* b0 = reinterpret_cast<const uint4*>(B0) + (size_t)oct * ldp;
+  const uint4* b1 = reinterpret_cast<const uint4*>(B1) + (size_t)oct * ldp;
+  for (int p = pbeg + pg; p < pend; p += 8) {
+    const float sv = s[p];
+    const uint4 x = b0[p], y = b1[p];
+    const unsigned xw[4] = {x.x, x.y, x.z, x.w}, yw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] += sv * bf_lo(xw[j]) + bf_lo(yw[j]);
+      acc[2 * j + 1] += sv * bf_hi(xw[j]) + bf_hi(yw[j]);
+    }
+    if (oct == 0) ssum += sv;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[pg][oct * 8 + e] = acc[e];
+  if (oct == 0) red[pg][256] = ssum;
+  __syncthreads();
+  for (int k = tid; k < 257; k += 256) {
+    float v = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += red[g][k];
+    out[(size_t)blockIdx.x * split_stride + k] = v;
   }
 }
 

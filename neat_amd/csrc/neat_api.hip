@@ -191,20 +191,26 @@ inline bool ws_eligible(int epi, const LayerArgsH& a) {
   if (a.bias && (epi != EPI_RELU || a.bias_rot != 0)) return false;
   return true;
 }
+hipError_t dispatch_ws_args(hipStream_t st, int epi, const LayerArgsWS& a) {
+  switch (epi) {
+    case EPI_LINEAR: return launch_layer_ws<EPI_LINEAR>(st, a);
+    case EPI_LINACC: return launch_layer_ws<EPI_LINACC>(st, a);
+    case EPI_RELU: return launch_layer_ws<EPI_RELU>(st, a);
+    case EPI_REV: return launch_layer_ws<EPI_REV>(st, a);
+    case EPI_TAN: return launch_layer_ws<EPI_TAN>(st, a);
+    case EPI_BWD: return launch_layer_ws<EPI_BWD>(st, a);
+    case EPI_BWD8: return launch_layer_ws<EPI_BWD8>(st, a);
+    case EPI_BWD_RELU: return launch_layer_ws<EPI_BWD_RELU>(st, a);
+  }
+  return hipErrorInvalidValue;
+}
 hipError_t dispatch_ws(hipStream_t st, int epi, const LayerArgsH& h) {
   LayerArgsWS a{};
   a.in = reinterpret_cast<const u16*>(h.in[0].p); a.Wp = h.Wp; a.bias = h.bias;
   a.aux0 = h.aux0; a.aux1 = h.aux1;
   a.out0 = reinterpret_cast<u16*>(h.out0); a.out1 = reinterpret_cast<u16*>(h.out1);
-  a.N = h.N; a.in_octs = (h.in[0].rows + 7) / 8; a.ldp = h.ldp;
-  switch (epi) {
-    case EPI_RELU: return launch_layer_ws<EPI_RELU>(st, a);
-    case EPI_REV: return launch_layer_ws<EPI_REV>(st, a);
-    case EPI_TAN: return launch_layer_ws<EPI_TAN>(st, a);
-    case EPI_BWD: return launch_layer_ws<EPI_BWD>(st, a);
-    case EPI_BWD_RELU: return launch_layer_ws<EPI_BWD_RELU>(st, a);
-  }
-  return hipErrorInvalidValue;
+  a.N = h.N; a.in_octs = (h.in[0].rows + 7) / 8; a.ldp = h.ldp; a.kstride = 16;
+  return dispatch_ws_args(st, epi, a);
 }
 #define EPI_SWITCH(FN, st, epi, a, nt)                                         \
   switch (epi) {                                                              \
@@ -244,11 +250,12 @@ const In NOIN = In{Arr{}, 0};
 // out[n][p] = epi(Wm in + bias) with Wm = pack `pid`; N <= pack rows (only the leading rows are computed)
 hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bias, int N, Arr out0, Arr out1 = Arr{},
                  int n_split = 1 << 30, Arr aux0 = Arr{}, Arr aux1 = Arr{}, int accumulate = 0, int bias_rot = 0, int bias_n = 1 << 30,
-                 const float* padfill = nullptr, int padfill_rows = 0) {
+                 const float* padfill = nullptr, int padfill_rows = 0, int tile0 = 0) {
+  // tile0: compute packed rows [32 tile0, 32 tile0 + N) only (bf16 build: the small-input rows of the transposed head layer)
   const PackDesc2& d = c.L().d[pid];
-  const float* wp = c.packed + d.offset;
+  const float* wp = c.packed + d.offset + (size_t)tile0 * (d.Kpad / 16) * 64 * 4;
   const int k_in = (c.prec && in1.rows > 0 ? pad8(in0.rows) : in0.rows) + in1.rows;
-  if (k_in != d.K || N > d.N) return hipErrorInvalidValue;
+  if (k_in != d.K || N + 32 * tile0 > d.N || (tile0 && !c.prec)) return hipErrorInvalidValue;
   // algorithmic flops (true N, K, P) and algorithmic HBM bytes (every operand row once, weights once)
   double bytes = 0.0;
   {
@@ -291,6 +298,26 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
   return e;
 }
 
+// a hidden-size layer straight on the weight-stationary kernel (bf16 build; rows [0, N) of pack `pid`, K = 256 columns)
+hipError_t layer_ws(const Ctx& c, int pid, int epi, Arr in0, int N, Arr out0, Arr aux0 = Arr{}, Arr aux1 = Arr{},
+                    const float* srow = nullptr, const float* wrow = nullptr, const float* wrow_scale = nullptr) {
+  const PackDesc2& d = c.L().d[pid];
+  if (!c.prec || !in0.bf16 || !out0.bf16 || N > 256 || N > d.N || d.Kpad < 256) return hipErrorInvalidValue;
+  LayerArgsWS a{};
+  a.in = reinterpret_cast<const u16*>(in0.p); a.Wp = reinterpret_cast<const uint4*>(c.packed + d.offset);
+  a.aux0 = reinterpret_cast<const u16*>(aux0.p); a.aux1 = reinterpret_cast<const u16*>(aux1.p);
+  a.out0 = reinterpret_cast<u16*>(out0.p);
+  a.srow = srow; a.wrow = wrow; a.wrow_scale = wrow_scale;
+  a.N = N; a.in_octs = 32; a.ldp = c.ldp; a.kstride = d.Kpad / 16;
+  const double P = (double)c.P;
+  const double bytes = 256 * P * 2.0 + N * P * 2.0 * (1 + (aux0.p ? 1 : 0) + (aux1.p ? 1 : 0)) + (srow ? P * 4.0 : 0.0) + N * 256 * 2.0;
+  ProfSlot* ps = prof_begin(c.st, 0, 2.0 * N * 256 * P, bytes);
+  hipError_t e = dispatch_ws_args(c.st, epi, a);
+  prof_end(c.st, ps);
+  dbg_sync(c.st, "layer_ws pid/epi/N", pid, epi, N);
+  return e;
+}
+
 inline dim3 grid1(int n, int b = 256) { return dim3((n + b - 1) / b); }
 
 // ------------------------------------------------------------------------------------------------
@@ -298,6 +325,7 @@ inline dim3 grid1(int n, int b = 256) { return dim3((n + b - 1) / b); }
 // ------------------------------------------------------------------------------------------------
 struct SdfWs {
   float *x, *E, *sdfraw, *sdf, *mask, *g, *e0, *es, *Eh, *gh, *abar8, *ones, *partial;   // fp32 feature-major
+  Arr featc;                      // bf16 build: cotangent of the 256 feature rows of lin8 (octet-major); abar8 row 0 keeps the sdf row
   Arr Ebf, Ebf4, Ehbf, Ehbf4;     // bf16 build: octet-major copies of the PE rows 0..38 / 7..38 and of their tangents
   Arr h[9], feat, u[8], vh[9], m[8];                                                   // big (bf16 in the bf16 build)
   size_t total;
@@ -330,7 +358,7 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
     for (int l = 1; l <= 8; ++l) w.vh[l] = big(256);
     for (int l = 0; l < 8; ++l) w.m[l] = big(256);
     w.abar8 = take(257); w.ones = take(1);
-    if (prec) { w.Ebf = big(20); w.Ebf4 = big(16); w.Ehbf = big(20); w.Ehbf4 = big(16); }
+    if (prec) { w.Ebf = big(20); w.Ebf4 = big(16); w.Ehbf = big(20); w.Ehbf4 = big(16); w.featc = big(256); }
     w.partial = base ? base + off : nullptr;
     off += WPARTIAL_FLOATS;
   }
@@ -463,7 +491,10 @@ void oct_pack(const Ctx& c, std::initializer_list<PackJob> jobs) {
 }
 inline bool oct_operands(const Ctx& c) { return c.prec && g_wgrad_h3; }
 
-hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_in, int npairs, int N, const neat_net_grads* gr) {
+struct RowDot { const float* s; Arr B0, B1; };     // one more gradient row: sum_p s[p] B0[k][p] + B1[k][p] (the sdf row of lin8)
+
+hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_in, int npairs, int N, const neat_net_grads* gr,
+                 const RowDot* rd = nullptr) {
   if (!gr->dv[layer_id]) return hipSuccess;
   const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
   const int K = d.s0p + (kI[layer_id] - d.s0);      // packed column count of the B operand
@@ -476,7 +507,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     for (int t = 0; t < 3; ++t) wbytes += pairs_in[q].rowsB[t] * (double)c.P * (pairs_in[q].B[t].bf16 ? 2.0 : 4.0);
   }
   WreduceArgs r{};
-  int splits;
+  int splits, chunk_used = 0;
   if (!c.prec) {
     // fp32: 128x128 tiles; the bias gradient is the column of the `ones` row appended to pair 0's B
     WPair pairs[2] = {pairs_in[0], npairs > 1 ? pairs_in[1] : WPair{}};
@@ -527,6 +558,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + W3P - 1) / W3P * W3P;
       if (chunk < 2 * W3P) chunk = 2 * W3P;
       splits = (c.P + chunk - 1) / chunk;
+      chunk_used = chunk;
       ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * (K + 1) * 4.0);
       for (int part = 0; part < (two ? 2 : 1); ++part) {
         WgradArgsH3 a{};
@@ -555,6 +587,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + HBP - 1) / HBP * HBP;
     if (chunk < 2 * HBP) chunk = 2 * HBP;
     splits = (c.P + chunk - 1) / chunk;
+    chunk_used = chunk;
     const int ntile = (N + 255) / 256, ktiles = (K + 255) / 256;
     WgradArgsH a{};
     for (int q = 0; q < npairs; ++q) {
@@ -571,13 +604,20 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
     }
   }
+  int Nred = N;
+  if (rd) {            // extra row N of the partial tiles (bf16 build, K = 256)
+    if (!c.prec || K != 256 || !rd->B0.bf16 || !rd->B1.bf16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(splits), dim3(256), 0, c.st, rd->s, reinterpret_cast<const u16*>(rd->B0.p),
+                       reinterpret_cast<const u16*>(rd->B1.p), c.P, c.ldp, chunk_used, w.partial + (size_t)N * r.row_stride, r.split_stride);
+    Nred = N + 1;
+  }
   r.partial = w.partial; r.splits = splits;
   if (splits > 2 * WGROUPS) {
     // two-stage, deterministic: bandwidth-bound group sums first, then the per-row finish on 8 partials
     const int Kld = (int)r.split_stride, per = (splits + WGROUPS - 1) / WGROUPS;
     float* stage = w.partial + (WPARTIAL_FLOATS - WSTAGE_FLOATS);
-    hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld / 4 + 127) / 128, WGROUPS, N), dim3(128), 0, c.st,
-                       w.partial, splits, Kld / 4, WGROUPS, per, N, stage);
+    hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld / 4 + 127) / 128, WGROUPS, Nred), dim3(128), 0, c.st,
+                       w.partial, splits, Kld / 4, WGROUPS, per, Nred, stage);
     r.partial = stage; r.splits = (splits + per - 1) / per;
     r.row_stride = (size_t)WGROUPS * Kld; r.split_stride = Kld;
   }
@@ -610,7 +650,8 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   }
   // reverse chain: a^_{l-1} = (W_l^T a^_l) phi'(a_{l-1}) + m_{l-1}   (in place in m)
   if (!c.prec) e = layer(c, L.tr[8], EPI_BWD, in(F(w.abar8), 257), NOIN, nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
-  else e = layer(c, L.tr[8], EPI_BWD, in(F(w.abar8 + c.ldp), 256), in(F(w.abar8), 1), nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
+  else if (g_layer_ws) e = layer_ws(c, L.tr[8], EPI_BWD8, w.featc, 256, w.m[7], w.h[8], w.m[7], w.abar8, c.net->v[8], c.rowscale(8));
+  else e = layer(c, L.tr[8], EPI_BWD, in(w.featc, 256), in(F(w.abar8), 1), nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
   if (e != hipSuccess) return e;
   for (int l = 7; l >= 1; --l) {
     const int N = l == 4 ? 217 : kI[l];
@@ -621,7 +662,15 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   if (oct) oct_pack(c, {{w.E, PE_ROWS, w.Ebf}, {w.E + 7 * (size_t)c.ldp, 32, w.Ebf4}, {w.Eh, PE_ROWS, w.Ehbf}, {w.Eh + 7 * (size_t)c.ldp, 32, w.Ehbf4}});
   for (int l = 0; l <= 8; ++l) {
     WPair pr[2] = {};
-    const int rot8 = (l == 8 && c.prec) ? 1 : 0;
+    if (l == 8 && c.prec) {
+      // feature rows: featc x h8 on the streaming kernel; the sdf row (cotangent abar8 row 0; its second-order part is
+      // the plain row sum of vh8, the adjoint seed being 1) as one extra partial row
+      pr[0].A = w.featc; pr[0].rowsA = 256; pr[0].B[0] = w.h[8]; pr[0].rowsB[0] = 256;
+      RowDot rd{w.abar8, w.h[8], w.vh[8]};
+      if ((e = wgrad(c, w, 8, pr, 1, 256, gr, &rd)) != hipSuccess) return e;
+      continue;
+    }
+    const int rot8 = 0;
     pr[0].A = l == 8 ? F(w.abar8) : w.m[l]; pr[0].rowsA = kO[l]; pr[0].A_rot = rot8; pr[0].A_mod = rot8 ? 257 : 0;
     pr[1].A = l == 8 ? F(w.ones) : w.u[l];  pr[1].rowsA = l == 8 ? 1 : kO[l]; pr[1].A_rot = rot8; pr[1].A_mod = rot8 ? 257 : 0;
     if (l == 0) {
@@ -683,8 +732,14 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, in(F(top), top_rows), NOIN, nullptr, 256, ab[3], Arr{}, 1 << 30, hh[4])) != hipSuccess) return e;
     for (int l = 3; l >= 1; --l)
       if ((e = layer(c, L.tr[base + l], EPI_BWD_RELU, in(ab[l], 256), NOIN, nullptr, 256, ab[l - 1], Arr{}, 1 << 30, hh[l])) != hipSuccess) return e;
-    if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, 256 + srows, F(w.abar8 + c.ldp),
-                   F(head ? h.sc_a : h.sc_r), 256, Arr{}, Arr{}, head)) != hipSuccess) return e;
+    if (c.prec) {
+      // feature cotangent (256 rows, octet-major bf16: render writes, attraction adds) on the streaming kernel; the few
+      // small-input rows (packed rows 256..) with the narrow-output path
+      if ((e = layer_ws(c, L.tr[base], head ? EPI_LINACC : EPI_LINEAR, ab[0], 256, w.featc, head ? w.featc : Arr{})) != hipSuccess) return e;
+      if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, srows, F(head ? h.sc_a : h.sc_r), Arr{}, 1 << 30,
+                     Arr{}, Arr{}, 0, 0, 1 << 30, nullptr, 0, 8)) != hipSuccess) return e;
+    } else if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, 256 + srows, F(w.abar8 + c.ldp),
+                          F(head ? h.sc_a : h.sc_r), 256, Arr{}, Arr{}, head)) != hipSuccess) return e;
     for (int l = 0; l <= 4; ++l) {
       WPair pr[1] = {};
       pr[0].A = l == 4 ? (oct ? (head ? h.topbf_a : h.topbf_r) : F(top)) : ab[l]; pr[0].rowsA = kO[base + l];
@@ -870,6 +925,7 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
   hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8);
+  if (precision) oct_pack(c, {{w.abar8 + c.ldp, 256, w.featc}});
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, (const float*)nullptr, (const float*)nullptr,
                      d_grad, w.mask, P, c.ldp, w.gh, P, (const float*)nullptr);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));

@@ -337,7 +337,9 @@ def test_bf16_full_size_properties(dev):
 @pytest.mark.parametrize("R,S", [(1024, 128), (37, 50), (3, 7)])
 def test_bf16_layer_kernels_agree(dev, R, S):
     """layer_kernel_ws (weight-stationary, LDS-DMA ring) against layer_kernel_h on the same inputs: the same bf16 products
-    accumulated in fp32 in the same k order, so outputs and gradients must agree to fp32 rounding of the epilogue."""
+    accumulated in fp32 in the same k order, so outputs agree to fp32 rounding of the epilogue.  Gradients: the first
+    layer of the reverse chain takes the sdf row of lin8 as an fp32 rank-1 term in the ws kernel and as a bf16 weight
+    column in layer_kernel_h, hence the 1e-3."""
     from neat_amd import _lib, rend_util
     m = build_model(dev, "rough", seed=4, train=True).set_precision("bf16")
     sc = synth.synth_scene(seed=4, n_rays=R)
@@ -366,7 +368,7 @@ def test_bf16_layer_kernels_agree(dev, R, S):
     for k in g0:
         assert torch.isfinite(g1[k]).all(), k
         err = float((g1[k] - g0[k]).abs().max())
-        assert err <= 1e-4 * float(g0[k].abs().max()) + 1e-12, (k, err, float(g0[k].abs().max()))
+        assert err <= 1e-3 * float(g0[k].abs().max()) + 1e-12, (k, err, float(g0[k].abs().max()))
 
 
 @pytest.mark.parametrize("R,S", [(1024, 128), (37, 50), (3, 7)])
