@@ -193,17 +193,18 @@ __global__ void adam_flat_kernel(float* __restrict__ p, AdamSegs segs, float* __
     if (t < segs.nseg) { s_g[t] = gp; s_a1[t] = a1; s_a2[t] = a2; }
   }
   __syncthreads();
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int lo = 0, hi = segs.nseg - 1;            // segment of element i: last s with off[s] <= i
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid - 1; }
-  const float* gp = s_g[lo];
-  if (!gp) return;                           // parameter without a gradient this step: untouched, as torch.optim.Adam
-  const float g = gp[i - s_off[lo]];
-  const float mm = beta1 * m[i] + (1.0f - beta1) * g;
-  const float vv = beta2 * v[i] + (1.0f - beta2) * g * g;
-  m[i] = mm; v[i] = vv;
-  p[i] -= s_a1[lo] * (mm / (sqrtf(vv) * s_a2[lo] + eps));
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int lo = 0, hi = segs.nseg - 1;            // segment of element i: last s with off[s] <= i
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid - 1; }
+    const float* gp = s_g[lo];
+    if (!gp) continue;                         // parameter without a gradient this step: untouched, as torch.optim.Adam
+    const float g = gp[i - s_off[lo]];
+    const float mm = beta1 * m[i] + (1.0f - beta1) * g;
+    const float vv = beta2 * v[i] + (1.0f - beta2) * g * g;
+    m[i] = mm; v[i] = vv;
+    p[i] -= s_a1[lo] * (mm / (sqrtf(vv) * s_a2[lo] + eps));
+  }
 }
 
 }  // namespace neat

@@ -420,9 +420,17 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
     ProfSlot* ps = prof_begin(c.st, 2, fl, fbytes);
     if (g_fused_ws) {
       // weight-stationary persistent kernel: batches of 128 points (64 when that balances the CUs better)
+      static bool attr_done = false;      // raise the dynamic-LDS limit of all variants once (not a stream operation: keep it out of graph capture)
+      if (!attr_done) {
+        hipError_t e0 = hipSuccess;
+        auto raise = [&](auto kern, int bytes) { if (e0 == hipSuccess) e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+        raise(&sdf_fused_ws_kernel<4, false>, FwsCfg<4>::LDS); raise(&sdf_fused_ws_kernel<4, true>, FwsCfg<4>::LDS);
+        raise(&sdf_fused_ws_kernel<3, false>, FwsCfg<3>::LDS); raise(&sdf_fused_ws_kernel<3, true>, FwsCfg<3>::LDS);
+        raise(&sdf_fused_ws_kernel<2, false>, FwsCfg<2>::LDS); raise(&sdf_fused_ws_kernel<2, true>, FwsCfg<2>::LDS);
+        if (e0 != hipSuccess) return e0;
+        attr_done = true;
+      }
       auto go = [&](auto kern, int BP, int lds_bytes) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
         const int nbatch = (c.ldp + BP - 1) / BP;
         const int per_wg = (nbatch + g_ws_grid - 1) / g_ws_grid;
         hipLaunchKernelGGL(kern, dim3((nbatch + per_wg - 1) / per_wg), dim3(FWT), lds_bytes, c.st, a, nbatch, per_wg);
@@ -536,6 +544,8 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       if (e != hipSuccess) return e;
       attr_set = true;
     }
+    const int Kld2 = (K + 1 + 7) / 8 * 8;      // partial row length: K columns + bias, not the 320 of the widest layer (the reduction reads all of it)
+    if (Kld2 > W2LDK) return hipErrorInvalidValue;
     // all-bf16 octet-major operands: the streaming tr16 kernel.  Shapes: K <= 256 in one launch (B may continue in a
     // second array at an octet boundary: skip layer), or [256 | few rows] as two launches into disjoint partial columns
     bool h3 = g_wgrad_h3 && N <= 256;
@@ -578,11 +588,11 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
         }
         a.octsB = (a.K + 7) / 8;
         a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-        a.partial = w.partial; a.row_stride = (size_t)splits * W2LDK; a.split_stride = W2LDK;
+        a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2;
         hipLaunchKernelGGL(wgrad_kernel_h3, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
       }
       prof_end(c.st, ps);
-      r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
+      r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
     } else {
     int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + HBP - 1) / HBP * HBP;
     if (chunk < 2 * HBP) chunk = 2 * HBP;
@@ -597,11 +607,11 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       a.pair[q].padB0 = s.B[0].bf16 ? pad8(s.rowsB[0]) : s.rowsB[0];
     }
     a.npairs = npairs; a.N = N; a.Kt = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-    a.partial = w.partial; a.row_stride = (size_t)splits * W2LDK; a.split_stride = W2LDK; a.ktiles = ktiles; a.bias_col = K;
+    a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.ktiles = ktiles; a.bias_col = K;
     ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * (K + 1) * 4.0);
     hipLaunchKernelGGL(wgrad_kernel_h2, dim3(ntile * ktiles, splits), dim3(W2T), W2_LDS_BYTES, c.st, a);
     prof_end(c.st, ps);
-    r.row_stride = (size_t)splits * W2LDK; r.split_stride = W2LDK;
+    r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
     }
   }
   int Nred = N;
@@ -1072,7 +1082,8 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   segs.nseg = nseg;
   const long long n = seg_offsets[nseg];
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
                      exp_avg_sq, n, beta1, beta2, eps);
   return (int)hipGetLastError();
 }

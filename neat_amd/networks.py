@@ -257,6 +257,7 @@ class VolSDFNetwork(_HipModule):
         import weakref
         for head in (self.rendering_network, self.attraction_network):
             head.__dict__["_neat_owner"] = weakref.ref(self)
+        self.static_randoms = None        # see _cpu_random
         self.z_vals_override = None       # bench/tests: given depth samples [R,S] bypass the sampler
         self.set_precision(conf.get_string("hip_precision", default="fp32"))      # new optional key, default = parity build
 
@@ -314,7 +315,7 @@ class VolSDFNetwork(_HipModule):
     def _z_vals(self, ray_dirs, cam_loc):
         if self.z_vals_override is not None:
             z = self.z_vals_override
-            idx = _to_device_async(torch.randint(z.shape[-1], (z.shape[0],)), z.device)
+            idx = self._cpu_random("eik_idx", lambda: torch.randint(z.shape[-1], (z.shape[0],)), z.device)
             return z, z.gather(1, idx.unsqueeze(-1))
         return self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self)
 
@@ -406,10 +407,23 @@ class VolSDFNetwork(_HipModule):
             output["normal_map"] = nmap
         return output
 
+    def _cpu_random(self, name, draw, device):
+        """Randoms are drawn on the CPU (the reference's RNG stream).  Normally: draw + asynchronous pinned copy.  With
+        `static_randoms` set (a dict; HIP-graph capture / replay, neat_amd.train.Trainer): the forward reads a persistent
+        device tensor per draw site, which the trainer refills (same draw order) before every replay."""
+        if self.static_randoms is None:
+            return _to_device_async(draw(), device)
+        slot = self.static_randoms.get(name)
+        if slot is None:
+            t = draw()
+            slot = {"draw": draw, "dev": t.to(device), "order": len(self.static_randoms)}
+            self.static_randoms[name] = slot
+        return slot["dev"]
+
     def _eikonal_points(self, n_rays, cam_loc, ray_dirs, z_eik, junctions):
         """Eikonal points: uniform in the bounding cube + one near-surface sample per ray (rend_a :515-527)."""
         r = self.scene_bounding_sphere
-        eik = _to_device_async(torch.empty(n_rays, 3).uniform_(-r, r), ray_dirs.device)
+        eik = self._cpu_random("eik_uniform", lambda: torch.empty(n_rays, 3).uniform_(-r, r), ray_dirs.device)
         eik = torch.cat([eik, cam_loc + z_eik * ray_dirs], 0)
         if junctions is not None:
             eik = torch.cat([eik, junctions], 0)

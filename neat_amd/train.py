@@ -23,8 +23,14 @@ class Trainer:
             self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.1 ** (1.0 / decay_steps))
         self.bucket = FlatGradBucket(self.model.parameters())
+        self._graph, self._captured, self._ring_pos, self.capture_error = None, None, 0, None
 
     def step(self, model_input, ground_truth):
+        if self._graph is not None:
+            return self._replay(model_input, ground_truth)
+        return self.step_eager(model_input, ground_truth)
+
+    def step_eager(self, model_input, ground_truth):
         out = self.model(model_input)
         losses = self.loss(out, ground_truth)
         self.optimizer.zero_grad(set_to_none=True)
@@ -33,6 +39,96 @@ class Trainer:
         self.optimizer.step()
         self.scheduler.step()
         return out, losses
+
+    # ---- HIP-graph mode: forward + loss + backward are captured once and replayed; the gradient all-reduce, the Adam
+    # launch and the scheduler stay outside (their arguments change every step).  Valid while the batch keeps its shapes
+    # and its wireframe (one graph per view in a real run); the step must be free of host synchronisation, which the
+    # hot path is when the depth samples are given or come from a sync-free sampler.
+    def capture(self, model_input, ground_truth, warmup=2):
+        """Returns True if the step is now replayed from a HIP graph, False if capture was not possible (stays eager)."""
+        if self.device.type != "cuda" or self._graph is not None:
+            return self._graph is not None
+        tensor_keys = [k for k, v in model_input.items() if isinstance(v, torch.Tensor)]
+        self._static_in = dict(model_input)
+        self._static_gt = dict(ground_truth)
+        for k in tensor_keys:
+            self._static_in[k] = model_input[k].clone()
+        for k, v in ground_truth.items():
+            if isinstance(v, torch.Tensor):
+                self._static_gt[k] = v.to(self.device).clone()
+        self.model.static_randoms = {}
+        self.loss.nan_check = "off"
+        try:
+            if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up runs on a side stream on purpose
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                   # warm-up on the side stream: lazy inits, allocator, draw sites
+                for _ in range(warmup):
+                    self._refill_randoms()
+                    self._fwd_bwd()
+                    self._finish_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._refill_randoms()
+            self.optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._captured = self._fwd_bwd(zero=False)
+            self._graph = graph
+            self._static_grads = [(p, p.grad) for p in self.model.parameters()]
+            self._finish_step()                             # the capture pass itself does not execute: replay it once
+            return True
+        except Exception as exc:                            # a sync inside the step, an uncapturable op ...
+            self.model.static_randoms = None
+            self.loss.nan_check = "deferred"
+            self._graph = None
+            self.capture_error = exc
+            torch.cuda.synchronize()
+            return False
+
+    def _fwd_bwd(self, zero=True):
+        out = self.model(self._static_in)
+        losses = self.loss(out, self._static_gt)
+        if zero:
+            self.optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        return out, losses
+
+    def _finish_step(self):
+        if self._graph is not None:
+            for p, g in self._static_grads:                 # an eager step in between re-pointed .grad: the graph writes the captured tensors
+                if p.grad is not g:
+                    p.grad = g
+            self._graph.replay()
+        self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        self.scheduler.step()
+
+    def _refill_randoms(self):
+        """Fresh CPU draws, in the forward's draw order, into the persistent device tensors (pinned staging ring)."""
+        slots = sorted(self.model.static_randoms.values(), key=lambda s: s["order"])
+        for slot in slots:
+            ring = slot.setdefault("ring", [])
+            if len(ring) < 4:
+                ring.append((torch.empty_like(slot["dev"], device="cpu").pin_memory(), torch.cuda.Event()))
+            pinned, ev = ring[self._ring_pos % len(ring)] if len(ring) == 4 else ring[-1]
+            ev.synchronize()                                # the copy that last used this staging buffer is long done
+            pinned.copy_(slot["draw"]())
+            slot["dev"].copy_(pinned, non_blocking=True)
+            ev.record()
+        self._ring_pos += 1
+
+    def _replay(self, model_input, ground_truth):
+        for k, v in model_input.items():
+            if isinstance(v, torch.Tensor) and v is not self._static_in[k]:
+                self._static_in[k].copy_(v, non_blocking=True)
+        for k, v in ground_truth.items():
+            if isinstance(v, torch.Tensor) and v is not self._static_gt[k]:
+                self._static_gt[k].copy_(v, non_blocking=True)
+        self._refill_randoms()
+        self._finish_step()
+        return self._captured
 
 
 def synthetic_batch(seed, n_rays, device, view=0):

@@ -518,3 +518,32 @@ def test_flat_adam_matches_torch_adam(dev):
             assert list(our2._steps) == list(our._steps) and torch.equal(our2.exp_avg, our.exp_avg)
     for a, b in zip(ref_p, our_p):
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
+
+
+def test_graph_replay_equals_eager(dev):
+    """Trainer.capture(): forward + loss + backward replayed from a HIP graph must walk exactly the eager trajectory
+    (same CPU random stream, same kernels): parameters after 6 steps agree."""
+    from neat_amd.train import Trainer, synthetic_batch
+
+    def run(graph):
+        torch.manual_seed(7)
+        tr = Trainer(device=dev, state_dict={k: T(v) for k, v in synth.synth_state_dict(11, "rough").items()})
+        _, inp, gt = synthetic_batch(11, 96, dev)
+        tr.model.z_vals_override = T(synth.synth_z_vals(11, 96, 50)).to(dev)
+        losses = []
+        if graph:
+            assert tr.capture(inp, gt, warmup=2), repr(tr.capture_error)      # = 3 optimizer steps
+            n = 3
+        else:
+            n = 6
+        for _ in range(n):
+            _, lo = tr.step(inp, gt)
+            losses.append(float(lo["loss"]))
+        return {k: p.detach().clone() for k, p in tr.model.named_parameters()}, losses
+
+    p_e, l_e = run(False)
+    p_g, l_g = run(True)
+    assert abs(l_e[-1] - l_g[-1]) <= 1e-5 * abs(l_e[-1])
+    for k in p_e:
+        err = float((p_e[k] - p_g[k]).abs().max())
+        assert err <= 1e-5 * max(1.0, float(p_e[k].abs().max())), (k, err)
