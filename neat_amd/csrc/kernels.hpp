@@ -471,6 +471,7 @@ __global__ void posenc6_kernel(const float* __restrict__ x_fm, int ldp, float* _
 }
 
 // tangent seed  E^ = J g^ : derivative of PE-6 along g^ (rows as posenc6_kernel)
+template <bool FAST>
 __global__ void posenc6_tangent_kernel(const float* __restrict__ x_fm, const float* __restrict__ gh_fm, int ldp,
                                        float* __restrict__ Eh) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,8 +483,8 @@ __global__ void posenc6_tangent_kernel(const float* __restrict__ x_fm, const flo
     float f = 1.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      Eh[(size_t)(3 + 6 * k + c) * ldp + p] = f * cosf(xc * f) * gc;
-      Eh[(size_t)(6 + 6 * k + c) * ldp + p] = -f * sinf(xc * f) * gc;
+      Eh[(size_t)(3 + 6 * k + c) * ldp + p] = f * (FAST ? __cosf(xc * f) : cosf(xc * f)) * gc;
+      Eh[(size_t)(6 + 6 * k + c) * ldp + p] = -f * (FAST ? __sinf(xc * f) : sinf(xc * f)) * gc;
       f *= 2.0f;
     }
   }
@@ -501,6 +502,8 @@ __global__ void adjoint_seed_kernel(const float* __restrict__ v8, const float* _
 }
 
 // normals + sphere clamp:  g = J^T (e0 + eskip) ; sdf = min(raw, scale (radius - |x|))  (rend_a :111-129)
+// FAST (bf16 build): hardware sin/cos (|arg| <= 96, abs error ~1e-6); the fp32 build keeps libm's for the 1e-4 parity bar
+template <bool FAST>
 __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float* __restrict__ out8,
                                     const float* __restrict__ e0, const float* __restrict__ es, int P, int ldp,
                                     float radius, float scale, float* __restrict__ sdf, float* __restrict__ g_fm,
@@ -523,7 +526,8 @@ __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float*
       for (int k = 0; k < 6; ++k) {
         const float es_ = e0[(size_t)(3 + 6 * k + c) * ldp + p] + es[(size_t)(3 + 6 * k + c) * ldp + p];
         const float ec_ = e0[(size_t)(6 + 6 * k + c) * ldp + p] + es[(size_t)(6 + 6 * k + c) * ldp + p];
-        acc += f * cosf(xv[c] * f) * es_ - f * sinf(xv[c] * f) * ec_;
+        const float ang = xv[c] * f;
+        acc += f * (FAST ? __cosf(ang) : cosf(ang)) * es_ - f * (FAST ? __sinf(ang) : sinf(ang)) * ec_;
         f *= 2.0f;
       }
       gv[c] = acc;

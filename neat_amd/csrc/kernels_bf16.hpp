@@ -329,6 +329,9 @@ struct LayerArgsWS {
   u16* out0; u16* out1;
   int N, in_octs, ldp, ntiles, per_wg;                   // 32-point tiles in total / per workgroup (contiguous)
   int kstride;                                           // k-steps per row tile in the pack (16, or 17 when a 257th column follows)
+  const u16* in2; int split_oct;                         // input octets >= split_oct come from in2 (skip layer: [vh4 | PE^]); 32 = none
+  int n_split; float* out1f;                             // EPI_REV: rows >= n_split leave as fp32 feature-major rows (n - n_split), no phi'
+  float* out0f;                                          // OUTF variants: out0 is fp32 feature-major [N][ldp]
 };
 // epilogues that exist only in the weight-stationary kernel
 constexpr int EPI_LINACC = 8;      // out0 = acc + aux0                      (feature cotangent: second head adds to the first)
@@ -355,7 +358,8 @@ __device__ __forceinline__ void ws_wait_barrier(int n) {     // n = DMA instruct
   }
 }
 
-template <int EPI>
+// KS: k-steps (16: K = 256; 1: K <= 16, the narrow cotangents entering the heads' backward); OUTF: narrow fp32 output
+template <int EPI, int KS = 16, bool OUTF = false>
 __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
   typedef WsCfg<EPI> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char wslds[];
@@ -368,12 +372,14 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
   // DMA: per stage this wave moves octets 4w..4w+3 of the input and of each epilogue operand (2 instructions each:
   // 2 octets x 32 points); LDS image [octet][point] x 16 B is lane-linear per instruction
   const unsigned dma_off = (unsigned)(4 * wave) * (WSP * 16);
-  auto dma = [&](const u16* base, int tile, unsigned dst, int max_oct) {
+  auto dma = [&](const u16* base, int tile, unsigned dst, int max_oct, const u16* base2 = nullptr, int split = 1 << 30) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // octets past the end of a 217-row array would be uninitialised memory (x zero weight = NaN): re-read a valid one
-      const int oct = min(4 * wave + 2 * i + (lane >> 5), max_oct);
-      const u16* s2 = base + ((size_t)oct * a.ldp + (size_t)tile * WSP + (lane & 31)) * 8;
+      int oct = min(4 * wave + 2 * i + (lane >> 5), max_oct);
+      const u16* b = base;
+      if (oct >= split) { b = base2; oct -= split; }
+      const u16* s2 = b + ((size_t)oct * a.ldp + (size_t)tile * WSP + (lane & 31)) * 8;
       const unsigned d2 = __builtin_amdgcn_readfirstlane(dst + i * (2 * WSP * 16));
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     const unsigned stage = lds_base + (unsigned)(tau % C::NS) * C::STAGE;
     const unsigned slot = stage + dma_off;
     const int tile = t_begin + tau;
-    dma(a.in, tile, slot, a.in_octs - 1);
+    dma(a.in, tile, slot, a.in_octs - 1, a.in2, a.split_oct);
     if (C::NAUX >= 1) dma(a.aux0, tile, slot + WS_TILE, 31);
     if (C::NAUX >= 2) dma(a.aux1, tile, slot + 2 * WS_TILE, 31);
     if (C::HAS_S) {          // this wave's private copy of the 32 per-point scalars (both half-waves fetch the same 128 B)
@@ -401,15 +407,15 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
 
   // stationary operands: this wave's 32 x 256 slice of W (A fragments) and its per-row constants in accumulator layout
   const bool live = wave * 32 < a.N;
-  uint4 wreg[16];
+  uint4 wreg[KS];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) wreg[ks] = live ? a.Wp[((size_t)wave * a.kstride + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
-  float bias[16];             // EPI_RELU / EPI_LINEAR: bias ; EPI_BWD8: the sdf row of lin8 (effective weight)
+  for (int ks = 0; ks < KS; ++ks) wreg[ks] = live ? a.Wp[((size_t)wave * a.kstride + ks) * 64 + lane] : make_uint4(0u, 0u, 0u, 0u);
+  float bias[16];             // EPI_RELU / EPI_LINEAR / EPI_SIGMOID: bias ; EPI_BWD8: the sdf row of lin8 (effective weight)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     float b = 0.0f;
-    if ((EPI == EPI_RELU || EPI == EPI_LINEAR) && a.bias && n < a.N) b = a.bias[n];
+    if ((EPI == EPI_RELU || EPI == EPI_LINEAR || EPI == EPI_SIGMOID) && a.bias && n < a.N) b = a.bias[n];
     if (EPI == EPI_BWD8 && n < a.N) b = a.wrow[n] * a.wrow_scale[0];
     bias[r] = b;
   }
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const uint4 bv = *reinterpret_cast<const uint4*>(slot + bfrag + ks * (2 * WSP * 16));
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
     }
@@ -454,8 +460,9 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
         float r0 = 0.0f, r1 = 0.0f;
         if (EPI == EPI_RELU) r0 = fmaxf(v + bias[4 * q + e], 0.0f);
         else if (EPI == EPI_LINEAR) r0 = v + bias[4 * q + e];
+        else if (EPI == EPI_SIGMOID) r0 = 1.0f / (1.0f + __expf(-(v + bias[4 * q + e])));
         else if (EPI == EPI_LINACC) r0 = v + x0[e];
-        else if (EPI == EPI_REV) r0 = v * dphi_fast(x0[e]);
+        else if (EPI == EPI_REV) { r0 = (n0 + e < a.n_split) ? v * dphi_fast(x0[e]) : 0.0f; r1 = v; }
         else if (EPI == EPI_TAN) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
         else if (EPI == EPI_BWD) r0 = v * dphi_fast(x0[e]) + x1[e];
         else if (EPI == EPI_BWD8) r0 = (v + bias[4 * q + e] * sp) * dphi_fast(x0[e]) + x1[e];
@@ -463,9 +470,21 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
         if (n0 + e >= a.N) { r0 = 0.0f; r1 = 0.0f; }       // padded rows of the last octet: finite zeros
         o0[e] = r0; o1[e] = r1;
       }
+      if (OUTF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + e < a.N) a.out0f[(unsigned)(n0 + e) * (unsigned)a.ldp + (unsigned)p] = o0[e];
+        continue;
+      }
       const unsigned oidx = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)p) * 8u + (unsigned)(n0 & 7);
-      *reinterpret_cast<uint2*>(a.out0 + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
+      if (EPI != EPI_REV || n0 < ((a.n_split + 7) & ~7))        // (split layer: out0 ends with the octet that holds row n_split-1)
+        *reinterpret_cast<uint2*>(a.out0 + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
       if (EPI == EPI_TAN) *reinterpret_cast<uint2*>(a.out1 + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+      if (EPI == EPI_REV && n0 + 3 >= a.n_split && a.out1f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + e >= a.n_split && n0 + e < a.N) a.out1f[(unsigned)(n0 + e - a.n_split) * (unsigned)a.ldp + (unsigned)p] = o1[e];
+      }
     }
   }
 }
@@ -1409,9 +1428,17 @@ __global__ void adjoint_seed_kernel_h(const float* __restrict__ v8, const float*
 
 // bf16 octet-major [C rows] -> row-major fp32 [P, C] at column offset col0 of a [P, ldc] matrix
 __global__ void oct_to_rm_kernel(const u16* __restrict__ src, int P, int C, int ldp, float* __restrict__ dst, int ldc, int col0) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  // one thread per (point, octet): 16-byte read, 8 consecutive floats of the row out (grid.y = octets)
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
   if (p >= P) return;
-  for (int c = 0; c < C; ++c) dst[(size_t)p * ldc + col0 + c] = bf2f(src[oct_index(c, p, ldp)]);
+  const uint4 v = reinterpret_cast<const uint4*>(src)[(size_t)o * ldp + p];
+  const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+  float* d = dst + (size_t)p * ldc + col0 + o * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (o * 8 + 2 * j < C) d[2 * j] = bf_lo(w4[j]);
+    if (o * 8 + 2 * j + 1 < C) d[2 * j + 1] = bf_hi(w4[j]);
+  }
 }
 __global__ void rm_to_oct_kernel(const float* __restrict__ src, int P, int C, int ldp, u16* __restrict__ dst) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;

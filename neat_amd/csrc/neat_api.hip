@@ -163,10 +163,10 @@ int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persist
 int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
-template <int EPI> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
+template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_ws<EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_ws<EPI, KS, OUTF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI>::LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -175,21 +175,40 @@ template <int EPI> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS&
   a.ntiles = a.ldp / WSP;
   a.per_wg = (a.ntiles + g_ws_grid - 1) / g_ws_grid;
   const int grid = (a.ntiles + a.per_wg - 1) / a.per_wg;
-  hipLaunchKernelGGL((layer_kernel_ws<EPI>), dim3(grid), dim3(WST), WsCfg<EPI>::LDS, st, a);
+  hipLaunchKernelGGL((layer_kernel_ws<EPI, KS, OUTF>), dim3(grid), dim3(WST), WsCfg<EPI>::LDS, st, a);
   return hipGetLastError();
 }
 // the weight-stationary kernel covers: one bf16 octet-major input of up to 256 rows (K = 256 packed columns), bf16
 // outputs without split / accumulate / pad-fill, and the epilogues of the hidden layers
-inline bool ws_eligible(int epi, const LayerArgsH& a) {
-  if (!g_layer_ws) return false;
-  if (!(epi == EPI_RELU || epi == EPI_REV || epi == EPI_TAN || epi == EPI_BWD || epi == EPI_BWD_RELU)) return false;
-  if (a.Kpad != 256 || !a.in[0].bf16 || a.in[0].rows < 193 || a.in[0].rows > 256 || a.in[1].rows != 0) return false;
-  if (a.in[0].rows != 256 && (a.in[0].rows + 7) / 8 * 8 != 224) return false;       // 217-row arrays occupy 28 octets only
-  if (!a.out0_bf16 || a.N > 256 || a.N < 193 || a.n_split < a.N || a.accumulate || a.padfill) return false;
-  if (epi == EPI_TAN && (!a.out1 || !a.out1_bf16)) return false;
-  if (epi != EPI_TAN && a.out1) return false;
-  if (a.bias && (epi != EPI_RELU || a.bias_rot != 0)) return false;
-  return true;
+// shapes: (a) hidden: one bf16 input of 256 (or 217/224) rows, optionally continued by a 32-row bf16 array at octet 28
+// (skip layer), bf16 output(s); EPI_REV may split rows >= n_split into fp32 rows; (b) narrow fp32 outputs (N <= 256,
+// LINEAR / SIGMOID) from a 256-row bf16 input; (c) K <= 16 bf16 input (one octet) into EPI_BWD_RELU.
+inline int ws_shape(int epi, const LayerArgsH& a) {
+  if (!g_layer_ws) return 0;
+  const bool seg1 = a.in[1].rows != 0;
+  if (!a.in[0].bf16 || a.accumulate || a.padfill || (a.bias && a.bias_rot != 0)) return 0;
+  if (a.Kpad == 16 && !seg1 && a.in[0].rows <= 8) {                      // (c)
+    return (epi == EPI_BWD_RELU && a.out0_bf16 && a.N == 256 && !a.out1 && !a.bias) ? 3 : 0;
+  }
+  if (a.Kpad != 256) return 0;
+  const int oct0 = (a.in[0].rows + 7) / 8;
+  if (seg1) { if (!(a.in[1].bf16 && a.in[1].rows == 32 && oct0 == 28)) return 0; }
+  else if (!(a.in[0].rows == 256 || oct0 == 28)) return 0;
+  if (!a.out0_bf16) {                                                    // (b)
+    return ((epi == EPI_LINEAR || epi == EPI_SIGMOID) && !seg1 && a.in[0].rows == 256 && a.N <= 256 && a.n_split >= a.N && !a.out1) ? 2 : 0;
+  }
+  if (a.N > 256 || a.N < 193) return 0;
+  if (epi == EPI_REV) {
+    if (a.n_split < a.N) { if (!a.out1 || a.out1_bf16 || a.n_split < 193) return 0; }
+    else if (a.out1) return 0;
+    return a.bias ? 0 : 1;
+  }
+  if (a.n_split < a.N) return 0;
+  if (epi == EPI_TAN) return (a.out1 && a.out1_bf16 && !a.bias) ? 1 : 0;
+  if (a.out1) return 0;
+  if (epi == EPI_RELU) return 1;
+  if (epi == EPI_BWD || epi == EPI_BWD_RELU) return a.bias ? 0 : 1;
+  return 0;
 }
 hipError_t dispatch_ws_args(hipStream_t st, int epi, const LayerArgsWS& a) {
   switch (epi) {
@@ -204,12 +223,17 @@ hipError_t dispatch_ws_args(hipStream_t st, int epi, const LayerArgsWS& a) {
   }
   return hipErrorInvalidValue;
 }
-hipError_t dispatch_ws(hipStream_t st, int epi, const LayerArgsH& h) {
+hipError_t dispatch_ws(hipStream_t st, int epi, const LayerArgsH& h, int shape) {
   LayerArgsWS a{};
   a.in = reinterpret_cast<const u16*>(h.in[0].p); a.Wp = h.Wp; a.bias = h.bias;
+  a.in2 = reinterpret_cast<const u16*>(h.in[1].p); a.split_oct = h.in[1].rows ? 28 : 32;
   a.aux0 = h.aux0; a.aux1 = h.aux1;
   a.out0 = reinterpret_cast<u16*>(h.out0); a.out1 = reinterpret_cast<u16*>(h.out1);
-  a.N = h.N; a.in_octs = (h.in[0].rows + 7) / 8; a.ldp = h.ldp; a.kstride = 16;
+  a.out0f = reinterpret_cast<float*>(h.out0); a.out1f = reinterpret_cast<float*>(h.out1); a.n_split = h.n_split;
+  a.N = h.N; a.in_octs = (h.in[0].rows + 7) / 8 + (h.in[1].rows ? 4 : 0); a.ldp = h.ldp; a.kstride = h.Kpad / 16;
+  if (shape == 3) return launch_layer_ws<EPI_BWD_RELU, 1, false>(st, a);
+  if (shape == 2) return epi == EPI_SIGMOID ? launch_layer_ws<EPI_SIGMOID, 16, true>(st, a) : launch_layer_ws<EPI_LINEAR, 16, true>(st, a);
+  if (epi == EPI_REV && h.n_split >= h.N) { a.out1f = nullptr; a.n_split = 1 << 30; }
   return dispatch_ws_args(st, epi, a);
 }
 #define EPI_SWITCH(FN, st, epi, a, nt)                                         \
@@ -226,6 +250,13 @@ hipError_t dispatch_ws(hipStream_t st, int epi, const LayerArgsH& h) {
   return hipErrorInvalidValue;
 hipError_t dispatch_f(hipStream_t st, int epi, const LayerArgs& a, int nt) { EPI_SWITCH(launch_layer_f, st, epi, a, nt) }
 hipError_t dispatch_h(hipStream_t st, int epi, const LayerArgsH& a, int nt) { EPI_SWITCH(launch_layer_h, st, epi, a, nt) }
+
+// sdf_finalize_kernel<FAST>: hardware sin/cos in the bf16 build
+#define FINALIZE_LAUNCH(c, ...)                                                                                         \
+  do {                                                                                                                   \
+    if ((c).prec) hipLaunchKernelGGL(sdf_finalize_kernel<true>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__);     \
+    else hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__);             \
+  } while (0)
 
 struct Ctx {
   hipStream_t st;
@@ -291,7 +322,8 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
     a.aux0 = reinterpret_cast<const u16*>(aux0.p); a.aux1 = reinterpret_cast<const u16*>(aux1.p);
     a.padfill = padfill; a.padfill_rows = padfill_rows;
     if ((aux0.p && !aux0.bf16) || (aux1.p && !aux1.bf16) || (out1.p && (out1.bf16 != (epi == EPI_TAN)))) return hipErrorInvalidValue;
-    e = ws_eligible(epi, a) ? dispatch_ws(c.st, epi, a) : dispatch_h(c.st, epi, a, c.ldp / BMH);
+    const int shape = ws_shape(epi, a);
+    e = shape ? dispatch_ws(c.st, epi, a, shape) : dispatch_h(c.st, epi, a, c.ldp / BMH);
   }
   prof_end(c.st, ps);
   dbg_sync(c.st, "layer pid/epi/N", pid, epi, N);
@@ -309,6 +341,7 @@ hipError_t layer_ws(const Ctx& c, int pid, int epi, Arr in0, int N, Arr out0, Ar
   a.out0 = reinterpret_cast<u16*>(out0.p);
   a.srow = srow; a.wrow = wrow; a.wrow_scale = wrow_scale;
   a.N = N; a.in_octs = 32; a.ldp = c.ldp; a.kstride = d.Kpad / 16;
+  a.split_oct = 32; a.n_split = 1 << 30;
   const double P = (double)c.P;
   const double bytes = 256 * P * 2.0 + N * P * 2.0 * (1 + (aux0.p ? 1 : 0) + (aux1.p ? 1 : 0)) + (srow ? P * 4.0 : 0.0) + N * 256 * 2.0;
   ProfSlot* ps = prof_begin(c.st, 0, 2.0 * N * 256 * P, bytes);
@@ -646,14 +679,17 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
 hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grads* gr) {
   const PackLayout& L = c.L();
   hipError_t e;
-  hipLaunchKernelGGL(posenc6_tangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
+  if (c.prec) hipLaunchKernelGGL(posenc6_tangent_kernel<true>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
+  else hipLaunchKernelGGL(posenc6_tangent_kernel<false>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
   hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, c.P, c.ldp);
+  // bf16 build: octet-major copies of the PE rows and their tangents for the streaming kernels (skip layer, lin0 / lin4 gradients)
+  if (c.prec) oct_pack(c, {{w.E, PE_ROWS, w.Ebf}, {w.E + 7 * (size_t)c.ldp, 32, w.Ebf4}, {w.Eh, PE_ROWS, w.Ehbf}, {w.Eh + 7 * (size_t)c.ldp, 32, w.Ehbf4}});
   // tangent chain (forward-mode along g^): vh_{l+1} = tangent of h_{l+1}, m_l = extra cotangent of a_l
   // bf16 build: the 217-row arrays of the skip layer carry the first 7 PE rows in the padding of their last octet, so
   // lin4's input is [h4 | PE0..6] (224 rows, octet aligned) + PE7..38 (32 rows) = 256 columns
   for (int l = 0; l < 8; ++l) {
     In a = l == 0 ? in(F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? (c.prec ? 224 : 217) : 256);
-    In b = l == 4 ? (c.prec ? in(F(w.Eh + 7 * (size_t)c.ldp), 32) : in(F(w.Eh), PE_ROWS)) : NOIN;
+    In b = l == 4 ? (c.prec ? in(w.Ehbf4, 32) : in(F(w.Eh), PE_ROWS)) : NOIN;
     const bool fill = c.prec && l == 3;
     if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l], 0, 0, 1 << 30,
                    fill ? w.Eh : nullptr, fill ? 7 : 0)) != hipSuccess) return e;
@@ -669,7 +705,6 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   }
   // weight gradients: dW_l = a^_l in_l^T + u_l vhat_l^T  (+ bias column from the ones row)
   const bool oct = oct_operands(c);
-  if (oct) oct_pack(c, {{w.E, PE_ROWS, w.Ebf}, {w.E + 7 * (size_t)c.ldp, 32, w.Ebf4}, {w.Eh, PE_ROWS, w.Ehbf}, {w.Eh + 7 * (size_t)c.ldp, 32, w.Ehbf4}});
   for (int l = 0; l <= 8; ++l) {
     WPair pr[2] = {};
     if (l == 8 && c.prec) {
@@ -739,7 +774,7 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     const int top_rows = head ? 6 : 3;
     const float* small = head ? h.small_a : h.small_r;
     const int srows = head ? SMALL_A : SMALL_R;
-    if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, in(F(top), top_rows), NOIN, nullptr, 256, ab[3], Arr{}, 1 << 30, hh[4])) != hipSuccess) return e;
+    if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, in(oct ? (head ? h.topbf_a : h.topbf_r) : F(top), top_rows), NOIN, nullptr, 256, ab[3], Arr{}, 1 << 30, hh[4])) != hipSuccess) return e;
     for (int l = 3; l >= 1; --l)
       if ((e = layer(c, L.tr[base + l], EPI_BWD_RELU, in(ab[l], 256), NOIN, nullptr, 256, ab[l - 1], Arr{}, 1 << 30, hh[l])) != hipSuccess) return e;
     if (c.prec) {
@@ -815,9 +850,9 @@ void export_out8(const Ctx& c, const SdfWs& w, float* out257, float* feat) {
   if (c.prec) {
     if (out257) {
       hipLaunchKernelGGL(fm_col_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, out257, 257, 0);
-      hipLaunchKernelGGL(oct_to_rm_kernel, grid1(P), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, out257, 257, 1);
+      hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, out257, 257, 1);
     }
-    if (feat) hipLaunchKernelGGL(oct_to_rm_kernel, grid1(P), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, feat, 256, 0);
+    if (feat) hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, feat, 256, 0);
   } else {
     if (out257) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, 257, c.ldp, out257, 0);
     if (feat) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.feat.f(), P, 256, c.ldp, feat, 0);
@@ -914,14 +949,14 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
   }
   if (mode == 0) {
     NEAT_CHECK(sdf_primal(c, w, false));
-    hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, (const float*)nullptr,
+    FINALIZE_LAUNCH(c, w.x, w.sdfraw, (const float*)nullptr,
                        (const float*)nullptr, P, c.ldp, radius, scale, w.sdf, (float*)nullptr, (float*)nullptr, sdf, (float*)nullptr,
                        P, (float*)nullptr);
     return (int)hipGetLastError();
   }
   NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w));
-  hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
+  FINALIZE_LAUNCH(c, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
                      w.sdf, w.g, w.mask, sdf, grad, P, (float*)nullptr);
   export_out8(c, w, out257, feat);
   return (int)hipGetLastError();
@@ -989,7 +1024,7 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
   hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points, eik_points, E);
   NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w));
-  hipLaunchKernelGGL(sdf_finalize_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
+  FINALIZE_LAUNCH(c, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
                      w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
   // the heads run over every column of the tile grid; only the first R*S columns are consumed
   hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, Pm, S, c.ldp, h.small_r, h.small_a);
