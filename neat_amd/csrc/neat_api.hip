@@ -180,15 +180,19 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
 }
 // the weight-stationary kernel covers: one bf16 octet-major input of up to 256 rows (K = 256 packed columns), bf16
 // outputs without split / accumulate / pad-fill, and the epilogues of the hidden layers
+// (c) K <= 64 bf16 input (PE tangent rows into EPI_TAN, the 3/6-row cotangents into EPI_BWD_RELU).
 // shapes: (a) hidden: one bf16 input of 256 (or 217/224) rows, optionally continued by a 32-row bf16 array at octet 28
 // (skip layer), bf16 output(s); EPI_REV may split rows >= n_split into fp32 rows; (b) narrow fp32 outputs (N <= 256,
-// LINEAR / SIGMOID) from a 256-row bf16 input; (c) K <= 16 bf16 input (one octet) into EPI_BWD_RELU.
+// LINEAR / SIGMOID) from a 256-row bf16 input.
 inline int ws_shape(int epi, const LayerArgsH& a) {
   if (!g_layer_ws) return 0;
   const bool seg1 = a.in[1].rows != 0;
   if (!a.in[0].bf16 || a.accumulate || a.padfill || (a.bias && a.bias_rot != 0)) return 0;
-  if (a.Kpad == 16 && !seg1 && a.in[0].rows <= 8) {                      // (c)
-    return (epi == EPI_BWD_RELU && a.out0_bf16 && a.N == 256 && !a.out1 && !a.bias) ? 3 : 0;
+  if (a.Kpad == 64 && !seg1) {                                           // (c) K <= 64: narrow cotangents / PE tangent rows
+    if (!a.out0_bf16 || a.N != 256 || a.n_split < a.N || a.bias) return 0;
+    if (epi == EPI_BWD_RELU) return a.out1 ? 0 : 3;
+    if (epi == EPI_TAN) return (a.out1 && a.out1_bf16) ? 3 : 0;
+    return 0;
   }
   if (a.Kpad != 256) return 0;
   const int oct0 = (a.in[0].rows + 7) / 8;
@@ -231,7 +235,7 @@ hipError_t dispatch_ws(hipStream_t st, int epi, const LayerArgsH& h, int shape) 
   a.out0 = reinterpret_cast<u16*>(h.out0); a.out1 = reinterpret_cast<u16*>(h.out1);
   a.out0f = reinterpret_cast<float*>(h.out0); a.out1f = reinterpret_cast<float*>(h.out1); a.n_split = h.n_split;
   a.N = h.N; a.in_octs = (h.in[0].rows + 7) / 8 + (h.in[1].rows ? 4 : 0); a.ldp = h.ldp; a.kstride = h.Kpad / 16;
-  if (shape == 3) return launch_layer_ws<EPI_BWD_RELU, 1, false>(st, a);
+  if (shape == 3) return epi == EPI_TAN ? launch_layer_ws<EPI_TAN, 4, false>(st, a) : launch_layer_ws<EPI_BWD_RELU, 4, false>(st, a);
   if (shape == 2) return epi == EPI_SIGMOID ? launch_layer_ws<EPI_SIGMOID, 16, true>(st, a) : launch_layer_ws<EPI_LINEAR, 16, true>(st, a);
   if (epi == EPI_REV && h.n_split >= h.N) { a.out1f = nullptr; a.n_split = 1 << 30; }
   return dispatch_ws_args(st, epi, a);
@@ -688,7 +692,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   // bf16 build: the 217-row arrays of the skip layer carry the first 7 PE rows in the padding of their last octet, so
   // lin4's input is [h4 | PE0..6] (224 rows, octet aligned) + PE7..38 (32 rows) = 256 columns
   for (int l = 0; l < 8; ++l) {
-    In a = l == 0 ? in(F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? (c.prec ? 224 : 217) : 256);
+    In a = l == 0 ? in(c.prec ? w.Ehbf : F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? (c.prec ? 224 : 217) : 256);
     In b = l == 4 ? (c.prec ? in(w.Ehbf4, 32) : in(F(w.Eh), PE_ROWS)) : NOIN;
     const bool fill = c.prec && l == 3;
     if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l], 0, 0, 1 << 30,
