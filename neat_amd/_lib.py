@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 2
+ABI_VERSION = 3
 PRECISIONS = {"fp32": 0, "bf16": 1}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libneat_hip.so")

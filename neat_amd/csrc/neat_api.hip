@@ -872,7 +872,7 @@ bool bad_prec(int p) { return p != F32 && p != BF16; }
 // ================================================================================================
 extern "C" {
 
-int neat_abi_version(void) { return 2; }
+int neat_abi_version(void) { return 3; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
   if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
