@@ -764,33 +764,28 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
     int bi = n + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
     biasl[8 * 256 + n] = VALUES ? (n == 0 ? a.bias[8][0] : 0.0f) : a.bias[8][bi];
   }
-  // resident fragments: lin0 (K = 64: 4 k-steps) and this wave's two k-steps of the sdf row of lin8
-  uint4 w0[4], ws8[2];
-  auto load_small = [&](bool first) {      // lin0 slice (before a batch) / sdf-row k-steps (one layer ahead of lin8)
+  // ONE register set for the weight slice: all NT point tiles of a layer are multiplied first (NT independent accumulator
+  // chains: a single chain of 16 dependent MFMAs runs at the MFMA latency and exposes every LDS read), then the slice of
+  // the NEXT layer is loaded into the same registers and its L2 latency hides under this layer's epilogue.
+  uint4 ws8[2], wreg[16];
+  {
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));
-    if (first) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) w0[ks] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[0]) + voff + (wave * 4 + ks) * 1024);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        ws8[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[8]) + voff + (((VALUES ? 0 : 8) * 16 + 2 * wave + j) * 1024));
-    }
-  };
-  load_small(true);
-  uint4 wA[16], wB[16];
-  auto load_w = [&](uint4 (&w)[16], const uint4* Wl, bool on) {
-    // The per-lane offset is laundered through an empty asm: otherwise the 128 fragment addresses of the 8 layers are
+    for (int j = 0; j < 2; ++j)          // this wave's two k-steps of the sdf row of lin8 stay resident
+      ws8[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[8]) + voff + (((VALUES ? 0 : 8) * 16 + 2 * wave + j) * 1024));
+  }
+  auto load_w = [&](const uint4* Wl, int KS, bool on) {
+    // The per-lane offset is laundered through an empty asm: otherwise the fragment addresses of all layers are
     // loop-invariant, get hoisted out of the batch loop and spilled (2 VGPRs each).  SGPR base + this offset + immediate.
-    unsigned voff = (unsigned)(wave * 16 * 64 + lane) * 16u;
+    unsigned voff = (unsigned)(wave * KS * 64 + lane) * 16u;
     asm volatile("" : "+v"(voff));
     const char* base = reinterpret_cast<const char*>(Wl);
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      w[ks] = on ? *reinterpret_cast<const uint4*>(base + voff + ks * 1024) : make_uint4(0u, 0u, 0u, 0u);
+      if (ks < KS) wreg[ks] = on ? *reinterpret_cast<const uint4*>(base + voff + ks * 1024) : make_uint4(0u, 0u, 0u, 0u);
   };
-  load_w(wA, a.Wp[1], true);
+  load_w(a.Wp[0], 4, true);
 
   const int b_begin = blockIdx.x * per_wg, b_end = min(nbatch, b_begin + per_wg);
   for (int b = b_begin; b < b_end; ++b) {
@@ -815,59 +810,65 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
     }
     __syncthreads();
 
-    // one hidden layer: dst[rows of this wave] = softplus(W src + b), optionally streamed to HBM
-    auto hidden = [&](const uint4* w, int KS, const unsigned char* src, unsigned char* dst, int l, int N, u16* hout) {
+    // one hidden layer: dst[rows of this wave] = softplus(W src + b), optionally streamed to HBM; then `next` is loaded
+    auto hidden = [&](int KS, const unsigned char* src, unsigned char* dst, int l, int N, u16* hout, const uint4* next, int nextKS, bool next_on) {
       const float* bl = biasl + l * 256;
-#pragma unroll 1
-      for (int t = 0; t < nt; ++t) {
-        f32x16 acc;
+      f32x16 acc[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const unsigned char* bp = src + ((size_t)hi * BP + t * 32 + (lane & 31)) * 16;
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          if (ks < KS) {
-            const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&w[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      const unsigned char* bp = src + ((size_t)hi * BP + (lane & 31)) * 16;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks < KS) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16 + t * 32 * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc[t], 0, 0, 0);
           }
-          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // at most 4 B fragments in flight: the weights own the registers
         }
-        if (wave * 32 >= N) continue;
-        const int pl = t * 32 + (lane & 31);
+        if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // bound the number of B fragments in flight
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (next) load_w(next, nextKS, next_on);
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave * 32 < N) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n0 = wave * 32 + 8 * g + 4 * hi;
-          if (n0 >= N) continue;
-          const float4 bb = *reinterpret_cast<const float4*>(bl + n0);
-          const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
-          float o[4];
+        for (int t = 0; t < NT; ++t) {
+          if (t >= nt) break;
+          const int pl = t * 32 + (lane & 31);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? softplus100_fast(acc[4 * g + e] + bq[e]) : 0.0f;
-          u16* lp = reinterpret_cast<u16*>(dst) + ((n0 >> 3) * BP + pl) * 8 + (n0 & 7);
-          if (n0 + 3 < N) {
-            const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
-            *reinterpret_cast<uint2*>(lp) = pk;
-            if (hout) {                                    // 32-bit byte offset (arrays < 4 GiB) off the layer's base pointer
-              const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
-              *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + go) = pk;
+          for (int g = 0; g < 4; ++g) {
+            const int n0 = wave * 32 + 8 * g + 4 * hi;
+            if (n0 >= N) continue;
+            const float4 bb = *reinterpret_cast<const float4*>(bl + n0);
+            const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? softplus100_fast(acc[t][4 * g + e] + bq[e]) : 0.0f;
+            u16* lp = reinterpret_cast<u16*>(dst) + ((n0 >> 3) * BP + pl) * 8 + (n0 & 7);
+            if (n0 + 3 < N) {
+              const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+              *reinterpret_cast<uint2*>(lp) = pk;
+              if (hout) {                                    // 32-bit byte offset (arrays < 4 GiB) off the layer's base pointer
+                const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + go) = pk;
+              }
+            } else {                                         // lin3: the quad holding row 216 (rows 217.. receive the PE copy)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (n0 + e < N) lp[e] = f2bf(o[e]);
             }
-          } else {                                         // lin3: the quad holding row 216 (rows 217.. receive the PE copy)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (n0 + e < N) lp[e] = f2bf(o[e]);
           }
         }
       }
       __syncthreads();
     };
 
-    // lin0: PE -> XA (w0 resident); lin1 (wA) ... lin8 (wB); the slice two layers ahead loads while a layer computes
-    hidden(w0, 4, PE, XA, 0, 256, save ? a.h[1] : nullptr);
-    load_w(wB, a.Wp[2], true);
-    hidden(wA, 16, XA, XB, 1, 256, save ? a.h[2] : nullptr);
-    load_w(wA, a.Wp[3], wave * 32 < 217);
-    hidden(wB, 16, XB, XA, 2, 256, save ? a.h[3] : nullptr);
-    load_w(wB, a.Wp[4], true);
-    hidden(wA, 16, XA, XB, 3, 217, nullptr);
+    hidden(4, PE, XA, 0, 256, save ? a.h[1] : nullptr, a.Wp[1], 16, true);
+    hidden(16, XA, XB, 1, 256, save ? a.h[2] : nullptr, a.Wp[2], 16, true);
+    hidden(16, XB, XA, 2, 256, save ? a.h[3] : nullptr, a.Wp[3], 16, wave * 32 < 217);
+    hidden(16, XA, XB, 3, 217, nullptr, a.Wp[4], 16, true);
     // skip connection (rend_a :87-88): rows 217..255 of lin4's input are the 39 PE rows (1/sqrt2 folded into W4)
     {
       u16* xb16 = reinterpret_cast<u16*>(XB);
@@ -883,49 +884,61 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
         }
       }
     }
-    load_w(wA, a.Wp[5], true);
-    hidden(wB, 16, XB, XA, 4, 256, save ? a.h[5] : nullptr);
-    load_w(wB, a.Wp[6], true);
-    hidden(wA, 16, XA, XB, 5, 256, save ? a.h[6] : nullptr);
-    load_w(wA, a.Wp[7], true);
-    hidden(wB, 16, XB, XA, 6, 256, save ? a.h[7] : nullptr);
-    if (!VALUES) load_w(wB, a.Wp[8], true);
-    load_small(false);
-    hidden(wA, 16, XA, XB, 7, 256, save ? a.h[8] : nullptr);
-    if (b + 1 < b_end) { load_w(wA, a.Wp[1], true); load_small(true); }     // next batch's lin1 and lin0 slices
+    hidden(16, XB, XA, 4, 256, save ? a.h[5] : nullptr, a.Wp[5], 16, true);
+    hidden(16, XA, XB, 5, 256, save ? a.h[6] : nullptr, a.Wp[6], 16, true);
+    hidden(16, XB, XA, 6, 256, save ? a.h[7] : nullptr, a.Wp[7], 16, true);
+    hidden(16, XA, XB, 7, 256, save ? a.h[8] : nullptr, VALUES ? a.Wp[0] : a.Wp[8], VALUES ? 4 : 16, true);
 
     // ---- lin8: 256 feature rows (save mode) + the sdf row, split over the waves' k-steps and reduced through LDS
     float* red = reinterpret_cast<float*>(PE);             // [8 waves][BP]
-#pragma unroll 1
-    for (int t = 0; t < nt; ++t) {
-      const unsigned char* bp = XB + ((size_t)hi * BP + t * 32 + (lane & 31)) * 16;
-      f32x16 accs;
+    {
+      const unsigned char* bp = XB + ((size_t)hi * BP + (lane & 31)) * 16;
+      f32x16 accs[NT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)(2 * wave + j) * 2 * BP * 16);
-        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&ws8[j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) accs[t][r] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)(2 * wave + j) * 2 * BP * 16 + t * 32 * 16);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&ws8[j]), *reinterpret_cast<const bf16x8*>(&bv), accs[t], 0, 0, 0);
+        }
+      if (hi == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) red[wave * BP + t * 32 + lane] = accs[t][0];
       }
-      if (hi == 0) red[wave * BP + t * 32 + lane] = accs[0];
       if (!VALUES) {
-        f32x16 acc;
+        f32x16 acc[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wB[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
-          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        const int pl = t * 32 + (lane & 31);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n0 = wave * 32 + 8 * g + 4 * hi;
-          const float4 bb = *reinterpret_cast<const float4*>(biasl + 8 * 256 + n0);
-          const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
-          *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.feat) + go) =
-              make_uint2(pack2(acc[4 * g] + bb.x, acc[4 * g + 1] + bb.y), pack2(acc[4 * g + 2] + bb.z, acc[4 * g + 3] + bb.w));
+          for (int t = 0; t < NT; ++t) {
+            const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16 + t * 32 * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc[t], 0, 0, 0);
+          }
+          if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < b_end) load_w(a.Wp[0], 4, true);      // next batch's lin0 slice
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t >= nt) break;
+          const int pl = t * 32 + (lane & 31);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n0 = wave * 32 + 8 * g + 4 * hi;
+            const float4 bb = *reinterpret_cast<const float4*>(biasl + 8 * 256 + n0);
+            const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.feat) + go) =
+                make_uint2(pack2(acc[t][4 * g] + bb.x, acc[t][4 * g + 1] + bb.y), pack2(acc[t][4 * g + 2] + bb.z, acc[t][4 * g + 3] + bb.w));
+          }
         }
       }
     }
