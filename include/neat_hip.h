@@ -128,6 +128,15 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
  * PARITY UNPINNED: hawp is an empty submodule here; semantics are those the call sites rely on. */
 int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream);
 
+/* ---- a11 / a14 glue as single launches.  neat_project2d = VolSDFNetwork.project2D (model/networks/neat_wfr_rend_a.py:317-326):
+ * K [3,3] and w2c [3,4] = [R|T] row-major on the device, X [N,3] -> uv [N,2]; its backward gives d_X from d_uv.
+ * neat_line_loss = VolSDFLoss.get_line_loss (model/networks/loss_wfr.py:34-45): pred, gt [R,4], weight [R] ->
+ * out2 = {loss, number of gated lines}, per_line [R], d_pred [R,4] = d loss / d pred. */
+int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream);
+int neat_project2d_backward(const float* K, const float* w2c, const float* X, int N, const float* d_uv, float* d_X, void* stream);
+int neat_line_loss(const float* pred, const float* gt, const float* weight, int R, float threshold, float* out2, float* per_line,
+                   float* d_pred, void* stream);
+
 /* ---- a16: Adam step over one flat fp32 parameter buffer = torch.optim.Adam(lr) as the reference trainer builds it
  * (training/volsdf_train.py:177; no weight decay, no amsgrad).  The parameters and both moments are flat [n]; the
  * gradients stay where autograd left them: grads[s] (device pointer, or NULL = no gradient this step: that segment is

@@ -207,4 +207,102 @@ __global__ void adam_flat_kernel(float* __restrict__ p, AdamSegs segs, float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// R-sized glue of the junction block and the loss as single launches (the torch formulations cost ~16 and ~30 tiny kernels
+// each and the step has five projections and two line losses).
+// project2D (model/networks/neat_wfr_rend_a.py:317-326):  cam = K (R x + T);  w = cam_z (+-1e-8 if |cam_z| < 1e-8);
+// uv = cam_xy / w.  K: [3,3] row-major, w2c: [3,4] row-major = [R | T].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void project_point(const float* K, const float* M, const float x[3], float cam[3], float& w) {
+  float c[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c[i] = M[4 * i] * x[0] + M[4 * i + 1] * x[1] + M[4 * i + 2] * x[2] + M[4 * i + 3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cam[i] = K[3 * i] * c[0] + K[3 * i + 1] * c[1] + K[3 * i + 2] * c[2];
+  w = cam[2];
+  if (fabsf(w) < 1e-8f) w += (w >= 0.0f) ? 1e-8f : -1e-8f;
+}
+
+__global__ void project2d_kernel(const float* __restrict__ K, const float* __restrict__ w2c, const float* __restrict__ X, int N,
+                                 float* __restrict__ uv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float x[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+  float cam[3], w;
+  project_point(K, w2c, x, cam, w);
+  uv[2 * i] = cam[0] / w; uv[2 * i + 1] = cam[1] / w;
+}
+
+// d_X = R^T K^T d_cam with d_cam = (d_u / w, d_v / w, -(d_u u + d_v v) / w)
+__global__ void project2d_bwd_kernel(const float* __restrict__ K, const float* __restrict__ w2c, const float* __restrict__ X, int N,
+                                     const float* __restrict__ d_uv, float* __restrict__ d_X) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float x[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+  float cam[3], w;
+  project_point(K, w2c, x, cam, w);
+  const float du = d_uv[2 * i], dv = d_uv[2 * i + 1];
+  const float dcam[3] = {du / w, dv / w, -(du * (cam[0] / w) + dv * (cam[1] / w)) / w};
+  float dc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) dc[j] = K[j] * dcam[0] + K[3 + j] * dcam[1] + K[6 + j] * dcam[2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) d_X[3 * i + j] = w2c[j] * dc[0] + w2c[4 + j] * dc[1] + w2c[8 + j] * dc[2];
+}
+
+// Endpoint-order-invariant L1 between 2-D segments, gated (model/networks/loss_wfr.py:34-45), one workgroup:
+//   target = gt or gt with its endpoints swapped, whichever is closer in L2;  per_line = mean_c |pred - target|
+//   loss = sum(per_line w [per_line < thr]) / max(#[per_line < thr], 1)
+// out[0] = loss, out[1] = count; per_line [R]; d_pred [R,4] = d loss / d pred.
+__global__ __launch_bounds__(1024) void line_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                         const float* __restrict__ weight, int R, float thr, float* __restrict__ out,
+                                                         float* __restrict__ per_line, float* __restrict__ d_pred) {
+  __shared__ float s_sum[16], s_cnt[16];
+  __shared__ float s_inv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float sum = 0.0f, cnt = 0.0f;
+  for (int r = tid; r < R; r += blockDim.x) {
+    float p[4], g[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { p[c] = pred[4 * r + c]; g[c] = gt[4 * r + c]; }
+    float ds = 0.0f, df = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const float a = p[c] - g[c], b = p[c] - g[c ^ 2]; ds += a * a; df += b * b; }
+    const bool straight = ds < df;
+    float l = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) l += fabsf(p[c] - (straight ? g[c] : g[c ^ 2]));
+    l *= 0.25f;
+    per_line[r] = l;
+    if (l < thr) { sum += l * weight[r]; cnt += 1.0f; }
+  }
+  sum = wave_sum(sum); cnt = wave_sum(cnt);
+  if (lane == 0) { s_sum[wave] = sum; s_cnt[wave] = cnt; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += s_sum[w]; b += s_cnt[w]; }
+    const float den = fmaxf(b, 1.0f);
+    out[0] = a / den; out[1] = b;
+    s_inv = 1.0f / den;
+  }
+  __syncthreads();
+  const float inv = s_inv;
+  for (int r = tid; r < R; r += blockDim.x) {
+    float p[4], g[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { p[c] = pred[4 * r + c]; g[c] = gt[4 * r + c]; }
+    float ds = 0.0f, df = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const float a = p[c] - g[c], b = p[c] - g[c ^ 2]; ds += a * a; df += b * b; }
+    const bool straight = ds < df;
+    const float coef = (per_line[r] < thr) ? weight[r] * inv * 0.25f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = p[c] - (straight ? g[c] : g[c ^ 2]);
+      d_pred[4 * r + c] = coef * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
+    }
+  }
+}
+
 }  // namespace neat

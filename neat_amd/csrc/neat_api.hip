@@ -1127,6 +1127,27 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   return (int)hipGetLastError();
 }
 
+int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream) {
+  if (N <= 0) return 0;
+  if (!K || !w2c || !X || !uv) return -1;
+  hipLaunchKernelGGL(project2d_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, w2c, X, N, uv);
+  return (int)hipGetLastError();
+}
+
+int neat_project2d_backward(const float* K, const float* w2c, const float* X, int N, const float* d_uv, float* d_X, void* stream) {
+  if (N <= 0) return 0;
+  if (!K || !w2c || !X || !d_uv || !d_X) return -1;
+  hipLaunchKernelGGL(project2d_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, w2c, X, N, d_uv, d_X);
+  return (int)hipGetLastError();
+}
+
+int neat_line_loss(const float* pred, const float* gt, const float* weight, int R, float threshold, float* out2, float* per_line,
+                   float* d_pred, void* stream) {
+  if (R <= 0 || !pred || !gt || !weight || !out2 || !per_line || !d_pred) return -1;
+  hipLaunchKernelGGL(line_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, gt, weight, R, threshold, out2, per_line, d_pred);
+  return (int)hipGetLastError();
+}
+
 size_t neat_lsap_ws_bytes(int nr, int nc) {
   const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
   return (mn + 2 * mx) * sizeof(double) + ((size_t)nr + 5 * mx + 2 * mn) * sizeof(int);

@@ -8,7 +8,12 @@ from .general import get_class
 
 
 def _symmetric_line_l1(pred, gt, weight, threshold=100):
-    """Endpoint-order-invariant L1 between 2-D segments [N,4], gated at `threshold` px (loss_wfr.py:34-45)."""
+    """Endpoint-order-invariant L1 between 2-D segments [N,4], gated at `threshold` px (loss_wfr.py:34-45).
+    CUDA tensors: one HIP launch (`neat_line_loss`); the torch formulation below is the CPU path and the test reference."""
+    if pred.is_cuda:
+        from . import ops
+        loss, per_line, _ = ops.line_loss(pred, gt, weight, threshold)
+        return loss, per_line
     flipped = torch.cat([gt[:, 2:4], gt[:, 0:2]], -1)
     with torch.no_grad():
         straight = ((pred - gt) ** 2).sum(-1, keepdim=True) < ((pred - flipped) ** 2).sum(-1, keepdim=True)

@@ -8,6 +8,8 @@ runs in neat_amd/csrc; what stays in torch here is the R-sized glue of the attra
 import math
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 
@@ -258,6 +260,8 @@ class VolSDFNetwork(_HipModule):
         for head in (self.rendering_network, self.attraction_network):
             head.__dict__["_neat_owner"] = weakref.ref(self)
         self.static_randoms = None        # see _cpu_random
+        self.use_side_stream = int(os.environ.get("NEAT_SIDE_STREAMS", "0"))   # forward(): bit 0: ffn(latents), bit 1: get_outputs(points3d) on a second stream
+        self._side = {}
         self.z_vals_override = None       # bench/tests: given depth samples [R,S] bypass the sampler
         self.set_precision(conf.get_string("hip_precision", default="fp32"))      # new optional key, default = parity build
 
@@ -343,22 +347,65 @@ class VolSDFNetwork(_HipModule):
         output = {"points": points, "rgb_values": rgb, "sdf": sdf_s, "depth": depth, "xyz": xyz}
 
         # ---- attraction field / junctions (rend_a :424-513); R-sized, stays in torch -------------------
+        # Two pieces of this block do not feed the matching below and run on a side stream, concurrently with it: the
+        # global junctions ffn(latents) (depends on parameters only; autograd runs its backward on that stream too, next
+        # to the render backward) and get_outputs(points3d) with the l3d geometry (latency-bound R-point launches).
         points3d = xyz
-        p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
+        main = torch.cuda.current_stream() if xyz.is_cuda else None
+        side = self._side_stream(xyz.device) if (main is not None and self.use_side_stream) else None
         w2c = torch.linalg.inv_ex(pose[0]).inverse[:3]       # inv_ex: no host-side singularity check, no sync
         Rm, T = w2c[:, :3], w2c[:, 3:]
         K3 = intrinsics[0, :3, :3]
         eye = torch.eye(3, device=K3.device)
-        lines2d = self.project2D(K3, Rm, T, lines3d.detach())
-        lines2d_calib = self.project2D(eye, Rm, T, lines3d)
-        l_dirs, l_orig = self._rays(input, "uv_proj")
-        den = (l_dirs * p3_grad).sum(-1)
-        den = den + torch.where(den >= 0, torch.full_like(den, 1e-6), torch.full_like(den, -1e-6))
-        t = (((points3d - l_orig) * p3_grad).sum(-1) / den).detach()
-        l3d = l_orig + l_dirs * t.unsqueeze(-1)
-        with torch.no_grad():
-            a, b = l3d - lines3d[:, 0], l3d - lines3d[:, 1]
-            l3d_score = torch.linalg.cross(a, b).norm(dim=-1) / (lines3d[:, 0] - lines3d[:, 1]).norm(dim=-1)
+
+        def l3d_block():
+            p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
+            l_dirs, l_orig = self._rays(input, "uv_proj")
+            den = (l_dirs * p3_grad).sum(-1)
+            den = den + torch.where(den >= 0, torch.full_like(den, 1e-6), torch.full_like(den, -1e-6))
+            t = (((points3d - l_orig) * p3_grad).sum(-1) / den).detach()
+            l3d = l_orig + l_dirs * t.unsqueeze(-1)
+            with torch.no_grad():
+                a, b = l3d - lines3d[:, 0], l3d - lines3d[:, 1]
+                l3d_score = torch.linalg.cross(a, b).norm(dim=-1) / (lines3d[:, 0] - lines3d[:, 1]).norm(dim=-1)
+            return p3_sdf, l3d, l3d_score
+
+        j3d_global = None
+        if side is not None:
+            side_b = self._side_stream(xyz.device, 1)
+            side.wait_stream(main)
+            side_b.wait_stream(main)
+            if self.training:
+                if self.use_side_stream & 1:
+                    with torch.cuda.stream(side):
+                        j3d_global = self.ffn(self.latents)
+                    j3d_global.record_stream(main)
+                else:
+                    j3d_global = self.ffn(self.latents)
+            if self.use_side_stream & 2:
+                with torch.cuda.stream(side_b):
+                    p3_sdf, l3d, l3d_score = l3d_block()
+                for tns in (p3_sdf, l3d, l3d_score):
+                    tns.record_stream(main)
+            else:
+                p3_sdf, l3d, l3d_score = l3d_block()
+                side_b = None
+            if self.training and self.use_l3d and side_b is not None:
+                main.wait_stream(side_b)
+                side_b = None
+        else:
+            side_b = None
+            if self.training:
+                j3d_global = self.ffn(self.latents)
+            p3_sdf, l3d, l3d_score = l3d_block()
+        if xyz.is_cuda:        # one launch per projection (forward / backward) instead of ~16 R-sized torch kernels
+            K3c, w2c3 = K3.contiguous(), w2c.contiguous()
+            proj = lambda Kc, X: ops.project2d(Kc, w2c3, X)
+        else:
+            K3c = K3
+            proj = lambda Kc, X: self.project2D(Kc, Rm, T, X)
+        lines2d = proj(K3c, lines3d.detach())
+        lines2d_calib = proj(eye, lines3d)
         if self.training:
             if self.dbscan_enabled:
                 cand3d = self.cluster_dbscan(lines3d.detach().cpu().numpy().reshape(-1, 3), eps=0.01, min_samples=2)
@@ -368,8 +415,12 @@ class VolSDFNetwork(_HipModule):
                 cand3d = torch.cat([lines3d[keep].detach().reshape(-1, 3), l3d[keep]], 0)
             else:
                 cand3d = lines3d.detach().reshape(-1, 3)
-            cand2d = self.project2D(K3, Rm, T, cand3d)
-            cand2d_calib = self.project2D(eye, Rm, T, cand3d)
+            if self.dbscan_enabled or self.use_l3d:
+                cand2d = proj(K3c, cand3d)
+                cand2d_calib = proj(eye, cand3d)
+            else:      # the candidates ARE the line end points: their projections were just computed (same arithmetic, same values)
+                cand2d = lines2d.reshape(-1, 2)
+                cand2d_calib = lines2d_calib.detach().reshape(-1, 2)
             gt2d = _device_copy(input["wireframe"][0], "vertices", cand2d.device)
             cost = ((cand2d[None] - gt2d[:, None]) ** 2).sum(-1).sqrt()
             # Hungarian matching on the device (reference: scipy on the host, :473); every gt junction / candidate of the
@@ -382,14 +433,19 @@ class VolSDFNetwork(_HipModule):
                 output["median"] = median
             else:
                 good = matched < 10
-            j3d_global = self.ffn(self.latents)
+            if side is not None:
+                main.wait_stream(side)          # join: the global junctions are needed from here on
             # the reference compacts with `[good]` (:478-489), a data-dependent shape; here the matched candidates stay
             # padded + mask (what neat_amd.loss reads) and the compact tensors are built only if somebody asks for them
             output = JunctionOutputs(output, good, {"j2d_local": cand2d[cols], "j3d_local": cand3d[cols],
                                                     "j2d_local_calib": cand2d_calib[cols]})
             output["j3d_global"] = j3d_global
-            output["j2d_global"] = self.project2D(K3, Rm, T, j3d_global)
-            output["j2d_global_calib"] = self.project2D(eye, Rm, T, j3d_global)
+            output["j2d_global"] = proj(K3c, j3d_global)
+            output["j2d_global_calib"] = proj(eye, j3d_global)
+        if side_b is not None:
+            main.wait_stream(side_b)            # join: get_outputs(points3d) / l3d ran next to the matching above
+        elif side is not None and not self.training:
+            main.wait_stream(side)
         output["l3d"] = l3d
         output["points3d"] = points3d
         output["lines3d"] = lines3d
@@ -406,6 +462,12 @@ class VolSDFNetwork(_HipModule):
         else:
             output["normal_map"] = nmap
         return output
+
+    def _side_stream(self, device, idx=0):
+        key = (str(device), idx)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
 
     def _cpu_random(self, name, draw, device):
         """Randoms are drawn on the CPU (the reference's RNG stream).  Normally: draw + asynchronous pinned copy.  With

@@ -321,3 +321,59 @@ def linear_sum_assignment(cost, row_mask=None):
     ws = torch.empty(max(int(lib.neat_lsap_ws_bytes(nr, nc)), 8), device=cost.device, dtype=torch.uint8)
     _lib.check(lib.neat_lsap(_p(cost), nr, nc, _p(mask), _p(rows), _p(cols), _p(n_match), _p(ws), _stream()), "neat_lsap")
     return rows, cols, n_match
+
+
+class Project2DFn(torch.autograd.Function):
+    """VolSDFNetwork.project2D as one launch forward, one backward (gradient w.r.t. the points only)."""
+
+    @staticmethod
+    def forward(ctx, K3, w2c, X):
+        lib = _lib.lib()
+        K3, w2c = _f32c(K3.detach()), _f32c(w2c.detach())
+        Xc = _f32c(X.detach().reshape(-1, 3))
+        uv = torch.empty(Xc.shape[0], 2, device=Xc.device)
+        _lib.check(lib.neat_project2d(_p(K3), _p(w2c), _p(Xc), Xc.shape[0], _p(uv), _stream()), "neat_project2d")
+        ctx.save_for_backward(K3, w2c, Xc)
+        ctx.shape = X.shape
+        return uv.reshape(*X.shape[:-1], 2)
+
+    @staticmethod
+    def backward(ctx, d_uv):
+        K3, w2c, Xc = ctx.saved_tensors
+        d = _f32c(d_uv.reshape(-1, 2))
+        dX = torch.empty_like(Xc)
+        _lib.check(_lib.lib().neat_project2d_backward(_p(K3), _p(w2c), _p(Xc), Xc.shape[0], _p(d), _p(dX), _stream()),
+                   "neat_project2d_backward")
+        return None, None, dX.reshape(ctx.shape)
+
+
+def project2d(K3, w2c, X):
+    """K3 [3,3], w2c [3,4] = [R|T] (contiguous), X [...,3] -> [...,2]."""
+    return Project2DFn.apply(K3, w2c, X)
+
+
+class LineLossFn(torch.autograd.Function):
+    """VolSDFLoss.get_line_loss in one launch: (loss, per_line, count); d loss / d pred is produced by the same launch."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, weight, threshold):
+        lib = _lib.lib()
+        pred_c, gt_c, w_c = _f32c(pred.detach()), _f32c(gt.detach()), _f32c(weight.detach().reshape(-1))
+        R = pred_c.shape[0]
+        out2 = torch.empty(2, device=pred_c.device)
+        per_line = torch.empty(R, device=pred_c.device)
+        d_pred = torch.empty(R, 4, device=pred_c.device)
+        _lib.check(lib.neat_line_loss(_p(pred_c), _p(gt_c), _p(w_c), R, float(threshold), _p(out2), _p(per_line), _p(d_pred),
+                                      _stream()), "neat_line_loss")
+        ctx.save_for_backward(d_pred)
+        ctx.mark_non_differentiable(per_line)
+        return out2[0], per_line, out2[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_per_line, g_count):
+        (d_pred,) = ctx.saved_tensors
+        return g_loss * d_pred, None, None, None
+
+
+def line_loss(pred, gt, weight, threshold=100.0):
+    return LineLossFn.apply(pred, gt, weight, threshold)

@@ -547,3 +547,43 @@ def test_graph_replay_equals_eager(dev):
     for k in p_e:
         err = float((p_e[k] - p_g[k]).abs().max())
         assert err <= 1e-5 * max(1.0, float(p_e[k].abs().max())), (k, err)
+
+
+def test_project2d_and_line_loss_kernels_vs_torch(dev):
+    """The single-launch glue kernels against the torch formulations they replace (values and gradients)."""
+    from neat_amd import networks, ops
+    from neat_amd.loss import _symmetric_line_l1
+    gen = torch.Generator().manual_seed(3)
+    m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    K = torch.tensor([[560.0, 0.3, 256.0], [0.0, 555.0, 250.0], [0.0, 0.0, 1.0]])
+    w2c = torch.cat([torch.linalg.qr(torch.randn(3, 3, generator=gen))[0], torch.randn(3, 1, generator=gen)], 1)
+    X = torch.randn(777, 2, 3, generator=gen) * 0.7 + torch.tensor([0.0, 0.0, 3.0])
+    X[5, 0] = torch.tensor([0.1, 0.2, 0.0]) - 0.0           # a point that lands (almost) on the camera plane is still finite
+    Xa = X.clone().requires_grad_(True)
+    ref = m.project2D(K, w2c[:, :3], w2c[:, 3:], Xa)
+    cot = torch.randn(ref.shape, generator=gen)
+    (ref * cot).sum().backward()
+    Xb = X.clone().to(dev).requires_grad_(True)
+    got = ops.project2d(K.to(dev), w2c.to(dev).contiguous(), Xb)
+    (got * cot.to(dev)).sum().backward()
+    close(got, ref, tol=1e-5, what="project2d")
+    close(Xb.grad, Xa.grad, tol=1e-4, what="project2d backward")
+    # line loss: mixed straight / flipped targets, some lines beyond the gate, zero weights
+    R = 1500
+    gt = torch.rand(R, 4, generator=gen) * 512
+    pred = gt.clone()
+    pred[::2] = pred[::2][:, [2, 3, 0, 1]]
+    pred = pred + torch.randn(R, 4, generator=gen) * 3
+    pred[::7] += 400.0
+    w = torch.rand(R, 1, generator=gen)
+    w[::5] = 0.0
+    for thr in (100.0, 5.0):
+        pa = pred.clone().requires_grad_(True)
+        l_ref, pl_ref = _symmetric_line_l1(pa, gt, w, thr)
+        l_ref.backward()
+        pb = pred.clone().to(dev).requires_grad_(True)
+        l_got, pl_got = _symmetric_line_l1(pb, gt.to(dev), w.to(dev), thr)
+        (2.0 * l_got).backward()
+        close(l_got.reshape(1), l_ref.reshape(1), tol=1e-5, what="line loss")
+        close(pl_got, pl_ref, tol=1e-5, what="per-line error")
+        close(pb.grad, 2.0 * pa.grad, tol=1e-5, what="line loss backward")
