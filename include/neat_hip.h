@@ -132,6 +132,8 @@ int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int*
  * K [3,3] and w2c [3,4] = [R|T] row-major on the device, X [N,3] -> uv [N,2]; its backward gives d_X from d_uv.
  * neat_line_loss = VolSDFLoss.get_line_loss (model/networks/loss_wfr.py:34-45): pred, gt [R,4], weight [R] ->
  * out2 = {loss, number of gated lines}, per_line [R], d_pred [R,4] = d loss / d pred. */
+/* inverse of one n x n matrix (n <= 4, row stride lda): pose.inverse() (rend_a :440), K.inverse() (loss_wfr.py:59) */
+int neat_inv_small(const float* A, int n, int lda, float* out, void* stream);
 int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream);
 int neat_project2d_backward(const float* K, const float* w2c, const float* X, int N, const float* d_uv, float* d_X, void* stream);
 int neat_line_loss(const float* pred, const float* gt, const float* weight, int R, float threshold, float* out2, float* per_line,

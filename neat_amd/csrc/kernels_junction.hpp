@@ -305,4 +305,27 @@ __global__ __launch_bounds__(1024) void line_loss_kernel(const float* __restrict
   }
 }
 
+// inverse of one small (n <= 4) matrix by Gauss-Jordan elimination with partial pivoting, one thread: the pose and
+// intrinsics inverses of the junction block / loss (rend_a :440, loss_wfr.py:59) cost a dozen rocSOLVER launches each
+__global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float a[4][8];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) { a[i][j] = A[i * lda + j]; a[i][n + j] = (i == j) ? 1.0f : 0.0f; }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r) if (fabsf(a[r][c]) > fabsf(a[piv][c])) piv = r;
+    if (piv != c) for (int j = 0; j < 2 * n; ++j) { const float t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    const float inv = 1.0f / a[c][c];
+    for (int j = 0; j < 2 * n; ++j) a[c][j] *= inv;
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const float f = a[r][c];
+      for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) out[i * n + j] = a[i][n + j];
+}
+
 }  // namespace neat

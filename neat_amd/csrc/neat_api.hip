@@ -1127,6 +1127,12 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   return (int)hipGetLastError();
 }
 
+int neat_inv_small(const float* A, int n, int lda, float* out, void* stream) {
+  if (!A || !out || n < 1 || n > 4 || lda < n) return -1;
+  hipLaunchKernelGGL(inv_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, n, lda, out);
+  return (int)hipGetLastError();
+}
+
 int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream) {
   if (N <= 0) return 0;
   if (!K || !w2c || !X || !uv) return -1;

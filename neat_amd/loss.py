@@ -7,6 +7,11 @@ from torch import nn
 from .general import get_class
 
 
+def _inv3(K):
+    from . import ops
+    return ops.inv_small(K)
+
+
 def _symmetric_line_l1(pred, gt, weight, threshold=100):
     """Endpoint-order-invariant L1 between 2-D segments [N,4], gated at `threshold` px (loss_wfr.py:34-45).
     CUDA tensors: one HIP launch (`neat_line_loss`); the torch formulation below is the CPU path and the test reference."""
@@ -75,7 +80,7 @@ class VolSDFLoss(nn.Module):
         close = per_line < 100
         # bring the GT segments into calibrated (K^-1) coordinates for the differentiable term (:59-65)
         ends = seg_gt.reshape(-1, 2)
-        ends_h = (torch.linalg.inv_ex(model_outputs["K"]).inverse @ torch.cat([ends, torch.ones_like(ends[:, :1])], -1).t()).t()
+        ends_h = (_inv3(model_outputs["K"]) @ torch.cat([ends, torch.ones_like(ends[:, :1])], -1).t()).t()
         seg_gt_calib = (ends_h[:, :2] / ends_h[:, 2, None]).reshape(-1, 4)
         line_loss, _ = self.get_line_loss(model_outputs["lines2d_calib"].reshape(-1, 4), seg_gt_calib,
                                           seg_w * close.reshape(-1, 1))

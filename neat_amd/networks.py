@@ -353,7 +353,7 @@ class VolSDFNetwork(_HipModule):
         points3d = xyz
         main = torch.cuda.current_stream() if xyz.is_cuda else None
         side = self._side_stream(xyz.device) if (main is not None and self.use_side_stream) else None
-        w2c = torch.linalg.inv_ex(pose[0]).inverse[:3]       # inv_ex: no host-side singularity check, no sync
+        w2c = ops.inv_small(pose[0])[:3]                     # one launch, no host-side singularity check, no sync
         Rm, T = w2c[:, :3], w2c[:, 3:]
         K3 = intrinsics[0, :3, :3]
         eye = torch.eye(3, device=K3.device)

@@ -377,3 +377,15 @@ class LineLossFn(torch.autograd.Function):
 
 def line_loss(pred, gt, weight, threshold=100.0):
     return LineLossFn.apply(pred, gt, weight, threshold)
+
+
+def inv_small(A):
+    """Inverse of one [n,n] matrix, n <= 4, in one launch (no host-side singularity check, no sync); no gradient."""
+    A = A.detach()
+    if not A.is_cuda:
+        return torch.linalg.inv_ex(A).inverse
+    A = _f32c(A)
+    n = A.shape[-1]
+    out = torch.empty(n, n, device=A.device)
+    _lib.check(_lib.lib().neat_inv_small(_p(A), n, n, _p(out), _stream()), "neat_inv_small")
+    return out
