@@ -27,6 +27,7 @@ struct LsapArgs {
   int* n_match;
   double* wsd;             // u[N] v[M] sp[M]
   int* wsi;                // rowlist[nr] path[M] col4row[N] row4col[M] remaining[M] SR[N] SC[M] tmp[M]
+  int use_lds, lds_int_off; // work arrays in dynamic LDS instead (doubles first, ints at byte offset lds_int_off)
 };
 
 struct LsapKey { double val; int it; int un; };
@@ -79,13 +80,18 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
   const int kmax = min(a.nr, a.nc);
   for (int k = tid; k < kmax; k += nt) { a.row_ind[k] = -1; a.col_ind[k] = -1; }
 
-  int* rowlist = a.wsi;
+  // work arrays: in LDS when they fit (every step of the augmenting path is a chain of dependent reads by one thread;
+  // at L2 latency that chain is most of the run time for the small problems of a training step), else in `ws`
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsap_lds[];
+  double* wsd = a.use_lds ? reinterpret_cast<double*>(lsap_lds) : a.wsd;
+  int* wsi = a.use_lds ? reinterpret_cast<int*>(lsap_lds + a.lds_int_off) : a.wsi;
+  int* rowlist = wsi;
   const unsigned char* mask = a.row_mask;
   const int n_eff = lsap_compact(a.nr, [&](int i) { return mask ? mask[i] != 0 : true; }, rowlist, s_wave, &s_base);
   const bool T = a.nc < n_eff;
   const int N = T ? a.nc : n_eff, M = T ? n_eff : a.nc;
   if (N == 0) { if (tid == 0) *a.n_match = 0; return; }
-  double* u = a.wsd; double* v = u + N; double* sp = v + M;
+  double* u = wsd; double* v = u + N; double* sp = v + M;
   int* path = rowlist + a.nr; int* col4row = path + M; int* row4col = col4row + N; int* remaining = row4col + M;
   int* SR = remaining + M; int* SC = SR + N; int* tmp = SC + M;
   const float* C = a.cost;

@@ -1166,7 +1166,18 @@ int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, 
   if (!cost || !row_ind || !col_ind || !ws) return -1;
   const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
   LsapArgs a{cost, nr, nc, row_mask, row_ind, col_ind, n_match, (double*)ws, (int*)((double*)ws + mn + 2 * mx)};
-  hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(LSAP_WG), 0, (hipStream_t)stream, a);
+  const size_t dbytes = (mn + 2 * mx) * sizeof(double), ibytes = ((size_t)nr + 5 * mx + 2 * mn) * sizeof(int);
+  size_t lds = 0;
+  if (dbytes + ibytes <= 144 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    a.use_lds = 1; a.lds_int_off = (int)dbytes; lds = dbytes + ibytes;
+  }
+  hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(LSAP_WG), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

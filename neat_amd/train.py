@@ -24,6 +24,7 @@ class Trainer:
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.1 ** (1.0 / decay_steps))
         self.bucket = FlatGradBucket(self.model.parameters())
         self._graph, self._captured, self._ring_pos, self.capture_error = None, None, 0, None
+        self._seen = {}
 
     def step(self, model_input, ground_truth):
         if self._graph is not None:
@@ -53,9 +54,11 @@ class Trainer:
         self._static_gt = dict(ground_truth)
         for k in tensor_keys:
             self._static_in[k] = model_input[k].clone()
+            self._seen[(id(self._static_in), k)] = (model_input[k].data_ptr(), model_input[k]._version)
         for k, v in ground_truth.items():
             if isinstance(v, torch.Tensor):
                 self._static_gt[k] = v.to(self.device).clone()
+                self._seen[(id(self._static_gt), k)] = (v.data_ptr(), v._version)
         self.model.static_randoms = {}
         self.loss.nan_check = "off"
         try:
@@ -120,12 +123,15 @@ class Trainer:
         self._ring_pos += 1
 
     def _replay(self, model_input, ground_truth):
-        for k, v in model_input.items():
-            if isinstance(v, torch.Tensor) and v is not self._static_in[k]:
-                self._static_in[k].copy_(v, non_blocking=True)
-        for k, v in ground_truth.items():
-            if isinstance(v, torch.Tensor) and v is not self._static_gt[k]:
-                self._static_gt[k].copy_(v, non_blocking=True)
+        # inputs that changed since the last step are copied into the captured tensors (same object, same version: skip)
+        for static, fresh in ((self._static_in, model_input), (self._static_gt, ground_truth)):
+            for k, v in fresh.items():
+                if not isinstance(v, torch.Tensor) or v is static[k]:
+                    continue
+                tag = (v.data_ptr(), v._version)
+                if self._seen.get((id(static), k)) != tag:
+                    static[k].copy_(v, non_blocking=True)
+                    self._seen[(id(static), k)] = tag
         self._refill_randoms()
         self._finish_step()
         return self._captured
