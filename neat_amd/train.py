@@ -76,7 +76,8 @@ class Trainer:
             self._refill_randoms()
             self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: a NCCL/RCCL watchdog thread may touch the runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 self._captured = self._fwd_bwd(zero=False)
             self._graph = graph
             self._static_grads = [(p, p.grad) for p in self.model.parameters()]

@@ -31,6 +31,16 @@ def _worker(rank, world, port, out_dir):
     assert bucket.numel == 15 + 7 + 1
     bucket.all_reduce_mean()
     torch.save([p.grad for p in params], os.path.join(out_dir, f"grads{rank}.pt"))
+    # gradients that are views of one flat allocation (what the HIP backward returns) are reduced in place
+    q = [torch.nn.Parameter(torch.zeros(4, 2)), torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))]
+    flat = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    q[0].grad, q[1].grad = flat[:8].view(4, 2), flat[8:11]
+    q[2].grad = torch.full((2,), float(rank))
+    b2 = dp.FlatGradBucket(q)
+    b2.all_reduce_mean()
+    assert b2._plan == [(0, 1)]
+    assert torch.allclose(flat, torch.arange(11, dtype=torch.float32) * 1.5) and q[0].grad.data_ptr() == flat.data_ptr()
+    assert torch.allclose(q[2].grad, torch.full((2,), 0.5))
     scal = dp.all_reduce_scalars({"loss": torch.tensor(float(rank + 1))})
     assert abs(float(scal["loss"]) - 1.5) < 1e-6
     assert dp.shard_rays(4096, world) == 2048 and dp.rank_seed(42, rank) == 42 + rank
