@@ -132,6 +132,13 @@ int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int*
  * K [3,3] and w2c [3,4] = [R|T] row-major on the device, X [N,3] -> uv [N,2]; its backward gives d_X from d_uv.
  * neat_line_loss = VolSDFLoss.get_line_loss (model/networks/loss_wfr.py:34-45): pred, gt [R,4], weight [R] ->
  * out2 = {loss, number of gated lines}, per_line [R], d_pred [R,4] = d loss / d pred. */
+/* global-junction MLP ffn(latents) (rend_a :303-313, :491): x [J,256] -> relu(W0 x + b0) -> relu(W1 . + b1) -> W2 . + b2 = y [J,3];
+ * torch nn.Linear layouts (W [out,in]); h1, h2 [J,256] are saved for the backward; ws2 = 2 J 256 floats of scratch. */
+int neat_ffn_forward(const float* x, int J, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                     const float* b2, float* h1, float* h2, float* y, void* stream);
+int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, const float* W2, const float* h1, const float* h2,
+                      const float* dy, float* ws2, float* dx, float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2,
+                      void* stream);
 /* inverse of one n x n matrix (n <= 4, row stride lda): pose.inverse() (rend_a :440), K.inverse() (loss_wfr.py:59) */
 int neat_inv_small(const float* A, int n, int lda, float* out, void* stream);
 int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream);

@@ -334,4 +334,108 @@ __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, fl
     for (int j = 0; j < n; ++j) out[i * n + j] = a[i][n + j];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Global-junction MLP  j3d = W2 relu(W1 relu(W0 z + b0) + b1) + b2  (VolSDFNetwork.ffn on the latents, rend_a :303-313,491):
+// J x 256 -> 256 -> 256 -> 3 in fp32.  Three launches replace ~25 (six latency-bound library GEMMs on 64 rows, bias / relu
+// / reduction kernels): forward and data-backward are parallel over junction rows (FFN_RB rows per workgroup, thread =
+// feature), the weight gradients are parallel over output features (deterministic sums over the rows).
+// ---------------------------------------------------------------------------------------------
+constexpr int FFN_H = 256, FFN_RB = 8;
+
+__global__ __launch_bounds__(FFN_H) void ffn_forward_kernel(const float* __restrict__ x, int J, const float* __restrict__ W0,
+    const float* __restrict__ b0, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ b2, float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ y) {
+  __shared__ float xs[FFN_RB][FFN_H], hs[FFN_RB][FFN_H];
+  const int n = threadIdx.x, r0 = blockIdx.x * FFN_RB;
+  const int nr = min(FFN_RB, J - r0);
+  for (int r = 0; r < FFN_RB; ++r) xs[r][n] = r < nr ? x[(size_t)(r0 + r) * FFN_H + n] : 0.0f;
+  __syncthreads();
+  auto dense = [&](const float* __restrict__ W, const float* __restrict__ b, float (&in)[FFN_RB][FFN_H], float (&acc)[FFN_RB]) {
+#pragma unroll
+    for (int r = 0; r < FFN_RB; ++r) acc[r] = b[n];
+    const float4* wr = reinterpret_cast<const float4*>(W + (size_t)n * FFN_H);
+    for (int k4 = 0; k4 < FFN_H / 4; ++k4) {
+      const float4 w = wr[k4];
+#pragma unroll
+      for (int r = 0; r < FFN_RB; ++r)
+        acc[r] += w.x * in[r][4 * k4] + w.y * in[r][4 * k4 + 1] + w.z * in[r][4 * k4 + 2] + w.w * in[r][4 * k4 + 3];
+    }
+  };
+  float acc[FFN_RB];
+  dense(W0, b0, xs, acc);
+  for (int r = 0; r < FFN_RB; ++r) { const float v = fmaxf(acc[r], 0.0f); hs[r][n] = v; if (r < nr) h1[(size_t)(r0 + r) * FFN_H + n] = v; }
+  __syncthreads();
+  dense(W1, b1, hs, acc);
+  __syncthreads();
+  for (int r = 0; r < FFN_RB; ++r) { const float v = fmaxf(acc[r], 0.0f); xs[r][n] = v; if (r < nr) h2[(size_t)(r0 + r) * FFN_H + n] = v; }
+  __syncthreads();
+  if (n < 3 * FFN_RB) {
+    const int r = n / 3, c = n % 3;
+    float v = b2[c];
+    for (int k = 0; k < FFN_H; ++k) v += W2[c * FFN_H + k] * xs[r][k];
+    if (r < nr) y[(size_t)(r0 + r) * 3 + c] = v;
+  }
+}
+
+// d_a2 = (W2^T dy) [h2 > 0] ; d_a1 = (W1^T d_a2) [h1 > 0] ; dx = W0^T d_a1
+__global__ __launch_bounds__(FFN_H) void ffn_backward_data_kernel(const float* __restrict__ dy, int J, const float* __restrict__ W0,
+    const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ h1, const float* __restrict__ h2,
+    float* __restrict__ d_a1, float* __restrict__ d_a2, float* __restrict__ dx) {
+  __shared__ float ds[FFN_RB][FFN_H];
+  __shared__ float dys[FFN_RB][3];
+  const int k = threadIdx.x, r0 = blockIdx.x * FFN_RB;
+  const int nr = min(FFN_RB, J - r0);
+  if (k < 3 * FFN_RB) dys[k / 3][k % 3] = (k / 3 < nr) ? dy[(size_t)(r0 + k / 3) * 3 + k % 3] : 0.0f;
+  __syncthreads();
+  for (int r = 0; r < FFN_RB; ++r) {
+    float v = dys[r][0] * W2[k] + dys[r][1] * W2[FFN_H + k] + dys[r][2] * W2[2 * FFN_H + k];
+    v = (r < nr && h2[(size_t)(r0 + r) * FFN_H + k] > 0.0f) ? v : 0.0f;
+    ds[r][k] = v;
+    if (r < nr) d_a2[(size_t)(r0 + r) * FFN_H + k] = v;
+  }
+  __syncthreads();
+  auto back = [&](const float* __restrict__ W, float (&acc)[FFN_RB]) {       // acc[r] = sum_n ds[r][n] W[n][k]
+#pragma unroll
+    for (int r = 0; r < FFN_RB; ++r) acc[r] = 0.0f;
+    for (int n = 0; n < FFN_H; ++n) {
+      const float w = W[(size_t)n * FFN_H + k];
+#pragma unroll
+      for (int r = 0; r < FFN_RB; ++r) acc[r] += ds[r][n] * w;
+    }
+  };
+  float acc[FFN_RB];
+  back(W1, acc);
+  __syncthreads();
+  for (int r = 0; r < FFN_RB; ++r) {
+    const float v = (r < nr && h1[(size_t)(r0 + r) * FFN_H + k] > 0.0f) ? acc[r] : 0.0f;
+    ds[r][k] = v;
+    if (r < nr) d_a1[(size_t)(r0 + r) * FFN_H + k] = v;
+  }
+  __syncthreads();
+  back(W0, acc);
+  for (int r = 0; r < nr; ++r) dx[(size_t)(r0 + r) * FFN_H + k] = acc[r];
+}
+
+// blockIdx.y: 0: dW0 = d_a1^T x, db0 ; 1: dW1 = d_a2^T h1, db1 ; 2 (rows 0..2): dW2 = dy^T h2, db2.  blockIdx.x = output row.
+__global__ __launch_bounds__(FFN_H) void ffn_backward_weights_kernel(const float* __restrict__ x, const float* __restrict__ h1,
+    const float* __restrict__ h2, const float* __restrict__ d_a1, const float* __restrict__ d_a2, const float* __restrict__ dy, int J,
+    float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
+    float* __restrict__ db2) {
+  const int k = threadIdx.x, n = blockIdx.x, which = blockIdx.y;
+  if (which == 2 && n >= 3) return;
+  const float* d = which == 0 ? d_a1 : (which == 1 ? d_a2 : dy);
+  const float* in = which == 0 ? x : (which == 1 ? h1 : h2);
+  const int ldd = which == 2 ? 3 : FFN_H;
+  float acc = 0.0f, bsum = 0.0f;
+  for (int j = 0; j < J; ++j) {
+    const float dv = d[(size_t)j * ldd + n];
+    acc += dv * in[(size_t)j * FFN_H + k];
+    bsum += dv;
+  }
+  float* dW = which == 0 ? dW0 : (which == 1 ? dW1 : dW2);
+  float* db = which == 0 ? db0 : (which == 1 ? db1 : db2);
+  dW[(size_t)n * FFN_H + k] = acc;
+  if (k == 0) db[n] = bsum;
+}
+
 }  // namespace neat

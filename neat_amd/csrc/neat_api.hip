@@ -1127,6 +1127,27 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   return (int)hipGetLastError();
 }
 
+int neat_ffn_forward(const float* x, int J, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                     const float* b2, float* h1, float* h2, float* y, void* stream) {
+  if (J <= 0) return 0;
+  if (!x || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !h1 || !h2 || !y) return -1;
+  hipLaunchKernelGGL(ffn_forward_kernel, dim3((J + FFN_RB - 1) / FFN_RB), dim3(FFN_H), 0, (hipStream_t)stream, x, J, W0, b0, W1, b1, W2, b2, h1, h2, y);
+  return (int)hipGetLastError();
+}
+
+int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, const float* W2, const float* h1, const float* h2,
+                      const float* dy, float* ws2, float* dx, float* dW0, float* db0, float* dW1, float* db1, float* dW2, float* db2,
+                      void* stream) {
+  if (J <= 0) return 0;
+  if (!x || !W0 || !W1 || !W2 || !h1 || !h2 || !dy || !ws2 || !dx || !dW0 || !db0 || !dW1 || !db1 || !dW2 || !db2) return -1;
+  float* d_a1 = ws2; float* d_a2 = ws2 + (size_t)J * FFN_H;
+  hipLaunchKernelGGL(ffn_backward_data_kernel, dim3((J + FFN_RB - 1) / FFN_RB), dim3(FFN_H), 0, (hipStream_t)stream, dy, J, W0, W1, W2, h1, h2,
+                     d_a1, d_a2, dx);
+  hipLaunchKernelGGL(ffn_backward_weights_kernel, dim3(FFN_H, 3), dim3(FFN_H), 0, (hipStream_t)stream, x, h1, h2, d_a1, d_a2, dy, J, dW0, db0,
+                     dW1, db1, dW2, db2);
+  return (int)hipGetLastError();
+}
+
 int neat_inv_small(const float* A, int n, int lda, float* out, void* stream) {
   if (!A || !out || n < 1 || n > 4 || lda < n) return -1;
   hipLaunchKernelGGL(inv_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, n, lda, out);

@@ -378,10 +378,10 @@ class VolSDFNetwork(_HipModule):
             if self.training:
                 if self.use_side_stream & 1:
                     with torch.cuda.stream(side):
-                        j3d_global = self.ffn(self.latents)
+                        j3d_global = self._global_junctions()
                     j3d_global.record_stream(main)
                 else:
-                    j3d_global = self.ffn(self.latents)
+                    j3d_global = self._global_junctions()
             if self.use_side_stream & 2:
                 with torch.cuda.stream(side_b):
                     p3_sdf, l3d, l3d_score = l3d_block()
@@ -396,7 +396,7 @@ class VolSDFNetwork(_HipModule):
         else:
             side_b = None
             if self.training:
-                j3d_global = self.ffn(self.latents)
+                j3d_global = self._global_junctions()
             p3_sdf, l3d, l3d_score = l3d_block()
         if xyz.is_cuda:        # one launch per projection (forward / backward) instead of ~16 R-sized torch kernels
             K3c, w2c3 = K3.contiguous(), w2c.contiguous()
@@ -462,6 +462,16 @@ class VolSDFNetwork(_HipModule):
         else:
             output["normal_map"] = nmap
         return output
+
+    def _global_junctions(self):
+        """ffn(latents) (rend_a :491).  The shipped architecture (Linear-ReLU-Linear-ReLU-Linear, 256 wide) on CUDA goes
+        through three HIP launches; anything else through the torch modules."""
+        lin = [m for m in self.ffn if isinstance(m, nn.Linear)]
+        if (self.latents.is_cuda and len(self.ffn) == 5 and len(lin) == 3 and self.latents.shape[1] == 256
+                and tuple(lin[0].weight.shape) == (256, 256) and tuple(lin[1].weight.shape) == (256, 256)
+                and tuple(lin[2].weight.shape) == (3, 256)):
+            return ops.ffn_junctions(self.latents, lin)
+        return self.ffn(self.latents)
 
     def _side_stream(self, device, idx=0):
         key = (str(device), idx)

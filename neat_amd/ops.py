@@ -389,3 +389,38 @@ def inv_small(A):
     out = torch.empty(n, n, device=A.device)
     _lib.check(_lib.lib().neat_inv_small(_p(A), n, n, _p(out), _stream()), "neat_inv_small")
     return out
+
+
+class FfnFn(torch.autograd.Function):
+    """ffn(latents) = Linear-ReLU-Linear-ReLU-Linear (256 -> 256 -> 256 -> 3) in three launches (forward, data backward,
+    weight backward) instead of ~25 latency-bound library GEMM / bias / relu kernels on a few dozen rows."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, W1, b1, W2, b2):
+        lib = _lib.lib()
+        args = [_f32c(t.detach()) for t in (x, W0, b0, W1, b1, W2, b2)]
+        J = args[0].shape[0]
+        h1, h2 = torch.empty(J, 256, device=x.device), torch.empty(J, 256, device=x.device)
+        y = torch.empty(J, 3, device=x.device)
+        _lib.check(lib.neat_ffn_forward(_p(args[0]), J, *[_p(t) for t in args[1:]], _p(h1), _p(h2), _p(y), _stream()), "neat_ffn_forward")
+        ctx.save_for_backward(args[0], args[1], args[3], args[5], h1, h2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W0, W1, W2, h1, h2 = ctx.saved_tensors
+        J = x.shape[0]
+        dy = _f32c(dy)
+        ws2 = torch.empty(2 * J * 256, device=x.device)
+        dx = torch.empty_like(x)
+        flat = torch.empty(2 * (256 * 256 + 256) + 3 * 256 + 3, device=x.device)
+        dW0, db0, dW1, db1, dW2, db2 = flat.split([65536, 256, 65536, 256, 768, 3])
+        _lib.check(_lib.lib().neat_ffn_backward(_p(x), J, _p(W0), _p(W1), _p(W2), _p(h1), _p(h2), _p(dy), _p(ws2), _p(dx), _p(dW0), _p(db0),
+                                               _p(dW1), _p(db1), _p(dW2), _p(db2), _stream()), "neat_ffn_backward")
+        return dx, dW0.view(256, 256), db0, dW1.view(256, 256), db1, dW2.view(3, 256), db2
+
+
+def ffn_junctions(x, linears):
+    """linears: the three nn.Linear modules of VolSDFNetwork.ffn."""
+    l0, l1, l2 = linears
+    return FfnFn.apply(x, l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias)

@@ -26,6 +26,7 @@ gathered = [torch.empty_like(flat) for _ in range(world)]
 dist.all_gather(gathered, flat)
 diff = max(float((g - gathered[0]).abs().max()) for g in gathered)
 if rank == 0:
+    print("in-place all-reduce groups:", [len(g) for g in tr.bucket._plan], "of", len(tr.bucket.params), "tensors")
     print(f"graph captured: {ok} ({tr.capture_error!r}); loss {float(lo['loss']):.5f}; max parameter difference across ranks: {diff:.3e}")
     assert diff == 0.0
 dist.destroy_process_group()

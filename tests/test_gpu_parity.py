@@ -587,3 +587,25 @@ def test_project2d_and_line_loss_kernels_vs_torch(dev):
         close(l_got.reshape(1), l_ref.reshape(1), tol=1e-5, what="line loss")
         close(pl_got, pl_ref, tol=1e-5, what="per-line error")
         close(pb.grad, 2.0 * pa.grad, tol=1e-5, what="line loss backward")
+
+
+@pytest.mark.parametrize("J", [64, 100, 1024])
+def test_ffn_kernels_vs_torch(dev, J):
+    """ffn(latents) through the three HIP launches against the torch modules (values and every gradient)."""
+    from neat_amd import ops
+    torch.manual_seed(J)
+    ffn = torch.nn.Sequential(torch.nn.Linear(256, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256), torch.nn.ReLU(),
+                              torch.nn.Linear(256, 3)).to(dev)
+    x = torch.randn(J, 256, device=dev, requires_grad=True)
+    cot = torch.randn(J, 3, device=dev)
+    ref = ffn(x)
+    (ref * cot).sum().backward()
+    g_ref = [x.grad.clone()] + [p.grad.clone() for p in ffn.parameters()]
+    x.grad = None
+    ffn.zero_grad()
+    got = ops.ffn_junctions(x, [ffn[0], ffn[2], ffn[4]])
+    (got * cot).sum().backward()
+    g_got = [x.grad] + [p.grad for p in ffn.parameters()]
+    close(got, ref, tol=1e-5, what="ffn forward")
+    for a, b in zip(g_got, g_ref):
+        close(a, b, tol=2e-5, what="ffn backward")
