@@ -59,6 +59,7 @@ struct LayerArgsH {
   void* out0; void* out1;     // out1 receives rows >= n_split (row - n_split)
   int out0_bf16, out1_bf16, n_split, accumulate;
   const u16* aux0; const u16* aux1;     // bf16 octet-major, same row indexing as out0
+  const u16* padfill_oct;                   // the same rows as an octet-major bf16 array (what layer_kernel_ws reads), or null
   const float* padfill; int padfill_rows;   // rows [N, N+padfill_rows) of out0 receive these fp32 rows (skip layer: the
                                             // first 7 PE rows ride in the padding of the 217-row h4 octets); out1 gets 0
 };
@@ -332,18 +333,25 @@ struct LayerArgsWS {
   const u16* in2; int split_oct;                         // input octets >= split_oct come from in2 (skip layer: [vh4 | PE^]); 32 = none
   int n_split; float* out1f;                             // EPI_REV: rows >= n_split leave as fp32 feature-major rows (n - n_split), no phi'
   float* out0f;                                          // OUTF variants: out0 is fp32 feature-major [N][ldp]
+  int x_octs;                                            // KS = 20: valid octets of in2 (the rest of its 8-octet slot is zero weight)
+  const u16* padfill;                                    // EPI_TAN_PF: octet-major array whose rows 0..6 fill rows N..N+6 of out0
 };
 // epilogues that exist only in the weight-stationary kernel
 constexpr int EPI_LINACC = 8;      // out0 = acc + aux0                      (feature cotangent: second head adds to the first)
 constexpr int EPI_BWD8 = 9;        // out0 = (acc + wrow[n] s[p]) phi'(aux0) + aux1   (first layer of the reverse chain: the
                                    // sdf row of lin8 enters as a rank-1 term, s = cotangent of the raw sdf, fp32 per point)
-template <int EPI> struct WsCfg {
-  static constexpr int NAUX = (EPI == EPI_TAN || EPI == EPI_BWD || EPI == EPI_BWD8) ? 2
+constexpr int EPI_TAN_PF = 10;     // EPI_TAN for lin3 (217 rows): rows 217..223 of out0 <- rows 0..6 of a small octet-major array
+                                   // (the PE tangent rows that ride in the padding of the skip layer's input), out1 <- 0
+template <int EPI, int KS = 16> struct WsCfg {
+  static constexpr int NAUX = (EPI == EPI_TAN || EPI == EPI_TAN_PF || EPI == EPI_BWD || EPI == EPI_BWD8) ? 2
                               : ((EPI == EPI_REV || EPI == EPI_BWD_RELU || EPI == EPI_LINACC) ? 1 : 0);
   static constexpr int HAS_S = EPI == EPI_BWD8 ? 1 : 0;
-  static constexpr int NS = NAUX == 2 ? 3 : 4;           // ring depth: 3 x 48 KiB or 4 x (16|32) KiB
-  static constexpr int STAGE = WS_TILE * (1 + NAUX) + HAS_S * 8 * 256;
-  static constexpr int G = 2 * (1 + NAUX) + HAS_S;       // DMA instructions per stage per wave
+  static constexpr int HAS_PF = EPI == EPI_TAN_PF ? 1 : 0;
+  static constexpr int XOCT = KS > 16 ? 8 : 0;           // input octets beyond the 32 of the main array (K = 320: [256 | 64])
+  static constexpr int IN_TILE = (32 + XOCT) * WSP * 16;
+  static constexpr int NS = NAUX == 2 ? 3 : 4;           // ring depth: 3 x 48 KiB or 4 x (16|20|32) KiB
+  static constexpr int STAGE = IN_TILE + WS_TILE * NAUX + HAS_S * 8 * 256 + HAS_PF * 1024;
+  static constexpr int G = 2 * (1 + NAUX) + HAS_S + HAS_PF + (XOCT ? 1 : 0);       // DMA instructions per stage per wave
   static constexpr int LDS = NS * STAGE;
 };
 
@@ -353,6 +361,7 @@ __device__ __forceinline__ void ws_wait_barrier(int n) {     // n = DMA instruct
     case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
   }
@@ -361,7 +370,7 @@ __device__ __forceinline__ void ws_wait_barrier(int n) {     // n = DMA instruct
 // KS: k-steps (16: K = 256; 1: K <= 16, the narrow cotangents entering the heads' backward); OUTF: narrow fp32 output
 template <int EPI, int KS = 16, bool OUTF = false>
 __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
-  typedef WsCfg<EPI> C;
+  typedef WsCfg<EPI, KS> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char wslds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -386,20 +395,34 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
                    : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
     }
   };
+  auto dma1 = [&](const void* src, unsigned dst, bool wide) {
+    const unsigned d2 = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    if (wide)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(d2) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(d2) : "memory");
+  };
+  constexpr unsigned AUX0 = C::IN_TILE, AUX1 = C::IN_TILE + WS_TILE, EXTRA = C::IN_TILE + WS_TILE * C::NAUX;
   auto issue = [&](int tau) {
     const unsigned stage = lds_base + (unsigned)(tau % C::NS) * C::STAGE;
     const unsigned slot = stage + dma_off;
     const int tile = t_begin + tau;
     dma(a.in, tile, slot, a.in_octs - 1, a.in2, a.split_oct);
-    if (C::NAUX >= 1) dma(a.aux0, tile, slot + WS_TILE, 31);
-    if (C::NAUX >= 2) dma(a.aux1, tile, slot + 2 * WS_TILE, 31);
-    if (C::HAS_S) {          // this wave's private copy of the 32 per-point scalars (both half-waves fetch the same 128 B)
-      const float* s2 = a.srow + (size_t)tile * WSP + (lane & 31);
-      const unsigned d2 = __builtin_amdgcn_readfirstlane(stage + WS_TILE * (1 + C::NAUX) + wave * 256);
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
+    if (C::XOCT) {           // octets 32..39 of the packed input come from the small second array (2 octets x 32 points per
+                             // instruction; waves 4..7 repeat what waves 0..3 fetch so that every wave issues the same count)
+      const int oct = min(2 * (wave & 3) + (lane >> 5), a.x_octs - 1);
+      dma1(a.in2 + ((size_t)oct * a.ldp + (size_t)tile * WSP + (lane & 31)) * 8, stage + (32 + 2 * (wave & 3)) * (WSP * 16), true);
     }
+    if (C::NAUX >= 1) dma(a.aux0, tile, slot + AUX0, 31);
+    if (C::NAUX >= 2) dma(a.aux1, tile, slot + AUX1, 31);
+    if (C::HAS_S)            // this wave's private copy of the 32 per-point scalars (both half-waves fetch the same 128 B)
+      dma1(a.srow + (size_t)tile * WSP + (lane & 31), stage + EXTRA + wave * 256, false);
+    if (C::HAS_PF)           // octet 0 of the pad-fill array: every wave writes the SAME bytes to the same 1 KiB (both half-waves
+                             // fetch the same 512 B), so each wave's own counted wait covers the copy it reads
+      dma1(a.padfill + ((size_t)tile * WSP + (lane & 31)) * 8, stage + EXTRA, true);
   };
 #pragma unroll
   for (int t = 0; t < C::NS - 1; ++t)
@@ -439,18 +462,18 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     if (!live) continue;
     const int p = (t_begin + tau) * WSP + (lane & 31);
     float sp = 0.0f;
-    if (C::HAS_S) sp = *reinterpret_cast<const float*>(slot + WS_TILE * (1 + C::NAUX) + wave * 256 + (lane & 31) * 4);
+    if (C::HAS_S) sp = *reinterpret_cast<const float*>(slot + EXTRA + wave * 256 + (lane & 31) * 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n0 = wave * 32 + 8 * q + 4 * (lane >> 5);
       if (n0 >= Npad) continue;
       float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {0.f, 0.f, 0.f, 0.f};
       if (C::NAUX >= 1) {
-        const uint2 r = *reinterpret_cast<const uint2*>(slot + WS_TILE + efrag + q * (WSP * 16));
+        const uint2 r = *reinterpret_cast<const uint2*>(slot + AUX0 + efrag + q * (WSP * 16));
         x0[0] = bf_lo(r.x); x0[1] = bf_hi(r.x); x0[2] = bf_lo(r.y); x0[3] = bf_hi(r.y);
       }
       if (C::NAUX >= 2) {
-        const uint2 r = *reinterpret_cast<const uint2*>(slot + 2 * WS_TILE + efrag + q * (WSP * 16));
+        const uint2 r = *reinterpret_cast<const uint2*>(slot + AUX1 + efrag + q * (WSP * 16));
         x1[0] = bf_lo(r.x); x1[1] = bf_hi(r.x); x1[2] = bf_lo(r.y); x1[3] = bf_hi(r.y);
       }
       float o0[4], o1[4];
@@ -463,11 +486,15 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
         else if (EPI == EPI_SIGMOID) r0 = 1.0f / (1.0f + __expf(-(v + bias[4 * q + e])));
         else if (EPI == EPI_LINACC) r0 = v + x0[e];
         else if (EPI == EPI_REV) { r0 = (n0 + e < a.n_split) ? v * dphi_fast(x0[e]) : 0.0f; r1 = v; }
-        else if (EPI == EPI_TAN) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
+        else if (EPI == EPI_TAN || EPI == EPI_TAN_PF) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
         else if (EPI == EPI_BWD) r0 = v * dphi_fast(x0[e]) + x1[e];
         else if (EPI == EPI_BWD8) r0 = (v + bias[4 * q + e] * sp) * dphi_fast(x0[e]) + x1[e];
         else if (EPI == EPI_BWD_RELU) r0 = x0[e] > 0.0f ? v : 0.0f;
-        if (n0 + e >= a.N) { r0 = 0.0f; r1 = 0.0f; }       // padded rows of the last octet: finite zeros
+        if (n0 + e >= a.N) {                                // padded rows of the last octet: finite zeros, or the pad-fill rows
+          r0 = 0.0f; r1 = 0.0f;
+          if (C::HAS_PF && n0 + e < a.N + 7)
+            r0 = bf2f(*reinterpret_cast<const u16*>(slot + EXTRA + (lane & 31) * 16 + (n0 + e - a.N) * 2));
+        }
         o0[e] = r0; o1[e] = r1;
       }
       if (OUTF) {
@@ -479,7 +506,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
       const unsigned oidx = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)p) * 8u + (unsigned)(n0 & 7);
       if (EPI != EPI_REV || n0 < ((a.n_split + 7) & ~7))        // (split layer: out0 ends with the octet that holds row n_split-1)
         *reinterpret_cast<uint2*>(a.out0 + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
-      if (EPI == EPI_TAN) *reinterpret_cast<uint2*>(a.out1 + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+      if (EPI == EPI_TAN || EPI == EPI_TAN_PF) *reinterpret_cast<uint2*>(a.out1 + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
       if (EPI == EPI_REV && n0 + 3 >= a.n_split && a.out1f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)

@@ -167,7 +167,7 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_ws<EPI, KS, OUTF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI>::LDS);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI, KS>::LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -175,7 +175,7 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
   a.ntiles = a.ldp / WSP;
   a.per_wg = (a.ntiles + g_ws_grid - 1) / g_ws_grid;
   const int grid = (a.ntiles + a.per_wg - 1) / a.per_wg;
-  hipLaunchKernelGGL((layer_kernel_ws<EPI, KS, OUTF>), dim3(grid), dim3(WST), WsCfg<EPI>::LDS, st, a);
+  hipLaunchKernelGGL((layer_kernel_ws<EPI, KS, OUTF>), dim3(grid), dim3(WST), (WsCfg<EPI, KS>::LDS), st, a);
   return hipGetLastError();
 }
 // the weight-stationary kernel covers: one bf16 octet-major input of up to 256 rows (K = 256 packed columns), bf16
@@ -187,7 +187,15 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
 inline int ws_shape(int epi, const LayerArgsH& a) {
   if (!g_layer_ws) return 0;
   const bool seg1 = a.in[1].rows != 0;
-  if (!a.in[0].bf16 || a.accumulate || a.padfill || (a.bias && a.bias_rot != 0)) return 0;
+  if (!a.in[0].bf16 || a.accumulate || (a.bias && a.bias_rot != 0)) return 0;
+  if (a.padfill) {                                                       // (d) lin3's tangent layer: pad-fill rows from an octet-major copy
+    return (epi == EPI_TAN && a.padfill_oct && a.padfill_rows == 7 && a.N == 217 && a.Kpad == 256 && !seg1 && a.in[0].rows == 256 &&
+            a.out0_bf16 && a.out1 && a.out1_bf16 && a.n_split >= a.N && !a.bias) ? 5 : 0;
+  }
+  if (a.Kpad == 320) {                                                   // (e) head input layers: [256 feature rows | few small rows]
+    return (epi == EPI_RELU && seg1 && a.in[1].bf16 && a.in[0].rows == 256 && a.in[1].rows <= 64 && a.out0_bf16 && a.N == 256 &&
+            a.n_split >= a.N && !a.out1) ? 4 : 0;
+  }
   if (a.Kpad == 64 && !seg1) {                                           // (c) K <= 64: narrow cotangents / PE tangent rows
     if (!a.out0_bf16 || a.N != 256 || a.n_split < a.N || a.bias) return 0;
     if (epi == EPI_BWD_RELU) return a.out1 ? 0 : 3;
@@ -235,6 +243,8 @@ hipError_t dispatch_ws(hipStream_t st, int epi, const LayerArgsH& h, int shape) 
   a.out0 = reinterpret_cast<u16*>(h.out0); a.out1 = reinterpret_cast<u16*>(h.out1);
   a.out0f = reinterpret_cast<float*>(h.out0); a.out1f = reinterpret_cast<float*>(h.out1); a.n_split = h.n_split;
   a.N = h.N; a.in_octs = (h.in[0].rows + 7) / 8 + (h.in[1].rows ? 4 : 0); a.ldp = h.ldp; a.kstride = h.Kpad / 16;
+  if (shape == 5) { a.padfill = h.padfill_oct; return launch_layer_ws<EPI_TAN_PF, 16, false>(st, a); }
+  if (shape == 4) { a.split_oct = 32; a.in_octs = 32; a.x_octs = (h.in[1].rows + 7) / 8; return launch_layer_ws<EPI_RELU, 20, false>(st, a); }
   if (shape == 3) return epi == EPI_TAN ? launch_layer_ws<EPI_TAN, 4, false>(st, a) : launch_layer_ws<EPI_BWD_RELU, 4, false>(st, a);
   if (shape == 2) return epi == EPI_SIGMOID ? launch_layer_ws<EPI_SIGMOID, 16, true>(st, a) : launch_layer_ws<EPI_LINEAR, 16, true>(st, a);
   if (epi == EPI_REV && h.n_split >= h.N) { a.out1f = nullptr; a.n_split = 1 << 30; }
@@ -285,7 +295,7 @@ const In NOIN = In{Arr{}, 0};
 // out[n][p] = epi(Wm in + bias) with Wm = pack `pid`; N <= pack rows (only the leading rows are computed)
 hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bias, int N, Arr out0, Arr out1 = Arr{},
                  int n_split = 1 << 30, Arr aux0 = Arr{}, Arr aux1 = Arr{}, int accumulate = 0, int bias_rot = 0, int bias_n = 1 << 30,
-                 const float* padfill = nullptr, int padfill_rows = 0, int tile0 = 0) {
+                 const float* padfill = nullptr, int padfill_rows = 0, int tile0 = 0, Arr padfill_oct = Arr{}) {
   // tile0: compute packed rows [32 tile0, 32 tile0 + N) only (bf16 build: the small-input rows of the transposed head layer)
   const PackDesc2& d = c.L().d[pid];
   const float* wp = c.packed + d.offset + (size_t)tile0 * (d.Kpad / 16) * 64 * 4;
@@ -324,7 +334,7 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
     a.out0 = out0.p; a.out1 = out1.p; a.out0_bf16 = out0.bf16; a.out1_bf16 = out1.bf16;
     a.n_split = n_split; a.accumulate = accumulate;
     a.aux0 = reinterpret_cast<const u16*>(aux0.p); a.aux1 = reinterpret_cast<const u16*>(aux1.p);
-    a.padfill = padfill; a.padfill_rows = padfill_rows;
+    a.padfill = padfill; a.padfill_rows = padfill_rows; a.padfill_oct = reinterpret_cast<const u16*>(padfill_oct.p);
     if ((aux0.p && !aux0.bf16) || (aux1.p && !aux1.bf16) || (out1.p && (out1.bf16 != (epi == EPI_TAN)))) return hipErrorInvalidValue;
     const int shape = ws_shape(epi, a);
     e = shape ? dispatch_ws(c.st, epi, a, shape) : dispatch_h(c.st, epi, a, c.ldp / BMH);
@@ -696,7 +706,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     In b = l == 4 ? (c.prec ? in(w.Ehbf4, 32) : in(F(w.Eh), PE_ROWS)) : NOIN;
     const bool fill = c.prec && l == 3;
     if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l], 0, 0, 1 << 30,
-                   fill ? w.Eh : nullptr, fill ? 7 : 0)) != hipSuccess) return e;
+                   fill ? w.Eh : nullptr, fill ? 7 : 0, 0, fill ? w.Ehbf : Arr{})) != hipSuccess) return e;
   }
   // reverse chain: a^_{l-1} = (W_l^T a^_l) phi'(a_{l-1}) + m_{l-1}   (in place in m)
   if (!c.prec) e = layer(c, L.tr[8], EPI_BWD, in(F(w.abar8), 257), NOIN, nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
@@ -748,12 +758,15 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
 hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat) {
   const PackLayout& L = c.L();
   hipError_t e;
+  // bf16 build: octet-major copies of the small head inputs (the input layers then stream like every other layer)
+  if (c.prec) oct_pack(c, {{h.small_r, SMALL_R, h.smallbf_r}, {h.small_a, SMALL_A, h.smallbf_a}});
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
     const Arr* hh = head ? h.ha : h.hr;
     const float* small = head ? h.small_a : h.small_r;
     const int srows = head ? SMALL_A : SMALL_R;
-    if ((e = layer(c, L.fwd[base], EPI_RELU, in(feat, 256), in(F(small), srows), c.net->b[base], 256, hh[1])) != hipSuccess) return e;
+    const In small_in = c.prec ? in(head ? h.smallbf_a : h.smallbf_r, srows) : in(F(small), srows);
+    if ((e = layer(c, L.fwd[base], EPI_RELU, in(feat, 256), small_in, c.net->b[base], 256, hh[1])) != hipSuccess) return e;
     for (int l = 1; l < 4; ++l)
       if ((e = layer(c, L.fwd[base + l], EPI_RELU, in(hh[l], 256), NOIN, c.net->b[base + l], 256, hh[l + 1])) != hipSuccess) return e;
     if (head == 0) e = layer(c, L.fwd[base + 4], EPI_SIGMOID, in(hh[4], 256), NOIN, c.net->b[base + 4], 3, F(h.rgb));
@@ -769,7 +782,7 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
   const PackLayout& L = c.L();
   hipError_t e;
   const bool oct = oct_operands(c);
-  if (oct) oct_pack(c, {{h.small_r, SMALL_R, h.smallbf_r}, {h.small_a, SMALL_A, h.smallbf_a}, {h.zrgb, 3, h.topbf_r}, {h.dlin, 6, h.topbf_a}});
+  if (oct) oct_pack(c, {{h.zrgb, 3, h.topbf_r}, {h.dlin, 6, h.topbf_a}});      // (the small inputs were packed by heads_forward)
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
     const Arr* hh = head ? h.ha : h.hr;
@@ -1122,7 +1135,7 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   const long long n = seg_offsets[nseg];
   if (n <= 0) return 0;
   const long long blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
                      exp_avg_sq, n, beta1, beta2, eps);
   return (int)hipGetLastError();
 }

@@ -7,6 +7,16 @@ from torch import nn
 from .general import get_class
 
 
+_I34 = {}
+
+
+def _identity34(device):
+    key = str(device)
+    if key not in _I34:
+        _I34[key] = torch.eye(3, 4, device=device)
+    return _I34[key]
+
+
 def _inv3(K):
     from . import ops
     return ops.inv_small(K)
@@ -80,8 +90,13 @@ class VolSDFLoss(nn.Module):
         close = per_line < 100
         # bring the GT segments into calibrated (K^-1) coordinates for the differentiable term (:59-65)
         ends = seg_gt.reshape(-1, 2)
-        ends_h = (_inv3(model_outputs["K"]) @ torch.cat([ends, torch.ones_like(ends[:, :1])], -1).t()).t()
-        seg_gt_calib = (ends_h[:, :2] / ends_h[:, 2, None]).reshape(-1, 4)
+        ends_1 = torch.cat([ends, torch.ones_like(ends[:, :1])], -1)
+        if ends.is_cuda:          # K^-1 [x, y, 1] and the division by its third component = one projection launch
+            from . import ops
+            seg_gt_calib = ops.project2d(_inv3(model_outputs["K"]), _identity34(ends.device), ends_1).reshape(-1, 4)
+        else:
+            ends_h = (_inv3(model_outputs["K"]) @ ends_1.t()).t()
+            seg_gt_calib = (ends_h[:, :2] / ends_h[:, 2, None]).reshape(-1, 4)
         line_loss, _ = self.get_line_loss(model_outputs["lines2d_calib"].reshape(-1, 4), seg_gt_calib,
                                           seg_w * close.reshape(-1, 1))
         self._check_deferred()

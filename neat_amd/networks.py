@@ -365,9 +365,11 @@ class VolSDFNetwork(_HipModule):
             den = den + torch.where(den >= 0, torch.full_like(den, 1e-6), torch.full_like(den, -1e-6))
             t = (((points3d - l_orig) * p3_grad).sum(-1) / den).detach()
             l3d = l_orig + l_dirs * t.unsqueeze(-1)
-            with torch.no_grad():
-                a, b = l3d - lines3d[:, 0], l3d - lines3d[:, 1]
-                l3d_score = torch.linalg.cross(a, b).norm(dim=-1) / (lines3d[:, 0] - lines3d[:, 1]).norm(dim=-1)
+            l3d_score = None
+            if self.training and self.use_l3d:      # only the l3d candidate filter reads the score (rend_a :455-468)
+                with torch.no_grad():
+                    a, b = l3d - lines3d[:, 0], l3d - lines3d[:, 1]
+                    l3d_score = torch.linalg.cross(a, b).norm(dim=-1) / (lines3d[:, 0] - lines3d[:, 1]).norm(dim=-1)
             return p3_sdf, l3d, l3d_score
 
         j3d_global = None
@@ -386,7 +388,8 @@ class VolSDFNetwork(_HipModule):
                 with torch.cuda.stream(side_b):
                     p3_sdf, l3d, l3d_score = l3d_block()
                 for tns in (p3_sdf, l3d, l3d_score):
-                    tns.record_stream(main)
+                    if tns is not None:
+                        tns.record_stream(main)
             else:
                 p3_sdf, l3d, l3d_score = l3d_block()
                 side_b = None
