@@ -199,12 +199,33 @@ __global__ void adam_flat_kernel(float* __restrict__ p, AdamSegs segs, float* __
     if (t < segs.nseg) { s_g[t] = gp; s_a1[t] = a1; s_a2[t] = a2; }
   }
   __syncthreads();
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int lo = 0, hi = segs.nseg - 1;            // segment of element i: last s with off[s] <= i
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid - 1; }
+  // four consecutive elements per thread: one segment search, then the segment only moves forward
+  const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  int lo = 0, hi = segs.nseg - 1;              // segment of element i0: last s with off[s] <= i0
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i0) lo = mid; else hi = mid - 1; }
+  const long long iend = i0 + 4 < n ? i0 + 4 : n;
+  if (iend <= s_off[lo + 1] && iend == i0 + 4) {                 // the usual case: all four in one segment
     const float* gp = s_g[lo];
-    if (!gp) continue;                         // parameter without a gradient this step: untouched, as torch.optim.Adam
+    if (!gp) return;                           // parameter without a gradient this step: untouched, as torch.optim.Adam
+    const float a1 = s_a1[lo], a2 = s_a2[lo];
+    const float* gq = gp + (i0 - s_off[lo]);
+    float4 mm = *reinterpret_cast<const float4*>(m + i0), vv = *reinterpret_cast<const float4*>(v + i0), pp = *reinterpret_cast<const float4*>(p + i0);
+    float* me = reinterpret_cast<float*>(&mm); float* ve = reinterpret_cast<float*>(&vv); float* pe = reinterpret_cast<float*>(&pp);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = gq[e];
+      me[e] = beta1 * me[e] + (1.0f - beta1) * g;
+      ve[e] = beta2 * ve[e] + (1.0f - beta2) * g * g;
+      pe[e] -= a1 * (me[e] / (sqrtf(ve[e]) * a2 + eps));
+    }
+    *reinterpret_cast<float4*>(m + i0) = mm; *reinterpret_cast<float4*>(v + i0) = vv; *reinterpret_cast<float4*>(p + i0) = pp;
+    return;
+  }
+  for (long long i = i0; i < iend; ++i) {
+    while (i >= s_off[lo + 1]) ++lo;
+    const float* gp = s_g[lo];
+    if (!gp) continue;
     const float g = gp[i - s_off[lo]];
     const float mm = beta1 * m[i] + (1.0f - beta1) * g;
     const float vv = beta2 * v[i] + (1.0f - beta2) * g * g;
@@ -314,10 +335,13 @@ __global__ __launch_bounds__(1024) void line_loss_kernel(const float* __restrict
 // inverse of one small (n <= 4) matrix by Gauss-Jordan elimination with partial pivoting, one thread: the pose and
 // intrinsics inverses of the junction block / loss (rend_a :440, loss_wfr.py:59) cost a dozen rocSOLVER launches each
 __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ float sA[16];
+  if (threadIdx.x < n * n) sA[threadIdx.x] = A[(threadIdx.x / n) * lda + threadIdx.x % n];      // one parallel fetch, not 16 dependent ones
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   float a[4][8];
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) { a[i][j] = A[i * lda + j]; a[i][n + j] = (i == j) ? 1.0f : 0.0f; }
+    for (int j = 0; j < n; ++j) { a[i][j] = sA[i * n + j]; a[i][n + j] = (i == j) ? 1.0f : 0.0f; }
   for (int c = 0; c < n; ++c) {
     int piv = c;
     for (int r = c + 1; r < n; ++r) if (fabsf(a[r][c]) > fabsf(a[piv][c])) piv = r;
@@ -350,15 +374,22 @@ __global__ __launch_bounds__(FFN_H) void ffn_forward_kernel(const float* __restr
   const int nr = min(FFN_RB, J - r0);
   for (int r = 0; r < FFN_RB; ++r) xs[r][n] = r < nr ? x[(size_t)(r0 + r) * FFN_H + n] : 0.0f;
   __syncthreads();
+  // thread n owns output feature n and walks its weight row in 32-column chunks: 8 independent float4 loads per chunk
+  // (whole cache lines, deep memory parallelism) instead of 64 loads at dependent latency
   auto dense = [&](const float* __restrict__ W, const float* __restrict__ b, float (&in)[FFN_RB][FFN_H], float (&acc)[FFN_RB]) {
 #pragma unroll
     for (int r = 0; r < FFN_RB; ++r) acc[r] = b[n];
-    const float4* wr = reinterpret_cast<const float4*>(W + (size_t)n * FFN_H);
-    for (int k4 = 0; k4 < FFN_H / 4; ++k4) {
-      const float4 w = wr[k4];
+#pragma unroll 1
+    for (int kc = 0; kc < FFN_H; kc += 32) {
+      float4 w4[8];
+      const float4* wr = reinterpret_cast<const float4*>(W + (size_t)n * FFN_H + kc);
 #pragma unroll
-      for (int r = 0; r < FFN_RB; ++r)
-        acc[r] += w.x * in[r][4 * k4] + w.y * in[r][4 * k4 + 1] + w.z * in[r][4 * k4 + 2] + w.w * in[r][4 * k4 + 3];
+      for (int j = 0; j < 8; ++j) w4[j] = wr[j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < FFN_RB; ++r)
+          acc[r] += w4[j].x * in[r][kc + 4 * j] + w4[j].y * in[r][kc + 4 * j + 1] + w4[j].z * in[r][kc + 4 * j + 2] + w4[j].w * in[r][kc + 4 * j + 3];
     }
   };
   float acc[FFN_RB];

@@ -1134,8 +1134,8 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   segs.nseg = nseg;
   const long long n = seg_offsets[nseg];
   if (n <= 0) return 0;
-  const long long blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
+  const long long blocks = (n + 1023) / 1024;          // 4 consecutive elements per thread
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
                      exp_avg_sq, n, beta1, beta2, eps);
   return (int)hipGetLastError();
 }
