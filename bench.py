@@ -155,6 +155,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if graphed:
+        tr.check_nan()
     prof_elapsed, prof_note = elapsed, "HIP events over the timed region"
     if not args.no_prof and graphed:
         # a graph replay does not pass through the library's launch code, so its kernels cannot be bracketed with events:

@@ -123,7 +123,32 @@ class Trainer:
             ev.record()
         self._ring_pos += 1
 
+    def _same_batch_layout(self, model_input, ground_truth):
+        """The captured graph is valid for batches with the captured tensor shapes and the captured non-tensor entries
+        (the wireframe of the view: its vertex count shapes the matching)."""
+        for static, fresh in ((self._static_in, model_input), (self._static_gt, ground_truth)):
+            if set(static) != set(fresh):
+                return False
+            for k, v in fresh.items():
+                if isinstance(v, torch.Tensor):
+                    if v.shape != static[k].shape or v.dtype != static[k].dtype:
+                        return False
+                elif isinstance(v, (list, tuple)):
+                    if len(v) != len(static[k]) or any(a is not b for a, b in zip(v, static[k])):
+                        return False
+                elif v is not static[k] and v != static[k]:
+                    return False
+        return True
+
+    def check_nan(self):
+        """Graph mode keeps the line-loss NaN flag on the device (loss.nan_check == "off"); this reads it (one sync)."""
+        flag = self.loss.nan_flag
+        if flag is not None and bool(flag.item()):
+            raise FloatingPointError("line loss is NaN (the reference drops into pdb here, loss_wfr.py:66-67)")
+
     def _replay(self, model_input, ground_truth):
+        if not self._same_batch_layout(model_input, ground_truth):
+            return self.step_eager(model_input, ground_truth)      # another view / batch size: this graph does not apply
         # inputs that changed since the last step are copied into the captured tensors (same object, same version: skip)
         for static, fresh in ((self._static_in, model_input), (self._static_gt, ground_truth)):
             for k, v in fresh.items():

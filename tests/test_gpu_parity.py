@@ -609,3 +609,33 @@ def test_ffn_kernels_vs_torch(dev, J):
     close(got, ref, tol=1e-5, what="ffn forward")
     for a, b in zip(g_got, g_ref):
         close(a, b, tol=2e-5, what="ffn backward")
+
+
+def test_graph_falls_back_for_other_batches(dev):
+    """A captured step only replays for batches with the captured layout; another view (other wireframe object) or another
+    ray count runs eagerly, and the next matching batch replays again."""
+    from neat_amd.train import Trainer, synthetic_batch
+    torch.manual_seed(3)
+    tr = Trainer(device=dev, state_dict={k: T(v) for k, v in synth.synth_state_dict(5, "rough").items()})
+    _, inp, gt = synthetic_batch(5, 64, dev)
+    _, inp2, gt2 = synthetic_batch(6, 64, dev, view=1)
+    _, inp3, gt3 = synthetic_batch(7, 32, dev)
+    # depth samples come from the sampler here (host syncs): capture must fail cleanly and leave an eager trainer
+    assert not tr.capture(inp, gt) and tr.capture_error is not None
+    tr.step(inp, gt)
+    tr.model.z_vals_override = T(synth.synth_z_vals(5, 64, 40)).to(dev)
+    assert tr.capture(inp, gt), repr(tr.capture_error)
+    calls = {"eager": 0}
+    orig = tr.step_eager
+    tr.step_eager = lambda a, b: (calls.__setitem__("eager", calls["eager"] + 1), orig(a, b))[1]
+    tr.step(inp, gt)
+    assert calls["eager"] == 0
+    tr.step(inp2, gt2)                       # other wireframe -> eager
+    assert calls["eager"] == 1
+    tr.model.z_vals_override = None
+    tr.step(inp3, gt3)                       # other ray count -> eager (sampler path)
+    assert calls["eager"] == 2
+    tr.model.z_vals_override = T(synth.synth_z_vals(5, 64, 40)).to(dev)
+    _, lo = tr.step(inp, gt)
+    assert calls["eager"] == 2 and torch.isfinite(lo["loss"])
+    tr.check_nan()
