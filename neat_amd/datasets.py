@@ -108,7 +108,7 @@ class BlenderDataset(torch.utils.data.Dataset):
             m, l, a = compute_point_line_attraction(lines, self.img_res, self.distance)
             self.masks.append(m)
             self.labels.append(l)
-            self.att_points.append(a.cpu())
+            self.att_points.append(a)          # stays on the device, like the reference's `uv_proj` (trainers do not move it)
 
     def __len__(self):
         return self.n_images

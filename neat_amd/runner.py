@@ -1,0 +1,132 @@
+"""Training runner in the shape of the reference's `training/exp_runner.py` + `VolSDFTrainRunner`
+(code/training/volsdf_train.py:66-410): same conf files, same loop (per-iteration re-sampling of the rays and
+ExponentialLR step), same checkpoint layout (`checkpoints/{Model,Optimizer,Scheduler}Parameters/{epoch,latest}.pth` with
+the reference's dict keys), so checkpoints move between the two code bases.  Visualisation, tensorboard, git logging and
+the open3d dumps of the reference runner are out of scope.
+
+    python -m neat_amd.runner --conf /path/to/confs/abc-neat-a.conf --data_root /path/to/data --nepoch 2000
+
+Class paths in the conf that name the reference's dataset / model / loss are mapped to their neat_amd counterparts (the
+conf may also name neat_amd classes directly, which is all the reference's own runner needs)."""
+import argparse
+import os
+import time
+
+import torch
+
+from . import conf as conf_mod
+from . import rend_util
+from .general import get_class
+
+CLASS_MAP = {
+    "datasets.blender_hawp_dataset.BlenderDataset": "neat_amd.datasets.BlenderDataset",
+    "model.networks.neat_wfr_rend_a.VolSDFNetwork": "neat_amd.networks.VolSDFNetwork",
+    "model.networks.loss_wfr.VolSDFLoss": "neat_amd.loss.VolSDFLoss",
+}
+SUBDIRS = ("ModelParameters", "OptimizerParameters", "SchedulerParameters")
+
+
+class TrainRunner:
+    def __init__(self, conf, nepochs, exps_folder="exps", expname="", scan_id=-1, data_root="../data", device="cuda:0",
+                 timestamp=None, precision=None, log_freq=50):
+        self.conf = conf_mod.parse_file(conf) if isinstance(conf, str) else conf
+        self.nepochs = nepochs
+        self.device = torch.device(device)
+        self.expname = self.conf.get_string("train.expname") + expname
+        if scan_id != -1:
+            self.expname += f"/{scan_id}"
+        self.timestamp = timestamp or time.strftime("%Y_%m_%d_%H_%M_%S")
+        self.expdir = os.path.join(exps_folder, self.expname)
+        self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")
+        for sub in SUBDIRS:
+            os.makedirs(os.path.join(self.checkpoints_path, sub), exist_ok=True)
+        cls = lambda key: get_class(CLASS_MAP.get(self.conf.get_string(key), self.conf.get_string(key)))
+        dataset_conf = dict(self.conf.get_config("dataset").items())
+        if scan_id != -1:
+            dataset_conf["scan_id"] = scan_id
+        ds_cls = cls("train.dataset_class")
+        if ds_cls.__module__.startswith("neat_amd"):
+            dataset_conf["data_root"] = data_root
+        self.train_dataset = ds_cls(**dataset_conf)
+        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=True,
+                                                            collate_fn=self.train_dataset.collate_fn)
+        self.model = cls("train.model_class")(conf=self.conf.get_config("model")).to(self.device)
+        if precision is not None and hasattr(self.model, "set_precision"):
+            self.model.set_precision(precision)
+        self.loss = cls("train.loss_class")(**dict(self.conf.get_config("loss").items()))
+        self.lr = self.conf.get_float("train.learning_rate")
+        if self.device.type == "cuda":
+            from .optim import FlatAdam
+            self.optimizer = FlatAdam(self.model.parameters(), lr=self.lr)
+        else:
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr)
+        decay_rate = self.conf.get_float("train.sched_decay_rate", default=0.1)
+        decay_steps = self.nepochs * len(self.train_dataset)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, decay_rate ** (1.0 / decay_steps))
+        self.num_pixels = self.conf.get_int("train.num_pixels")
+        self.checkpoint_freq = self.conf.get_int("train.checkpoint_freq", default=100)
+        self.start_epoch = 0
+        self.log_freq = log_freq
+
+    def load_checkpoints(self, checkpoints_dir, checkpoint="latest"):
+        """Continue from a run of this runner or of the reference's (volsdf_train.py:187-207)."""
+        state = torch.load(os.path.join(checkpoints_dir, SUBDIRS[0], f"{checkpoint}.pth"), map_location=self.device)
+        self.model.load_state_dict(state["model_state_dict"], strict=False)
+        self.start_epoch = state["epoch"]
+
+    def save_checkpoints(self, epoch):
+        payload = (("model_state_dict", self.model.state_dict()), ("optimizer_state_dict", self.optimizer.state_dict()),
+                   ("scheduler_state_dict", self.scheduler.state_dict()))
+        for sub, (key, sd) in zip(SUBDIRS, payload):
+            for name in (str(epoch), "latest"):
+                torch.save({"epoch": epoch, key: sd}, os.path.join(self.checkpoints_path, sub, f"{name}.pth"))
+
+    def run(self):
+        history = []
+        epoch = self.start_epoch
+        for epoch in range(self.start_epoch, self.nepochs + 1):
+            if epoch % self.checkpoint_freq == 0:
+                self.save_checkpoints(epoch)
+            self.train_dataset.change_sampling_idx(self.num_pixels)
+            self.model.train()
+            for it, (indices, model_input, ground_truth) in enumerate(self.train_dataloader):
+                for k in ("intrinsics", "uv", "pose", "uv_proj"):
+                    model_input[k] = model_input[k].to(self.device)
+                outputs = self.model(model_input)
+                losses = self.loss(outputs, ground_truth)
+                self.optimizer.zero_grad()
+                losses["loss"].backward()
+                self.optimizer.step()
+                self.train_dataset.change_sampling_idx(self.num_pixels)
+                self.scheduler.step()
+                if (it + 1) % self.log_freq == 0 or it + 1 == len(self.train_dataloader):
+                    with torch.no_grad():
+                        psnr = rend_util.get_psnr(outputs["rgb_values"], ground_truth["rgb"].to(self.device).reshape(-1, 3))
+                    history.append((epoch, it, float(losses["loss"].detach()), float(psnr)))
+                    print(f"{self.expname}/{self.timestamp} [{epoch}] ({it}/{len(self.train_dataloader)}): "
+                          f"loss = {history[-1][2]:.4f}, psnr = {history[-1][3]:.3f}", flush=True)
+        self.save_checkpoints(epoch)
+        return history
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--conf", required=True)
+    ap.add_argument("--nepoch", type=int, default=2000)
+    ap.add_argument("--expname", default="")
+    ap.add_argument("--exps_folder", default="exps")
+    ap.add_argument("--scan_id", type=int, default=-1)
+    ap.add_argument("--data_root", default="../data")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None)
+    ap.add_argument("--is_continue", default=None, help="checkpoints directory of the run to continue")
+    ap.add_argument("--checkpoint", default="latest")
+    args = ap.parse_args()
+    torch.manual_seed(42)              # exp_runner.py:36,49-51
+    runner = TrainRunner(args.conf, args.nepoch, args.exps_folder, args.expname, args.scan_id, args.data_root, precision=args.precision)
+    if args.is_continue:
+        runner.load_checkpoints(args.is_continue, args.checkpoint)
+    runner.run()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,42 @@
+"""Secondary workloads of SURVEY 8d (not the headline): (1) the full train step WITH the error-bound sampler (conf default
+N_samples = 64 -> 98 samples per ray), (2) eval-mode forward in 2048-ray chunks as neat-final-parsing.py drives the model.
+Prints one JSON line each.  usage: python scripts/bench_sampler.py [--precision bf16]"""
+import argparse, json, sys, time
+import torch
+sys.path.insert(0, '.')
+from neat_amd import synth
+from neat_amd.train import Trainer, synthetic_batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--precision", default="bf16")
+ap.add_argument("--steps", type=int, default=20)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(42)
+tr = Trainer(device=dev, state_dict={k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()})
+tr.model.set_precision(args.precision)
+_, inp, gt = synthetic_batch(42, 1024, dev)
+for _ in range(3):
+    tr.step(inp, gt)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    out, lo = tr.step(inp, gt)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+S = out["points"].shape[0] // 1024 if out["points"].dim() == 2 else out["points"].shape[1]
+print(json.dumps({"workload": "train step with ErrorBoundSampler, 1024 rays, conf-default sampler", "ms_per_step": 1e3 * dt,
+                  "samples_per_ray": S, "ray_samples_per_s": 1024 * S / dt, "rays_per_s": 1024 / dt, "precision": args.precision}))
+tr.model.eval()
+_, inp2, _ = synthetic_batch(43, 2048, dev)
+with torch.no_grad():
+    for _ in range(3):
+        o = tr.model(inp2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o = tr.model(inp2)
+    torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+print(json.dumps({"workload": "eval forward (sampler + render + junction block), one 2048-ray chunk", "ms_per_chunk": 1e3 * dt,
+                  "rays_per_s": 2048 / dt, "precision": args.precision}))

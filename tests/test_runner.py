@@ -1,0 +1,77 @@
+"""the runner (conf file -> dataset -> model -> loop -> checkpoints in the reference's layout) end to end on a
+synthetic scene directory.  GPU test (dataset attraction field, model and optimizer are HIP-only)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _hocon(d, indent=0):
+    pad = "    " * indent
+    out = []
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.append(f"{pad}{k}{{\n{_hocon(v, indent + 1)}{pad}}}")
+        elif isinstance(v, bool):
+            out.append(f"{pad}{k} = {'True' if v else 'False'}")
+        elif isinstance(v, (list, tuple)):
+            out.append(f"{pad}{k} = [{', '.join(str(x) for x in v)}]")
+        else:
+            out.append(f"{pad}{k} = {v}")
+    return "\n".join(out) + "\n"
+
+
+def _toy_scene(root, res=64, n_views=3):
+    from PIL import Image
+    from neat_amd import synth
+    (root / "images").mkdir(parents=True)
+    (root / "hawp").mkdir()
+    rng = np.random.default_rng(0)
+    intr, extr = [], []
+    for v in range(n_views):
+        sc = synth.synth_scene(seed=v, n_rays=4, res=res, view=v)
+        K = sc["intrinsics"][0, :3, :3].copy()
+        K[0, 0] = K[1, 1] = 70.0
+        intr.append(K.astype(np.float64))
+        extr.append(sc["pose"][0])
+        Image.fromarray(rng.integers(0, 255, (res, res, 3), dtype=np.uint8)).save(root / "images" / f"image_{v:04d}.png")
+        verts = rng.uniform(8, res - 8, (8, 2)).round(2).tolist()
+        edges = [[0, 1], [1, 2], [2, 3], [3, 0], [4, 5], [5, 6]]
+        json.dump({"vertices": verts, "vertices-score": [0.9] * 8, "edges": edges, "edges-weights": [0.99] * len(edges),
+                   "height": res, "width": res}, open(root / "hawp" / f"image_{v:04d}.json", "w"))
+    np.savez(root / "cameras.npz", intrinsics=np.stack(intr), extrinsics=np.stack(extr))
+
+
+@pytest.mark.gpu
+def test_runner_trains_and_checkpoints(tmp_path):
+    from neat_amd import networks, synth
+    from neat_amd.runner import TrainRunner
+    _toy_scene(tmp_path / "data" / "abc" / "toy")
+    conf = {"train": {"expname": "toy_neat", "dataset_class": "datasets.blender_hawp_dataset.BlenderDataset",
+                      "model_class": "model.networks.neat_wfr_rend_a.VolSDFNetwork", "loss_class": "model.networks.loss_wfr.VolSDFLoss",
+                      "learning_rate": 5.0e-4, "num_pixels": 128, "checkpoint_freq": 1},
+            "loss": dict(synth.ABC_NEAT_A_LOSS_CONF),
+            "dataset": {"data_dir": "abc/toy", "img_res": [64, 64], "reverse_coordinate": True},
+            "model": synth.ABC_NEAT_A_MODEL_CONF}
+    path = tmp_path / "toy.conf"
+    path.write_text(_hocon(conf))
+    runner = TrainRunner(str(path), nepochs=1, exps_folder=str(tmp_path / "exps"), data_root=str(tmp_path / "data"), log_freq=1)
+    assert type(runner.model).__module__ == "neat_amd.networks" and type(runner.train_dataset).__module__ == "neat_amd.datasets"
+    hist = runner.run()
+    assert len(hist) == 2 * 3 and all(np.isfinite(h[2]) for h in hist)
+    ck = runner.checkpoints_path
+    for sub, key in (("ModelParameters", "model_state_dict"), ("OptimizerParameters", "optimizer_state_dict"),
+                     ("SchedulerParameters", "scheduler_state_dict")):
+        for name in ("0", "1", "latest"):
+            blob = torch.load(os.path.join(ck, sub, f"{name}.pth"), map_location="cpu")
+            assert blob["epoch"] in (0, 1) and key in blob
+    sd = torch.load(os.path.join(ck, "ModelParameters", "latest.pth"), map_location="cpu")["model_state_dict"]
+    assert len(sd) == 65
+    fresh = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    fresh.load_state_dict(sd, strict=True)
+    again = TrainRunner(str(path), nepochs=2, exps_folder=str(tmp_path / "exps2"), data_root=str(tmp_path / "data"), log_freq=100)
+    again.load_checkpoints(ck)
+    assert again.start_epoch == 1
+    assert torch.equal(again.model.state_dict()["latents"].cpu(), sd["latents"])
