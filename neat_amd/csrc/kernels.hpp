@@ -319,11 +319,15 @@ struct WreduceArgs {
   int bias_col;              // column of the partial holding the bias gradient (= packed K), or -1
 };
 
-__global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
-  // one workgroup per output row: wave w sums splits w, w+4, ... (independent loads, unrolled), LDS combine,
+// NW waves per workgroup: 4 for a handful of partials (after a group-sum stage, fp32 build), 16 to sum the ~245 split
+// partials of the bf16 build directly (one pass over the partial buffer instead of group-sum + finish: the row is
+// 245 x ~1 KiB, 16 waves keep 16 x 4 independent loads in flight)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wreduce_wnorm_kernel(WreduceArgs a) {
+  // one workgroup per output row: wave w sums splits w, w+NW, ... (independent loads, unrolled), LDS combine,
   // then wave 0 applies the weight-norm backward.
   constexpr int MAXC = 5;                 // up to 320 input columns (+ bias column handled by lane 0 of each wave)
-  __shared__ float red[4][MAXC * 64 + 1];
+  __shared__ float red[NW][MAXC * 64 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int o = blockIdx.x;
   float acc[MAXC], bacc = 0.0f;
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
   const int on = (o - a.rot + a.O) % a.O;                    // packed row of source row o
   const size_t row_off = (size_t)on * a.row_stride, split_stride = a.split_stride;
 #pragma unroll 4
-  for (int sp = wave; sp < a.splits; sp += 4) {
+  for (int sp = wave; sp < a.splits; sp += NW) {
     const float* src = a.partial + sp * split_stride + row_off;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) if (jcol[c] >= 0) acc[c] += src[jcol[c]];
@@ -356,7 +360,10 @@ __global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
     dw[c] = 0.0f; vv[c] = 0.0f;
     if (i < a.I) {
       const int k = c * 64 + lane;
-      dw[c] = (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * a.scale;
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w][k];
+      dw[c] = t * a.scale;
       vv[c] = a.v[(size_t)o * a.I + i];
       dot += dw[c] * vv[c];
       nrm2 += vv[c] * vv[c];
@@ -374,7 +381,12 @@ __global__ __launch_bounds__(WG) void wreduce_wnorm_kernel(WreduceArgs a) {
   }
   if (lane == 0) {
     a.dg[o] = dot * inv;
-    if (a.db && a.bias_col >= 0) a.db[o] = red[0][MAXC * 64] + red[1][MAXC * 64] + red[2][MAXC * 64] + red[3][MAXC * 64];
+    if (a.db && a.bias_col >= 0) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w][MAXC * 64];
+      a.db[o] = t;
+    }
   }
 }
 
