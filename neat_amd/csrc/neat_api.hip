@@ -159,6 +159,7 @@ template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a
   if (a.out0_bf16) return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4, true>(st, a) : launch_layer_h_pt<EPI, 2, true>(st, a);
   return launch_layer_h_pt<EPI, 2, false>(st, a);
 }
+int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
 int g_wreduce_direct = 0;   // bf16 weight-gradient reduction: 0 = group sums + finish (faster: 4.43 vs 4.63 ms/step), 1 = one 16-wave pass per row
 int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persistent kernel, 0 = sdf_fused_kernel_h
 int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
@@ -716,25 +717,21 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   else if (g_layer_ws) e = layer_ws(c, L.tr[8], EPI_BWD8, w.featc, 256, w.m[7], w.h[8], w.m[7], w.abar8, c.net->v[8], c.rowscale(8));
   else e = layer(c, L.tr[8], EPI_BWD, in(w.featc, 256), in(F(w.abar8), 1), nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
   if (e != hipSuccess) return e;
-  for (int l = 7; l >= 1; --l) {
-    const int N = l == 4 ? 217 : kI[l];
-    if ((e = layer(c, L.tr[l], EPI_BWD, in(w.m[l], kO[l]), NOIN, nullptr, N, w.m[l - 1], Arr{}, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
-  }
-  // weight gradients: dW_l = a^_l in_l^T + u_l vhat_l^T  (+ bias column from the ones row)
+  // weight gradients: dW_l = a^_l in_l^T + u_l vhat_l^T  (+ bias column).  The gradient of layer l is launched right
+  // after the reverse step that produced a^_l (g_wgrad_interleave): a^_l is then read twice (weight gradient, next reverse
+  // step) while it is still in the 256 MB Infinity Cache instead of after all eight reverse steps.
   const bool oct = oct_operands(c);
-  for (int l = 0; l <= 8; ++l) {
+  auto wgrad_layer = [&](int l) -> hipError_t {
     WPair pr[2] = {};
     if (l == 8 && c.prec) {
       // feature rows: featc x h8 on the streaming kernel; the sdf row (cotangent abar8 row 0; its second-order part is
       // the plain row sum of vh8, the adjoint seed being 1) as one extra partial row
       pr[0].A = w.featc; pr[0].rowsA = 256; pr[0].B[0] = w.h[8]; pr[0].rowsB[0] = 256;
       RowDot rd{w.abar8, w.h[8], w.vh[8]};
-      if ((e = wgrad(c, w, 8, pr, 1, 256, gr, &rd)) != hipSuccess) return e;
-      continue;
+      return wgrad(c, w, 8, pr, 1, 256, gr, &rd);
     }
-    const int rot8 = 0;
-    pr[0].A = l == 8 ? F(w.abar8) : w.m[l]; pr[0].rowsA = kO[l]; pr[0].A_rot = rot8; pr[0].A_mod = rot8 ? 257 : 0;
-    pr[1].A = l == 8 ? F(w.ones) : w.u[l];  pr[1].rowsA = l == 8 ? 1 : kO[l]; pr[1].A_rot = rot8; pr[1].A_mod = rot8 ? 257 : 0;
+    pr[0].A = l == 8 ? F(w.abar8) : w.m[l]; pr[0].rowsA = kO[l];
+    pr[1].A = l == 8 ? F(w.ones) : w.u[l];  pr[1].rowsA = l == 8 ? 1 : kO[l];
     if (l == 0) {
       pr[0].B[0] = oct ? w.Ebf : F(w.E); pr[0].rowsB[0] = PE_ROWS;
       pr[1].B[0] = oct ? w.Ehbf : F(w.Eh); pr[1].rowsB[0] = PE_ROWS;
@@ -750,8 +747,18 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       pr[0].B[0] = w.h[l]; pr[0].rowsB[0] = 256;
       pr[1].B[0] = w.vh[l]; pr[1].rowsB[0] = 256;
     }
-    if ((e = wgrad(c, w, l, pr, 2, kO[l], gr)) != hipSuccess) return e;
+    return wgrad(c, w, l, pr, 2, kO[l], gr);
+  };
+  const bool inter = g_wgrad_interleave != 0;
+  if (inter && (e = wgrad_layer(8)) != hipSuccess) return e;
+  for (int l = 7; l >= 1; --l) {
+    if (inter && (e = wgrad_layer(l)) != hipSuccess) return e;
+    const int N = l == 4 ? 217 : kI[l];
+    if ((e = layer(c, L.tr[l], EPI_BWD, in(w.m[l], kO[l]), NOIN, nullptr, N, w.m[l - 1], Arr{}, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
   }
+  if (inter) return wgrad_layer(0);
+  for (int l = 0; l <= 8; ++l)
+    if ((e = wgrad_layer(l)) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -897,6 +904,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 3 && value >= 1 && value <= 4096) { g_ws_grid = value; return 0; }
   if (key == 4 && (value == 0 || value == 1)) { g_fused_ws = value; return 0; }
   if (key == 6 && (value == 0 || value == 1)) { g_wreduce_direct = value; return 0; }
+  if (key == 7 && (value == 0 || value == 1)) { g_wgrad_interleave = value; return 0; }
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   return -1;
 }
