@@ -1,6 +1,7 @@
 """Secondary workloads of SURVEY 8d (not the headline): (1) the full train step WITH the error-bound sampler (conf default
 N_samples = 64 -> 98 samples per ray), (2) eval-mode forward in 2048-ray chunks as neat-final-parsing.py drives the model.
-Prints one JSON line each.  usage: python scripts/bench_sampler.py [--precision bf16]"""
+Prints one JSON line each.  (3) C3-style: 2048 rays x 128 given samples with the DTU conf switches (dbscan_enabled, 1024 global junctions), eager.
+Prints one JSON line each.  usage: python scripts/bench_workloads.py [--precision bf16]"""
 import argparse, json, sys, time
 import torch
 sys.path.insert(0, '.')
@@ -40,3 +41,29 @@ with torch.no_grad():
 dt = (time.perf_counter() - t0) / args.steps
 print(json.dumps({"workload": "eval forward (sampler + render + junction block), one 2048-ray chunk", "ms_per_chunk": 1e3 * dt,
                   "rays_per_s": 2048 / dt, "precision": args.precision}))
+
+# ---- C3-style: DTU switches (dbscan on the host as the reference does, use_median off, 1024 junction latents), 2048 x 128 given samples
+import copy
+from neat_amd import networks
+conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+conf.update(dbscan_enabled=True, use_median=False)
+conf["global_junctions"] = dict(conf["global_junctions"], num_junctions=1024)
+sd = synth.synth_state_dict(42, "rough", num_junctions=1024)
+for dbscan in (True, False):
+    conf["dbscan_enabled"] = dbscan
+    tr3 = Trainer(model_conf=conf, device=dev, state_dict={k: torch.tensor(v) for k, v in sd.items()})
+    tr3.model.set_precision(args.precision)
+    _, inp3, gt3 = synthetic_batch(42, 2048, dev)
+    tr3.model.z_vals_override = torch.tensor(synth.synth_z_vals(42, 2048, 128)).to(dev)
+    for _ in range(3):
+        tr3.step(inp3, gt3)
+    graphed = tr3.capture(inp3, gt3) if not dbscan else False
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr3.step(inp3, gt3)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"workload": f"C3-style train step: 2048 rays x 128 given samples, 1024 junction latents, dbscan_enabled={dbscan}",
+                      "launch": "hip graph" if graphed else "eager", "ms_per_step": 1e3 * dt, "ray_samples_per_s": 2048 * 128 / dt,
+                      "rays_per_s": 2048 / dt, "precision": args.precision}))
