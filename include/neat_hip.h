@@ -160,8 +160,15 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
  * (rows with 0 do not take part: replaces the reference's `[good]` compaction); outputs row_ind/col_ind
  * [min(nr,nc)] int64 sorted by row and padded with -1, *n_match = number of pairs (-1 if a cost is not finite). */
 size_t neat_lsap_ws_bytes(int nr, int nc);
-int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, long long* row_ind, long long* col_ind,
-              int* n_match, void* ws, void* stream);
+int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, const unsigned char* col_mask, long long* row_ind,
+              long long* col_ind, int* n_match, void* ws, void* stream);
+/* (col_mask [nc] bytes or NULL: columns with 0 do not take part -- padded candidate sets such as the DBSCAN centres below) */
+
+/* DBSCAN(eps, min_samples = 2) + cluster means of n <= 8192 3-D points = VolSDFNetwork.cluster_dbscan
+ * (model/networks/neat_wfr_rend_a.py:328-339; sklearn on the host in the reference).  centres: (n/2) x 3 floats followed
+ * by n/2 ints of scratch; clusters in sklearn's order (by first member), padded; valid [n/2] bytes; *count = clusters. */
+size_t neat_dbscan_ws_bytes(int n);
+int neat_dbscan_means(const float* points, int n, double eps, float* centres, unsigned char* valid, int* count, void* ws, void* stream);
 
 /* ---- a9 alone: volume_rendering :540-554 given sdf [R,S] -> weights [R,S] (used by tests) -------- */
 int neat_volume_weights(const float* z, const float* sdf, int R, int S, const float* beta, float* weights, void* stream);

@@ -57,7 +57,9 @@ _SIGNATURES = {
     "neat_adam_step": (ctypes.c_int, [c_fp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int),
                                       ctypes.c_int, c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp]),
     "neat_lsap_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
-    "neat_lsap": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "neat_lsap": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "neat_dbscan_ws_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "neat_dbscan_means": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_double, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_volume_weights": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_set_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "neat_prof_enable": (ctypes.c_int, [ctypes.c_int]),

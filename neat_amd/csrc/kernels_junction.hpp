@@ -28,6 +28,7 @@ struct LsapArgs {
   double* wsd;             // u[N] v[M] sp[M]
   int* wsi;                // rowlist[nr] path[M] col4row[N] row4col[M] remaining[M] SR[N] SC[M] tmp[M]
   int use_lds, lds_int_off; // work arrays in dynamic LDS instead (doubles first, ints at byte offset lds_int_off)
+  const unsigned char* col_mask;   // [nc] or nullptr: columns with 0 do not take part (padded candidate sets)
 };
 
 struct LsapKey { double val; int it; int un; };
@@ -68,7 +69,9 @@ __device__ int lsap_compact(int n, F flag, int* out, int* s_wave, int* s_base) {
     if (tid == 0) { int t = 0; for (int w = 0; w < nw; ++w) t += s_wave[w]; *s_base += t; }
     __syncthreads();
   }
-  return *s_base;
+  const int total = *s_base;
+  __syncthreads();          // everyone has read the count before a later call resets it (a fast thread 0 used to race ahead)
+  return total;
 }
 
 __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
@@ -88,16 +91,19 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
   int* rowlist = wsi;
   const unsigned char* mask = a.row_mask;
   const int n_eff = lsap_compact(a.nr, [&](int i) { return mask ? mask[i] != 0 : true; }, rowlist, s_wave, &s_base);
-  const bool T = a.nc < n_eff;
-  const int N = T ? a.nc : n_eff, M = T ? n_eff : a.nc;
+  int* collist = rowlist + a.nr;
+  const unsigned char* cmask = a.col_mask;
+  const int c_eff = lsap_compact(a.nc, [&](int j) { return cmask ? cmask[j] != 0 : true; }, collist, s_wave, &s_base);
+  const bool T = c_eff < n_eff;
+  const int N = T ? c_eff : n_eff, M = T ? n_eff : c_eff;
   if (N == 0) { if (tid == 0) *a.n_match = 0; return; }
   double* u = wsd; double* v = u + N; double* sp = v + M;
-  int* path = rowlist + a.nr; int* col4row = path + M; int* row4col = col4row + N; int* remaining = row4col + M;
+  int* path = collist + a.nc; int* col4row = path + M; int* row4col = col4row + N; int* remaining = row4col + M;
   int* SR = remaining + M; int* SC = SR + N; int* tmp = SC + M;
   const float* C = a.cost;
   const int nc0 = a.nc;
   auto cost = [&](int i, int j) -> double {
-    return (double)(T ? C[(size_t)rowlist[j] * nc0 + i] : C[(size_t)rowlist[i] * nc0 + j]);
+    return (double)(T ? C[(size_t)rowlist[j] * nc0 + collist[i]] : C[(size_t)rowlist[i] * nc0 + collist[j]]);
   };
   for (int i = tid; i < N; i += nt) { u[i] = 0.0; col4row[i] = -1; }
   for (int j = tid; j < M; j += nt) { v[j] = 0.0; row4col[j] = -1; }
@@ -165,10 +171,10 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
   }
   if (s_fail) { if (tid == 0) *a.n_match = -1; return; }
   if (!T) {
-    for (int i = tid; i < N; i += nt) { a.row_ind[i] = rowlist[i]; a.col_ind[i] = col4row[i]; }
+    for (int i = tid; i < N; i += nt) { a.row_ind[i] = rowlist[i]; a.col_ind[i] = collist[col4row[i]]; }
   } else {      // problem rows are the original columns: emit pairs sorted by original row
     const int cnt = lsap_compact(M, [&](int k) { return row4col[k] != -1; }, tmp, s_wave, &s_base);
-    for (int q = tid; q < cnt; q += nt) { const int k = tmp[q]; a.row_ind[q] = rowlist[k]; a.col_ind[q] = row4col[k]; }
+    for (int q = tid; q < cnt; q += nt) { const int k = tmp[q]; a.row_ind[q] = rowlist[k]; a.col_ind[q] = collist[row4col[k]]; }
   }
   if (tid == 0) *a.n_match = N;
 }
@@ -467,6 +473,105 @@ __global__ __launch_bounds__(FFN_H) void ffn_backward_weights_kernel(const float
   float* db = which == 0 ? db0 : (which == 1 ? db1 : db2);
   dW[(size_t)n * FFN_H + k] = acc;
   if (k == 0) db[n] = bsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DBSCAN(eps, min_samples = 2) of n 3-D points and the cluster means, on the device: the junction candidates of the
+// DTU / BlendedMVS confs (VolSDFNetwork.cluster_dbscan, rend_a :328-339, sklearn on the host in the reference).  With
+// min_samples = 2 every point that has a neighbour within eps is a core point, so the clusters are exactly the
+// connected components (of size >= 2) of the eps-graph, and sklearn numbers them by their first point: ascending minimum
+// index.  Output is padded: centres [n/2][3] in that order, valid [n/2], *count.
+//   1. dbscan_adjacency_kernel: n x n adjacency bitmask (float64 distances of the float32 points, as sklearn computes them)
+//   2. dbscan_cluster_kernel (one workgroup): min-label propagation with pointer jumping over the bitmask, ordered
+//      compaction of the component minima, means summed in index order (deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ void dbscan_adjacency_kernel(const float* __restrict__ pts, int n, double eps2, unsigned* __restrict__ adj, int words) {
+  const int i = blockIdx.x;
+  const double xi = pts[3 * i], yi = pts[3 * i + 1], zi = pts[3 * i + 2];
+  for (int w = threadIdx.x; w < words; w += blockDim.x) {
+    unsigned bits = 0u;
+    for (int b = 0; b < 32; ++b) {
+      const int j = 32 * w + b;
+      if (j < n && j != i) {
+        const double dx = xi - (double)pts[3 * j], dy = yi - (double)pts[3 * j + 1], dz = zi - (double)pts[3 * j + 2];
+        if (dx * dx + dy * dy + dz * dz <= eps2) bits |= 1u << b;
+      }
+    }
+    adj[(size_t)i * words + w] = bits;
+  }
+}
+
+constexpr int DBSCAN_MAXN = 8192;
+__global__ __launch_bounds__(1024) void dbscan_cluster_kernel(const float* __restrict__ pts, int n, const unsigned* __restrict__ adj,
+                                                              int words, float* __restrict__ centres, unsigned char* __restrict__ valid,
+                                                              int* __restrict__ count) {
+  __shared__ int lab[DBSCAN_MAXN];
+  __shared__ int s_changed, s_wave[16], s_base;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < n; i += nt) lab[i] = i;
+  __syncthreads();
+  while (true) {
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {                       // hook: smallest label among the neighbours
+      int m = lab[i];
+      const unsigned* row = adj + (size_t)i * words;
+      for (int w = 0; w < words; ++w) {
+        unsigned bits = row[w];
+        while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; m = min(m, lab[32 * w + b]); }
+      }
+      if (m < lab[i]) { atomicMin(&lab[lab[i]], m); atomicMin(&lab[i], m); s_changed = 1; }
+    }
+    __syncthreads();
+    for (int r = 0; r < 16; ++r) {                            // pointer jumping: labels become component minima quickly
+      for (int i = tid; i < n; i += nt) { const int l = lab[i]; const int ll = lab[l]; if (ll < l) lab[i] = ll; }
+      __syncthreads();
+    }
+    if (!s_changed) break;
+    __syncthreads();
+  }
+  // a component of size >= 2 <=> its minimum has a neighbour
+  auto is_rep = [&](int i) {
+    if (lab[i] != i) return false;
+    const unsigned* row = adj + (size_t)i * words;
+    for (int w = 0; w < words; ++w) if (row[w]) return true;
+    return false;
+  };
+  const int maxc = n / 2;
+  for (int k = tid; k < maxc; k += nt) { valid[k] = 0; centres[3 * k] = 0.f; centres[3 * k + 1] = 0.f; centres[3 * k + 2] = 0.f; }
+  __syncthreads();
+  // ordered compaction of the representatives (ascending index = sklearn's cluster numbering); reps land in adj-free scratch: lab is
+  // still needed, so the list goes to the tail of `centres`' companion: reuse s_wave/s_base machinery with a global list
+  int* replist = reinterpret_cast<int*>(centres + 3 * maxc);      // caller provides n/2 ints of space behind the centres
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  for (int b0 = 0; b0 < n; b0 += nt) {
+    const int i = b0 + tid;
+    const bool f = i < n && is_rep(i);
+    const unsigned long long bal = __ballot(f);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    if (f) replist[off + before] = i;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < nw; ++w) t += s_wave[w]; s_base += t; }
+    __syncthreads();
+  }
+  const int nclu = s_base;
+  __syncthreads();
+  for (int k = tid; k < nclu; k += nt) {                      // mean of the members in index order
+    const int r = replist[k];
+    float sx = 0.f, sy = 0.f, sz = 0.f; int cnt = 0;
+    for (int j = r; j < n; ++j)
+      if (lab[j] == r) { sx += pts[3 * j]; sy += pts[3 * j + 1]; sz += pts[3 * j + 2]; ++cnt; }
+    const float inv = 1.0f / (float)cnt;
+    centres[3 * k] = sx * inv; centres[3 * k + 1] = sy * inv; centres[3 * k + 2] = sz * inv;
+    valid[k] = 1;
+  }
+  if (tid == 0) *count = nclu;
 }
 
 }  // namespace neat

@@ -1202,17 +1202,18 @@ int neat_line_loss(const float* pred, const float* gt, const float* weight, int 
 
 size_t neat_lsap_ws_bytes(int nr, int nc) {
   const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
-  return (mn + 2 * mx) * sizeof(double) + ((size_t)nr + 5 * mx + 2 * mn) * sizeof(int);
+  return (mn + 2 * mx) * sizeof(double) + ((size_t)nr + (size_t)nc + 5 * mx + 2 * mn) * sizeof(int);
 }
 
-int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, long long* row_ind, long long* col_ind,
-              int* n_match, void* ws, void* stream) {
+int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, const unsigned char* col_mask, long long* row_ind,
+              long long* col_ind, int* n_match, void* ws, void* stream) {
   if (nr < 0 || nc < 0 || !n_match) return -1;
   if (nr == 0 || nc == 0) return (int)hipMemsetAsync(n_match, 0, sizeof(int), (hipStream_t)stream);
   if (!cost || !row_ind || !col_ind || !ws) return -1;
   const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
   LsapArgs a{cost, nr, nc, row_mask, row_ind, col_ind, n_match, (double*)ws, (int*)((double*)ws + mn + 2 * mx)};
-  const size_t dbytes = (mn + 2 * mx) * sizeof(double), ibytes = ((size_t)nr + 5 * mx + 2 * mn) * sizeof(int);
+  a.col_mask = col_mask;
+  const size_t dbytes = (mn + 2 * mx) * sizeof(double), ibytes = ((size_t)nr + (size_t)nc + 5 * mx + 2 * mn) * sizeof(int);
   size_t lds = 0;
   if (dbytes + ibytes <= 144 * 1024) {
     static bool attr_set = false;
@@ -1224,6 +1225,16 @@ int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, 
     a.use_lds = 1; a.lds_int_off = (int)dbytes; lds = dbytes + ibytes;
   }
   hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(LSAP_WG), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+size_t neat_dbscan_ws_bytes(int n) { return (size_t)n * ((size_t)(n + 31) / 32) * sizeof(unsigned); }
+
+int neat_dbscan_means(const float* points, int n, double eps, float* centres, unsigned char* valid, int* count, void* ws, void* stream) {
+  if (n <= 0 || n > DBSCAN_MAXN || !points || !centres || !valid || !count || !ws || !(eps > 0.0)) return -1;
+  const int words = (n + 31) / 32;
+  hipLaunchKernelGGL(dbscan_adjacency_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, points, n, eps * eps, (unsigned*)ws, words);
+  hipLaunchKernelGGL(dbscan_cluster_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, points, n, (const unsigned*)ws, words, centres, valid, count);
   return (int)hipGetLastError();
 }
 

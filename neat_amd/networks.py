@@ -410,8 +410,14 @@ class VolSDFNetwork(_HipModule):
         lines2d = proj(K3c, lines3d.detach())
         lines2d_calib = proj(eye, lines3d)
         if self.training:
+            cand_valid = None
             if self.dbscan_enabled:
-                cand3d = self.cluster_dbscan(lines3d.detach().cpu().numpy().reshape(-1, 3), eps=0.01, min_samples=2)
+                if lines3d.is_cuda and 2 <= 2 * n_rays <= ops.DBSCAN_MAX_POINTS:
+                    # DBSCAN(eps = 0.01, min_samples = 2) + cluster means on the device: padded centres + validity mask,
+                    # no host round trip (reference: sklearn on the host, :328-339, :460)
+                    cand3d, cand_valid, _ = ops.dbscan_means(lines3d.detach().reshape(-1, 3), 0.01)
+                else:
+                    cand3d = self.cluster_dbscan(lines3d.detach().cpu().numpy().reshape(-1, 3), eps=0.01, min_samples=2)
             elif self.use_l3d:
                 thr = l3d_score.median().clamp_min(0.01)
                 keep = l3d_score < thr          # data-dependent shape: one host sync, as the reference (:465-468)
@@ -426,16 +432,31 @@ class VolSDFNetwork(_HipModule):
                 cand2d_calib = lines2d_calib.detach().reshape(-1, 2)
             gt2d = _device_copy(input["wireframe"][0], "vertices", cand2d.device)
             cost = ((cand2d[None] - gt2d[:, None]) ** 2).sum(-1).sqrt()
-            # Hungarian matching on the device (reference: scipy on the host, :473); every gt junction / candidate of the
-            # smaller side is matched, so the pair count min(V, C) is static and nothing has to come back to the host
-            rows, cols, _ = ops.linear_sum_assignment(cost)
-            matched = cost[rows, cols]
+            # Hungarian matching on the device (reference: scipy on the host, :473).  Without a candidate mask every gt
+            # junction / candidate of the smaller side is matched, so the pair count min(V, C) is static; with the padded
+            # DBSCAN centres the pairs beyond the device-side count come back as -1 and are masked out
+            rows, cols, _ = ops.linear_sum_assignment(cost, None, cand_valid)
+            if cand_valid is None:
+                matched = cost[rows, cols]
+                pair_ok = None
+            else:
+                pair_ok = rows >= 0
+                rows, cols = rows.clamp_min(0), cols.clamp_min(0)
+                matched = torch.where(pair_ok, cost[rows, cols], torch.full_like(cost[rows, cols], float("nan")))
             if self.use_median:
-                median = matched.detach().median() if matched.numel() > 0 else matched.new_tensor(10.0)
+                if matched.numel() == 0:
+                    median = matched.new_tensor(10.0)
+                elif pair_ok is None:
+                    median = matched.detach().median()
+                else:
+                    median = torch.nanmedian(matched.detach())
+                    median = torch.where(torch.isnan(median), torch.full_like(median, 10.0), median)
                 good = matched < median
                 output["median"] = median
             else:
                 good = matched < 10
+            if pair_ok is not None:
+                good = good & pair_ok
             if side is not None:
                 main.wait_stream(side)          # join: the global junctions are needed from here on
             # the reference compacts with `[good]` (:478-489), a data-dependent shape; here the matched candidates stay

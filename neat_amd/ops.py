@@ -306,9 +306,9 @@ def sampler_finish(samples, z, pick, near, far, eik_idx):
     return out, zeik
 
 
-def linear_sum_assignment(cost, row_mask=None):
+def linear_sum_assignment(cost, row_mask=None, col_mask=None):
     """scipy.optimize.linear_sum_assignment on the device, no host round trip (neat_lsap).
-    cost [nr,nc] float32; row_mask [nr] bool: rows that take part (None = all).
+    cost [nr,nc] float32; row_mask [nr] / col_mask [nc] bool: rows / columns that take part (None = all).
     -> row_ind, col_ind int64 [min(nr,nc)] sorted by row and padded with -1, n_match int32 [1] (on the device)."""
     lib = _lib.lib()
     cost = _f32c(cost.detach())
@@ -318,8 +318,9 @@ def linear_sum_assignment(cost, row_mask=None):
     cols = torch.empty(k, device=cost.device, dtype=torch.int64)
     n_match = torch.empty(1, device=cost.device, dtype=torch.int32)
     mask = None if row_mask is None else row_mask.to(torch.uint8).contiguous()
+    cmask = None if col_mask is None else col_mask.to(torch.uint8).contiguous()
     ws = torch.empty(max(int(lib.neat_lsap_ws_bytes(nr, nc)), 8), device=cost.device, dtype=torch.uint8)
-    _lib.check(lib.neat_lsap(_p(cost), nr, nc, _p(mask), _p(rows), _p(cols), _p(n_match), _p(ws), _stream()), "neat_lsap")
+    _lib.check(lib.neat_lsap(_p(cost), nr, nc, _p(mask), _p(cmask), _p(rows), _p(cols), _p(n_match), _p(ws), _stream()), "neat_lsap")
     return rows, cols, n_match
 
 
@@ -424,3 +425,23 @@ def ffn_junctions(x, linears):
     """linears: the three nn.Linear modules of VolSDFNetwork.ffn."""
     l0, l1, l2 = linears
     return FfnFn.apply(x, l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias)
+
+
+DBSCAN_MAX_POINTS = 8192
+
+
+def dbscan_means(points, eps):
+    """DBSCAN(eps, min_samples=2) + cluster means on the device (neat_dbscan_means).  points [n,3] CUDA float32, n <= 8192.
+    -> centres [n//2, 3] (sklearn's cluster order, zero padded), valid [n//2] bool, count int32 [1] -- no host sync."""
+    lib = _lib.lib()
+    pts = _f32c(points.detach().reshape(-1, 3))
+    n = pts.shape[0]
+    if n > DBSCAN_MAX_POINTS or n < 2:
+        raise RuntimeError(f"dbscan_means handles 2..{DBSCAN_MAX_POINTS} points, got {n}")
+    buf = torch.empty(n // 2, 4, device=pts.device)                      # centres followed by n/2 ints of scratch
+    valid = torch.empty(n // 2, device=pts.device, dtype=torch.uint8)
+    count = torch.empty(1, device=pts.device, dtype=torch.int32)
+    ws = torch.empty(int(lib.neat_dbscan_ws_bytes(n)), device=pts.device, dtype=torch.uint8)
+    flat = buf.view(-1)
+    _lib.check(lib.neat_dbscan_means(_p(pts), n, float(eps), _p(flat), _p(valid), _p(count), _p(ws), _stream()), "neat_dbscan_means")
+    return flat[:3 * (n // 2)].view(n // 2, 3), valid.bool(), count

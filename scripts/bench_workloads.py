@@ -42,7 +42,7 @@ dt = (time.perf_counter() - t0) / args.steps
 print(json.dumps({"workload": "eval forward (sampler + render + junction block), one 2048-ray chunk", "ms_per_chunk": 1e3 * dt,
                   "rays_per_s": 2048 / dt, "precision": args.precision}))
 
-# ---- C3-style: DTU switches (dbscan on the host as the reference does, use_median off, 1024 junction latents), 2048 x 128 given samples
+# ---- C3-style: DTU switches (dbscan_enabled -> device DBSCAN, use_median off, 1024 junction latents), 2048 x 128 given samples
 import copy
 from neat_amd import networks
 conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
@@ -57,7 +57,7 @@ for dbscan in (True, False):
     tr3.model.z_vals_override = torch.tensor(synth.synth_z_vals(42, 2048, 128)).to(dev)
     for _ in range(3):
         tr3.step(inp3, gt3)
-    graphed = tr3.capture(inp3, gt3) if not dbscan else False
+    graphed = tr3.capture(inp3, gt3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

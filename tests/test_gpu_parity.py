@@ -639,3 +639,53 @@ def test_graph_falls_back_for_other_batches(dev):
     _, lo = tr.step(inp, gt)
     assert calls["eager"] == 2 and torch.isfinite(lo["loss"])
     tr.check_nan()
+
+
+def test_device_dbscan_path_equals_host_path(dev):
+    """DTU-style conf: the junction block with DBSCAN + matching on the device (padded centres + masks) against the same
+    block with sklearn on the host (the reference's way, forced by a ray count above the device kernel's limit check):
+    same matched junctions, same loss and gradients."""
+    import copy
+    from neat_amd import networks, ops
+    from neat_amd.loss import VolSDFLoss
+    from tests.util_replay import RngReplay
+    conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+    conf.update(dbscan_enabled=True, use_median=False)
+    sd = {k: T(v) for k, v in synth.synth_state_dict(9, "rough").items()}
+    R, S = 192, 40
+    sc = synth.synth_scene(seed=9, n_rays=R)
+    z = T(synth.synth_z_vals(9, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(9)
+    eik_idx = torch.randint(S, (R,), generator=gen)
+    eik_uniform = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
+    gt = {"rgb": T(sc["gt_rgb"]).to(dev), "lines2d": T(sc["gt_lines2d"]).to(dev)}
+    res = []
+    EPS = 0.25        # the forward's eps = 0.01 finds no cluster in this synthetic scene: widen it (both paths) so the test bites
+    dev_dbscan = ops.dbscan_means
+    for device_path in (True, False):
+        m = networks.VolSDFNetwork(conf)
+        m.load_state_dict(sd)
+        m.to(dev).train()
+        m.z_vals_override = z
+        host_dbscan = m.cluster_dbscan
+        m.cluster_dbscan = lambda points, eps=0.01, min_samples=2: host_dbscan(points, eps=EPS, min_samples=2)
+        limit = ops.DBSCAN_MAX_POINTS
+        try:
+            ops.dbscan_means = lambda pts, eps: dev_dbscan(pts, EPS)
+            if not device_path:
+                ops.DBSCAN_MAX_POINTS = 1            # forces the sklearn branch
+            with RngReplay([("randint", eik_idx), ("uniform_", eik_uniform)]):
+                out = m(scene_inputs(sc, dev))
+        finally:
+            ops.DBSCAN_MAX_POINTS = limit
+            ops.dbscan_means = dev_dbscan
+        lo = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)(out, gt)
+        lo["loss"].backward()
+        res.append((out["j3d_local"].detach(), float(lo["loss"].detach()), float(lo["j3d_loss"].detach()),
+                    m.latents.grad.detach().clone(), m.implicit_network.lin3.weight_v.grad.detach().clone()))
+    (ja, la, j3a, ga, wa), (jb, lb, j3b, gb, wb) = res
+    assert ja.shape == jb.shape and ja.shape[0] > 0
+    close(ja, jb, tol=1e-5, what="matched local junctions")
+    assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)) and abs(j3a - j3b) <= 1e-6 * max(1.0, abs(j3b))
+    close(ga, gb, tol=1e-5, what="latents grad")
+    close(wa, wb, tol=1e-5, what="lin3 grad")

@@ -75,3 +75,61 @@ def test_lazy_outputs_equal_compaction():
     assert "j3d_local" in out and "nope" not in out
     assert out["j3d_local"].shape == (2, 3) and out["j3d_local"][1, 0] == 6
     assert set(out.keys()) >= {"rgb_values", "j3d_local", "j2d_local", "j2d_local_calib"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nr,nc,seed", [(8, 200, 0), (60, 40, 1), (30, 30, 2)])
+def test_col_mask_is_compaction(nr, nc, seed):
+    """Masked columns behave like deleting them before scipy (padded candidate sets, e.g. the DBSCAN centres)."""
+    from neat_amd import ops
+    rng = np.random.default_rng(seed)
+    cost = rng.uniform(0, 10, (nr, nc)).astype(np.float32)
+    cmask = rng.uniform(size=nc) < 0.5
+    rmask = rng.uniform(size=nr) < 0.8
+    r, c, n = ops.linear_sum_assignment(torch.tensor(cost).cuda(), torch.tensor(rmask).cuda(), torch.tensor(cmask).cuda())
+    n = int(n.item())
+    r, c = r.cpu().numpy(), c.cpu().numpy()
+    keep_r, keep_c = np.nonzero(rmask)[0], np.nonzero(cmask)[0]
+    sr, sc = scipy_lsa(cost[np.ix_(keep_r, keep_c)])
+    assert n == len(sr) and (r[n:] == -1).all()
+    assert (r[:n] == keep_r[sr]).all() and (c[:n] == keep_c[sc]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed", [(64, 0), (2048, 1), (4096, 2), (8192, 3)])
+def test_dbscan_means_vs_sklearn(n, seed):
+    """neat_dbscan_means against sklearn.cluster.DBSCAN(eps=0.01, min_samples=2) + per-cluster means (what the reference
+    computes on the host, rend_a :328-339): same clusters in the same order, same centres."""
+    from sklearn.cluster import DBSCAN
+    from neat_amd import ops
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-1, 1, (max(n // 16, 2), 3))
+    pts = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 0.002, (n, 3))
+    pts[: n // 8] = rng.uniform(-1, 1, (n // 8, 3))                     # isolated points = noise
+    t = np.linspace(0, 1, n // 8)[:, None]
+    pts[n // 8: n // 4] = np.array([0.5, -0.5, 0.2]) + t * np.array([0.6, 0.1, -0.3])      # a long chain: one cluster through many hops
+    pts = pts.astype(np.float32)
+    labels = DBSCAN(eps=0.01, min_samples=2).fit(pts).labels_
+    ref = np.array([pts[labels == i].mean(axis=0) for i in range(labels.max() + 1)]).reshape(-1, 3)
+    got, valid, count = ops.dbscan_means(torch.tensor(pts).cuda(), 0.01)
+    k = int(count.item())
+    assert k == len(ref) and int(valid.sum()) == k and bool(valid[:k].all())
+    assert np.abs(got[:k].cpu().numpy() - ref).max() <= 1e-6
+    assert float(got[k:].abs().max()) == 0.0 if k < got.shape[0] else True
+
+
+@pytest.mark.gpu
+def test_few_rows_many_columns_repeatedly():
+    """Regression: the count returned by the in-kernel compaction used to be read after a fast thread could reset it
+    (hang / fault with 1-2 participating rows, timing dependent).  Many launches of the shapes a training step produces."""
+    from neat_amd import ops
+    rng = np.random.default_rng(5)
+    for it in range(60):
+        cost = rng.uniform(0, 50, (8, 1024)).astype(np.float32)
+        mask = np.zeros(8, bool)
+        mask[rng.choice(8, 1 + it % 2, replace=False)] = True
+        r, c, n = ops.linear_sum_assignment(torch.tensor(cost).cuda(), torch.tensor(mask).cuda())
+        n = int(n.item())
+        keep = np.nonzero(mask)[0]
+        sr, sc = scipy_lsa(cost[keep])
+        assert n == len(sr) and (r[:n].cpu().numpy() == keep[sr]).all() and (c[:n].cpu().numpy() == sc).all()
