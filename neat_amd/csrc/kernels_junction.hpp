@@ -464,7 +464,15 @@ __global__ __launch_bounds__(FFN_H) void ffn_backward_weights_kernel(const float
   const float* in = which == 0 ? x : (which == 1 ? h1 : h2);
   const int ldd = which == 2 ? 3 : FFN_H;
   float acc = 0.0f, bsum = 0.0f;
-  for (int j = 0; j < J; ++j) {
+  int j = 0;
+  for (; j + 4 <= J; j += 4) {              // four rows in flight (the sum order stays j = 0, 1, 2, ...)
+    float dv[4], xv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dv[t] = d[(size_t)(j + t) * ldd + n]; xv[t] = in[(size_t)(j + t) * FFN_H + k]; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc += dv[t] * xv[t]; bsum += dv[t]; }
+  }
+  for (; j < J; ++j) {
     const float dv = d[(size_t)j * ldd + n];
     acc += dv * in[(size_t)j * FFN_H + k];
     bsum += dv;
@@ -481,74 +489,62 @@ __global__ __launch_bounds__(FFN_H) void ffn_backward_weights_kernel(const float
 // min_samples = 2 every point that has a neighbour within eps is a core point, so the clusters are exactly the
 // connected components (of size >= 2) of the eps-graph, and sklearn numbers them by their first point: ascending minimum
 // index.  Output is padded: centres [n/2][3] in that order, valid [n/2], *count.
-//   1. dbscan_adjacency_kernel: n x n adjacency bitmask (float64 distances of the float32 points, as sklearn computes them)
-//   2. dbscan_cluster_kernel (one workgroup): min-label propagation with pointer jumping over the bitmask, ordered
-//      compaction of the component minima, means summed in index order (deterministic).
+//   1. dbscan_union_kernel: every pair closer than eps (float64 distances of the float32 points, as sklearn computes them) is
+//      merged in a lock-free union-find whose links always point from the larger root to the smaller one, so the root of a
+//      component is its minimum index whatever the order of the merges;
+//   2. dbscan_finish_kernel (one workgroup): roots -> LDS, ordered compaction of the component minima that have a
+//      neighbour, means summed in index order (deterministic).
 // ---------------------------------------------------------------------------------------------
-__global__ void dbscan_adjacency_kernel(const float* __restrict__ pts, int n, double eps2, unsigned* __restrict__ adj, int words) {
+__global__ void dbscan_init_kernel(int* __restrict__ parent, int* __restrict__ has_nb, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { parent[i] = i; has_nb[i] = 0; }
+}
+
+__device__ __forceinline__ int dbscan_find(int* parent, int x) {
+  while (true) {
+    const int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp != p) atomicMin(&parent[x], gp);      // path halving; parents only ever decrease
+    x = p;
+  }
+}
+
+__global__ void dbscan_union_kernel(const float* __restrict__ pts, int n, double eps2, int* __restrict__ parent, int* __restrict__ has_nb) {
   const int i = blockIdx.x;
   const double xi = pts[3 * i], yi = pts[3 * i + 1], zi = pts[3 * i + 2];
-  for (int w = threadIdx.x; w < words; w += blockDim.x) {
-    unsigned bits = 0u;
-    for (int b = 0; b < 32; ++b) {
-      const int j = 32 * w + b;
-      if (j < n && j != i) {
-        const double dx = xi - (double)pts[3 * j], dy = yi - (double)pts[3 * j + 1], dz = zi - (double)pts[3 * j + 2];
-        if (dx * dx + dy * dy + dz * dz <= eps2) bits |= 1u << b;
-      }
+  for (int j = i + 1 + threadIdx.x; j < n; j += blockDim.x) {
+    const double dx = xi - (double)pts[3 * j], dy = yi - (double)pts[3 * j + 1], dz = zi - (double)pts[3 * j + 2];
+    if (dx * dx + dy * dy + dz * dz > eps2) continue;
+    has_nb[i] = 1; has_nb[j] = 1;
+    int a = i, b = j;
+    while (true) {
+      a = dbscan_find(parent, a); b = dbscan_find(parent, b);
+      if (a == b) break;
+      const int lo = min(a, b), hi = max(a, b);
+      if (atomicCAS(&parent[hi], hi, lo) == hi) break;      // hi was still a root: linked under the smaller root
+      a = lo; b = hi;                                        // somebody re-rooted hi meanwhile: find again
     }
-    adj[(size_t)i * words + w] = bits;
   }
 }
 
 constexpr int DBSCAN_MAXN = 8192;
-__global__ __launch_bounds__(1024) void dbscan_cluster_kernel(const float* __restrict__ pts, int n, const unsigned* __restrict__ adj,
-                                                              int words, float* __restrict__ centres, unsigned char* __restrict__ valid,
-                                                              int* __restrict__ count) {
+__global__ __launch_bounds__(1024) void dbscan_finish_kernel(const float* __restrict__ pts, int n, int* __restrict__ parent,
+                                                             const int* __restrict__ has_nb, float* __restrict__ centres,
+                                                             unsigned char* __restrict__ valid, int* __restrict__ count) {
   __shared__ int lab[DBSCAN_MAXN];
-  __shared__ int s_changed, s_wave[16], s_base;
+  __shared__ int s_wave[16], s_base;
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int i = tid; i < n; i += nt) lab[i] = i;
-  __syncthreads();
-  while (true) {
-    if (tid == 0) s_changed = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) {                       // hook: smallest label among the neighbours
-      int m = lab[i];
-      const unsigned* row = adj + (size_t)i * words;
-      for (int w = 0; w < words; ++w) {
-        unsigned bits = row[w];
-        while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; m = min(m, lab[32 * w + b]); }
-      }
-      if (m < lab[i]) { atomicMin(&lab[lab[i]], m); atomicMin(&lab[i], m); s_changed = 1; }
-    }
-    __syncthreads();
-    for (int r = 0; r < 16; ++r) {                            // pointer jumping: labels become component minima quickly
-      for (int i = tid; i < n; i += nt) { const int l = lab[i]; const int ll = lab[l]; if (ll < l) lab[i] = ll; }
-      __syncthreads();
-    }
-    if (!s_changed) break;
-    __syncthreads();
-  }
-  // a component of size >= 2 <=> its minimum has a neighbour
-  auto is_rep = [&](int i) {
-    if (lab[i] != i) return false;
-    const unsigned* row = adj + (size_t)i * words;
-    for (int w = 0; w < words; ++w) if (row[w]) return true;
-    return false;
-  };
+  for (int i = tid; i < n; i += nt) lab[i] = dbscan_find(parent, i);
   const int maxc = n / 2;
   for (int k = tid; k < maxc; k += nt) { valid[k] = 0; centres[3 * k] = 0.f; centres[3 * k + 1] = 0.f; centres[3 * k + 2] = 0.f; }
-  __syncthreads();
-  // ordered compaction of the representatives (ascending index = sklearn's cluster numbering); reps land in adj-free scratch: lab is
-  // still needed, so the list goes to the tail of `centres`' companion: reuse s_wave/s_base machinery with a global list
   int* replist = reinterpret_cast<int*>(centres + 3 * maxc);      // caller provides n/2 ints of space behind the centres
   if (tid == 0) s_base = 0;
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-  for (int b0 = 0; b0 < n; b0 += nt) {
+  for (int b0 = 0; b0 < n; b0 += nt) {          // ordered compaction of the representatives (ascending = sklearn's numbering)
     const int i = b0 + tid;
-    const bool f = i < n && is_rep(i);
+    const bool f = i < n && lab[i] == i && has_nb[i] != 0;
     const unsigned long long bal = __ballot(f);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) s_wave[wave] = __popcll(bal);

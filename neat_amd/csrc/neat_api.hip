@@ -1228,13 +1228,14 @@ int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, 
   return (int)hipGetLastError();
 }
 
-size_t neat_dbscan_ws_bytes(int n) { return (size_t)n * ((size_t)(n + 31) / 32) * sizeof(unsigned); }
+size_t neat_dbscan_ws_bytes(int n) { return (size_t)n * 2 * sizeof(int); }
 
 int neat_dbscan_means(const float* points, int n, double eps, float* centres, unsigned char* valid, int* count, void* ws, void* stream) {
   if (n <= 0 || n > DBSCAN_MAXN || !points || !centres || !valid || !count || !ws || !(eps > 0.0)) return -1;
-  const int words = (n + 31) / 32;
-  hipLaunchKernelGGL(dbscan_adjacency_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, points, n, eps * eps, (unsigned*)ws, words);
-  hipLaunchKernelGGL(dbscan_cluster_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, points, n, (const unsigned*)ws, words, centres, valid, count);
+  int* parent = (int*)ws; int* has_nb = parent + n;
+  hipLaunchKernelGGL(dbscan_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, parent, has_nb, n);
+  hipLaunchKernelGGL(dbscan_union_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, points, n, eps * eps, parent, has_nb);
+  hipLaunchKernelGGL(dbscan_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, points, n, parent, has_nb, centres, valid, count);
   return (int)hipGetLastError();
 }
 
