@@ -50,6 +50,10 @@ _SIGNATURES = {
     "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_ffn_forward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 10),
     "neat_ffn_backward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 15),
+    "neat_loss_terms": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
+                                       c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "neat_loss_pairs": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp,
+                                       c_fp, c_fp]),
     "neat_inv_small": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d_backward": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),

@@ -570,4 +570,105 @@ __global__ __launch_bounds__(1024) void dbscan_finish_kernel(const float* __rest
   if (tid == 0) *count = nclu;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tail of VolSDFLoss.forward (model/networks/loss_wfr.py:68-137) in two launches around the junction matching:
+//   loss_terms_kernel : rgb L1 (mean), eikonal ((|g| - 1)^2 mean), their cotangents, and the junction pair cost
+//                       cdist_1(loc3, glo3) + 0.1 cdist_1(loc2c, glo2c)  [K, J]
+//   loss_pairs_kernel : matched-pair means (3-D, calibrated 2-D, pixel 2-D), the count of pairs with cost < 10, and the
+//                       cotangents of the global junctions (only matched entries are non-zero)
+// One workgroup each (R, E, K, J are a few thousand at most); sums by wave shuffles + LDS, fixed order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* s_red) {          // all threads get the sum; blockDim.x = 1024
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
+  return t;
+}
+
+struct LossTermsArgs {
+  const float* rgb; const float* rgb_gt; int R;
+  const float* gtheta; int E;
+  const float* loc3; const float* loc2c; int K;
+  const float* glo3; const float* glo2c; int J;
+  float* scal;                 // [0] rgb loss, [1] eikonal loss
+  float* d_rgb; float* d_gtheta; float* pair_cost;
+};
+
+__global__ __launch_bounds__(1024) void loss_terms_kernel(LossTermsArgs a) {
+  __shared__ float s_red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float acc = 0.0f;
+  const float inv_rgb = 1.0f / (float)(3 * a.R);
+  for (int i = tid; i < 3 * a.R; i += nt) {
+    const float d = a.rgb[i] - a.rgb_gt[i];
+    acc += fabsf(d);
+    a.d_rgb[i] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv_rgb;
+  }
+  const float rgb_loss = block_sum(acc, s_red) * inv_rgb;
+  acc = 0.0f;
+  const float inv_e = a.E > 0 ? 1.0f / (float)a.E : 0.0f;
+  for (int i = tid; i < a.E; i += nt) {
+    const float gx = a.gtheta[3 * i], gy = a.gtheta[3 * i + 1], gz = a.gtheta[3 * i + 2];
+    const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+    acc += (nrm - 1.0f) * (nrm - 1.0f);
+    const float c = nrm > 0.0f ? 2.0f * (nrm - 1.0f) * inv_e / nrm : 0.0f;        // d/dg |g| = g/|g| (0 at the origin, as torch)
+    a.d_gtheta[3 * i] = c * gx; a.d_gtheta[3 * i + 1] = c * gy; a.d_gtheta[3 * i + 2] = c * gz;
+  }
+  const float eik = block_sum(acc, s_red) * inv_e;
+  if (tid == 0) { a.scal[0] = rgb_loss; a.scal[1] = eik; }
+  for (int idx = tid; idx < a.K * a.J; idx += nt) {
+    const int k = idx / a.J, j = idx % a.J;
+    float c3 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) c3 += fabsf(a.loc3[3 * k + c] - a.glo3[3 * j + c]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) c2 += fabsf(a.loc2c[2 * k + c] - a.glo2c[2 * j + c]);
+    a.pair_cost[idx] = c3 + 0.1f * c2;
+  }
+}
+
+struct LossPairsArgs {
+  const long long* ri; const long long* ci; const int* n_match; int Kmax;      // pairs (padded with -1)
+  const float* loc3; const float* loc2c; const float* loc2;
+  const float* glo3; const float* glo2c; const float* glo2; int J;
+  const float* pair_cost;
+  float* scal;                 // [2] j3d, [3] j2d (calibrated), [4] j2d (pixels), [5] count of pairs with cost < 10
+  float* d_glo3; float* d_glo2c;                                               // [J,3], [J,2], fully written
+};
+
+__global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
+  __shared__ float s_red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < 3 * a.J; i += nt) a.d_glo3[i] = 0.0f;
+  for (int i = tid; i < 2 * a.J; i += nt) a.d_glo2c[i] = 0.0f;
+  __syncthreads();
+  const int n = max(*a.n_match, 0);
+  const float inv = 1.0f / (float)max(n, 1);
+  float s3 = 0.0f, s2 = 0.0f, spx = 0.0f, cnt = 0.0f;
+  for (int q = tid; q < a.Kmax; q += nt) {
+    const long long r = a.ri[q], c = a.ci[q];
+    if (r < 0 || c < 0 || q >= n) continue;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const float d = a.loc3[3 * r + e] - a.glo3[3 * c + e];
+      s3 += fabsf(d);
+      a.d_glo3[3 * c + e] = -(d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv;     // each global junction is matched at most once
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float d = a.loc2c[2 * r + e] - a.glo2c[2 * c + e];
+      s2 += fabsf(d);
+      a.d_glo2c[2 * c + e] = -(d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv;
+      spx += fabsf(a.loc2[2 * r + e] - a.glo2[2 * c + e]);
+    }
+    if (a.pair_cost[r * a.J + c] < 10.0f) cnt += 1.0f;
+  }
+  s3 = block_sum(s3, s_red); s2 = block_sum(s2, s_red); spx = block_sum(spx, s_red); cnt = block_sum(cnt, s_red);
+  if (tid == 0) { a.scal[2] = s3 * inv; a.scal[3] = s2 * inv; a.scal[4] = spx * inv; a.scal[5] = cnt; }
+}
+
 }  // namespace neat

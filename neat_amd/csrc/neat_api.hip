@@ -1173,6 +1173,25 @@ int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, c
   return (int)hipGetLastError();
 }
 
+int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E, const float* loc3, const float* loc2c, int K,
+                    const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost, void* stream) {
+  if (R <= 0 || !rgb || !rgb_gt || !scal || !d_rgb || E < 0 || K < 0 || J < 0) return -1;
+  if ((E > 0 && (!gtheta || !d_gtheta)) || (K > 0 && J > 0 && (!loc3 || !loc2c || !glo3 || !glo2c || !pair_cost))) return -1;
+  LossTermsArgs a{rgb, rgb_gt, R, gtheta, E, loc3, loc2c, (J > 0 ? K : 0), glo3, glo2c, J, scal, d_rgb, d_gtheta, pair_cost};
+  hipLaunchKernelGGL(loss_terms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
+                    const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
+                    float* d_glo3, float* d_glo2c, void* stream) {
+  if (Kmax < 0 || J <= 0 || !ri || !ci || !n_match || !loc3 || !loc2c || !loc2 || !glo3 || !glo2c || !glo2 || !pair_cost || !scal ||
+      !d_glo3 || !d_glo2c) return -1;
+  LossPairsArgs a{ri, ci, n_match, Kmax, loc3, loc2c, loc2, glo3, glo2c, glo2, J, pair_cost, scal, d_glo3, d_glo2c};
+  hipLaunchKernelGGL(loss_pairs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 int neat_inv_small(const float* A, int n, int lda, float* out, void* stream) {
   if (!A || !out || n < 1 || n > 4 || lda < n) return -1;
   hipLaunchKernelGGL(inv_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, n, lda, out);

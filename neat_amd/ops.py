@@ -445,3 +445,55 @@ def dbscan_means(points, eps):
     flat = buf.view(-1)
     _lib.check(lib.neat_dbscan_means(_p(pts), n, float(eps), _p(flat), _p(valid), _p(count), _p(ws), _stream()), "neat_dbscan_means")
     return flat[:3 * (n // 2)].view(n // 2, 3), valid.bool(), count
+
+
+class LossTailFn(torch.autograd.Function):
+    """rgb L1 + eikonal + junction pair terms of VolSDFLoss and the weighted total, in two launches around neat_lsap.
+    Differentiable inputs: rgb, grad_theta, the global junctions (3-D and calibrated 2-D) and the line loss."""
+
+    @staticmethod
+    def forward(ctx, rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2):
+        lib = _lib.lib()
+        dev = rgb.device
+        c = lambda t: None if t is None else _f32c(t.detach())
+        rgb_c, gt_c, gth_c = c(rgb), c(rgb_gt.reshape(-1, 3)), c(gtheta)
+        glo3_c, glo2c_c, glo2_c, loc3_c, loc2c_c, loc2_c = c(glo3), c(glo2c), c(glo2), c(loc3), c(loc2c), c(loc2)
+        R, E = rgb_c.shape[0], 0 if gth_c is None else gth_c.shape[0]
+        K = 0 if loc3_c is None else loc3_c.shape[0]
+        J = 0 if glo3_c is None else glo3_c.shape[0]
+        scal = torch.zeros(8, device=dev)
+        d_rgb = torch.empty_like(rgb_c)
+        d_gth = torch.empty_like(gth_c) if E else None
+        pair_cost = torch.empty(K, J, device=dev) if K and J else None
+        _lib.check(lib.neat_loss_terms(_p(rgb_c), _p(gt_c), R, _p(gth_c), E, _p(loc3_c), _p(loc2c_c), K, _p(glo3_c), _p(glo2c_c), J,
+                                       _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), _stream()), "neat_loss_terms")
+        d_glo3 = d_glo2c = None
+        if K and J:
+            ri, ci, n_match = linear_sum_assignment(pair_cost, good)
+            d_glo3, d_glo2c = torch.empty_like(glo3_c), torch.empty_like(glo2c_c)
+            _lib.check(lib.neat_loss_pairs(_p(ri), _p(ci), _p(n_match), ri.shape[0], _p(loc3_c), _p(loc2c_c), _p(loc2_c), _p(glo3_c),
+                                           _p(glo2c_c), _p(glo2_c), J, _p(pair_cost), _p(scal), _p(d_glo3), _p(d_glo2c), _stream()),
+                       "neat_loss_pairs")
+        loss = scal[0] + w_eik * scal[1] + w_j3 * scal[2] + w_j2 * scal[3] + w_line * line_loss.detach()
+        ctx.save_for_backward(d_rgb, d_gth, d_glo3, d_glo2c)
+        ctx.weights = (w_eik, w_line, w_j3, w_j2)
+        ctx.shapes = (rgb.shape, None if gtheta is None else gtheta.shape, None if glo3 is None else glo3.shape,
+                      None if glo2c is None else glo2c.shape)
+        ctx.mark_non_differentiable(scal)
+        return loss, scal
+
+    @staticmethod
+    def backward(ctx, g_loss, g_scal):
+        d_rgb, d_gth, d_glo3, d_glo2c = ctx.saved_tensors
+        w_eik, w_line, w_j3, w_j2 = ctx.weights
+        s_rgb, s_gth, s_glo3, s_glo2c = ctx.shapes
+        return (g_loss * d_rgb.view(s_rgb),
+                None if d_gth is None else (g_loss * w_eik) * d_gth.view(s_gth),
+                None if d_glo3 is None else (g_loss * w_j3) * d_glo3.view(s_glo3),
+                None if d_glo2c is None else (g_loss * w_j2) * d_glo2c.view(s_glo2c),
+                g_loss * w_line, None, None, None, None, None, None, None, None, None, None)
+
+
+def loss_tail(rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2):
+    return LossTailFn.apply(rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good,
+                            float(w_eik), float(w_line), float(w_j3), float(w_j2))

@@ -689,3 +689,38 @@ def test_device_dbscan_path_equals_host_path(dev):
     assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)) and abs(j3a - j3b) <= 1e-6 * max(1.0, abs(j3b))
     close(ga, gb, tol=1e-5, what="latents grad")
     close(wa, wb, tol=1e-5, what="lin3 grad")
+
+
+@pytest.mark.parametrize("use_median,R", [(True, 96), (False, 33)])
+def test_fused_loss_tail_vs_torch_formulation(dev, use_median, R):
+    """VolSDFLoss with the fused tail (neat_loss_terms / neat_loss_pairs) against the torch formulation of the same
+    lines on one set of model outputs: every reported scalar and the gradients that leave the loss."""
+    import copy
+    from neat_amd import networks
+    from neat_amd.loss import VolSDFLoss
+    conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+    conf["use_median"] = use_median
+    torch.manual_seed(1)
+    m = networks.VolSDFNetwork(conf)
+    m.load_state_dict({k: T(v) for k, v in synth.synth_state_dict(13, "rough").items()})
+    m.to(dev).train()
+    sc = synth.synth_scene(seed=13, n_rays=R)
+    m.z_vals_override = T(synth.synth_z_vals(13, R, 24)).to(dev)
+    gt = {"rgb": T(sc["gt_rgb"]).to(dev), "lines2d": T(sc["gt_lines2d"]).to(dev)}
+    out = m(scene_inputs(sc, dev))
+    leaves = [out["rgb_values"], out["grad_theta"], out["j3d_global"], out["lines3d"]]
+    res = []
+    for fused in (False, True):
+        lf = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)
+        lf.fused_tail = fused
+        lo = lf(out, gt)
+        grads = torch.autograd.grad(lo["loss"], leaves, retain_graph=True, allow_unused=True)
+        res.append((lo, grads))
+    (la, ga), (lb, gb) = res
+    for k in ("loss", "rgb_loss", "eikonal_loss", "line_loss", "l2d_loss", "j3d_loss", "j2d_loss", "j2d_stat", "jcount", "count"):
+        a, b = float(la[k].detach().float()), float(lb[k].detach().float())
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (k, a, b)
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            close(y, x, tol=1e-5, what="loss-tail gradient")
