@@ -136,12 +136,13 @@ int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int*
  * neat_loss_terms -> scal[0] = L1 rgb loss (mean), scal[1] = eikonal loss, d_rgb [R,3], d_gtheta [E,3] (cotangents for unit
  * upstream gradient), pair_cost [K,J] = cdist_1(loc3, glo3) + 0.1 cdist_1(loc2c, glo2c);
  * neat_loss_pairs (ri, ci, n_match from neat_lsap over pair_cost) -> scal[2..5] = mean 3-D / calibrated 2-D / pixel 2-D pair
- * distance and the count of pairs with cost < 10; d_glo3 [J,3], d_glo2c [J,2] = cotangents of the global junctions. */
+ * distance and the count of pairs with cost < 10, scal[6] = rgb + w_eik eik + w_line line_loss[0] + w_j3 j3d + w_j2 j2d;
+ * d_glo3 [J,3], d_glo2c [J,2] = cotangents of the global junctions. */
 int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E, const float* loc3, const float* loc2c, int K,
                     const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost, void* stream);
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
-                    float* d_glo3, float* d_glo2c, void* stream);
+                    float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, void* stream);
 /* global-junction MLP ffn(latents) (rend_a :303-313, :491): x [J,256] -> relu(W0 x + b0) -> relu(W1 . + b1) -> W2 . + b2 = y [J,3];
  * torch nn.Linear layouts (W [out,in]); h1, h2 [J,256] are saved for the backward; ws2 = 2 J 256 floats of scratch. */
 int neat_ffn_forward(const float* x, int J, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,

@@ -53,7 +53,7 @@ _SIGNATURES = {
     "neat_loss_terms": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
                                        c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_loss_pairs": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp,
-                                       c_fp, c_fp]),
+                                       c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp]),
     "neat_inv_small": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d_backward": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),

@@ -638,6 +638,7 @@ struct LossPairsArgs {
   const float* pair_cost;
   float* scal;                 // [2] j3d, [3] j2d (calibrated), [4] j2d (pixels), [5] count of pairs with cost < 10
   float* d_glo3; float* d_glo2c;                                               // [J,3], [J,2], fully written
+  const float* line_loss; float w_eik, w_line, w_j3, w_j2;                     // scal[6] = rgb + w_eik eik + w_line line + w_j3 j3d + w_j2 j2d
 };
 
 __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
@@ -668,7 +669,10 @@ __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
     if (a.pair_cost[r * a.J + c] < 10.0f) cnt += 1.0f;
   }
   s3 = block_sum(s3, s_red); s2 = block_sum(s2, s_red); spx = block_sum(spx, s_red); cnt = block_sum(cnt, s_red);
-  if (tid == 0) { a.scal[2] = s3 * inv; a.scal[3] = s2 * inv; a.scal[4] = spx * inv; a.scal[5] = cnt; }
+  if (tid == 0) {
+    a.scal[2] = s3 * inv; a.scal[3] = s2 * inv; a.scal[4] = spx * inv; a.scal[5] = cnt;
+    a.scal[6] = a.scal[0] + a.w_eik * a.scal[1] + a.w_line * a.line_loss[0] + a.w_j3 * (s3 * inv) + a.w_j2 * (s2 * inv);
+  }
 }
 
 }  // namespace neat

@@ -1184,10 +1184,11 @@ int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* g
 
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
-                    float* d_glo3, float* d_glo2c, void* stream) {
+                    float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, void* stream) {
   if (Kmax < 0 || J <= 0 || !ri || !ci || !n_match || !loc3 || !loc2c || !loc2 || !glo3 || !glo2c || !glo2 || !pair_cost || !scal ||
-      !d_glo3 || !d_glo2c) return -1;
-  LossPairsArgs a{ri, ci, n_match, Kmax, loc3, loc2c, loc2, glo3, glo2c, glo2, J, pair_cost, scal, d_glo3, d_glo2c};
+      !d_glo3 || !d_glo2c || !line_loss) return -1;
+  LossPairsArgs a{ri, ci, n_match, Kmax, loc3, loc2c, loc2, glo3, glo2c, glo2, J, pair_cost, scal, d_glo3, d_glo2c, line_loss, w_eik, w_line,
+                  w_j3, w_j2};
   hipLaunchKernelGGL(loss_pairs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

@@ -472,9 +472,12 @@ class LossTailFn(torch.autograd.Function):
             ri, ci, n_match = linear_sum_assignment(pair_cost, good)
             d_glo3, d_glo2c = torch.empty_like(glo3_c), torch.empty_like(glo2c_c)
             _lib.check(lib.neat_loss_pairs(_p(ri), _p(ci), _p(n_match), ri.shape[0], _p(loc3_c), _p(loc2c_c), _p(loc2_c), _p(glo3_c),
-                                           _p(glo2c_c), _p(glo2_c), J, _p(pair_cost), _p(scal), _p(d_glo3), _p(d_glo2c), _stream()),
+                                           _p(glo2c_c), _p(glo2_c), J, _p(pair_cost), _p(scal), _p(d_glo3), _p(d_glo2c),
+                                           _p(_f32c(line_loss.detach().reshape(1))), w_eik, w_line, w_j3, w_j2, _stream()),
                        "neat_loss_pairs")
-        loss = scal[0] + w_eik * scal[1] + w_j3 * scal[2] + w_j2 * scal[3] + w_line * line_loss.detach()
+            loss = scal[6].clone()
+        else:
+            loss = scal[0] + w_eik * scal[1] + w_line * line_loss.detach()
         ctx.save_for_backward(d_rgb, d_gth, d_glo3, d_glo2c)
         ctx.weights = (w_eik, w_line, w_j3, w_j2)
         ctx.shapes = (rgb.shape, None if gtheta is None else gtheta.shape, None if glo3 is None else glo3.shape,
