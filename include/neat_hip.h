@@ -132,6 +132,14 @@ int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int*
  * K [3,3] and w2c [3,4] = [R|T] row-major on the device, X [N,3] -> uv [N,2]; its backward gives d_X from d_uv.
  * neat_line_loss = VolSDFLoss.get_line_loss (model/networks/loss_wfr.py:34-45): pred, gt [R,4], weight [R] ->
  * out2 = {loss, number of gated lines}, per_line [R], d_pred [R,4] = d loss / d pred. */
+/* junction block pieces (model/networks/neat_wfr_rend_a.py:441-489) as single launches: neat_l3d (:441-447: plane intersection per ray),
+ * neat_junction_cost (:472: cost[v][c] = |cand2d[c] - gt2d[v]|), neat_junction_gate (:474-489: matched costs of the neat_lsap pairs,
+ * median or 10 px gate, matched candidates gathered into padded [K,.] arrays + mask; K <= 2048). */
+int neat_l3d(const float* x, const float* o, const float* d, const float* normal, int R, float* l3d, void* stream);
+int neat_junction_cost(const float* cand2d, const float* gt2d, int V, int C, float* cost, void* stream);
+int neat_junction_gate(const long long* rows, const long long* cols, int K, const float* cost, int C, const float* cand3d,
+                       const float* cand2d, const float* cand2d_calib, int use_median, float* median, unsigned char* good, float* j3d,
+                       float* j2d, float* j2d_calib, void* stream);
 /* the tail of VolSDFLoss.forward (model/networks/loss_wfr.py:68-137) as two launches around the junction matching (neat_lsap):
  * neat_loss_terms -> scal[0] = L1 rgb loss (mean), scal[1] = eikonal loss, d_rgb [R,3], d_gtheta [E,3] (cotangents for unit
  * upstream gradient), pair_cost [K,J] = cdist_1(loc3, glo3) + 0.1 cdist_1(loc2c, glo2c);

@@ -50,6 +50,10 @@ _SIGNATURES = {
     "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_ffn_forward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 10),
     "neat_ffn_backward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 15),
+    "neat_l3d": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
+    "neat_junction_cost": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "neat_junction_gate": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp,
+                                          c_fp, c_fp, c_fp]),
     "neat_loss_terms": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
                                        c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_loss_pairs": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp,

@@ -675,4 +675,83 @@ __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// More of the junction block (rend_a :441-489) as single launches:
+//   l3d_kernel        : t = <x - o, n> / (<d, n> +- 1e-6), l3d = o + t d   (intersection of the projected-pixel ray with the
+//                       tangent plane of the rendered surface point), per ray
+//   junction_cost_kernel : cost[v][c] = | cand2d[c] - gt2d[v] |_2   (the arithmetic of torch's ((a-b)**2).sum(-1).sqrt())
+//   junction_gate_kernel : matched cost per pair, (nan)median gate or the fixed 10 px gate, and the matched candidates
+//                       gathered into padded [K, .] arrays + mask (pairs beyond the device-side count: masked, zeros)
+// ---------------------------------------------------------------------------------------------
+__global__ void l3d_kernel(const float* __restrict__ x, const float* __restrict__ o, const float* __restrict__ d,
+                           const float* __restrict__ nrm, int R, float* __restrict__ l3d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float den = 0.0f, num = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { den += d[3 * r + c] * nrm[3 * r + c]; num += (x[3 * r + c] - o[3 * r + c]) * nrm[3 * r + c]; }
+  den += den >= 0.0f ? 1e-6f : -1e-6f;
+  const float t = num / den;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) l3d[3 * r + c] = o[3 * r + c] + d[3 * r + c] * t;
+}
+
+__global__ void junction_cost_kernel(const float* __restrict__ cand2d, const float* __restrict__ gt2d, int V, int C, float* __restrict__ cost) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= V * C) return;
+  const int v = idx / C, c = idx % C;
+  const float dx = cand2d[2 * c] - gt2d[2 * v], dy = cand2d[2 * c + 1] - gt2d[2 * v + 1];
+  cost[idx] = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+}
+
+struct JunctionGateArgs {
+  const long long* rows; const long long* cols; int K;         // pairs from neat_lsap (-1 = no pair)
+  const float* cost; int C;
+  const float* cand3d; const float* cand2d; const float* cand2dc;
+  int use_median;
+  float* median;                                                // [1] (use_median)
+  unsigned char* good;                                          // [K]
+  float* j3d; float* j2d; float* j2dc;                          // [K,3], [K,2], [K,2]
+};
+
+__global__ __launch_bounds__(1024) void junction_gate_kernel(JunctionGateArgs a) {
+  __shared__ float s_m[2048];
+  __shared__ int s_n;
+  __shared__ float s_med;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (tid == 0) { s_n = 0; s_med = 10.0f; }
+  __syncthreads();
+  for (int k = tid; k < a.K; k += nt) {
+    const long long r = a.rows[k], c = a.cols[k];
+    const bool ok = r >= 0 && c >= 0;
+    s_m[k] = ok ? a.cost[r * a.C + c] : NAN;
+    if (ok) atomicAdd(&s_n, 1);
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (a.use_median && n > 0) {               // lower median of the valid matched costs = element of rank (n-1)/2 (torch.median / nanmedian)
+    const int want = (n - 1) / 2;
+    for (int k = tid; k < a.K; k += nt) {
+      const float v = s_m[k];
+      if (v != v) continue;
+      int rank = 0;
+      for (int j = 0; j < a.K; ++j) { const float w = s_m[j]; if (w == w && (w < v || (w == v && j < k))) ++rank; }
+      if (rank == want) s_med = v;
+    }
+  }
+  __syncthreads();
+  const float thr = a.use_median ? s_med : 10.0f;
+  if (tid == 0 && a.use_median) a.median[0] = s_med;
+  for (int k = tid; k < a.K; k += nt) {
+    const float v = s_m[k];
+    const bool ok = v == v;
+    a.good[k] = (ok && v < thr) ? 1 : 0;
+    const long long c = ok ? a.cols[k] : 0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) a.j3d[3 * k + e] = ok ? a.cand3d[3 * c + e] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { a.j2d[2 * k + e] = ok ? a.cand2d[2 * c + e] : 0.0f; a.j2dc[2 * k + e] = ok ? a.cand2dc[2 * c + e] : 0.0f; }
+  }
+}
+
 }  // namespace neat

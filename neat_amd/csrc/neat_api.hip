@@ -1193,6 +1193,31 @@ int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match
   return (int)hipGetLastError();
 }
 
+int neat_l3d(const float* x, const float* o, const float* d, const float* normal, int R, float* l3d, void* stream) {
+  if (R <= 0) return 0;
+  if (!x || !o || !d || !normal || !l3d) return -1;
+  hipLaunchKernelGGL(l3d_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, o, d, normal, R, l3d);
+  return (int)hipGetLastError();
+}
+
+int neat_junction_cost(const float* cand2d, const float* gt2d, int V, int C, float* cost, void* stream) {
+  if (V <= 0 || C <= 0) return 0;
+  if (!cand2d || !gt2d || !cost) return -1;
+  hipLaunchKernelGGL(junction_cost_kernel, dim3((V * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, cand2d, gt2d, V, C, cost);
+  return (int)hipGetLastError();
+}
+
+int neat_junction_gate(const long long* rows, const long long* cols, int K, const float* cost, int C, const float* cand3d,
+                       const float* cand2d, const float* cand2d_calib, int use_median, float* median, unsigned char* good, float* j3d,
+                       float* j2d, float* j2d_calib, void* stream) {
+  if (K <= 0) return 0;
+  if (K > 2048 || !rows || !cols || !cost || !cand3d || !cand2d || !cand2d_calib || !good || !j3d || !j2d || !j2d_calib ||
+      (use_median && !median)) return -1;
+  JunctionGateArgs a{rows, cols, K, cost, C, cand3d, cand2d, cand2d_calib, use_median, median, good, j3d, j2d, j2d_calib};
+  hipLaunchKernelGGL(junction_gate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 int neat_inv_small(const float* A, int n, int lda, float* out, void* stream) {
   if (!A || !out || n < 1 || n > 4 || lda < n) return -1;
   hipLaunchKernelGGL(inv_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, n, lda, out);

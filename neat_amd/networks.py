@@ -361,10 +361,13 @@ class VolSDFNetwork(_HipModule):
         def l3d_block():
             p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
             l_dirs, l_orig = self._rays(input, "uv_proj")
-            den = (l_dirs * p3_grad).sum(-1)
-            den = den + torch.where(den >= 0, torch.full_like(den, 1e-6), torch.full_like(den, -1e-6))
-            t = (((points3d - l_orig) * p3_grad).sum(-1) / den).detach()
-            l3d = l_orig + l_dirs * t.unsqueeze(-1)
+            if points3d.is_cuda:          # plane intersection per ray: one launch
+                l3d = ops.l3d_points(points3d, l_orig, l_dirs, p3_grad)
+            else:
+                den = (l_dirs * p3_grad).sum(-1)
+                den = den + torch.where(den >= 0, torch.full_like(den, 1e-6), torch.full_like(den, -1e-6))
+                t = (((points3d - l_orig) * p3_grad).sum(-1) / den).detach()
+                l3d = l_orig + l_dirs * t.unsqueeze(-1)
             l3d_score = None
             if self.training and self.use_l3d:      # only the l3d candidate filter reads the score (rend_a :455-468)
                 with torch.no_grad():
@@ -431,38 +434,45 @@ class VolSDFNetwork(_HipModule):
                 cand2d = lines2d.reshape(-1, 2)
                 cand2d_calib = lines2d_calib.detach().reshape(-1, 2)
             gt2d = _device_copy(input["wireframe"][0], "vertices", cand2d.device)
-            cost = ((cand2d[None] - gt2d[:, None]) ** 2).sum(-1).sqrt()
+            fused_gate = cand2d.is_cuda and min(gt2d.shape[0], cand2d.shape[0]) <= 2048
+            cost = ops.junction_cost(cand2d, gt2d) if fused_gate else ((cand2d[None] - gt2d[:, None]) ** 2).sum(-1).sqrt()
             # Hungarian matching on the device (reference: scipy on the host, :473).  Without a candidate mask every gt
             # junction / candidate of the smaller side is matched, so the pair count min(V, C) is static; with the padded
             # DBSCAN centres the pairs beyond the device-side count come back as -1 and are masked out
             rows, cols, _ = ops.linear_sum_assignment(cost, None, cand_valid)
-            if cand_valid is None:
-                matched = cost[rows, cols]
-                pair_ok = None
+            if fused_gate:
+                # matched costs, median / 10 px gate and the gathered matched candidates: one launch (:474-489)
+                median, good, j3_pad, j2_pad, j2c_pad = ops.junction_gate(rows, cols, cost, cand3d, cand2d, cand2d_calib, self.use_median)
+                if self.use_median:
+                    output["median"] = median
             else:
-                pair_ok = rows >= 0
-                rows, cols = rows.clamp_min(0), cols.clamp_min(0)
-                matched = torch.where(pair_ok, cost[rows, cols], torch.full_like(cost[rows, cols], float("nan")))
-            if self.use_median:
-                if matched.numel() == 0:
-                    median = matched.new_tensor(10.0)
-                elif pair_ok is None:
-                    median = matched.detach().median()
+                if cand_valid is None:
+                    matched = cost[rows, cols]
+                    pair_ok = None
                 else:
-                    median = torch.nanmedian(matched.detach())
-                    median = torch.where(torch.isnan(median), torch.full_like(median, 10.0), median)
-                good = matched < median
-                output["median"] = median
-            else:
-                good = matched < 10
-            if pair_ok is not None:
-                good = good & pair_ok
+                    pair_ok = rows >= 0
+                    rows, cols = rows.clamp_min(0), cols.clamp_min(0)
+                    matched = torch.where(pair_ok, cost[rows, cols], torch.full_like(cost[rows, cols], float("nan")))
+                if self.use_median:
+                    if matched.numel() == 0:
+                        median = matched.new_tensor(10.0)
+                    elif pair_ok is None:
+                        median = matched.detach().median()
+                    else:
+                        median = torch.nanmedian(matched.detach())
+                        median = torch.where(torch.isnan(median), torch.full_like(median, 10.0), median)
+                    good = matched < median
+                    output["median"] = median
+                else:
+                    good = matched < 10
+                if pair_ok is not None:
+                    good = good & pair_ok
+                j2_pad, j3_pad, j2c_pad = cand2d[cols], cand3d[cols], cand2d_calib[cols]
             if side is not None:
                 main.wait_stream(side)          # join: the global junctions are needed from here on
             # the reference compacts with `[good]` (:478-489), a data-dependent shape; here the matched candidates stay
             # padded + mask (what neat_amd.loss reads) and the compact tensors are built only if somebody asks for them
-            output = JunctionOutputs(output, good, {"j2d_local": cand2d[cols], "j3d_local": cand3d[cols],
-                                                    "j2d_local_calib": cand2d_calib[cols]})
+            output = JunctionOutputs(output, good, {"j2d_local": j2_pad, "j3d_local": j3_pad, "j2d_local_calib": j2c_pad})
             output["j3d_global"] = j3d_global
             output["j2d_global"] = proj(K3c, j3d_global)
             output["j2d_global_calib"] = proj(eye, j3d_global)

@@ -500,3 +500,35 @@ class LossTailFn(torch.autograd.Function):
 def loss_tail(rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2):
     return LossTailFn.apply(rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good,
                             float(w_eik), float(w_line), float(w_j3), float(w_j2))
+
+
+def l3d_points(x, origins, dirs, normals):
+    """l3d = o + t d with t = <x - o, n> / (<d, n> +- 1e-6) per ray (rend_a :441-447), one launch, no gradient."""
+    x, o, d, n = (_f32c(t.detach().reshape(-1, 3)) for t in (x, origins, dirs, normals))
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().neat_l3d(_p(x), _p(o), _p(d), _p(n), x.shape[0], _p(out), _stream()), "neat_l3d")
+    return out
+
+
+def junction_cost(cand2d, gt2d):
+    """cost [V, C] = |cand2d[c] - gt2d[v]|_2 (rend_a :472), one launch."""
+    cand2d, gt2d = _f32c(cand2d.detach()), _f32c(gt2d.detach())
+    V, C = gt2d.shape[0], cand2d.shape[0]
+    cost = torch.empty(V, C, device=cand2d.device)
+    _lib.check(_lib.lib().neat_junction_cost(_p(cand2d), _p(gt2d), V, C, _p(cost), _stream()), "neat_junction_cost")
+    return cost
+
+
+def junction_gate(rows, cols, cost, cand3d, cand2d, cand2d_calib, use_median):
+    """Matched costs of the pairs, median / 10 px gate and the gathered matched candidates (rend_a :474-489), one launch.
+    -> median [1] or None, good [K] bool, j3d [K,3], j2d [K,2], j2d_calib [K,2] (padded: pairs that do not exist are masked)."""
+    K = rows.shape[0]
+    dev = cost.device
+    cand3d, cand2d, cand2d_calib = _f32c(cand3d.detach()), _f32c(cand2d.detach()), _f32c(cand2d_calib.detach())
+    median = torch.empty(1, device=dev) if use_median else None
+    good = torch.empty(K, device=dev, dtype=torch.uint8)
+    j3d, j2d, j2dc = torch.empty(K, 3, device=dev), torch.empty(K, 2, device=dev), torch.empty(K, 2, device=dev)
+    _lib.check(_lib.lib().neat_junction_gate(_p(rows), _p(cols), K, _p(cost), cost.shape[1], _p(cand3d), _p(cand2d), _p(cand2d_calib),
+                                             1 if use_median else 0, _p(median), _p(good), _p(j3d), _p(j2d), _p(j2dc), _stream()),
+               "neat_junction_gate")
+    return (median.reshape(()) if use_median else None), good.bool(), j3d, j2d, j2dc

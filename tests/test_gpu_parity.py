@@ -724,3 +724,49 @@ def test_fused_loss_tail_vs_torch_formulation(dev, use_median, R):
         assert (x is None) == (y is None)
         if x is not None:
             close(y, x, tol=1e-5, what="loss-tail gradient")
+
+
+def test_junction_block_kernels_vs_torch(dev):
+    """neat_l3d / neat_junction_cost / neat_junction_gate against the torch formulations they replace."""
+    from neat_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    R = 777
+    x, o = torch.randn(R, 3, generator=gen), torch.randn(R, 3, generator=gen)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    n = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    den = (d * n).sum(-1)
+    den = den + torch.where(den >= 0, torch.full_like(den, 1e-6), torch.full_like(den, -1e-6))
+    ref = o + d * (((x - o) * n).sum(-1) / den).unsqueeze(-1)
+    got = ops.l3d_points(x.to(dev), o.to(dev), d.to(dev), n.to(dev))
+    ok = den.abs() > 1e-3                       # (near-parallel rays amplify the last ulp of the denominator)
+    close(got[ok.to(dev)], ref[ok], tol=1e-5, what="l3d")
+    C, V = 500, 23
+    cand2d, gt2d = torch.rand(C, 2, generator=gen) * 512, torch.rand(V, 2, generator=gen) * 512
+    cost_ref = ((cand2d[None] - gt2d[:, None]) ** 2).sum(-1).sqrt()
+    cost = ops.junction_cost(cand2d.to(dev), gt2d.to(dev))
+    cost_dev = ((cand2d.to(dev)[None] - gt2d.to(dev)[:, None]) ** 2).sum(-1).sqrt()
+    assert float((cost - cost_dev).abs().max()) <= 1.3e-4 and float((cost.cpu() - cost_ref).abs().max()) <= 1.3e-4    # a few ulp at ~500 (torch's device sqrt is not correctly rounded)
+    cost_ref = cost.cpu()
+    cand3d, cand2dc = torch.randn(C, 3, generator=gen), torch.randn(C, 2, generator=gen)
+    for use_median in (True, False):
+        for drop in (0, 5):
+            rows = torch.arange(V)
+            cols = torch.randperm(C, generator=gen)[:V]
+            if drop:
+                rows, cols = rows.clone(), cols.clone()
+                rows[-drop:], cols[-drop:] = -1, -1
+            okp = rows >= 0
+            m = torch.where(okp, cost_ref[rows.clamp_min(0), cols.clamp_min(0)], torch.full((V,), float("nan")))
+            if use_median:
+                med = torch.nanmedian(m)
+                good_ref = (m < med) & okp
+            else:
+                good_ref = (m < 10) & okp
+            median, good, j3, j2, j2c = ops.junction_gate(rows.to(dev), cols.to(dev), cost, cand3d.to(dev), cand2d.to(dev), cand2dc.to(dev),
+                                                          use_median)
+            if use_median:
+                assert float(median) == float(med)
+            assert torch.equal(good.cpu(), good_ref)
+            sel = okp
+            assert torch.equal(j3.cpu()[sel], cand3d[cols[sel]]) and torch.equal(j2.cpu()[sel], cand2d[cols[sel]])
+            assert torch.equal(j2c.cpu()[sel], cand2dc[cols[sel]]) and float(j3.cpu()[~sel].abs().sum()) == 0.0
