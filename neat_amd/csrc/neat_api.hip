@@ -159,6 +159,7 @@ template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a
   if (a.out0_bf16) return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4, true>(st, a) : launch_layer_h_pt<EPI, 2, true>(st, a);
   return launch_layer_h_pt<EPI, 2, false>(st, a);
 }
+int g_wgrad_batch = 1;      // the two heads' hidden-layer weight gradients in one launch per layer (half the partial tiles)
 int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
 int g_wreduce_direct = 0;   // bf16 weight-gradient reduction: 0 = group sums + finish (faster: 4.43 vs 4.63 ms/step), 1 = one 16-wave pass per row
 int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persistent kernel, 0 = sdf_fused_kernel_h
@@ -548,6 +549,66 @@ void oct_pack(const Ctx& c, std::initializer_list<PackJob> jobs) {
 }
 inline bool oct_operands(const Ctx& c) { return c.prec && g_wgrad_h3; }
 
+// second half of a weight gradient: deterministic reduction of the split partials described by `r` (partial, splits, strides),
+// un-permutation of the packed columns and the weight-norm backward into dv / dg / db of `layer_id`
+hipError_t wgrad_reduce(const Ctx& c, const SdfWs& w, int layer_id, WreduceArgs r, int Nred, int N, int K, const neat_net_grads* gr) {
+  const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
+  const int splits = r.splits;
+  const float* partial = r.partial;
+  const bool direct = c.prec && g_wreduce_direct;          // bf16 build: one 16-wave pass over all split partials
+  if (splits > 2 * WGROUPS && !direct) {
+    // two-stage, deterministic: bandwidth-bound group sums first, then the per-row finish on 8 partials
+    const int Kld = (int)r.split_stride, per = (splits + WGROUPS - 1) / WGROUPS;
+    float* stage = w.partial + (WPARTIAL_FLOATS - WSTAGE_FLOATS);
+    hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld / 4 + 127) / 128, WGROUPS, Nred), dim3(128), 0, c.st,
+                       partial, splits, Kld / 4, WGROUPS, per, Nred, stage);
+    r.partial = stage; r.splits = (splits + per - 1) / per;
+    r.row_stride = (size_t)WGROUPS * Kld; r.split_stride = Kld;
+  }
+  r.O = kO[layer_id]; r.I = kI[layer_id];
+  r.s0 = d.s0; r.s0p = d.s0p; r.off0 = d.off0; r.off1 = d.off1; r.rot = d.rot; r.scale = d.scale;
+  r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
+  r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
+  r.bias_col = K;
+  dbg_sync(c.st, "wgrad layer/N/K", layer_id, N, K);
+  if (direct && splits > 2 * WGROUPS) hipLaunchKernelGGL(wreduce_wnorm_kernel<16>, dim3(r.O), dim3(1024), 0, c.st, r);
+  else hipLaunchKernelGGL(wreduce_wnorm_kernel<4>, dim3(r.O), dim3(WG), 0, c.st, r);
+  dbg_sync(c.st, "wreduce layer/splits", layer_id, splits, 0);
+  return hipGetLastError();
+}
+
+// two same-shaped single-pair weight gradients (256 x 256, all bf16 octet-major: the hidden layers of the two heads) in ONE
+// launch of wgrad_kernel_h3: each problem gets half of the workgroups and twice the points per workgroup, so the machine is
+// as full as with one problem but only half the fp32 partial tiles are written and reduced
+hipError_t wgrad_two(const Ctx& c, const SdfWs& w, const int layer_id[2], const Arr A[2], const Arr B[2], const neat_net_grads* gr) {
+  if (!gr->dv[layer_id[0]] || !gr->dv[layer_id[1]]) return hipErrorInvalidValue;
+  const int N = 256, K = 256, Kld2 = (K + 1 + 7) / 8 * 8;
+  int chunk = ((c.ldp + W2SPLIT / 2 - 1) / (W2SPLIT / 2) + W3P - 1) / W3P * W3P;
+  if (chunk < 2 * W3P) chunk = 2 * W3P;
+  const int splits = (c.P + chunk - 1) / chunk;
+  const size_t region = (size_t)N * splits * Kld2;
+  if (2 * region > WPARTIAL_FLOATS - WSTAGE_FLOATS) return hipErrorInvalidValue;
+  WgradArgsH3 a{};
+  for (int q = 0; q < 2; ++q) {
+    a.A[q] = reinterpret_cast<const unsigned short*>(A[q].p); a.B[q] = reinterpret_cast<const unsigned short*>(B[q].p);
+    a.B2[q] = nullptr; a.rowsA[q] = 256;
+  }
+  a.splitB = 32; a.octsB = 32; a.npairs = 1; a.N = N; a.K = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
+  a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.col_off = 0; a.bias_col = K;
+  a.nprob = 2; a.prob_stride = region;
+  const double P = (double)c.P;
+  ProfSlot* ps = prof_begin(c.st, 1, 2.0 * 2.0 * N * K * P, 2.0 * (2.0 * 256 * P * 2.0 + (double)splits * N * (K + 1) * 4.0));
+  hipLaunchKernelGGL(wgrad_kernel_h3, dim3(2, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
+  prof_end(c.st, ps);
+  hipError_t e = hipGetLastError();
+  for (int q = 0; q < 2 && e == hipSuccess; ++q) {
+    WreduceArgs r{};
+    r.partial = w.partial + q * region; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
+    e = wgrad_reduce(c, w, layer_id[q], r, N, N, K, gr);
+  }
+  return e;
+}
+
 struct RowDot { const float* s; Arr B0, B1; };     // one more gradient row: sum_p s[p] B0[k][p] + B1[k][p] (the sdf row of lin8)
 
 hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_in, int npairs, int N, const neat_net_grads* gr,
@@ -671,26 +732,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     Nred = N + 1;
   }
   r.partial = w.partial; r.splits = splits;
-  const bool direct = c.prec && g_wreduce_direct;          // bf16 build: one 16-wave pass over all split partials
-  if (splits > 2 * WGROUPS && !direct) {
-    // two-stage, deterministic: bandwidth-bound group sums first, then the per-row finish on 8 partials
-    const int Kld = (int)r.split_stride, per = (splits + WGROUPS - 1) / WGROUPS;
-    float* stage = w.partial + (WPARTIAL_FLOATS - WSTAGE_FLOATS);
-    hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld / 4 + 127) / 128, WGROUPS, Nred), dim3(128), 0, c.st,
-                       w.partial, splits, Kld / 4, WGROUPS, per, Nred, stage);
-    r.partial = stage; r.splits = (splits + per - 1) / per;
-    r.row_stride = (size_t)WGROUPS * Kld; r.split_stride = Kld;
-  }
-  r.O = kO[layer_id]; r.I = kI[layer_id];
-  r.s0 = d.s0; r.s0p = d.s0p; r.off0 = d.off0; r.off1 = d.off1; r.rot = d.rot; r.scale = d.scale;
-  r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
-  r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
-  r.bias_col = K;
-  dbg_sync(c.st, "wgrad layer/N/K", layer_id, N, K);
-  if (direct && splits > 2 * WGROUPS) hipLaunchKernelGGL(wreduce_wnorm_kernel<16>, dim3(r.O), dim3(1024), 0, c.st, r);
-  else hipLaunchKernelGGL(wreduce_wnorm_kernel<4>, dim3(r.O), dim3(WG), 0, c.st, r);
-  dbg_sync(c.st, "wreduce layer/splits", layer_id, splits, 0);
-  return hipGetLastError();
+  return wgrad_reduce(c, w, layer_id, r, Nred, N, K, gr);
 }
 
 // double backward + backward: w.gh (cotangent of normals, masked) and w.abar8 (cotangent of lin8 output) are set
@@ -812,7 +854,29 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
                      Arr{}, Arr{}, 0, 0, 1 << 30, nullptr, 0, 8)) != hipSuccess) return e;
     } else if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, 256 + srows, F(w.abar8 + c.ldp),
                           F(head ? h.sc_a : h.sc_r), 256, Arr{}, Arr{}, head)) != hipSuccess) return e;
+  }
+  // weight gradients; the hidden layers l = 1..3 of the two heads have identical shapes: one launch per layer for both
+  const bool batch = oct && g_wgrad_batch && g_wgrad_h3;
+  static bool attr3 = false;
+  if (batch && !attr3) {
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES)) != hipSuccess) return e;
+    attr3 = true;
+  }
+  if (batch)
+    for (int l = 1; l <= 3; ++l) {
+      const int ids[2] = {L_REND + l, L_ATTR + l};
+      const Arr A[2] = {h.ar[l], h.aa[l]}, B[2] = {h.hr[l], h.ha[l]};
+      if ((e = wgrad_two(c, w, ids, A, B, gr)) != hipSuccess) return e;
+    }
+  for (int head = 0; head < 2; ++head) {
+    const int base = head ? L_ATTR : L_REND;
+    const Arr* hh = head ? h.ha : h.hr;
+    const Arr* ab = head ? h.aa : h.ar;
+    const float* top = head ? h.dlin : h.zrgb;
+    const float* small = head ? h.small_a : h.small_r;
+    const int srows = head ? SMALL_A : SMALL_R;
     for (int l = 0; l <= 4; ++l) {
+      if (batch && l >= 1 && l <= 3) continue;
       WPair pr[1] = {};
       pr[0].A = l == 4 ? (oct ? (head ? h.topbf_a : h.topbf_r) : F(top)) : ab[l]; pr[0].rowsA = kO[base + l];
       if (l == 0) {
@@ -905,6 +969,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 4 && (value == 0 || value == 1)) { g_fused_ws = value; return 0; }
   if (key == 6 && (value == 0 || value == 1)) { g_wreduce_direct = value; return 0; }
   if (key == 7 && (value == 0 || value == 1)) { g_wgrad_interleave = value; return 0; }
+  if (key == 8 && (value == 0 || value == 1)) { g_wgrad_batch = value; return 0; }
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   return -1;
 }

@@ -395,9 +395,15 @@ def test_bf16_wgrad_kernels_agree(dev, R, S):
 
     try:
         g2, g3 = grads(0), grads(1)
+        _lib.check(_lib.lib().neat_set_tuning(8, 0), "neat_set_tuning")      # the two heads' hidden layers as separate launches
+        g3_single = grads(1)
     finally:
         _lib.lib().neat_set_tuning(1, 1)
+        _lib.lib().neat_set_tuning(8, 1)
     assert len(g3) >= 57
+    for k in g3:      # batched (two problems per launch, half the splits) vs separate launches: summation order only
+        err = float((g3[k] - g3_single[k]).abs().max())
+        assert err <= 2e-5 * float(g3_single[k].abs().max()) + 1e-12, (k, err)
     for k in g2:
         assert torch.isfinite(g3[k]).all(), k
         err = float((g3[k] - g2[k]).abs().max())
