@@ -1235,13 +1235,13 @@ constexpr int W3T = 512, W3P = 32, W3NS = 4;
 constexpr int W3_STAGE = 2 * 256 * W3P * 2;          // bytes per stage: A | B, each 8 quads x 32 points x 64 B
 constexpr int W3_LDS_BYTES = W3NS * W3_STAGE;
 struct WgradArgsH3 {
-  const unsigned short* A[2]; const unsigned short* B[2]; int rowsA[2];
-  const unsigned short* B2[2];       // octets >= splitB of the B operand come from B2 (skip layer: [h4 | PE]); 32 = none
+  const unsigned short* A[4]; const unsigned short* B[4]; int rowsA[4];     // operand set of (problem p, pair q) at index p * npairs + q
+  const unsigned short* B2[4];       // octets >= splitB of the B operand come from B2 (skip layer: [h4 | PE]); 32 = none
   int splitB, octsB;                 // octets of B in total (K = packed columns <= 256)
   int npairs, N, K, P, ldp, chunk;
   float* partial; size_t row_stride, split_stride; int col_off, bias_col;   // partial column of B column 0 / of the bias (-1: none)
-  int nprob; size_t prob_stride;     // nprob = 2 (grid.x = 2): two INDEPENDENT single-pair problems, operand set = blockIdx.x, partials
-                                     // of problem 1 at partial + prob_stride (the two heads' hidden layers in one launch)
+  int nprob; size_t prob_stride;     // nprob = 2 (grid.x = 2): two INDEPENDENT problems of npairs pairs each, problem = blockIdx.x, partials
+                                     // of problem 1 at partial + prob_stride (two same-shaped layers in one launch: half the partial tiles)
 };
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
@@ -1255,8 +1255,8 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   const int pbeg = blockIdx.y * a.chunk;
   const int pend = min(a.P, pbeg + a.chunk);
   const int nsteps = (pend - pbeg + W3P - 1) / W3P;
-  const int prob = a.nprob == 2 ? (int)blockIdx.x : 0;            // independent-problems mode: one pair each
-  const int T = a.nprob == 2 ? nsteps : nsteps * a.npairs;
+  const int prob = a.nprob == 2 ? (int)blockIdx.x : 0;
+  const int T = nsteps * a.npairs;
   bool liveR[2], liveC[4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) liveR[i] = wr + 32 * i < a.N;
@@ -1278,11 +1278,14 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   // `s_waitcnt vmcnt(0)` in front of every ds_read that follows an LDS-DMA and the ring never holds more than one stage.
   const unsigned lds_base = (unsigned)(size_t)(lds_ptr)w3lds;
   auto issue = [&](int tau) {
-    const int q = a.nprob == 2 ? prob : (tau >= nsteps ? 1 : 0);
-    const int st = a.nprob == 2 ? tau : tau - q * nsteps;
-    const unsigned short* base = dop ? (q ? a.B[1] : a.B[0]) : (q ? a.A[1] : a.A[0]);
-    const unsigned short* base2 = q ? a.B2[1] : a.B2[0];
-    const int maxoct = dop ? a.octsB - 1 : ((q ? a.rowsA[1] : a.rowsA[0]) + 7) / 8 - 1;
+    const int q = tau >= nsteps ? 1 : 0;
+    const int st = tau - q * nsteps;
+    const int idx = prob * a.npairs + q;            // compile-time kernarg indices only: 4-way selects
+#define W3_SEL(arr) (idx == 0 ? a.arr[0] : (idx == 1 ? a.arr[1] : (idx == 2 ? a.arr[2] : a.arr[3])))
+    const unsigned short* base = dop ? W3_SEL(B) : W3_SEL(A);
+    const unsigned short* base2 = W3_SEL(B2);
+    const int maxoct = dop ? a.octsB - 1 : (W3_SEL(rowsA) + 7) / 8 - 1;
+#undef W3_SEL
     const unsigned slot = lds_base + (tau % W3NS) * W3_STAGE + dop * (W3_STAGE / 2);
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {
@@ -1317,10 +1320,10 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (tau + W3NS - 1 < T) issue(tau + W3NS - 1);
     const unsigned char* slot = w3lds + (tau % W3NS) * W3_STAGE;
-    const int st = (a.nprob != 2 && tau >= nsteps) ? tau - nsteps : tau;
+    const int st = tau >= nsteps ? tau - nsteps : tau;
     const int pb = pbeg + st * W3P;
     const bool tail = pb + W3P > pend;
-    const bool bias_now = do_bias && (a.nprob == 2 || tau < nsteps);
+    const bool bias_now = do_bias && tau < nsteps;
 #pragma unroll
     for (int s2 = 0; s2 < W3P / 16; ++s2) {
       uint4 av[2], bv[4];

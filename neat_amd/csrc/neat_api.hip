@@ -577,34 +577,46 @@ hipError_t wgrad_reduce(const Ctx& c, const SdfWs& w, int layer_id, WreduceArgs 
   return hipGetLastError();
 }
 
-// two same-shaped single-pair weight gradients (256 x 256, all bf16 octet-major: the hidden layers of the two heads) in ONE
-// launch of wgrad_kernel_h3: each problem gets half of the workgroups and twice the points per workgroup, so the machine is
-// as full as with one problem but only half the fp32 partial tiles are written and reduced
-hipError_t wgrad_two(const Ctx& c, const SdfWs& w, const int layer_id[2], const Arr A[2], const Arr B[2], const neat_net_grads* gr) {
-  if (!gr->dv[layer_id[0]] || !gr->dv[layer_id[1]]) return hipErrorInvalidValue;
+// two same-shaped weight gradients (K = 256 bf16 octet-major operands, up to two pairs each: hidden layers of the two heads, or two
+// hidden SDF layers) in ONE launch of wgrad_kernel_h3: each problem gets half of the workgroups and twice the points per
+// workgroup, so the machine is as full as with one problem but only half the fp32 partial tiles are written and reduced
+struct WProb { int layer_id; Arr A[2]; int rowsA[2]; Arr B[2]; };
+hipError_t wgrad_two(const Ctx& c, const SdfWs& w, const WProb (&pb)[2], int npairs, const neat_net_grads* gr) {
+  if (!gr->dv[pb[0].layer_id] || !gr->dv[pb[1].layer_id] || npairs < 1 || npairs > 2) return hipErrorInvalidValue;
   const int N = 256, K = 256, Kld2 = (K + 1 + 7) / 8 * 8;
   int chunk = ((c.ldp + W2SPLIT / 2 - 1) / (W2SPLIT / 2) + W3P - 1) / W3P * W3P;
   if (chunk < 2 * W3P) chunk = 2 * W3P;
   const int splits = (c.P + chunk - 1) / chunk;
   const size_t region = (size_t)N * splits * Kld2;
   if (2 * region > WPARTIAL_FLOATS - WSTAGE_FLOATS) return hipErrorInvalidValue;
-  WgradArgsH3 a{};
-  for (int q = 0; q < 2; ++q) {
-    a.A[q] = reinterpret_cast<const unsigned short*>(A[q].p); a.B[q] = reinterpret_cast<const unsigned short*>(B[q].p);
-    a.B2[q] = nullptr; a.rowsA[q] = 256;
+  static bool attr3 = false;
+  if (!attr3) {
+    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+    if (e0 != hipSuccess) return e0;
+    attr3 = true;
   }
-  a.splitB = 32; a.octsB = 32; a.npairs = 1; a.N = N; a.K = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
+  WgradArgsH3 a{};
+  double flops = 0.0, bytes = 0.0;
+  for (int p = 0; p < 2; ++p)
+    for (int q = 0; q < npairs; ++q) {
+      if (!pb[p].A[q].bf16 || !pb[p].B[q].bf16 || pb[p].rowsA[q] > 256) return hipErrorInvalidValue;
+      const int i = p * npairs + q;
+      a.A[i] = reinterpret_cast<const unsigned short*>(pb[p].A[q].p); a.B[i] = reinterpret_cast<const unsigned short*>(pb[p].B[q].p);
+      a.B2[i] = nullptr; a.rowsA[i] = pb[p].rowsA[q];
+      flops += 2.0 * pb[p].rowsA[q] * 256.0 * (double)c.P;
+      bytes += (pb[p].rowsA[q] + 256.0) * (double)c.P * 2.0;
+    }
+  a.splitB = 32; a.octsB = 32; a.npairs = npairs; a.N = N; a.K = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
   a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.col_off = 0; a.bias_col = K;
   a.nprob = 2; a.prob_stride = region;
-  const double P = (double)c.P;
-  ProfSlot* ps = prof_begin(c.st, 1, 2.0 * 2.0 * N * K * P, 2.0 * (2.0 * 256 * P * 2.0 + (double)splits * N * (K + 1) * 4.0));
+  ProfSlot* ps = prof_begin(c.st, 1, flops, bytes + 2.0 * (double)splits * N * (K + 1) * 4.0);
   hipLaunchKernelGGL(wgrad_kernel_h3, dim3(2, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
   prof_end(c.st, ps);
   hipError_t e = hipGetLastError();
   for (int q = 0; q < 2 && e == hipSuccess; ++q) {
     WreduceArgs r{};
     r.partial = w.partial + q * region; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
-    e = wgrad_reduce(c, w, layer_id[q], r, N, N, K, gr);
+    e = wgrad_reduce(c, w, pb[q].layer_id, r, N, N, K, gr);
   }
   return e;
 }
@@ -799,8 +811,22 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     if ((e = layer(c, L.tr[l], EPI_BWD, in(w.m[l], kO[l]), NOIN, nullptr, N, w.m[l - 1], Arr{}, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
   }
   if (inter) return wgrad_layer(0);
+  bool done[9] = {};
+  if (oct && g_wgrad_batch && g_wgrad_h3) {
+    // hidden layers with 256 packed input columns in pairs: two layers per launch, two (A, B) pairs each
+    const int pairs[3][2] = {{1, 2}, {5, 6}, {7, 3}};
+    for (const auto& pq : pairs) {
+      WProb pb[2];
+      for (int t = 0; t < 2; ++t) {
+        const int l = pq[t];
+        pb[t] = WProb{l, {w.m[l], w.u[l]}, {kO[l], kO[l]}, {w.h[l], w.vh[l]}};
+        done[l] = true;
+      }
+      if ((e = wgrad_two(c, w, pb, 2, gr)) != hipSuccess) return e;
+    }
+  }
   for (int l = 0; l <= 8; ++l)
-    if ((e = wgrad_layer(l)) != hipSuccess) return e;
+    if (!done[l] && (e = wgrad_layer(l)) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -857,16 +883,10 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
   }
   // weight gradients; the hidden layers l = 1..3 of the two heads have identical shapes: one launch per layer for both
   const bool batch = oct && g_wgrad_batch && g_wgrad_h3;
-  static bool attr3 = false;
-  if (batch && !attr3) {
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES)) != hipSuccess) return e;
-    attr3 = true;
-  }
   if (batch)
     for (int l = 1; l <= 3; ++l) {
-      const int ids[2] = {L_REND + l, L_ATTR + l};
-      const Arr A[2] = {h.ar[l], h.aa[l]}, B[2] = {h.hr[l], h.ha[l]};
-      if ((e = wgrad_two(c, w, ids, A, B, gr)) != hipSuccess) return e;
+      const WProb pb[2] = {{L_REND + l, {h.ar[l], Arr{}}, {256, 0}, {h.hr[l], Arr{}}}, {L_ATTR + l, {h.aa[l], Arr{}}, {256, 0}, {h.ha[l], Arr{}}}};
+      if ((e = wgrad_two(c, w, pb, 1, gr)) != hipSuccess) return e;
     }
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
