@@ -1234,14 +1234,15 @@ __global__ void oct_pack_kernel(OctPackArgs a) {
 constexpr int W3T = 512, W3P = 32, W3NS = 4;
 constexpr int W3_STAGE = 2 * 256 * W3P * 2;          // bytes per stage: A | B, each 8 quads x 32 points x 64 B
 constexpr int W3_LDS_BYTES = W3NS * W3_STAGE;
+constexpr int W3_SLOTS = 12;         // up to 6 problems x 2 pairs per launch
 struct WgradArgsH3 {
-  const unsigned short* A[4]; const unsigned short* B[4]; int rowsA[4];     // operand set of (problem p, pair q) at index p * npairs + q
-  const unsigned short* B2[4];       // octets >= splitB of the B operand come from B2 (skip layer: [h4 | PE]); 32 = none
+  const unsigned short* A[W3_SLOTS]; const unsigned short* B[W3_SLOTS]; int rowsA[W3_SLOTS];   // operand set of (problem p, pair q) at p * npairs + q
+  const unsigned short* B2[W3_SLOTS];  // octets >= splitB of the B operand come from B2 (skip layer: [h4 | PE]); 32 = none
   int splitB, octsB;                 // octets of B in total (K = packed columns <= 256)
   int npairs, N, K, P, ldp, chunk;
   float* partial; size_t row_stride, split_stride; int col_off, bias_col;   // partial column of B column 0 / of the bias (-1: none)
-  int nprob; size_t prob_stride;     // nprob = 2 (grid.x = 2): two INDEPENDENT problems of npairs pairs each, problem = blockIdx.x, partials
-                                     // of problem 1 at partial + prob_stride (two same-shaped layers in one launch: half the partial tiles)
+  int nprob; size_t prob_stride;     // nprob > 1 (grid.x = nprob): INDEPENDENT problems of npairs pairs each, problem p = blockIdx.x, its partials
+                                     // at partial + p * prob_stride (same-shaped layers in one launch: 1/nprob of the partial tiles per layer)
 };
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
@@ -1255,7 +1256,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   const int pbeg = blockIdx.y * a.chunk;
   const int pend = min(a.P, pbeg + a.chunk);
   const int nsteps = (pend - pbeg + W3P - 1) / W3P;
-  const int prob = a.nprob == 2 ? (int)blockIdx.x : 0;
+  const int prob = a.nprob > 1 ? (int)blockIdx.x : 0;
   const int T = nsteps * a.npairs;
   bool liveR[2], liveC[4];
 #pragma unroll
@@ -1277,15 +1278,25 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   // The DMA is issued from inline asm so that hipcc's waitcnt pass does not know about it: otherwise it puts
   // `s_waitcnt vmcnt(0)` in front of every ds_read that follows an LDS-DMA and the ring never holds more than one stage.
   const unsigned lds_base = (unsigned)(size_t)(lds_ptr)w3lds;
+  // operand set of (this problem, pair q) for this wave's DMA role, selected ONCE with compile-time kernarg indices (a runtime
+  // index would go through scratch; selecting inside the streaming loop costs ~150 scalar instructions per stage)
+  const unsigned short* opbase[2]; const unsigned short* opbase2[2]; int opmax[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = prob * a.npairs + q;
+    const unsigned short* pA = a.A[0]; const unsigned short* pB = a.B[0]; const unsigned short* p2 = a.B2[0];
+    int rA = a.rowsA[0];
+#pragma unroll
+    for (int k = 1; k < W3_SLOTS; ++k)
+      if (idx == k) { pA = a.A[k]; pB = a.B[k]; p2 = a.B2[k]; rA = a.rowsA[k]; }
+    opbase[q] = dop ? pB : pA; opbase2[q] = p2; opmax[q] = dop ? a.octsB - 1 : (rA + 7) / 8 - 1;
+  }
   auto issue = [&](int tau) {
     const int q = tau >= nsteps ? 1 : 0;
     const int st = tau - q * nsteps;
-    const int idx = prob * a.npairs + q;            // compile-time kernarg indices only: 4-way selects
-#define W3_SEL(arr) (idx == 0 ? a.arr[0] : (idx == 1 ? a.arr[1] : (idx == 2 ? a.arr[2] : a.arr[3])))
-    const unsigned short* base = dop ? W3_SEL(B) : W3_SEL(A);
-    const unsigned short* base2 = W3_SEL(B2);
-    const int maxoct = dop ? a.octsB - 1 : (W3_SEL(rowsA) + 7) / 8 - 1;
-#undef W3_SEL
+    const unsigned short* base = q ? opbase[1] : opbase[0];
+    const unsigned short* base2 = q ? opbase2[1] : opbase2[0];
+    const int maxoct = q ? opmax[1] : opmax[0];
     const unsigned slot = lds_base + (tau % W3NS) * W3_STAGE + dop * (W3_STAGE / 2);
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {

@@ -159,7 +159,7 @@ template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a
   if (a.out0_bf16) return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4, true>(st, a) : launch_layer_h_pt<EPI, 2, true>(st, a);
   return launch_layer_h_pt<EPI, 2, false>(st, a);
 }
-int g_wgrad_batch = 1;      // the two heads' hidden-layer weight gradients in one launch per layer (half the partial tiles)
+int g_wgrad_batch = 3;      // same-shaped hidden-layer weight gradients per launch (0 = one launch per layer; 2, 3 or 6 problems)
 int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
 int g_wreduce_direct = 0;   // bf16 weight-gradient reduction: 0 = group sums + finish (faster: 4.43 vs 4.63 ms/step), 1 = one 16-wave pass per row
 int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persistent kernel, 0 = sdf_fused_kernel_h
@@ -577,18 +577,21 @@ hipError_t wgrad_reduce(const Ctx& c, const SdfWs& w, int layer_id, WreduceArgs 
   return hipGetLastError();
 }
 
-// two same-shaped weight gradients (K = 256 bf16 octet-major operands, up to two pairs each: hidden layers of the two heads, or two
-// hidden SDF layers) in ONE launch of wgrad_kernel_h3: each problem gets half of the workgroups and twice the points per
-// workgroup, so the machine is as full as with one problem but only half the fp32 partial tiles are written and reduced
+// several same-shaped weight gradients (K = 256 bf16 octet-major operands, up to two pairs each: hidden layers of the two heads,
+// hidden SDF layers) in ONE launch of wgrad_kernel_h3: each of the nprob problems gets 1/nprob of the workgroups and nprob times
+// the points per workgroup, so the machine is as full as with one problem but only 1/nprob of the fp32 partial tiles per layer
+// are written and reduced
 struct WProb { int layer_id; Arr A[2]; int rowsA[2]; Arr B[2]; };
-hipError_t wgrad_two(const Ctx& c, const SdfWs& w, const WProb (&pb)[2], int npairs, const neat_net_grads* gr) {
-  if (!gr->dv[pb[0].layer_id] || !gr->dv[pb[1].layer_id] || npairs < 1 || npairs > 2) return hipErrorInvalidValue;
+hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob, int npairs, const neat_net_grads* gr) {
+  if (nprob < 2 || npairs < 1 || npairs > 2 || nprob * npairs > W3_SLOTS) return hipErrorInvalidValue;
+  for (int p = 0; p < nprob; ++p) if (!gr->dv[pb[p].layer_id]) return hipErrorInvalidValue;
   const int N = 256, K = 256, Kld2 = (K + 1 + 7) / 8 * 8;
-  int chunk = ((c.ldp + W2SPLIT / 2 - 1) / (W2SPLIT / 2) + W3P - 1) / W3P * W3P;
+  const int per_prob = (W2SPLIT + nprob - 1) / nprob;
+  int chunk = ((c.ldp + per_prob - 1) / per_prob + W3P - 1) / W3P * W3P;
   if (chunk < 2 * W3P) chunk = 2 * W3P;
   const int splits = (c.P + chunk - 1) / chunk;
   const size_t region = (size_t)N * splits * Kld2;
-  if (2 * region > WPARTIAL_FLOATS - WSTAGE_FLOATS) return hipErrorInvalidValue;
+  if ((size_t)nprob * region > WPARTIAL_FLOATS - WSTAGE_FLOATS) return hipErrorInvalidValue;
   static bool attr3 = false;
   if (!attr3) {
     hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
@@ -597,7 +600,7 @@ hipError_t wgrad_two(const Ctx& c, const SdfWs& w, const WProb (&pb)[2], int npa
   }
   WgradArgsH3 a{};
   double flops = 0.0, bytes = 0.0;
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < nprob; ++p)
     for (int q = 0; q < npairs; ++q) {
       if (!pb[p].A[q].bf16 || !pb[p].B[q].bf16 || pb[p].rowsA[q] > 256) return hipErrorInvalidValue;
       const int i = p * npairs + q;
@@ -608,12 +611,12 @@ hipError_t wgrad_two(const Ctx& c, const SdfWs& w, const WProb (&pb)[2], int npa
     }
   a.splitB = 32; a.octsB = 32; a.npairs = npairs; a.N = N; a.K = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
   a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.col_off = 0; a.bias_col = K;
-  a.nprob = 2; a.prob_stride = region;
-  ProfSlot* ps = prof_begin(c.st, 1, flops, bytes + 2.0 * (double)splits * N * (K + 1) * 4.0);
-  hipLaunchKernelGGL(wgrad_kernel_h3, dim3(2, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
+  a.nprob = nprob; a.prob_stride = region;
+  ProfSlot* ps = prof_begin(c.st, 1, flops, bytes + (double)nprob * splits * N * (K + 1) * 4.0);
+  hipLaunchKernelGGL(wgrad_kernel_h3, dim3(nprob, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
   prof_end(c.st, ps);
   hipError_t e = hipGetLastError();
-  for (int q = 0; q < 2 && e == hipSuccess; ++q) {
+  for (int q = 0; q < nprob && e == hipSuccess; ++q) {
     WreduceArgs r{};
     r.partial = w.partial + q * region; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
     e = wgrad_reduce(c, w, pb[q].layer_id, r, N, N, K, gr);
@@ -813,17 +816,16 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   if (inter) return wgrad_layer(0);
   bool done[9] = {};
   if (oct && g_wgrad_batch && g_wgrad_h3) {
-    // hidden layers with 256 packed input columns in pairs: two layers per launch, two (A, B) pairs each
-    const int pairs[3][2] = {{1, 2}, {5, 6}, {7, 3}};
-    for (const auto& pq : pairs) {
-      WProb pb[2];
-      for (int t = 0; t < 2; ++t) {
-        const int l = pq[t];
-        pb[t] = WProb{l, {w.m[l], w.u[l]}, {kO[l], kO[l]}, {w.h[l], w.vh[l]}};
-        done[l] = true;
-      }
-      if ((e = wgrad_two(c, w, pb, 2, gr)) != hipSuccess) return e;
+    // the six hidden layers with 256 packed input columns as six problems (two (A, B) pairs each) of one launch
+    const int ls[6] = {1, 2, 3, 5, 6, 7};
+    WProb pb[6];
+    for (int t = 0; t < 6; ++t) {
+      const int l = ls[t];
+      pb[t] = WProb{l, {w.m[l], w.u[l]}, {kO[l], kO[l]}, {w.h[l], w.vh[l]}};
+      done[l] = true;
     }
+    for (int t = 0; t < 6; t += g_wgrad_batch)
+      if ((e = wgrad_multi(c, w, pb + t, g_wgrad_batch, 2, gr)) != hipSuccess) return e;
   }
   for (int l = 0; l <= 8; ++l)
     if (!done[l] && (e = wgrad_layer(l)) != hipSuccess) return e;
@@ -883,11 +885,15 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
   }
   // weight gradients; the hidden layers l = 1..3 of the two heads have identical shapes: one launch per layer for both
   const bool batch = oct && g_wgrad_batch && g_wgrad_h3;
-  if (batch)
+  if (batch) {                    // 3 hidden layers x 2 heads: six single-pair problems, g_wgrad_batch per launch
+    WProb pb[6];
     for (int l = 1; l <= 3; ++l) {
-      const WProb pb[2] = {{L_REND + l, {h.ar[l], Arr{}}, {256, 0}, {h.hr[l], Arr{}}}, {L_ATTR + l, {h.aa[l], Arr{}}, {256, 0}, {h.ha[l], Arr{}}}};
-      if ((e = wgrad_two(c, w, pb, 1, gr)) != hipSuccess) return e;
+      pb[2 * (l - 1)] = WProb{L_REND + l, {h.ar[l], Arr{}}, {256, 0}, {h.hr[l], Arr{}}};
+      pb[2 * (l - 1) + 1] = WProb{L_ATTR + l, {h.aa[l], Arr{}}, {256, 0}, {h.ha[l], Arr{}}};
     }
+    for (int t = 0; t < 6; t += g_wgrad_batch)
+      if ((e = wgrad_multi(c, w, pb + t, g_wgrad_batch, 1, gr)) != hipSuccess) return e;
+  }
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
     const Arr* hh = head ? h.ha : h.hr;
@@ -989,7 +995,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 4 && (value == 0 || value == 1)) { g_fused_ws = value; return 0; }
   if (key == 6 && (value == 0 || value == 1)) { g_wreduce_direct = value; return 0; }
   if (key == 7 && (value == 0 || value == 1)) { g_wgrad_interleave = value; return 0; }
-  if (key == 8 && (value == 0 || value == 1)) { g_wgrad_batch = value; return 0; }
+  if (key == 8 && (value == 0 || value == 2 || value == 3 || value == 6)) { g_wgrad_batch = value; return 0; }
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   return -1;
 }

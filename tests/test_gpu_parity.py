@@ -397,13 +397,19 @@ def test_bf16_wgrad_kernels_agree(dev, R, S):
         g2, g3 = grads(0), grads(1)
         _lib.check(_lib.lib().neat_set_tuning(8, 0), "neat_set_tuning")      # the two heads' hidden layers as separate launches
         g3_single = grads(1)
+        batched = {}
+        for nb in (2, 6):
+            _lib.check(_lib.lib().neat_set_tuning(8, nb), "neat_set_tuning")
+            batched[nb] = grads(1)
     finally:
         _lib.lib().neat_set_tuning(1, 1)
-        _lib.lib().neat_set_tuning(8, 1)
+        _lib.lib().neat_set_tuning(8, 3)
     assert len(g3) >= 57
-    for k in g3:      # batched (two problems per launch, half the splits) vs separate launches: summation order only
-        err = float((g3[k] - g3_single[k]).abs().max())
-        assert err <= 2e-5 * float(g3_single[k].abs().max()) + 1e-12, (k, err)
+    batched[3] = g3
+    for nb, gb in batched.items():   # several problems per launch (1/nb of the splits each) vs separate launches: summation order only
+        for k in gb:
+            err = float((gb[k] - g3_single[k]).abs().max())
+            assert err <= 2e-5 * float(g3_single[k].abs().max()) + 1e-12, (nb, k, err)
     for k in g2:
         assert torch.isfinite(g3[k]).all(), k
         err = float((g3[k] - g2[k]).abs().max())
