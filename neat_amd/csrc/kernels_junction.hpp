@@ -185,58 +185,70 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
 // multi-tensor kernels over 65 tensors.  Arithmetic in torch's order:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g g ; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------
-constexpr int ADAM_MAXSEG = 96;
+constexpr int ADAM_MAXSEG = 96, ADAM_PASSES = 4;
 struct AdamSegs {                 // gradient of segment s covers [off[s], off[s+1]); per-segment bias corrections (torch counts steps per tensor)
   const float* g[ADAM_MAXSEG]; long long off[ADAM_MAXSEG + 1]; float lr_over_bc1[ADAM_MAXSEG], inv_sqrt_bc2[ADAM_MAXSEG]; int nseg;
 };
 
+constexpr int ADAM_SEGS_KERNARG_OFFSET = 8;     // adam_flat_kernel(float* p, AdamSegs segs, ...): segs follows the first pointer
 __global__ void adam_flat_kernel(float* __restrict__ p, AdamSegs segs, float* __restrict__ m, float* __restrict__ v,
                                  long long n, float beta1, float beta2, float eps) {
   __shared__ long long s_off[ADAM_MAXSEG + 1];
   __shared__ const float* s_g[ADAM_MAXSEG];
   __shared__ float s_a1[ADAM_MAXSEG], s_a2[ADAM_MAXSEG];
+  // the segment table is read from the kernel-argument segment through a pointer (plain indexed loads): indexing the
+  // by-value struct with a runtime index would copy it to scratch, and a compile-time select chain costs ~700 instructions
+  typedef const __attribute__((address_space(4))) char* karg_ptr;
+  typedef const __attribute__((address_space(4))) AdamSegs* karg_segs;
+  const karg_segs tab = (karg_segs)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + ADAM_SEGS_KERNARG_OFFSET);
   for (int t = threadIdx.x; t <= segs.nseg; t += blockDim.x) {
-    long long o = segs.off[0]; const float* gp = segs.g[0];      // compile-time kernarg indices only (a runtime index = scratch copy)
-    float a1 = segs.lr_over_bc1[0], a2 = segs.inv_sqrt_bc2[0];
-#pragma unroll
-    for (int k = 1; k <= ADAM_MAXSEG; ++k)
-      if (k == t) { o = segs.off[k]; if (k < ADAM_MAXSEG) { gp = segs.g[k]; a1 = segs.lr_over_bc1[k]; a2 = segs.inv_sqrt_bc2[k]; } }
-    s_off[t] = o;
-    if (t < segs.nseg) { s_g[t] = gp; s_a1[t] = a1; s_a2[t] = a2; }
+    s_off[t] = tab->off[t];
+    if (t < segs.nseg) { s_g[t] = tab->g[t]; s_a1[t] = tab->lr_over_bc1[t]; s_a2[t] = tab->inv_sqrt_bc2[t]; }
   }
   __syncthreads();
-  // four consecutive elements per thread: one segment search, then the segment only moves forward
-  const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i0 >= n) return;
-  int lo = 0, hi = segs.nseg - 1;              // segment of element i0: last s with off[s] <= i0
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i0) lo = mid; else hi = mid - 1; }
-  const long long iend = i0 + 4 < n ? i0 + 4 : n;
-  if (iend <= s_off[lo + 1] && iend == i0 + 4) {                 // the usual case: all four in one segment
-    const float* gp = s_g[lo];
-    if (!gp) return;                           // parameter without a gradient this step: untouched, as torch.optim.Adam
-    const float a1 = s_a1[lo], a2 = s_a2[lo];
-    const float* gq = gp + (i0 - s_off[lo]);
-    float4 mm = *reinterpret_cast<const float4*>(m + i0), vv = *reinterpret_cast<const float4*>(v + i0), pp = *reinterpret_cast<const float4*>(p + i0);
-    float* me = reinterpret_cast<float*>(&mm); float* ve = reinterpret_cast<float*>(&vv); float* pe = reinterpret_cast<float*>(&pp);
+  // ADAM_PASSES coalesced float4 passes per thread (the segment table above is built once per 4 * ADAM_PASSES * blockDim
+  // elements); per pass: one segment search for four consecutive elements, then the segment only moves forward
+  for (int pass = 0; pass < ADAM_PASSES; ++pass) {
+    const long long i0 = (((long long)blockIdx.x * ADAM_PASSES + pass) * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    int lo = 0, hi = segs.nseg - 1;              // segment of element i0: last s with off[s] <= i0
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i0) lo = mid; else hi = mid - 1; }
+    const long long iend = i0 + 4 < n ? i0 + 4 : n;
+    if (iend <= s_off[lo + 1] && iend == i0 + 4) {                 // the usual case: all four in one segment
+      const float* gp = s_g[lo];
+      if (!gp) continue;                         // parameter without a gradient this step: untouched, as torch.optim.Adam
+      const float a1 = s_a1[lo], a2 = s_a2[lo];
+      const float* gq = gp + (i0 - s_off[lo]);
+      float4 mm = *reinterpret_cast<const float4*>(m + i0), vv = *reinterpret_cast<const float4*>(v + i0), pp = *reinterpret_cast<const float4*>(p + i0);
+      float* me = reinterpret_cast<float*>(&mm); float* ve = reinterpret_cast<float*>(&vv); float* pe = reinterpret_cast<float*>(&pp);
+      float ge[4];
+      if ((reinterpret_cast<size_t>(gq) & 15) == 0) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gq);
+        ge[0] = g4.x; ge[1] = g4.y; ge[2] = g4.z; ge[3] = g4.w;
+      } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float g = gq[e];
-      me[e] = beta1 * me[e] + (1.0f - beta1) * g;
-      ve[e] = beta2 * ve[e] + (1.0f - beta2) * g * g;
-      pe[e] -= a1 * (me[e] / (sqrtf(ve[e]) * a2 + eps));
+        for (int e = 0; e < 4; ++e) ge[e] = gq[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = ge[e];
+        me[e] = beta1 * me[e] + (1.0f - beta1) * g;
+        ve[e] = beta2 * ve[e] + (1.0f - beta2) * g * g;
+        pe[e] -= a1 * (me[e] / (sqrtf(ve[e]) * a2 + eps));
+      }
+      *reinterpret_cast<float4*>(m + i0) = mm; *reinterpret_cast<float4*>(v + i0) = vv; *reinterpret_cast<float4*>(p + i0) = pp;
+      continue;
     }
-    *reinterpret_cast<float4*>(m + i0) = mm; *reinterpret_cast<float4*>(v + i0) = vv; *reinterpret_cast<float4*>(p + i0) = pp;
-    return;
-  }
-  for (long long i = i0; i < iend; ++i) {
-    while (i >= s_off[lo + 1]) ++lo;
-    const float* gp = s_g[lo];
-    if (!gp) continue;
-    const float g = gp[i - s_off[lo]];
-    const float mm = beta1 * m[i] + (1.0f - beta1) * g;
-    const float vv = beta2 * v[i] + (1.0f - beta2) * g * g;
-    m[i] = mm; v[i] = vv;
-    p[i] -= s_a1[lo] * (mm / (sqrtf(vv) * s_a2[lo] + eps));
+    for (long long i = i0; i < iend; ++i) {
+      while (i >= s_off[lo + 1]) ++lo;
+      const float* gp = s_g[lo];
+      if (!gp) continue;
+      const float g = gp[i - s_off[lo]];
+      const float mm = beta1 * m[i] + (1.0f - beta1) * g;
+      const float vv = beta2 * v[i] + (1.0f - beta2) * g * g;
+      m[i] = mm; v[i] = vv;
+      p[i] -= s_a1[lo] * (mm / (sqrtf(vv) * s_a2[lo] + eps));
+    }
   }
 }
 
@@ -340,28 +352,49 @@ __global__ __launch_bounds__(1024) void line_loss_kernel(const float* __restrict
 
 // inverse of one small (n <= 4) matrix by Gauss-Jordan elimination with partial pivoting, one thread: the pose and
 // intrinsics inverses of the junction block / loss (rend_a :440, loss_wfr.py:59) cost a dozen rocSOLVER launches each
+template <int NN>
+__device__ __forceinline__ void inv_small_body(const float* sA, float* __restrict__ out) {
+  float a[NN][2 * NN];                       // every index below is a compile-time constant: the matrix lives in registers
+#pragma unroll
+  for (int i = 0; i < NN; ++i)
+#pragma unroll
+    for (int j = 0; j < NN; ++j) { a[i][j] = sA[i * NN + j]; a[i][NN + j] = (i == j) ? 1.0f : 0.0f; }
+#pragma unroll
+  for (int c = 0; c < NN; ++c) {
+    // partial pivoting as compare-and-swap against the rows below: row c ends up with the largest |a[.][c]| (the rows
+    // below may end in another order than with one swap, which only permutes later pivot candidates)
+#pragma unroll
+    for (int r = c + 1; r < NN; ++r) {
+      const bool sw = fabsf(a[r][c]) > fabsf(a[c][c]);
+#pragma unroll
+      for (int j = 0; j < 2 * NN; ++j) { const float x = a[c][j], y = a[r][j]; a[c][j] = sw ? y : x; a[r][j] = sw ? x : y; }
+    }
+    const float inv = 1.0f / a[c][c];
+#pragma unroll
+    for (int j = 0; j < 2 * NN; ++j) a[c][j] *= inv;
+#pragma unroll
+    for (int r = 0; r < NN; ++r) {
+      if (r == c) continue;
+      const float f = a[r][c];
+#pragma unroll
+      for (int j = 0; j < 2 * NN; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NN; ++i)
+#pragma unroll
+    for (int j = 0; j < NN; ++j) out[i * NN + j] = a[i][NN + j];
+}
+
 __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, float* __restrict__ out) {
   __shared__ float sA[16];
   if (threadIdx.x < n * n) sA[threadIdx.x] = A[(threadIdx.x / n) * lda + threadIdx.x % n];      // one parallel fetch, not 16 dependent ones
   __syncthreads();
   if (threadIdx.x != 0) return;
-  float a[4][8];
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) { a[i][j] = sA[i * n + j]; a[i][n + j] = (i == j) ? 1.0f : 0.0f; }
-  for (int c = 0; c < n; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < n; ++r) if (fabsf(a[r][c]) > fabsf(a[piv][c])) piv = r;
-    if (piv != c) for (int j = 0; j < 2 * n; ++j) { const float t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
-    const float inv = 1.0f / a[c][c];
-    for (int j = 0; j < 2 * n; ++j) a[c][j] *= inv;
-    for (int r = 0; r < n; ++r) {
-      if (r == c) continue;
-      const float f = a[r][c];
-      for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j];
-    }
-  }
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) out[i * n + j] = a[i][n + j];
+  if (n == 4) inv_small_body<4>(sA, out);
+  else if (n == 3) inv_small_body<3>(sA, out);
+  else if (n == 2) inv_small_body<2>(sA, out);
+  else out[0] = 1.0f / sA[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,6 +404,7 @@ __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, fl
 // feature), the weight gradients are parallel over output features (deterministic sums over the rows).
 // ---------------------------------------------------------------------------------------------
 constexpr int FFN_H = 256, FFN_RB = 8;
+constexpr int FFN_FUSED_MIN_ROWS = 4096;  // up to this many rows the layers run as separate many-CU launches (ffn_dense_kernel)
 
 __global__ __launch_bounds__(FFN_H) void ffn_forward_kernel(const float* __restrict__ x, int J, const float* __restrict__ W0,
     const float* __restrict__ b0, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
@@ -418,7 +452,7 @@ __global__ __launch_bounds__(FFN_H) void ffn_forward_kernel(const float* __restr
 __global__ __launch_bounds__(FFN_H) void ffn_backward_data_kernel(const float* __restrict__ dy, int J, const float* __restrict__ W0,
     const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ h1, const float* __restrict__ h2,
     float* __restrict__ d_a1, float* __restrict__ d_a2, float* __restrict__ dx) {
-  __shared__ float ds[FFN_RB][FFN_H];
+  __shared__ __attribute__((aligned(16))) float ds[FFN_RB][FFN_H];
   __shared__ float dys[FFN_RB][3];
   const int k = threadIdx.x, r0 = blockIdx.x * FFN_RB;
   const int nr = min(FFN_RB, J - r0);
@@ -451,6 +485,71 @@ __global__ __launch_bounds__(FFN_H) void ffn_backward_data_kernel(const float* _
   __syncthreads();
   back(W0, acc);
   for (int r = 0; r < nr; ++r) dx[(size_t)(r0 + r) * FFN_H + k] = acc[r];
+}
+
+// One dense layer of the junction MLP for few rows, spread over many CUs (the fused kernels above keep 8 rows per
+// workgroup and walk the whole 256 KiB matrix per layer on ONE CU: with J = 64 latents that is 8 CUs at L2 latency):
+//   y[j][o] = epi( sum_i x[j][i] Wm(o, i) ),  Wm(o, i) = TRANS ? W[i * O + o] : W[o * I + i]
+//   epi: + bias[o] (if bias) ; relu (if relu) ; zero where gate[j][o] <= 0 (if gate: the relu mask of a backward step)
+// grid (ceil(J / 8), ceil(O / 32)); thread = (output o0 + (tid & 31), input slice tid >> 5 of 8); the 8 slice sums meet in LDS.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void ffn_dense_kernel(const float* __restrict__ x, int J, int I, int O, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gate, int relu, float* __restrict__ y, float* __restrict__ y2) {
+  __shared__ __attribute__((aligned(16))) float xs[FFN_RB][FFN_H];
+  __shared__ float red[8][FFN_RB][33];
+  const int tid = threadIdx.x, f = tid & 31, ks = tid >> 5;
+  const int r0 = blockIdx.x * FFN_RB, o = blockIdx.y * 32 + f;
+  const int nr = min(FFN_RB, J - r0);
+  for (int idx = tid; idx < FFN_RB * FFN_H; idx += 256) {
+    const int r = idx / FFN_H, i = idx % FFN_H;
+    xs[r][i] = (r < nr && i < I) ? x[(size_t)(r0 + r) * I + i] : 0.0f;
+  }
+  const int IS = ((I + 7) / 8 + 3) & ~3;           // inputs per slice (multiple of 4)
+  const int i0 = ks * IS, i1 = min(I, i0 + IS);
+  // the weights of this thread's slice first (independent loads in flight), then the FMAs
+  float w[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) w[t] = 0.0f;
+  if (o < O) {
+    if (!TRANS && (I & 3) == 0) {
+#pragma unroll
+      for (int t = 0; t < 32; t += 4)
+        if (i0 + t < i1) {
+          const float4 v = *reinterpret_cast<const float4*>(W + (size_t)o * I + i0 + t);
+          w[t] = v.x; w[t + 1] = v.y; w[t + 2] = v.z; w[t + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 32; ++t)
+        if (i0 + t < i1) w[t] = TRANS ? W[(size_t)(i0 + t) * O + o] : W[(size_t)o * I + i0 + t];
+    }
+  }
+  __syncthreads();
+  float acc[FFN_RB];
+#pragma unroll
+  for (int r = 0; r < FFN_RB; ++r) acc[r] = 0.0f;
+  if (i0 < I) {
+#pragma unroll
+    for (int t = 0; t < 32; t += 4)
+#pragma unroll
+      for (int r = 0; r < FFN_RB; ++r) {
+        const float4 x4 = *reinterpret_cast<const float4*>(&xs[r][min(i0 + t, FFN_H - 4)]);
+        acc[r] += x4.x * w[t]; acc[r] += x4.y * w[t + 1]; acc[r] += x4.z * w[t + 2]; acc[r] += x4.w * w[t + 3];
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < FFN_RB; ++r) red[ks][r][f] = acc[r];
+  __syncthreads();
+  const int r = ks;                                 // thread (row r, output f) finishes one output
+  if (r < nr && o < O) {
+    float v = bias ? bias[o] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][r][f];
+    if (relu) v = fmaxf(v, 0.0f);
+    if (gate && !(gate[(size_t)(r0 + r) * O + o] > 0.0f)) v = 0.0f;
+    y[(size_t)(r0 + r) * O + o] = v;
+    if (y2) y2[(size_t)(r0 + r) * O + o] = v;
+  }
 }
 
 // blockIdx.y: 0: dW0 = d_a1^T x, db0 ; 1: dW1 = d_a2^T h1, db1 ; 2 (rows 0..2): dW2 = dy^T h2, db2.  blockIdx.x = output row.

@@ -1237,7 +1237,8 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   segs.nseg = nseg;
   const long long n = seg_offsets[nseg];
   if (n <= 0) return 0;
-  const long long blocks = (n + 1023) / 1024;          // 4 consecutive elements per thread
+  const long long per_block = 1024LL * ADAM_PASSES;    // ADAM_PASSES float4 passes of 256 threads
+  const long long blocks = (n + per_block - 1) / per_block;
   hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
                      exp_avg_sq, n, beta1, beta2, eps);
   return (int)hipGetLastError();
@@ -1247,7 +1248,17 @@ int neat_ffn_forward(const float* x, int J, const float* W0, const float* b0, co
                      const float* b2, float* h1, float* h2, float* y, void* stream) {
   if (J <= 0) return 0;
   if (!x || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !h1 || !h2 || !y) return -1;
-  hipLaunchKernelGGL(ffn_forward_kernel, dim3((J + FFN_RB - 1) / FFN_RB), dim3(FFN_H), 0, (hipStream_t)stream, x, J, W0, b0, W1, b1, W2, b2, h1, h2, y);
+  hipStream_t st = (hipStream_t)stream;
+  if (J > FFN_FUSED_MIN_ROWS) {       // many rows: one fused launch, 8 rows per workgroup
+    hipLaunchKernelGGL(ffn_forward_kernel, dim3((J + FFN_RB - 1) / FFN_RB), dim3(FFN_H), 0, st, x, J, W0, b0, W1, b1, W2, b2, h1, h2, y);
+    return (int)hipGetLastError();
+  }
+  // few rows (the 64 latents of the ABC scenes): one launch per layer, each spread over rows x 32-output blocks
+  const dim3 gh((J + FFN_RB - 1) / FFN_RB, FFN_H / 32), g3((J + FFN_RB - 1) / FFN_RB, 1);
+  const float* nogate = nullptr; float* noy2 = nullptr;
+  hipLaunchKernelGGL(ffn_dense_kernel<false>, gh, dim3(256), 0, st, x, J, FFN_H, FFN_H, W0, b0, nogate, 1, h1, noy2);
+  hipLaunchKernelGGL(ffn_dense_kernel<false>, gh, dim3(256), 0, st, (const float*)h1, J, FFN_H, FFN_H, W1, b1, nogate, 1, h2, noy2);
+  hipLaunchKernelGGL(ffn_dense_kernel<false>, g3, dim3(256), 0, st, (const float*)h2, J, FFN_H, 3, W2, b2, nogate, 0, y, noy2);
   return (int)hipGetLastError();
 }
 
@@ -1257,8 +1268,16 @@ int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, c
   if (J <= 0) return 0;
   if (!x || !W0 || !W1 || !W2 || !h1 || !h2 || !dy || !ws2 || !dx || !dW0 || !db0 || !dW1 || !db1 || !dW2 || !db2) return -1;
   float* d_a1 = ws2; float* d_a2 = ws2 + (size_t)J * FFN_H;
-  hipLaunchKernelGGL(ffn_backward_data_kernel, dim3((J + FFN_RB - 1) / FFN_RB), dim3(FFN_H), 0, (hipStream_t)stream, dy, J, W0, W1, W2, h1, h2,
-                     d_a1, d_a2, dx);
+  hipStream_t st = (hipStream_t)stream;
+  if (J > FFN_FUSED_MIN_ROWS)
+    hipLaunchKernelGGL(ffn_backward_data_kernel, dim3((J + FFN_RB - 1) / FFN_RB), dim3(FFN_H), 0, st, dy, J, W0, W1, W2, h1, h2, d_a1, d_a2, dx);
+  else {
+    const dim3 gh((J + FFN_RB - 1) / FFN_RB, FFN_H / 32);
+    const float* nobias = nullptr; const float* nogate = nullptr; float* noy2 = nullptr;
+    hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, dy, J, 3, FFN_H, W2, nobias, h2, 0, d_a2, noy2);
+    hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a2, J, FFN_H, FFN_H, W1, nobias, h1, 0, d_a1, noy2);
+    hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a1, J, FFN_H, FFN_H, W0, nobias, nogate, 0, dx, noy2);
+  }
   hipLaunchKernelGGL(ffn_backward_weights_kernel, dim3(FFN_H, 3), dim3(FFN_H), 0, (hipStream_t)stream, x, h1, h2, d_a1, d_a2, dy, J, dW0, db0,
                      dW1, db1, dW2, db2);
   return (int)hipGetLastError();

@@ -367,13 +367,15 @@ class LineLossFn(torch.autograd.Function):
         _lib.check(lib.neat_line_loss(_p(pred_c), _p(gt_c), _p(w_c), R, float(threshold), _p(out2), _p(per_line), _p(d_pred),
                                       _stream()), "neat_line_loss")
         ctx.save_for_backward(d_pred)
-        ctx.mark_non_differentiable(per_line)
-        return out2[0], per_line, out2[1]
+        ctx.set_materialize_grads(False)
+        count = out2[1]
+        ctx.mark_non_differentiable(per_line, count)
+        return out2[0], per_line, count
 
     @staticmethod
     def backward(ctx, g_loss, g_per_line, g_count):
         (d_pred,) = ctx.saved_tensors
-        return g_loss * d_pred, None, None, None
+        return (None if g_loss is None else g_loss * d_pred), None, None, None
 
 
 def line_loss(pred, gt, weight, threshold=100.0):
@@ -462,15 +464,18 @@ class LossTailFn(torch.autograd.Function):
         K = 0 if loc3_c is None else loc3_c.shape[0]
         J = 0 if glo3_c is None else glo3_c.shape[0]
         scal = torch.zeros(8, device=dev)
-        d_rgb = torch.empty_like(rgb_c)
-        d_gth = torch.empty_like(gth_c) if E else None
+        # every gradient the two launches produce lives in ONE flat buffer, so that backward is two multiplies (per-element
+        # loss weight x upstream gradient, then x buffer) instead of one or two per tensor
+        have_pairs = bool(K and J)
+        sizes = [R * 3, E * 3, J * 3 if have_pairs else 0, J * 2 if have_pairs else 0]
+        flat = torch.empty(sum(sizes), device=dev)
+        d_rgb, d_gth, d_glo3, d_glo2c = flat.split(sizes)
+        d_gth = d_gth if E else None
         pair_cost = torch.empty(K, J, device=dev) if K and J else None
         _lib.check(lib.neat_loss_terms(_p(rgb_c), _p(gt_c), R, _p(gth_c), E, _p(loc3_c), _p(loc2c_c), K, _p(glo3_c), _p(glo2c_c), J,
                                        _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), _stream()), "neat_loss_terms")
-        d_glo3 = d_glo2c = None
         if K and J:
             ri, ci, n_match = linear_sum_assignment(pair_cost, good)
-            d_glo3, d_glo2c = torch.empty_like(glo3_c), torch.empty_like(glo2c_c)
             _lib.check(lib.neat_loss_pairs(_p(ri), _p(ci), _p(n_match), ri.shape[0], _p(loc3_c), _p(loc2c_c), _p(loc2_c), _p(glo3_c),
                                            _p(glo2c_c), _p(glo2_c), J, _p(pair_cost), _p(scal), _p(d_glo3), _p(d_glo2c),
                                            _p(_f32c(line_loss.detach().reshape(1))), w_eik, w_line, w_j3, w_j2, _stream()),
@@ -478,23 +483,40 @@ class LossTailFn(torch.autograd.Function):
             loss = scal[6].clone()
         else:
             loss = scal[0] + w_eik * scal[1] + w_line * line_loss.detach()
-        ctx.save_for_backward(d_rgb, d_gth, d_glo3, d_glo2c)
-        ctx.weights = (w_eik, w_line, w_j3, w_j2)
-        ctx.shapes = (rgb.shape, None if gtheta is None else gtheta.shape, None if glo3 is None else glo3.shape,
-                      None if glo2c is None else glo2c.shape)
+        ctx.save_for_backward(flat, _segment_weights(tuple(sizes) + (1,), (1.0, w_eik, w_j3, w_j2, w_line), dev))
+        ctx.sizes = sizes
+        ctx.set_materialize_grads(False)
+        ctx.shapes = (rgb.shape, None if gtheta is None else gtheta.shape, None if glo3 is None or not have_pairs else glo3.shape,
+                      None if glo2c is None or not have_pairs else glo2c.shape, line_loss.shape)
         ctx.mark_non_differentiable(scal)
         return loss, scal
 
     @staticmethod
     def backward(ctx, g_loss, g_scal):
-        d_rgb, d_gth, d_glo3, d_glo2c = ctx.saved_tensors
-        w_eik, w_line, w_j3, w_j2 = ctx.weights
-        s_rgb, s_gth, s_glo3, s_glo2c = ctx.shapes
-        return (g_loss * d_rgb.view(s_rgb),
-                None if d_gth is None else (g_loss * w_eik) * d_gth.view(s_gth),
-                None if d_glo3 is None else (g_loss * w_j3) * d_glo3.view(s_glo3),
-                None if d_glo2c is None else (g_loss * w_j2) * d_glo2c.view(s_glo2c),
-                g_loss * w_line, None, None, None, None, None, None, None, None, None, None)
+        if g_loss is None:
+            return (None,) * 15
+        flat, wvec = ctx.saved_tensors
+        scale = wvec * g_loss                        # [.. per-element loss weights .., w_line] x upstream gradient
+        g = (flat * scale[:-1]).split(ctx.sizes)
+        s_rgb, s_gth, s_glo3, s_glo2c, s_line = ctx.shapes
+        return (g[0].view(s_rgb),
+                None if s_gth is None else g[1].view(s_gth),
+                None if s_glo3 is None else g[2].view(s_glo3),
+                None if s_glo2c is None else g[3].view(s_glo2c),
+                scale[-1:].view(s_line), None, None, None, None, None, None, None, None, None, None)
+
+
+_SEG_WEIGHTS = {}
+
+
+def _segment_weights(sizes, weights, device):
+    """Per-element loss weights of LossTailFn's flat gradient buffer (cached per shape / weights / device)."""
+    key = (sizes, weights, str(device))
+    w = _SEG_WEIGHTS.get(key)
+    if w is None:
+        w = torch.cat([torch.full((n,), float(v)) for n, v in zip(sizes, weights)]).to(device)
+        _SEG_WEIGHTS[key] = w
+    return w
 
 
 def loss_tail(rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2):
