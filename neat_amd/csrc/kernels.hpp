@@ -323,13 +323,12 @@ struct WreduceArgs {
 // partials of the bf16 build directly (one pass over the partial buffer instead of group-sum + finish: the row is
 // 245 x ~1 KiB, 16 waves keep 16 x 4 independent loads in flight)
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void wreduce_wnorm_kernel(WreduceArgs a) {
+__device__ __forceinline__ void wreduce_wnorm_body(const WreduceArgs& a, const int o) {
   // one workgroup per output row: wave w sums splits w, w+NW, ... (independent loads, unrolled), LDS combine,
   // then wave 0 applies the weight-norm backward.
   constexpr int MAXC = 5;                 // up to 320 input columns (+ bias column handled by lane 0 of each wave)
   __shared__ float red[NW][MAXC * 64 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int o = blockIdx.x;
   float acc[MAXC], bacc = 0.0f;
   int jcol[MAXC];
 #pragma unroll
@@ -388,6 +387,21 @@ __global__ __launch_bounds__(64 * NW) void wreduce_wnorm_kernel(WreduceArgs a) {
       a.db[o] = t;
     }
   }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wreduce_wnorm_kernel(WreduceArgs a) { wreduce_wnorm_body<NW>(a, blockIdx.x); }
+
+// the finish of several layers in one launch (the problems of one batched weight-gradient launch): blockIdx.y = layer.
+// The argument table is read from the kernel-argument segment through a pointer -- indexing the by-value array with
+// blockIdx.y would copy it to scratch.
+constexpr int WREDUCE_BATCH = 6;
+struct WreduceBatch { WreduceArgs a[WREDUCE_BATCH]; };
+__global__ __launch_bounds__(256) void wreduce_wnorm_batch_kernel(WreduceBatch) {
+  const WreduceArgs* tab = (const WreduceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const WreduceArgs a = tab[blockIdx.y];
+  if ((int)blockIdx.x >= a.O) return;          // lin3 has 217 rows
+  wreduce_wnorm_body<4>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

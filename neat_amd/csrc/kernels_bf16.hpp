@@ -526,22 +526,32 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ s, const u16* __restrict__ B0, const u16* __restrict__ B1,
                                                      int P, int ldp, int chunk, float* __restrict__ out, size_t split_stride) {
   __shared__ float red[8][264];
-  const int tid = threadIdx.x, oct = tid & 31, pg = tid >> 5;          // 32 octets x 8 point lanes
+  const int tid = threadIdx.x, oct = tid >> 3, pg = tid & 7;           // 32 octets x 8 point lanes: 8 lanes = one 128-byte line of one octet row
   const int pbeg = blockIdx.x * chunk, pend = min(P, pbeg + chunk);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float ssum = 0.0f;
   const uint4* b0 = reinterpret_cast<const uint4*>(B0) + (size_t)oct * ldp;
   const uint4* b1 = reinterpret_cast<const uint4*>(B1) + (size_t)oct * ldp;
-  for (int p = pbeg + pg; p < pend; p += 8) {
-    const float sv = s[p];
-    const uint4 x = b0[p], y = b1[p];
-    const unsigned xw[4] = {x.x, x.y, x.z, x.w}, yw[4] = {y.x, y.y, y.z, y.w};
+  for (int pb = pbeg + pg; pb < pend; pb += 32) {       // four points per trip: eight independent 16-byte loads in flight
+    float sv[4]; uint4 x[4], y[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[2 * j] += sv * bf_lo(xw[j]) + bf_lo(yw[j]);
-      acc[2 * j + 1] += sv * bf_hi(xw[j]) + bf_hi(yw[j]);
+    for (int u = 0; u < 4; ++u) {
+      const int p = pb + 8 * u;
+      const bool ok = p < pend;
+      sv[u] = ok ? s[p] : 0.0f;
+      x[u] = ok ? b0[p] : make_uint4(0u, 0u, 0u, 0u);
+      y[u] = ok ? b1[p] : make_uint4(0u, 0u, 0u, 0u);
     }
-    if (oct == 0) ssum += sv;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned xw[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, yw[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += sv[u] * bf_lo(xw[j]) + bf_lo(yw[j]);
+        acc[2 * j + 1] += sv[u] * bf_hi(xw[j]) + bf_hi(yw[j]);
+      }
+      if (oct == 0) ssum += sv[u];
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[pg][oct * 8 + e] = acc[e];

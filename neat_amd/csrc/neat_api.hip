@@ -386,7 +386,7 @@ constexpr int W2SPLIT = 256;                // bf16 build (256x256 tiles): split
 constexpr int W2LDN = 288, W2LDK = 320;
 constexpr int W2_LDS_BYTES = 2 * 256 * HLD + 8 * 8 * 64 * 16;      // operand tiles + raw DMA ring
 constexpr int WGROUPS = 8;                  // stage-1 groups of the split reduction
-constexpr size_t WSTAGE_FLOATS = (size_t)WGROUPS * WLDN * WLDK;
+constexpr size_t WSTAGE_FLOATS = (size_t)WGROUPS * WREDUCE_BATCH * 256 * 264;   // >= WGROUPS*WLDN*WLDK; the group sums of up to 6 batched 256x(256+1) layers
 constexpr size_t WPARTIAL_FLOATS = (size_t)W2SPLIT * W2LDN * W2LDK + WSTAGE_FLOATS;   // >= WSPLIT*WLDN*WLDK + stage
 
 SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
@@ -616,12 +616,36 @@ hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob,
   hipLaunchKernelGGL(wgrad_kernel_h3, dim3(nprob, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
   prof_end(c.st, ps);
   hipError_t e = hipGetLastError();
-  for (int q = 0; q < nprob && e == hipSuccess; ++q) {
-    WreduceArgs r{};
-    r.partial = w.partial + q * region; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
-    e = wgrad_reduce(c, w, pb[q].layer_id, r, N, N, K, gr);
+  if (splits <= 2 * WGROUPS || nprob > WREDUCE_BATCH) {        // few points: finish each layer on its own
+    for (int q = 0; q < nprob && e == hipSuccess; ++q) {
+      WreduceArgs r{};
+      r.partial = w.partial + q * region; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
+      e = wgrad_reduce(c, w, pb[q].layer_id, r, N, N, K, gr);
+    }
+    return e;
   }
-  return e;
+  if (e != hipSuccess) return e;
+  // the reduction of all nprob layers in two launches: the regions are contiguous, so the group sums see nprob * N rows;
+  // then one finish launch (weight-norm backward) with blockIdx.y = layer
+  const int per = (splits + WGROUPS - 1) / WGROUPS, groups_used = (splits + per - 1) / per;
+  float* stage = w.partial + (WPARTIAL_FLOATS - WSTAGE_FLOATS);
+  hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld2 / 4 + 127) / 128, WGROUPS, nprob * N), dim3(128), 0, c.st,
+                     (const float*)w.partial, splits, Kld2 / 4, WGROUPS, per, nprob * N, stage);
+  WreduceBatch b{};
+  for (int q = 0; q < nprob; ++q) {
+    const int layer_id = pb[q].layer_id;
+    const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
+    WreduceArgs& r = b.a[q];
+    r.partial = stage + (size_t)q * N * WGROUPS * Kld2; r.splits = groups_used;
+    r.row_stride = (size_t)WGROUPS * Kld2; r.split_stride = Kld2;
+    r.O = kO[layer_id]; r.I = kI[layer_id];
+    r.s0 = d.s0; r.s0p = d.s0p; r.off0 = d.off0; r.off1 = d.off1; r.rot = d.rot; r.scale = d.scale;
+    r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
+    r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
+    r.bias_col = K;
+  }
+  hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(256, nprob), dim3(WG), 0, c.st, b);
+  return hipGetLastError();
 }
 
 struct RowDot { const float* s; Arr B0, B1; };     // one more gradient row: sum_p s[p] B0[k][p] + B1[k][p] (the sdf row of lin8)

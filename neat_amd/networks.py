@@ -178,6 +178,16 @@ class AttractionFieldNetwork(_Head):
         return self._standalone(points, normals, view_dirs, feature_vectors)[1]
 
 
+_EYE3 = {}
+
+
+def _eye3(device):
+    key = str(device)
+    if key not in _EYE3:
+        _EYE3[key] = torch.eye(3, device=device)
+    return _EYE3[key]
+
+
 def _to_device_async(t, device):
     """CPU-drawn randoms (the reference's RNG stream) -> device without stalling the host behind queued GPU work."""
     if device.type != "cuda":
@@ -356,7 +366,7 @@ class VolSDFNetwork(_HipModule):
         w2c = ops.inv_small(pose[0])[:3]                     # one launch, no host-side singularity check, no sync
         Rm, T = w2c[:, :3], w2c[:, 3:]
         K3 = intrinsics[0, :3, :3]
-        eye = torch.eye(3, device=K3.device)
+        eye = _eye3(K3.device)
 
         def l3d_block():
             p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
@@ -406,6 +416,7 @@ class VolSDFNetwork(_HipModule):
             p3_sdf, l3d, l3d_score = l3d_block()
         if xyz.is_cuda:        # one launch per projection (forward / backward) instead of ~16 R-sized torch kernels
             K3c, w2c3 = K3.contiguous(), w2c.contiguous()
+            K3 = K3c           # the loss inverts output["K"]: hand it the contiguous copy
             proj = lambda Kc, X: ops.project2d(Kc, w2c3, X)
         else:
             K3c = K3

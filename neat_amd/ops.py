@@ -32,6 +32,14 @@ def _f32c(t):
     return t.contiguous()
 
 
+def _as_u8(mask):
+    """bool / uint8 mask -> contiguous uint8 (a bool tensor is reinterpreted, not copied)."""
+    if mask is None:
+        return None
+    mask = mask.contiguous()
+    return mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+
+
 class NetHandle:
     """The 19 weight-normed layers of one model (heads may be absent) + a cache of the packed weights."""
 
@@ -317,8 +325,7 @@ def linear_sum_assignment(cost, row_mask=None, col_mask=None):
     rows = torch.empty(k, device=cost.device, dtype=torch.int64)
     cols = torch.empty(k, device=cost.device, dtype=torch.int64)
     n_match = torch.empty(1, device=cost.device, dtype=torch.int32)
-    mask = None if row_mask is None else row_mask.to(torch.uint8).contiguous()
-    cmask = None if col_mask is None else col_mask.to(torch.uint8).contiguous()
+    mask, cmask = _as_u8(row_mask), _as_u8(col_mask)
     ws = torch.empty(max(int(lib.neat_lsap_ws_bytes(nr, nc)), 8), device=cost.device, dtype=torch.uint8)
     _lib.check(lib.neat_lsap(_p(cost), nr, nc, _p(mask), _p(cmask), _p(rows), _p(cols), _p(n_match), _p(ws), _stream()), "neat_lsap")
     return rows, cols, n_match
@@ -446,7 +453,7 @@ def dbscan_means(points, eps):
     ws = torch.empty(int(lib.neat_dbscan_ws_bytes(n)), device=pts.device, dtype=torch.uint8)
     flat = buf.view(-1)
     _lib.check(lib.neat_dbscan_means(_p(pts), n, float(eps), _p(flat), _p(valid), _p(count), _p(ws), _stream()), "neat_dbscan_means")
-    return flat[:3 * (n // 2)].view(n // 2, 3), valid.bool(), count
+    return flat[:3 * (n // 2)].view(n // 2, 3), valid.view(torch.bool), count      # the kernel writes 0 / 1: reinterpret, no copy
 
 
 class LossTailFn(torch.autograd.Function):
@@ -553,4 +560,4 @@ def junction_gate(rows, cols, cost, cand3d, cand2d, cand2d_calib, use_median):
     _lib.check(_lib.lib().neat_junction_gate(_p(rows), _p(cols), K, _p(cost), cost.shape[1], _p(cand3d), _p(cand2d), _p(cand2d_calib),
                                              1 if use_median else 0, _p(median), _p(good), _p(j3d), _p(j2d), _p(j2dc), _stream()),
                "neat_junction_gate")
-    return (median.reshape(()) if use_median else None), good.bool(), j3d, j2d, j2dc
+    return (median.reshape(()) if use_median else None), good.view(torch.bool), j3d, j2d, j2dc   # 0 / 1 bytes: reinterpret, no copy

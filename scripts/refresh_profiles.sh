@@ -1,0 +1,11 @@
+R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $O/tests.log
+python bench.py > $O/bench_bf16.log 2>&1; tail -1 $O/bench_bf16.log > $O/bench_bf16.json
+python bench.py --precision fp32 > $O/bench_fp32.log 2>&1; tail -1 $O/bench_fp32.log > $O/bench_fp32.json
+cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > $O/prof_bf16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-prof > $O/prof_fp32.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph > $O/pmc_write.log 2>&1
+find $O -name "*kernel_trace*" -delete
+du -sh $O; find $O -type f | head -30
