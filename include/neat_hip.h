@@ -198,7 +198,14 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  * neat_prof_collect synchronises on the recorded events and returns the summed kernel time, the summed
  * ALGORITHMIC flops (2*N*K*P with the true layer dims), the summed ALGORITHMIC HBM bytes (each operand/result row once,
  * weights once) and the launch count since neat_prof_enable(1). */
-int neat_set_tuning(int key, int value);   /* key 0: bf16 layer-kernel point tile, value 2 (64 points, default) or 4 (128) */
+/* A/B switches for benchmarking and for the cross-check tests (tests/test_gpu_parity.py::test_bf16_*_kernels_agree); every
+ * setting computes the same result up to summation order.  Returns -1 for an unknown key / value.
+ *   0 bf16 layer-kernel point tile (2 = 64 points, 4 = 128)   1 weight gradient: 1 = tr16 streaming kernel, 0 = previous
+ *   2 hidden layers: 1 = weight-stationary streaming kernel   3 persistent workgroups of that kernel (default 256)
+ *   4 fused primal chain: 1 = weight-stationary               5 its batch in 32-point tiles (0 = auto, 2..4)
+ *   6 partial reduction: 1 = one 16-wave pass (default 0)     7 interleave weight gradients with the reverse chain (default 0)
+ *   8 same-shaped weight gradients per launch (0 = one layer per launch, 2, 3 = default, 6) */
+int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);
 

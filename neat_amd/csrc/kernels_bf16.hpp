@@ -781,7 +781,7 @@ template <int NT> struct FwsCfg {
 };
 
 template <int NT, bool VALUES>
-__global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int nbatch, int per_wg) {
+__global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int ntiles, int nwg) {
   typedef FwsCfg<NT> C;
   constexpr int BP = C::BP;
   extern __shared__ __attribute__((aligned(16))) unsigned char fws[];
@@ -828,10 +828,12 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
   };
   load_w(a.Wp[0], 4, true);
 
-  const int b_begin = blockIdx.x * per_wg, b_end = min(nbatch, b_begin + per_wg);
-  for (int b = b_begin; b < b_end; ++b) {
-    const int p0 = b * BP;
-    const int nt = min(NT, (a.ldp - p0) / 32);           // whole 32-point tiles inside the padded point range
+  // the 32-point tiles are split evenly over the workgroups (tile counts differ by at most one); each workgroup walks its
+  // range in batches of NT tiles, the last batch may be shorter (its missing tiles skip MFMAs, epilogue and stores)
+  const int t_begin = (int)(((long long)blockIdx.x * ntiles) / nwg), t_end = (int)(((long long)(blockIdx.x + 1) * ntiles) / nwg);
+  for (int tile0 = t_begin; tile0 < t_end; tile0 += NT) {
+    const int p0 = tile0 * 32;
+    const int nt = min(NT, t_end - tile0);
     // ---- positional encoding (embedder.py:12-36) into the PE octets (rows 39..63 zero)
     for (int idx = tid; idx < 64 * BP; idx += FWT) {
       const int j = idx / BP, p = idx % BP;
@@ -865,6 +867,7 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
         if (ks < KS) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
+            if (t >= nt) break;
             const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16 + t * 32 * 16);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc[t], 0, 0, 0);
           }
@@ -943,6 +946,7 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+          if (t >= nt) break;
           const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)(2 * wave + j) * 2 * BP * 16 + t * 32 * 16);
           accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&ws8[j]), *reinterpret_cast<const bf16x8*>(&bv), accs[t], 0, 0, 0);
         }
@@ -960,13 +964,14 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
         for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
+            if (t >= nt) break;
             const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16 + t * 32 * 16);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc[t], 0, 0, 0);
           }
           if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (b + 1 < b_end) load_w(a.Wp[0], 4, true);      // next batch's lin0 slice
+        if (tile0 + NT < t_end) load_w(a.Wp[0], 4, true);  // next batch's lin0 slice
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

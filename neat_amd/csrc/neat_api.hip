@@ -480,20 +480,21 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
         if (e0 != hipSuccess) return e0;
         attr_done = true;
       }
+      const int ntiles = c.ldp / 32;                 // ldp is a multiple of 64
+      const int nwg = ntiles < g_ws_grid ? ntiles : g_ws_grid;
       auto go = [&](auto kern, int BP, int lds_bytes) -> hipError_t {
-        const int nbatch = (c.ldp + BP - 1) / BP;
-        const int per_wg = (nbatch + g_ws_grid - 1) / g_ws_grid;
-        hipLaunchKernelGGL(kern, dim3((nbatch + per_wg - 1) / per_wg), dim3(FWT), lds_bytes, c.st, a, nbatch, per_wg);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(FWT), lds_bytes, c.st, a, ntiles, nwg);
         return hipGetLastError();
       };
-      // batch = 32*NT points: larger batches re-read the weights from L2 less often, but 1040 batches of 128 points only
-      // fill 208 of 256 CUs at the C2 size; pick the NT with the best (CU balance) / (weight traffic) trade-off
+      // batch = up to 32*NT points: larger batches re-read the weights from L2 less often.  The tiles are split evenly over
+      // the workgroups; the busiest one walks ceil(ntiles / nwg) tiles as full batches + one shorter batch
       auto cost = [&](int BP) {
-        const int nb = (c.ldp + BP - 1) / BP, per = (nb + g_ws_grid - 1) / g_ws_grid;
-        return (double)per * (BP + 48.0);            // rounds x (per-point work + per-batch weight streaming, in point units)
+        const int tiles = (ntiles + nwg - 1) / nwg, nt = BP / 32, rem = tiles % nt;
+        return (tiles / nt) * (BP + 48.0) + (rem ? rem * 32 + 48.0 : 0.0);     // per-point work + per-batch weight streaming, in point units
       };
       int nt_sel = g_fused_nt;
-      if (nt_sel == 0) { nt_sel = 2; for (int n = 3; n <= 4; ++n) if (cost(32 * n) < cost(32 * nt_sel)) nt_sel = n; }
+      // (NT = 4 has fewer batches still, but its save-mode variant spills registers and measures slower: tuning key 5 only)
+      if (nt_sel == 0) nt_sel = cost(96) < cost(64) ? 3 : 2;
       hipError_t e;
       if (nt_sel == 4) e = full ? go(&sdf_fused_ws_kernel<4, false>, 128, FwsCfg<4>::LDS) : go(&sdf_fused_ws_kernel<4, true>, 128, FwsCfg<4>::LDS);
       else if (nt_sel == 3) e = full ? go(&sdf_fused_ws_kernel<3, false>, 96, FwsCfg<3>::LDS) : go(&sdf_fused_ws_kernel<3, true>, 96, FwsCfg<3>::LDS);
