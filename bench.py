@@ -19,7 +19,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-R_RAYS, S_SAMPLES = 1024, 128
+R_RAYS, S_SAMPLES = int(os.environ.get("NEAT_BENCH_RAYS", "1024")), 128      # the env override is for scaling experiments only
 FLOP_PER_RAY_SAMPLE = 9.1254e6        # 4 562 688 MAC per ray-sample per train step
 CPU_BASELINE_THREADS = 16
 DEFAULT_PRECISION = "bf16"      # BASELINE.json configs[1]: "8x256 SDF MLP, bf16, 1x MI355X"; --precision fp32 = parity build

@@ -29,6 +29,8 @@ struct LsapArgs {
   int* wsi;                // rowlist[nr] path[M] col4row[N] row4col[M] remaining[M] SR[N] SC[M] tmp[M]
   int use_lds, lds_int_off; // work arrays in dynamic LDS instead (doubles first, ints at byte offset lds_int_off)
   const unsigned char* col_mask;   // [nc] or nullptr: columns with 0 do not take part (padded candidate sets)
+  int cost_lds_off;                // >= 0: the cost matrix is staged in dynamic LDS at this byte offset (every scan of a row is
+                                   // then an LDS read instead of an L2 round trip in a chain of dependent steps), -1: read from memory
 };
 
 struct LsapKey { double val; int it; int un; };
@@ -102,8 +104,15 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
   int* SR = remaining + M; int* SC = SR + N; int* tmp = SC + M;
   const float* C = a.cost;
   const int nc0 = a.nc;
+  const bool staged = a.use_lds && a.cost_lds_off >= 0;
+  const float* Cl = reinterpret_cast<const float*>(lsap_lds + (staged ? a.cost_lds_off : 0));
+  if (staged) {
+    float* dst = reinterpret_cast<float*>(lsap_lds + a.cost_lds_off);
+    for (int e = tid; e < a.nr * a.nc; e += nt) dst[e] = C[e];
+  }
   auto cost = [&](int i, int j) -> double {
-    return (double)(T ? C[(size_t)rowlist[j] * nc0 + collist[i]] : C[(size_t)rowlist[i] * nc0 + collist[j]]);
+    const int idx = T ? rowlist[j] * nc0 + collist[i] : rowlist[i] * nc0 + collist[j];
+    return (double)(staged ? Cl[idx] : C[idx]);
   };
   for (int i = tid; i < N; i += nt) { u[i] = 0.0; col4row[i] = -1; }
   for (int j = tid; j < M; j += nt) { v[j] = 0.0; row4col[j] = -1; }

@@ -159,7 +159,15 @@ template <int EPI> hipError_t launch_layer_h(hipStream_t st, const LayerArgsH& a
   if (a.out0_bf16) return g_pt_bf16 == 4 ? launch_layer_h_pt<EPI, 4, true>(st, a) : launch_layer_h_pt<EPI, 2, true>(st, a);
   return launch_layer_h_pt<EPI, 2, false>(st, a);
 }
-int g_wgrad_batch = 3;      // same-shaped hidden-layer weight gradients per launch (0 = one launch per layer; 2, 3 or 6 problems)
+int g_wgrad_batch = -1;     // same-shaped hidden-layer weight gradients per launch: -1 = by operand footprint (below), 0 = one launch
+                            // per layer, 2 / 3 / 6 = forced
+// Measured on MI355X (ms/step, same box): 131 k points: 2 -> 4.06, 3 -> 4.01, 6 -> 4.25; 262 k points: 0 -> 7.44, 2 -> 7.29,
+// 3 -> 7.75.  Fewer, longer point ranges per workgroup save partial tiles, but a launch whose operand arrays add up to
+// more than ~1 GB (six two-pair problems at 131 k points, three at 262 k) runs 2.5-2.9x slower per byte.
+inline int wgrad_batch_size(int ldp) {
+  if (g_wgrad_batch >= 0) return g_wgrad_batch;
+  return ldp <= 200000 ? 3 : (ldp <= 400000 ? 2 : 0);
+}
 int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
 int g_wreduce_direct = 0;   // bf16 weight-gradient reduction: 0 = group sums + finish (faster: 4.43 vs 4.63 ms/step), 1 = one 16-wave pass per row
 int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persistent kernel, 0 = sdf_fused_kernel_h
@@ -840,7 +848,8 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   }
   if (inter) return wgrad_layer(0);
   bool done[9] = {};
-  if (oct && g_wgrad_batch && g_wgrad_h3) {
+  const int nb2 = wgrad_batch_size(c.ldp);
+  if (oct && nb2 && g_wgrad_h3) {
     // the six hidden layers with 256 packed input columns as six problems (two (A, B) pairs each) of one launch
     const int ls[6] = {1, 2, 3, 5, 6, 7};
     WProb pb[6];
@@ -849,8 +858,8 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       pb[t] = WProb{l, {w.m[l], w.u[l]}, {kO[l], kO[l]}, {w.h[l], w.vh[l]}};
       done[l] = true;
     }
-    for (int t = 0; t < 6; t += g_wgrad_batch)
-      if ((e = wgrad_multi(c, w, pb + t, g_wgrad_batch, 2, gr)) != hipSuccess) return e;
+    for (int t = 0; t < 6; t += nb2)
+      if ((e = wgrad_multi(c, w, pb + t, nb2, 2, gr)) != hipSuccess) return e;
   }
   for (int l = 0; l <= 8; ++l)
     if (!done[l] && (e = wgrad_layer(l)) != hipSuccess) return e;
@@ -909,15 +918,16 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
                           F(head ? h.sc_a : h.sc_r), 256, Arr{}, Arr{}, head)) != hipSuccess) return e;
   }
   // weight gradients; the hidden layers l = 1..3 of the two heads have identical shapes: one launch per layer for both
-  const bool batch = oct && g_wgrad_batch && g_wgrad_h3;
+  const int nb1 = wgrad_batch_size(c.ldp);
+  const bool batch = oct && nb1 && g_wgrad_h3;
   if (batch) {                    // 3 hidden layers x 2 heads: six single-pair problems, g_wgrad_batch per launch
     WProb pb[6];
     for (int l = 1; l <= 3; ++l) {
       pb[2 * (l - 1)] = WProb{L_REND + l, {h.ar[l], Arr{}}, {256, 0}, {h.hr[l], Arr{}}};
       pb[2 * (l - 1) + 1] = WProb{L_ATTR + l, {h.aa[l], Arr{}}, {256, 0}, {h.ha[l], Arr{}}};
     }
-    for (int t = 0; t < 6; t += g_wgrad_batch)
-      if ((e = wgrad_multi(c, w, pb + t, g_wgrad_batch, 1, gr)) != hipSuccess) return e;
+    for (int t = 0; t < 6; t += nb1)
+      if ((e = wgrad_multi(c, w, pb + t, nb1, 1, gr)) != hipSuccess) return e;
   }
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
@@ -1020,7 +1030,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 4 && (value == 0 || value == 1)) { g_fused_ws = value; return 0; }
   if (key == 6 && (value == 0 || value == 1)) { g_wreduce_direct = value; return 0; }
   if (key == 7 && (value == 0 || value == 1)) { g_wgrad_interleave = value; return 0; }
-  if (key == 8 && (value == 0 || value == 2 || value == 3 || value == 6)) { g_wgrad_batch = value; return 0; }
+  if (key == 8 && (value == -1 || value == 0 || value == 2 || value == 3 || value == 6)) { g_wgrad_batch = value; return 0; }
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   return -1;
 }
@@ -1395,16 +1405,23 @@ int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, 
   a.col_mask = col_mask;
   const size_t dbytes = (mn + 2 * mx) * sizeof(double), ibytes = ((size_t)nr + (size_t)nc + 5 * mx + 2 * mn) * sizeof(int);
   size_t lds = 0;
-  if (dbytes + ibytes <= 144 * 1024) {
+  constexpr size_t LSAP_LDS_MAX = 156 * 1024;
+  a.cost_lds_off = -1;
+  if (dbytes + ibytes <= LSAP_LDS_MAX) {
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX);
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    a.use_lds = 1; a.lds_int_off = (int)dbytes; lds = dbytes + ibytes;
+    a.use_lds = 1; a.lds_int_off = (int)dbytes; lds = (dbytes + ibytes + 15) & ~(size_t)15;
+    const size_t cbytes = (size_t)nr * nc * sizeof(float);
+    if (lds + cbytes <= LSAP_LDS_MAX) { a.cost_lds_off = (int)lds; lds += cbytes; }      // the cost matrix too (8 x 2048 fits)
   }
-  hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(LSAP_WG), lds, (hipStream_t)stream, a);
+  // threads: two columns per thread, whole waves (a 16-wave barrier per step is most of the run time of a small problem)
+  int threads = (int)((mx + 1) / 2 + 63) / 64 * 64;
+  threads = threads < 64 ? 64 : (threads > LSAP_WG ? LSAP_WG : threads);
+  hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
