@@ -853,57 +853,63 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
     }
     __syncthreads();
 
-    // one hidden layer: dst[rows of this wave] = softplus(W src + b), optionally streamed to HBM; then `next` is loaded
+    // one hidden layer: dst[rows of this wave] = softplus(W src + b), optionally streamed to HBM; then `next` is loaded.
+    // Software pipeline over the point tiles: the 16 MFMAs of tile t are interleaved, k-step by k-step, with the epilogue
+    // of tile t-1 (bias, softplus, pack, LDS + HBM stores: ~190 VALU instructions per tile against 16 x 8 MFMA passes), so
+    // the matrix core and the vector ALU of the SIMD work at the same time instead of one after the other; only two
+    // accumulator tiles are live.  The B fragment of the next k-step is read from LDS one step ahead.
     auto hidden = [&](int KS, const unsigned char* src, unsigned char* dst, int l, int N, u16* hout, const uint4* next, int nextKS, bool next_on) {
       const float* bl = biasl + l * 256;
-      f32x16 acc[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
       const unsigned char* bp = src + ((size_t)hi * BP + (lane & 31)) * 16;
+      const bool rows_live = wave * 32 < N;
+      f32x16 acc[2];
+      auto epi_quad = [&](const f32x16& ac, int t, int g) {
+        const int n0 = wave * 32 + 8 * g + 4 * hi;
+        if (!rows_live || n0 >= N) return;
+        const int pl = t * 32 + (lane & 31);
+        const float4 bb = *reinterpret_cast<const float4*>(bl + n0);
+        const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
+        float o[4];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        if (ks < KS) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (t >= nt) break;
-            const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16 + t * 32 * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc[t], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? softplus100_fast(ac[4 * g + e] + bq[e]) : 0.0f;
+        u16* lp = reinterpret_cast<u16*>(dst) + ((n0 >> 3) * BP + pl) * 8 + (n0 & 7);
+        if (n0 + 3 < N) {
+          const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
+          *reinterpret_cast<uint2*>(lp) = pk;
+          if (hout) {                                    // 32-bit byte offset (arrays < 4 GiB) off the layer's base pointer
+            const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + go) = pk;
           }
+        } else {                                         // lin3: the quad holding row 216 (rows 217.. receive the PE copy)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n0 + e < N) lp[e] = f2bf(o[e]);
         }
-        if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // bound the number of B fragments in flight
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (next) load_w(next, nextKS, next_on);
-      __builtin_amdgcn_sched_barrier(0);
-      if (wave * 32 < N) {
+      };
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (t >= nt) break;
-          const int pl = t * 32 + (lane & 31);
+      for (int t = 0; t <= NT; ++t) {
+        const bool mma_on = t < NT && t < nt, epi_on = t >= 1 && t - 1 < nt;
+        if (t == NT) {                                   // every MFMA of this layer has been issued: the next slice may land
+          __builtin_amdgcn_sched_barrier(0);
+          if (next) load_w(next, nextKS, next_on);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16& am = acc[t & 1];
+        const f32x16& ae = acc[(t + 1) & 1];
+        if (mma_on) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n0 = wave * 32 + 8 * g + 4 * hi;
-            if (n0 >= N) continue;
-            const float4 bb = *reinterpret_cast<const float4*>(bl + n0);
-            const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
-            float o[4];
+          for (int r = 0; r < 16; ++r) am[r] = 0.0f;
+        }
+        uint4 bv = make_uint4(0u, 0u, 0u, 0u);
+        if (mma_on) bv = *reinterpret_cast<const uint4*>(bp + t * 32 * 16);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? softplus100_fast(acc[t][4 * g + e] + bq[e]) : 0.0f;
-            u16* lp = reinterpret_cast<u16*>(dst) + ((n0 >> 3) * BP + pl) * 8 + (n0 & 7);
-            if (n0 + 3 < N) {
-              const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
-              *reinterpret_cast<uint2*>(lp) = pk;
-              if (hout) {                                    // 32-bit byte offset (arrays < 4 GiB) off the layer's base pointer
-                const unsigned go = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)(p0 + pl)) * 16u + (unsigned)(n0 & 7) * 2u;
-                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + go) = pk;
-              }
-            } else {                                         // lin3: the quad holding row 216 (rows 217.. receive the PE copy)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (n0 + e < N) lp[e] = f2bf(o[e]);
-            }
+        for (int ks = 0; ks < 16; ++ks) {
+          if (mma_on && ks < KS) {
+            const uint4 cur = bv;
+            if (ks + 1 < KS) bv = *reinterpret_cast<const uint4*>(bp + (size_t)(ks + 1) * 2 * BP * 16 + t * 32 * 16);
+            am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&cur), am, 0, 0, 0);
           }
+          if (epi_on && (ks & 3) == 3) epi_quad(ae, t - 1, ks >> 2);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();
