@@ -1472,7 +1472,7 @@ __global__ __launch_bounds__(WG) void pack_kernel2(PackArgs2 a) {
   if (d.bf16) {
     const int KS = d.Kpad >> 4;
     uint4* out = reinterpret_cast<uint4*>(a.out + d.offset) + (size_t)nt * KS * 64;
-    for (int e = threadIdx.x; e < KS * 64; e += WG) {
+    for (int e = blockIdx.y * WG + threadIdx.x; e < KS * 64; e += WG * gridDim.y) {     // grid.y slices of a tile: short dependent chains
       const int s = e >> 6, ln = e & 63;
       const int n = nt * 32 + (ln & 31), kb = 16 * s + 8 * (ln >> 5);
       float w[8];
@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(WG) void pack_kernel2(PackArgs2 a) {
   } else {
     const int KS = d.Kpad >> 1;
     float* out = a.out + d.offset + (size_t)nt * KS * 64;
-    for (int e = threadIdx.x; e < KS * 64; e += WG) {
+    for (int e = blockIdx.y * WG + threadIdx.x; e < KS * 64; e += WG * gridDim.y) {
       const int s = e >> 6, ln = e & 63;
       out[e] = packed_weight(d, v, rs, O, I, nt * 32 + (ln & 31), 2 * s + (ln >> 5));
     }

@@ -1076,7 +1076,7 @@ int neat_pack_weights(const neat_net_params* net, float* packed, int precision, 
   for (int l = 0; l <= NLAYERS; ++l) pa.row_off[l] = L.row_off[l];
   for (int i = 0; i < L.npacks; ++i) pa.d[i] = L.d[i];
   pa.npacks = L.npacks; pa.out = packed;
-  hipLaunchKernelGGL(pack_kernel2, dim3(L.nblocks), dim3(WG), 0, st, pa);
+  hipLaunchKernelGGL(pack_kernel2, dim3(L.nblocks, 4), dim3(WG), 0, st, pa);      // 4 slices per 32-row tile: the pack is latency-bound
   return (int)hipGetLastError();
 }
 
@@ -1418,7 +1418,7 @@ int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, 
     const size_t cbytes = (size_t)nr * nc * sizeof(float);
     if (lds + cbytes <= LSAP_LDS_MAX) { a.cost_lds_off = (int)lds; lds += cbytes; }      // the cost matrix too (8 x 2048 fits)
   }
-  // threads: two columns per thread, whole waves (a 16-wave barrier per step is most of the run time of a small problem)
+  // threads: two columns per thread, whole waves (a small problem does not pay 16-wave barriers; eight columns per thread measured slower)
   int threads = (int)((mx + 1) / 2 + 63) / 64 * 64;
   threads = threads < 64 ? 64 : (threads > LSAP_WG ? LSAP_WG : threads);
   hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, a);
