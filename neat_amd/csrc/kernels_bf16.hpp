@@ -41,6 +41,21 @@ __device__ __forceinline__ float softplus100_fast(float a) {
   const float y = __builtin_amdgcn_exp2f(-fabsf(u));
   return (fmaxf(u, 0.0f) + __builtin_amdgcn_logf(1.0f + y)) * 0.0069314718055994531f;
 }
+// two activations at once on the packed fp32 ALU (v_pk_fma/add/mul_f32: two lanes of work per issue slot; exp2 / log2 and
+// max have no packed form): u = 100 log2(e) (acc + b) arrives as acc * C + b_scaled with the bias pre-scaled by C
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+constexpr float SOFTPLUS_C = 144.26950408889634f;
+__device__ __forceinline__ v2f_t softplus100_pk(v2f_t acc, v2f_t bias_scaled) {
+  const v2f_t cc = {SOFTPLUS_C, SOFTPLUS_C};
+  const v2f_t u = acc * cc + bias_scaled;
+  v2f_t y = {__builtin_amdgcn_exp2f(-fabsf(u.x)), __builtin_amdgcn_exp2f(-fabsf(u.y))};
+  const v2f_t one = {1.0f, 1.0f};
+  y = y + one;
+  const v2f_t lg = {__builtin_amdgcn_logf(y.x), __builtin_amdgcn_logf(y.y)};
+  const v2f_t m = {fmaxf(u.x, 0.0f), fmaxf(u.y, 0.0f)};
+  const v2f_t k = {0.0069314718055994531f, 0.0069314718055994531f};
+  return (m + lg) * k;
+}
 __device__ __forceinline__ float dphi_fast(float h) { return 1.0f - __expf(-100.0f * h); }
 
 // element (f, p) of an octet-major bf16 array
@@ -799,7 +814,7 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
     float v = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (l == k && n < (k == 3 ? 217 : 256)) v = a.bias[k][n];
-    biasl[idx] = v;
+    biasl[idx] = v * SOFTPLUS_C;             // hidden layers: pre-scaled for softplus100_pk
   }
   for (int n = tid; n < 257; n += FWT) {
     int bi = n + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
@@ -868,10 +883,11 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
         if (!rows_live || n0 >= N) return;
         const int pl = t * 32 + (lane & 31);
         const float4 bb = *reinterpret_cast<const float4*>(bl + n0);
-        const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
-        float o[4];
+        const v2f_t o01 = softplus100_pk(v2f_t{ac[4 * g], ac[4 * g + 1]}, v2f_t{bb.x, bb.y});
+        const v2f_t o23 = softplus100_pk(v2f_t{ac[4 * g + 2], ac[4 * g + 3]}, v2f_t{bb.z, bb.w});
+        float o[4] = {o01.x, o01.y, o23.x, o23.y};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (n0 + e < N) ? softplus100_fast(ac[4 * g + e] + bq[e]) : 0.0f;
+        for (int e = 0; e < 4; ++e) if (n0 + e >= N) o[e] = 0.0f;
         u16* lp = reinterpret_cast<u16*>(dst) + ((n0 >> 3) * BP + pl) * 8 + (n0 & 7);
         if (n0 + 3 < N) {
           const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));

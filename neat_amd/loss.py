@@ -85,6 +85,8 @@ class VolSDFLoss(nn.Module):
         self.steps += 1
         dev = model_outputs["rgb_values"].device
         seg_gt, seg_w = ground_truth["lines2d"][0].to(dev).split(4, dim=-1)
+        if dev.type == "cuda":      # column slices of [R,5]: one copy each here instead of one per consumer (two line losses, the reshape below)
+            seg_gt, seg_w = seg_gt.contiguous(), seg_w.contiguous()
         if "labels" in ground_truth:
             seg_w = seg_w * ground_truth["labels"][0, :, None].to(dev)
         l2d_uncalib, per_line = self.get_line_loss(model_outputs["lines2d"].reshape(-1, 4), seg_gt, seg_w)

@@ -201,7 +201,7 @@ def _device_copy(obj, attr, device):
     src = getattr(obj, attr)
     hit = cache.get((attr, str(device)))
     if hit is None or hit[0] is not src:
-        hit = (src, src.to(device))
+        hit = (src, src.to(device).contiguous())
         cache[(attr, str(device))] = hit
     return hit[1]
 
