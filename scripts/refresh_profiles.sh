@@ -1,3 +1,5 @@
+# Regenerates everything under profiles/ in ONE gpurun call:  rm -rf gpurun_out/refresh; gpurun --timeout 1500 -- 'bash scripts/refresh_profiles.sh'
+# (delete the local gpurun_out/refresh first: gpurun merges into it and stale rocprofv3 files of another PID would be picked up)
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $O/tests.log
 python bench.py > $O/bench_bf16.log 2>&1; tail -1 $O/bench_bf16.log > $O/bench_bf16.json
