@@ -350,6 +350,7 @@ struct LayerArgsWS {
   float* out0f;                                          // OUTF variants: out0 is fp32 feature-major [N][ldp]
   int x_octs;                                            // KS = 20: valid octets of in2 (the rest of its 8-octet slot is zero weight)
   const u16* padfill;                                    // EPI_TAN_PF: octet-major array whose rows 0..6 fill rows N..N+6 of out0
+  int tile_stride;                                       // 1: workgroup w owns tiles [w per_wg, (w+1) per_wg); gridDim.x: tiles w, w + grid, ...
 };
 // epilogues that exist only in the weight-stationary kernel
 constexpr int EPI_LINACC = 8;      // out0 = acc + aux0                      (feature cotangent: second head adds to the first)
@@ -393,8 +394,10 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wslds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t_begin = blockIdx.x * a.per_wg;
-  const int T = min(a.per_wg, a.ntiles - t_begin);
+  // tile of step tau: contiguous ranges (tile_stride 1) or interleaved over the workgroups (tile_stride = gridDim.x: at any
+  // moment the machine works on one contiguous window of every array)
+  const int t_begin = a.tile_stride == 1 ? blockIdx.x * a.per_wg : blockIdx.x;
+  const int T = a.tile_stride == 1 ? min(a.per_wg, a.ntiles - t_begin) : (a.ntiles - t_begin + a.tile_stride - 1) / a.tile_stride;
   if (T <= 0) return;
   const unsigned lds_base = (unsigned)(size_t)(lds_ptr)wslds;
   // DMA: per stage this wave moves octets 4w..4w+3 of the input and of each epilogue operand (2 instructions each:
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
   auto issue = [&](int tau) {
     const unsigned stage = lds_base + (unsigned)(tau % C::NS) * C::STAGE;
     const unsigned slot = stage + dma_off;
-    const int tile = t_begin + tau;
+    const int tile = t_begin + tau * a.tile_stride;
     dma(a.in, tile, slot, a.in_octs - 1, a.in2, a.split_oct);
     if (C::XOCT) {           // octets 32..39 of the packed input come from the small second array (2 octets x 32 points per
                              // instruction; waves 4..7 repeat what waves 0..3 fetch so that every wave issues the same count)
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
     }
     if (!live) continue;
-    const int p = (t_begin + tau) * WSP + (lane & 31);
+    const int p = (t_begin + tau * a.tile_stride) * WSP + (lane & 31);
     float sp = 0.0f;
     if (C::HAS_S) sp = *reinterpret_cast<const float*>(slot + EXTRA + wave * 256 + (lane & 31) * 4);
 #pragma unroll
@@ -1278,6 +1281,7 @@ struct WgradArgsH3 {
   int splitB, octsB;                 // octets of B in total (K = packed columns <= 256)
   int npairs, N, K, P, ldp, chunk;
   float* partial; size_t row_stride, split_stride; int col_off, bias_col;   // partial column of B column 0 / of the bias (-1: none)
+  int interleave;                    // stages of a workgroup: 0 = one contiguous chunk of points, 1 = every gridDim.y-th 32-point stage
   int nprob; size_t prob_stride;     // nprob > 1 (grid.x = nprob): INDEPENDENT problems of npairs pairs each, problem p = blockIdx.x, its partials
                                      // at partial + p * prob_stride (same-shaped layers in one launch: 1/nprob of the partial tiles per layer)
 };
@@ -1290,9 +1294,13 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = (wave >> 1) * 64, wc = (wave & 1) * 128;
-  const int pbeg = blockIdx.y * a.chunk;
-  const int pend = min(a.P, pbeg + a.chunk);
-  const int nsteps = (pend - pbeg + W3P - 1) / W3P;
+  // point stages of this workgroup: one contiguous chunk, or (interleave) stages y, y + splits, ... -- at any moment the
+  // machine then sweeps one contiguous window of every operand array
+  const int nsplit = gridDim.y;
+  const int pstep = a.interleave ? nsplit * W3P : W3P;
+  const int pbeg = a.interleave ? blockIdx.y * W3P : blockIdx.y * a.chunk;
+  const int pend = a.interleave ? a.P : min(a.P, pbeg + a.chunk);
+  const int nsteps = a.interleave ? ((a.P + W3P - 1) / W3P - (int)blockIdx.y + nsplit - 1) / nsplit : (pend - pbeg + W3P - 1) / W3P;
   const int prob = a.nprob > 1 ? (int)blockIdx.x : 0;
   const int T = nsteps * a.npairs;
   bool liveR[2], liveC[4];
@@ -1342,7 +1350,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       const uint4* seg = reinterpret_cast<const uint4*>(second ? base2 : base) + (size_t)(second ? oct - a.splitB : oct) * a.ldp;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int p = pbeg + st * W3P + 16 * i + dl_pt;
+        const int p = pbeg + st * pstep + 16 * i + dl_pt;
         const uint4* src = seg + p;
         const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (dq0 + hq) * 2048 + i * 1024);
         unsigned keep;
@@ -1369,7 +1377,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
     if (tau + W3NS - 1 < T) issue(tau + W3NS - 1);
     const unsigned char* slot = w3lds + (tau % W3NS) * W3_STAGE;
     const int st = tau >= nsteps ? tau - nsteps : tau;
-    const int pb = pbeg + st * W3P;
+    const int pb = pbeg + st * pstep;
     const bool tail = pb + W3P > pend;
     const bool bias_now = do_bias && tau < nsteps;
 #pragma unroll
