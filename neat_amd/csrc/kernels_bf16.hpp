@@ -848,8 +848,14 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
 
   // the 32-point tiles are split evenly over the workgroups (tile counts differ by at most one); each workgroup walks its
   // range in batches of NT tiles, the last batch may be shorter (its missing tiles skip MFMAs, epilogue and stores)
-  const int t_begin = (int)(((long long)blockIdx.x * ntiles) / nwg), t_end = (int)(((long long)(blockIdx.x + 1) * ntiles) / nwg);
-  for (int tile0 = t_begin; tile0 < t_end; tile0 += NT) {
+  // nwg < 0: batches of NT tiles interleaved over the -nwg workgroups (batch b -> workgroup b mod grid) instead of one
+  // contiguous tile range per workgroup
+  const bool inter = nwg < 0;
+  const int ng = inter ? -nwg : nwg;
+  const int t_begin = inter ? (int)blockIdx.x * NT : (int)(((long long)blockIdx.x * ntiles) / ng);
+  const int t_end = inter ? ntiles : (int)(((long long)(blockIdx.x + 1) * ntiles) / ng);
+  const int t_step = inter ? ng * NT : NT;
+  for (int tile0 = t_begin; tile0 < t_end; tile0 += t_step) {
     const int p0 = tile0 * 32;
     const int nt = min(NT, t_end - tile0);
     // ---- positional encoding (embedder.py:12-36) into the PE octets (rows 39..63 zero)
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
           if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (tile0 + NT < t_end) load_w(a.Wp[0], 4, true);  // next batch's lin0 slice
+        if (tile0 + t_step < t_end) load_w(a.Wp[0], 4, true);  // next batch's lin0 slice
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

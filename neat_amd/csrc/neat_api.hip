@@ -174,6 +174,7 @@ int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persist
 int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
+int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
   static bool attr_set = false;
@@ -494,7 +495,7 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
       const int ntiles = c.ldp / 32;                 // ldp is a multiple of 64
       const int nwg = ntiles < g_ws_grid ? ntiles : g_ws_grid;
       auto go = [&](auto kern, int BP, int lds_bytes) -> hipError_t {
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(FWT), lds_bytes, c.st, a, ntiles, nwg);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(FWT), lds_bytes, c.st, a, ntiles, g_fused_interleave ? -nwg : nwg);
         return hipGetLastError();
       };
       // batch = up to 32*NT points: larger batches re-read the weights from L2 less often.  The tiles are split evenly over
@@ -1036,6 +1037,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 8 && (value == -1 || value == 0 || value == 2 || value == 3 || value == 6)) { g_wgrad_batch = value; return 0; }
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   if (key == 9 && (value == 0 || value == 1)) { g_ws_interleave = value; return 0; }
+  if (key == 10 && (value == 0 || value == 1)) { g_fused_interleave = value; return 0; }
   return -1;
 }
 
