@@ -205,7 +205,10 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *   4 fused primal chain: 1 = weight-stationary               5 its batch in 32-point tiles (0 = auto, 2..4)
  *   6 partial reduction: 1 = one 16-wave pass (default 0)     7 interleave weight gradients with the reverse chain (default 0)
  *   8 same-shaped weight gradients per launch (-1 = by problem size (default), 0 = one layer per launch, 2, 3, 6)
- *   9 point tiles of the persistent streaming kernels: 1 = interleaved over the workgroups (default), 0 = one contiguous range each */
+ *   9 point tiles of the persistent streaming kernels: 1 = interleaved over the workgroups (default), 0 = one contiguous range each
+ *  10 fused primal chain: batches interleaved over the workgroups (default 0)
+ *  11 non-temporal accesses, bit mask (default 15): 1 / 2 = aux0 / aux1 fetch of the layer kernels, 4 = weight-gradient operands,
+ *     8 = `in` fetch of the layer kernels, 16 = out1 (m_l) store */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);

@@ -350,6 +350,7 @@ struct LayerArgsWS {
   float* out0f;                                          // OUTF variants: out0 is fp32 feature-major [N][ldp]
   int x_octs;                                            // KS = 20: valid octets of in2 (the rest of its 8-octet slot is zero weight)
   const u16* padfill;                                    // EPI_TAN_PF: octet-major array whose rows 0..6 fill rows N..N+6 of out0
+  int aux_nt;                                            // non-temporal: bit 0 / 1 fetch of aux0 / aux1, bit 2 fetch of `in`, bit 3 store of out1
   int tile_stride;                                       // 1: workgroup w owns tiles [w per_wg, (w+1) per_wg); gridDim.x: tiles w, w + grid, ...
 };
 // epilogues that exist only in the weight-stationary kernel
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
   // DMA: per stage this wave moves octets 4w..4w+3 of the input and of each epilogue operand (2 instructions each:
   // 2 octets x 32 points); LDS image [octet][point] x 16 B is lane-linear per instruction
   const unsigned dma_off = (unsigned)(4 * wave) * (WSP * 16);
-  auto dma = [&](const u16* base, int tile, unsigned dst, int max_oct, const u16* base2 = nullptr, int split = 1 << 30) {
+  auto dma = [&](const u16* base, int tile, unsigned dst, int max_oct, const u16* base2 = nullptr, int split = 1 << 30, bool nt = false) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // octets past the end of a 217-row array would be uninitialised memory (x zero weight = NaN): re-read a valid one
@@ -413,8 +414,12 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
       const u16* s2 = b + ((size_t)oct * a.ldp + (size_t)tile * WSP + (lane & 31)) * 8;
       const unsigned d2 = __builtin_amdgcn_readfirstlane(dst + i * (2 * WSP * 16));
       unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
+      if (nt)       // read-once operand written long ago: non-temporal, so that it does not displace the chain's own arrays from the caches
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
+      else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
     }
   };
   auto dma1 = [&](const void* src, unsigned dst, bool wide) {
@@ -432,14 +437,14 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     const unsigned stage = lds_base + (unsigned)(tau % C::NS) * C::STAGE;
     const unsigned slot = stage + dma_off;
     const int tile = t_begin + tau * a.tile_stride;
-    dma(a.in, tile, slot, a.in_octs - 1, a.in2, a.split_oct);
+    dma(a.in, tile, slot, a.in_octs - 1, a.in2, a.split_oct, (a.aux_nt & 4) != 0);
     if (C::XOCT) {           // octets 32..39 of the packed input come from the small second array (2 octets x 32 points per
                              // instruction; waves 4..7 repeat what waves 0..3 fetch so that every wave issues the same count)
       const int oct = min(2 * (wave & 3) + (lane >> 5), a.x_octs - 1);
       dma1(a.in2 + ((size_t)oct * a.ldp + (size_t)tile * WSP + (lane & 31)) * 8, stage + (32 + 2 * (wave & 3)) * (WSP * 16), true);
     }
-    if (C::NAUX >= 1) dma(a.aux0, tile, slot + AUX0, 31);
-    if (C::NAUX >= 2) dma(a.aux1, tile, slot + AUX1, 31);
+    if (C::NAUX >= 1) dma(a.aux0, tile, slot + AUX0, 31, nullptr, 1 << 30, (a.aux_nt & 1) != 0);
+    if (C::NAUX >= 2) dma(a.aux1, tile, slot + AUX1, 31, nullptr, 1 << 30, (a.aux_nt & 2) != 0);
     if (C::HAS_S)            // this wave's private copy of the 32 per-point scalars (both half-waves fetch the same 128 B)
       dma1(a.srow + (size_t)tile * WSP + (lane & 31), stage + EXTRA + wave * 256, false);
     if (C::HAS_PF)           // octet 0 of the pad-fill array: every wave writes the SAME bytes to the same 1 KiB (both half-waves
@@ -528,7 +533,12 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
       const unsigned oidx = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)p) * 8u + (unsigned)(n0 & 7);
       if (EPI != EPI_REV || n0 < ((a.n_split + 7) & ~7))        // (split layer: out0 ends with the octet that holds row n_split-1)
         *reinterpret_cast<uint2*>(a.out0 + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
-      if (EPI == EPI_TAN || EPI == EPI_TAN_PF) *reinterpret_cast<uint2*>(a.out1 + oidx) = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+      if (EPI == EPI_TAN || EPI == EPI_TAN_PF) {
+        const uint2 v1 = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+        typedef unsigned long long u64_t;
+        if (a.aux_nt & 8) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v1), reinterpret_cast<u64_t*>(a.out1 + oidx));   // m_l: next read by the weight gradient
+        else *reinterpret_cast<uint2*>(a.out1 + oidx) = v1;
+      }
       if (EPI == EPI_REV && n0 + 3 >= a.n_split && a.out1f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1287,6 +1297,7 @@ struct WgradArgsH3 {
   int splitB, octsB;                 // octets of B in total (K = packed columns <= 256)
   int npairs, N, K, P, ldp, chunk;
   float* partial; size_t row_stride, split_stride; int col_off, bias_col;   // partial column of B column 0 / of the bias (-1: none)
+  int nt_loads;                      // operand fetches non-temporal
   int interleave;                    // stages of a workgroup: 0 = one contiguous chunk of points, 1 = every gridDim.y-th 32-point stage
   int nprob; size_t prob_stride;     // nprob > 1 (grid.x = nprob): INDEPENDENT problems of npairs pairs each, problem p = blockIdx.x, its partials
                                      // at partial + p * prob_stride (same-shaped layers in one launch: 1/nprob of the partial tiles per layer)
@@ -1360,8 +1371,12 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
         const uint4* src = seg + p;
         const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (dq0 + hq) * 2048 + i * 1024);
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        if (a.nt_loads)      // operands are read once, long after they were written: keep them out of the way of the partial tiles
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        else
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
       }
     }
   };

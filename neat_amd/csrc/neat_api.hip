@@ -174,6 +174,8 @@ int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persist
 int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
+int g_ws_aux_nt = 15;       // non-temporal accesses (tuning key 11): bit 0 / 1 = fetch of aux0 / aux1 of the streaming layer kernels, bit 2 =
+                            // weight-gradient operands, bit 3 = `in` of the layer kernels, bit 4 = store of out1 (m_l)
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
@@ -189,6 +191,7 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
   a.per_wg = (a.ntiles + g_ws_grid - 1) / g_ws_grid;
   int grid = (a.ntiles + a.per_wg - 1) / a.per_wg;
   a.tile_stride = 1;
+  a.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 12);      // key bits 3 / 4 -> kernel bits 2 / 3
   if (g_ws_interleave) { grid = a.ntiles < g_ws_grid ? a.ntiles : g_ws_grid; a.tile_stride = grid; }
   hipLaunchKernelGGL((layer_kernel_ws<EPI, KS, OUTF>), dim3(grid), dim3(WST), (WsCfg<EPI, KS>::LDS), st, a);
   return hipGetLastError();
@@ -624,7 +627,7 @@ hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob,
     }
   a.splitB = 32; a.octsB = 32; a.npairs = npairs; a.N = N; a.K = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
   a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.col_off = 0; a.bias_col = K;
-  a.nprob = nprob; a.prob_stride = region; a.interleave = g_ws_interleave;
+  a.nprob = nprob; a.prob_stride = region; a.interleave = g_ws_interleave; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
   ProfSlot* ps = prof_begin(c.st, 1, flops, bytes + (double)nprob * splits * N * (K + 1) * 4.0);
   hipLaunchKernelGGL(wgrad_kernel_h3, dim3(nprob, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
   prof_end(c.st, ps);
@@ -750,7 +753,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
         }
         a.octsB = (a.K + 7) / 8;
         a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-        a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.interleave = g_ws_interleave;
+        a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.interleave = g_ws_interleave; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
         hipLaunchKernelGGL(wgrad_kernel_h3, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
       }
       prof_end(c.st, ps);
@@ -1038,6 +1041,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   if (key == 9 && (value == 0 || value == 1)) { g_ws_interleave = value; return 0; }
   if (key == 10 && (value == 0 || value == 1)) { g_fused_interleave = value; return 0; }
+  if (key == 11 && value >= 0 && value <= 31) { g_ws_aux_nt = value; return 0; }
   return -1;
 }
 
