@@ -203,7 +203,8 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *   0 bf16 layer-kernel point tile (2 = 64 points, 4 = 128)   1 weight gradient: 1 = tr16 streaming kernel, 0 = previous
  *   2 hidden layers: 1 = weight-stationary streaming kernel   3 persistent workgroups of that kernel (default 256)
  *   4 fused primal chain: 1 = weight-stationary               5 its batch in 32-point tiles (0 = auto, 2..4)
- *   6 partial reduction: 1 = one 16-wave pass (default 0)     7 interleave weight gradients with the reverse chain (default 0)
+ *   6 partial reduction: 2 = one launch, 16-byte loads (default), 0 = group sums + finish, 1 = one 16-wave pass
+ *   7 interleave weight gradients with the reverse chain (default 0)
  *   8 same-shaped weight gradients per launch (-1 = by problem size (default), 0 = one layer per launch, 2, 3, 6)
  *   9 point tiles of the persistent streaming kernels: 1 = interleaved over the workgroups (default), 0 = one contiguous range each
  *  10 fused primal chain: batches interleaved over the workgroups (default 0)

@@ -392,6 +392,69 @@ __device__ __forceinline__ void wreduce_wnorm_body(const WreduceArgs& a, const i
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void wreduce_wnorm_kernel(WreduceArgs a) { wreduce_wnorm_body<NW>(a, blockIdx.x); }
 
+// One-launch reduction for many split partials (bf16 build: 82..245 splits of 1 KiB rows): the workgroup of output row o
+// sums ITS packed row over all splits with 16-byte loads -- thread = (float4 column, one of up to 4 split sub-sequences),
+// eight independent loads in flight per thread -- combines the sub-sums in LDS in a fixed order (deterministic), and wave 0
+// applies the weight-norm backward.  Replaces wpartial_group_sum_kernel + wreduce_wnorm_kernel<4> (one launch and a
+// stage buffer less per layer).
+constexpr int WRD_MAXK4 = 80;            // partial row length in float4 (K + 1 <= 320)
+__device__ __forceinline__ void wreduce_direct_body(const WreduceArgs& a, const int o) {
+  constexpr int MAXC = 5;
+  __shared__ __attribute__((aligned(16))) float part[4][WRD_MAXK4 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Kld4 = (int)(a.split_stride >> 2);
+  const int nsub = min(4, (int)blockDim.x / Kld4);
+  const int sub = tid / Kld4, c4 = tid - sub * Kld4;
+  const int on = (o - a.rot + a.O) % a.O;                    // packed row of source row o
+  if (sub < nsub) {
+    const float4* src = reinterpret_cast<const float4*>(a.partial + (size_t)on * a.row_stride) + c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int sp = sub; sp < a.splits; sp += nsub) {
+      const float4 v = src[(size_t)sp * Kld4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(&part[sub][4 * c4]) = acc;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  float dw[MAXC], vv[MAXC];
+  float dot = 0.0f, nrm2 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = lane + 64 * c;          // source column
+    dw[c] = 0.0f; vv[c] = 0.0f;
+    if (i < a.I) {
+      const int j = (i >= a.off0 && i < a.off0 + a.s0) ? i - a.off0 : a.s0p + (i - a.off1);   // packed column
+      float t = 0.0f;
+      for (int w = 0; w < nsub; ++w) t += part[w][j];
+      dw[c] = t * a.scale;
+      vv[c] = a.v[(size_t)o * a.I + i];
+      dot += dw[c] * vv[c];
+      nrm2 += vv[c] * vv[c];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { dot += __shfl_xor(dot, off); nrm2 += __shfl_xor(nrm2, off); }
+  const float inv = 1.0f / sqrtf(nrm2);
+  const float go = a.g[o];
+  const float coef = dot * inv * inv;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = lane + 64 * c;
+    if (i < a.I) a.dv[(size_t)o * a.I + i] = go * inv * (dw[c] - coef * vv[c]);
+  }
+  if (lane == 0) {
+    a.dg[o] = dot * inv;
+    if (a.db && a.bias_col >= 0) {
+      float t = 0.0f;
+      for (int w = 0; w < nsub; ++w) t += part[w][a.bias_col];
+      a.db[o] = t;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void wreduce_direct_kernel(WreduceArgs a) { wreduce_direct_body(a, blockIdx.x); }
+
 // the finish of several layers in one launch (the problems of one batched weight-gradient launch): blockIdx.y = layer.
 // The argument table is read from the kernel-argument segment through a pointer -- indexing the by-value array with
 // blockIdx.y would copy it to scratch.
@@ -402,6 +465,12 @@ __global__ __launch_bounds__(256) void wreduce_wnorm_batch_kernel(WreduceBatch) 
   const WreduceArgs a = tab[blockIdx.y];
   if ((int)blockIdx.x >= a.O) return;          // lin3 has 217 rows
   wreduce_wnorm_body<4>(a, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void wreduce_direct_batch_kernel(WreduceBatch) {
+  const WreduceArgs* tab = (const WreduceArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const WreduceArgs a = tab[blockIdx.y];
+  if ((int)blockIdx.x >= a.O) return;
+  wreduce_direct_body(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

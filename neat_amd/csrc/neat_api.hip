@@ -169,7 +169,8 @@ inline int wgrad_batch_size(int ldp) {
   return ldp <= 200000 ? 3 : (ldp <= 400000 ? 2 : 0);
 }
 int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
-int g_wreduce_direct = 0;   // bf16 weight-gradient reduction: 0 = group sums + finish (faster: 4.43 vs 4.63 ms/step), 1 = one 16-wave pass per row
+int g_wreduce_direct = 2;   // bf16 weight-gradient reduction: 2 = one launch per layer / batch with 16-byte loads (wreduce_direct_kernel), 0 = group
+                            // sums + finish (two launches, stage buffer), 1 = one 16-wave pass with 4-byte loads (slowest)
 int g_fused_ws = 1;         // fused primal chain: 1 = weight-stationary persistent kernel, 0 = sdf_fused_kernel_h
 int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
@@ -571,8 +572,10 @@ hipError_t wgrad_reduce(const Ctx& c, const SdfWs& w, int layer_id, WreduceArgs 
   const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
   const int splits = r.splits;
   const float* partial = r.partial;
-  const bool direct = c.prec && g_wreduce_direct;          // bf16 build: one 16-wave pass over all split partials
-  if (splits > 2 * WGROUPS && !direct) {
+  const bool direct = c.prec && g_wreduce_direct == 1;    // bf16 build: one 16-wave pass over all split partials
+  const bool direct4 = c.prec && g_wreduce_direct == 2 && splits > 2 * WGROUPS && (r.split_stride & 3) == 0 &&
+                       r.split_stride / 4 <= WRD_MAXK4;    // one launch, 16-byte loads (wreduce_direct_kernel)
+  if (splits > 2 * WGROUPS && !direct && !direct4) {
     // two-stage, deterministic: bandwidth-bound group sums first, then the per-row finish on 8 partials
     const int Kld = (int)r.split_stride, per = (splits + WGROUPS - 1) / WGROUPS;
     float* stage = w.partial + (WPARTIAL_FLOATS - WSTAGE_FLOATS);
@@ -587,7 +590,8 @@ hipError_t wgrad_reduce(const Ctx& c, const SdfWs& w, int layer_id, WreduceArgs 
   r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
   r.bias_col = K;
   dbg_sync(c.st, "wgrad layer/N/K", layer_id, N, K);
-  if (direct && splits > 2 * WGROUPS) hipLaunchKernelGGL(wreduce_wnorm_kernel<16>, dim3(r.O), dim3(1024), 0, c.st, r);
+  if (direct4) hipLaunchKernelGGL(wreduce_direct_kernel, dim3(r.O), dim3(WG), 0, c.st, r);
+  else if (direct && splits > 2 * WGROUPS) hipLaunchKernelGGL(wreduce_wnorm_kernel<16>, dim3(r.O), dim3(1024), 0, c.st, r);
   else hipLaunchKernelGGL(wreduce_wnorm_kernel<4>, dim3(r.O), dim3(WG), 0, c.st, r);
   dbg_sync(c.st, "wreduce layer/splits", layer_id, splits, 0);
   return hipGetLastError();
@@ -643,24 +647,31 @@ hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob,
   if (e != hipSuccess) return e;
   // the reduction of all nprob layers in two launches: the regions are contiguous, so the group sums see nprob * N rows;
   // then one finish launch (weight-norm backward) with blockIdx.y = layer
+  const bool direct4 = g_wreduce_direct == 2;
   const int per = (splits + WGROUPS - 1) / WGROUPS, groups_used = (splits + per - 1) / per;
   float* stage = w.partial + (WPARTIAL_FLOATS - WSTAGE_FLOATS);
-  hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld2 / 4 + 127) / 128, WGROUPS, nprob * N), dim3(128), 0, c.st,
-                     (const float*)w.partial, splits, Kld2 / 4, WGROUPS, per, nprob * N, stage);
+  if (!direct4)
+    hipLaunchKernelGGL(wpartial_group_sum_kernel, dim3((Kld2 / 4 + 127) / 128, WGROUPS, nprob * N), dim3(128), 0, c.st,
+                       (const float*)w.partial, splits, Kld2 / 4, WGROUPS, per, nprob * N, stage);
   WreduceBatch b{};
   for (int q = 0; q < nprob; ++q) {
     const int layer_id = pb[q].layer_id;
     const PackDesc2& d = c.L().d[c.L().fwd[layer_id]];
     WreduceArgs& r = b.a[q];
-    r.partial = stage + (size_t)q * N * WGROUPS * Kld2; r.splits = groups_used;
-    r.row_stride = (size_t)WGROUPS * Kld2; r.split_stride = Kld2;
+    if (direct4) {
+      r.partial = w.partial + (size_t)q * region; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
+    } else {
+      r.partial = stage + (size_t)q * N * WGROUPS * Kld2; r.splits = groups_used;
+      r.row_stride = (size_t)WGROUPS * Kld2; r.split_stride = Kld2;
+    }
     r.O = kO[layer_id]; r.I = kI[layer_id];
     r.s0 = d.s0; r.s0p = d.s0p; r.off0 = d.off0; r.off1 = d.off1; r.rot = d.rot; r.scale = d.scale;
     r.v = c.net->v[layer_id]; r.g = c.net->g[layer_id];
     r.dv = gr->dv[layer_id]; r.dg = gr->dg[layer_id]; r.db = gr->db[layer_id];
     r.bias_col = K;
   }
-  hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(256, nprob), dim3(WG), 0, c.st, b);
+  if (direct4) hipLaunchKernelGGL(wreduce_direct_batch_kernel, dim3(256, nprob), dim3(WG), 0, c.st, b);
+  else hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(256, nprob), dim3(WG), 0, c.st, b);
   return hipGetLastError();
 }
 
@@ -1035,7 +1046,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 2 && (value == 0 || value == 1)) { g_layer_ws = value; return 0; }
   if (key == 3 && value >= 1 && value <= 4096) { g_ws_grid = value; return 0; }
   if (key == 4 && (value == 0 || value == 1)) { g_fused_ws = value; return 0; }
-  if (key == 6 && (value == 0 || value == 1)) { g_wreduce_direct = value; return 0; }
+  if (key == 6 && value >= 0 && value <= 2) { g_wreduce_direct = value; return 0; }
   if (key == 7 && (value == 0 || value == 1)) { g_wgrad_interleave = value; return 0; }
   if (key == 8 && (value == -1 || value == 0 || value == 2 || value == 3 || value == 6)) { g_wgrad_batch = value; return 0; }
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
