@@ -366,7 +366,7 @@ template <int EPI, int KS = 16> struct WsCfg {
   static constexpr int HAS_PF = EPI == EPI_TAN_PF ? 1 : 0;
   static constexpr int XOCT = KS > 16 ? 8 : 0;           // input octets beyond the 32 of the main array (K = 320: [256 | 64])
   static constexpr int IN_TILE = (32 + XOCT) * WSP * 16;
-  static constexpr int NS = NAUX == 2 ? 3 : 4;           // ring depth: 3 x 48 KiB or 4 x (16|20|32) KiB (8 x 16 KiB measured no faster)
+  static constexpr int NS = NAUX == 2 ? 3 : 4;           // ring depth: 3 x 48 KiB or 4 x (16|20|32) KiB (8 x 16 KiB / 6 x 20 KiB measured slower, twice)
   static constexpr int STAGE = IN_TILE + WS_TILE * NAUX + HAS_S * 8 * 256 + HAS_PF * 1024;
   static constexpr int G = 2 * (1 + NAUX) + HAS_S + HAS_PF + (XOCT ? 1 : 0);       // DMA instructions per stage per wave
   static constexpr int LDS = NS * STAGE;
