@@ -711,6 +711,15 @@ __global__ void zero_tail_kernel(float* __restrict__ a, int rows, int p_from, in
   if (p >= ldp) return;
   for (int r = 0; r < rows; ++r) a[(size_t)r * ldp + p] = 0.0f;
 }
+// the same for three arrays in one launch (the head cotangents and the sdf cotangent row beyond the ray samples)
+__global__ void zero_tail3_kernel(float* __restrict__ a, int rows_a, float* __restrict__ b, int rows_b, float* __restrict__ c, int rows_c,
+                                  int p_from, int ldp) {
+  const int p = p_from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ldp) return;
+  for (int r = 0; r < rows_a; ++r) a[(size_t)r * ldp + p] = 0.0f;
+  for (int r = 0; r < rows_b; ++r) b[(size_t)r * ldp + p] = 0.0f;
+  for (int r = 0; r < rows_c; ++r) c[(size_t)r * ldp + p] = 0.0f;
+}
 
 // ---------------------------------------------------------------------------------------------
 // compositing (rend_a :540-554 volume_rendering, :406-426 integrals); one wave per ray

@@ -807,7 +807,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   hipError_t e;
   if (c.prec) hipLaunchKernelGGL(posenc6_tangent_kernel<true>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
   else hipLaunchKernelGGL(posenc6_tangent_kernel<false>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
-  hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, c.P, c.ldp);
+  if (!c.prec) hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, c.P, c.ldp);
   // bf16 build: octet-major copies of the PE rows and their tangents for the streaming kernels (skip layer, lin0 / lin4 gradients)
   if (c.prec) oct_pack(c, {{w.E, PE_ROWS, w.Ebf}, {w.E + 7 * (size_t)c.ldp, 32, w.Ebf4}, {w.Eh, PE_ROWS, w.Ehbf}, {w.Eh + 7 * (size_t)c.ldp, 32, w.Ehbf4}});
   // tangent chain (forward-mode along g^): vh_{l+1} = tangent of h_{l+1}, m_l = extra cotangent of a_l
@@ -1228,12 +1228,11 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   cb.R = R; cb.S = S; cb.ldp = c.ldp; cb.beta_ptr = beta;
   cb.d_rgb = d_rgb; cb.d_lines3d = d_lines3d; cb.d_depth = d_depth; cb.d_xyz = d_xyz;
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
-  hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
+  if (!c.prec)      // the ones row is the bias column of the fp32 weight-gradient kernel; the bf16 kernels sum the rows of A themselves
+    hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, cb);
   if (c.ldp > Pm) {      // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents
-    hipLaunchKernelGGL(zero_tail_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, Pm, c.ldp);
-    hipLaunchKernelGGL(zero_tail_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.dlin, 6, Pm, c.ldp);
-    hipLaunchKernelGGL(zero_tail_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, w.abar8, 1, Pm, c.ldp);
+    hipLaunchKernelGGL(zero_tail3_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, h.dlin, 6, w.abar8, 1, Pm, c.ldp);
   }
   NEAT_CHECK(heads_backward(c, h, w, grads));
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
