@@ -350,6 +350,7 @@ struct LayerArgsWS {
   float* out0f;                                          // OUTF variants: out0 is fp32 feature-major [N][ldp]
   int x_octs;                                            // KS = 20: valid octets of in2 (the rest of its 8-octet slot is zero weight)
   const u16* padfill;                                    // EPI_TAN_PF: octet-major array whose rows 0..6 fill rows N..N+6 of out0
+  int wide_store;                                        // 1: bf16 outputs leave as 16-byte stores (v_permlane32_swap), 0: 8-byte
   int aux_nt;                                            // non-temporal: bit 0 / 1 fetch of aux0 / aux1, bit 2 fetch of `in`, bit 3 store of out1
   int tile_stride;                                       // 1: workgroup w owns tiles [w per_wg, (w+1) per_wg); gridDim.x: tiles w, w + grid, ...
 };
@@ -490,6 +491,9 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     const int p = (t_begin + tau * a.tile_stride) * WSP + (lane & 31);
     float sp = 0.0f;
     if (C::HAS_S) sp = *reinterpret_cast<const float*>(slot + EXTRA + wave * 256 + (lane & 31) * 4);
+    uint2 pk0[4], pk1[4];            // packed quads of out0 / out1 (wide stores: two quads travel as one 16-byte octet per lane)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { pk0[q] = make_uint2(0u, 0u); pk1[q] = make_uint2(0u, 0u); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n0 = wave * 32 + 8 * q + 4 * (lane >> 5);
@@ -530,19 +534,48 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
           if (n0 + e < a.N) a.out0f[(unsigned)(n0 + e) * (unsigned)a.ldp + (unsigned)p] = o0[e];
         continue;
       }
-      const unsigned oidx = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)p) * 8u + (unsigned)(n0 & 7);
-      if (EPI != EPI_REV || n0 < ((a.n_split + 7) & ~7))        // (split layer: out0 ends with the octet that holds row n_split-1)
-        *reinterpret_cast<uint2*>(a.out0 + oidx) = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
-      if (EPI == EPI_TAN || EPI == EPI_TAN_PF) {
-        const uint2 v1 = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
-        typedef unsigned long long u64_t;
-        if (a.aux_nt & 8) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v1), reinterpret_cast<u64_t*>(a.out1 + oidx));   // m_l: next read by the weight gradient
-        else *reinterpret_cast<uint2*>(a.out1 + oidx) = v1;
+      pk0[q] = make_uint2(pack2(o0[0], o0[1]), pack2(o0[2], o0[3]));
+      if (EPI == EPI_TAN || EPI == EPI_TAN_PF) pk1[q] = make_uint2(pack2(o1[0], o1[1]), pack2(o1[2], o1[3]));
+      if (!a.wide_store) {
+        const unsigned oidx = ((unsigned)(n0 >> 3) * (unsigned)a.ldp + (unsigned)p) * 8u + (unsigned)(n0 & 7);
+        if (EPI != EPI_REV || n0 < ((a.n_split + 7) & ~7))        // (split layer: out0 ends with the octet that holds row n_split-1)
+          *reinterpret_cast<uint2*>(a.out0 + oidx) = pk0[q];
+        if (EPI == EPI_TAN || EPI == EPI_TAN_PF) {
+          typedef unsigned long long u64_t;
+          if (a.aux_nt & 8) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, pk1[q]), reinterpret_cast<u64_t*>(a.out1 + oidx));   // m_l: next read by the weight gradient
+          else *reinterpret_cast<uint2*>(a.out1 + oidx) = pk1[q];
+        }
       }
       if (EPI == EPI_REV && n0 + 3 >= a.n_split && a.out1f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (n0 + e >= a.n_split && n0 + e < a.N) a.out1f[(unsigned)(n0 + e - a.n_split) * (unsigned)a.ldp + (unsigned)p] = o1[e];
+      }
+    }
+    if (!OUTF && a.wide_store) {
+      // 16-byte stores: the accumulator layout gives lane l rows 8q..8q+3 and lane l+32 rows 8q+4..8q+7 of a point; one
+      // v_permlane32_swap per dword hands lanes 0-31 the whole octet of quad 2j and lanes 32-63 the whole octet of quad 2j+1
+      // (half as many store instructions, 16 B per lane like a plain copy kernel)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ob = wave * 32 + 16 * j;
+        if (ob >= Npad) continue;
+        const int oct = (ob >> 3) + (lane >> 5);
+        const unsigned oidx = ((unsigned)oct * (unsigned)a.ldp + (unsigned)p) * 8u;
+        const bool in_range = oct * 8 < Npad;
+        {
+          typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+          const v2u_t s0 = __builtin_amdgcn_permlane32_swap(pk0[2 * j].x, pk0[2 * j + 1].x, false, false);
+          const v2u_t s1 = __builtin_amdgcn_permlane32_swap(pk0[2 * j].y, pk0[2 * j + 1].y, false, false);
+          if (in_range && (EPI != EPI_REV || oct * 8 < ((a.n_split + 7) & ~7)))
+            *reinterpret_cast<uint4*>(a.out0 + oidx) = make_uint4(s0.x, s1.x, s0.y, s1.y);
+        }
+        if (EPI == EPI_TAN || EPI == EPI_TAN_PF) {
+          typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+          const v2u_t s0 = __builtin_amdgcn_permlane32_swap(pk1[2 * j].x, pk1[2 * j + 1].x, false, false);
+          const v2u_t s1 = __builtin_amdgcn_permlane32_swap(pk1[2 * j].y, pk1[2 * j + 1].y, false, false);
+          if (in_range) *reinterpret_cast<uint4*>(a.out1 + oidx) = make_uint4(s0.x, s1.x, s0.y, s1.y);
+        }
       }
     }
   }

@@ -177,6 +177,7 @@ int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
 int g_ws_aux_nt = 15;       // non-temporal accesses (tuning key 11): bit 0 / 1 = fetch of aux0 / aux1 of the streaming layer kernels, bit 2 =
                             // weight-gradient operands, bit 3 = `in` of the layer kernels, bit 4 = store of out1 (m_l)
+int g_ws_wide_store = 1;    // streaming layer kernels: 16-byte output stores (tuning key 12)
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
@@ -192,6 +193,7 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
   a.per_wg = (a.ntiles + g_ws_grid - 1) / g_ws_grid;
   int grid = (a.ntiles + a.per_wg - 1) / a.per_wg;
   a.tile_stride = 1;
+  a.wide_store = g_ws_wide_store;
   a.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 12);      // key bits 3 / 4 -> kernel bits 2 / 3
   if (g_ws_interleave) { grid = a.ntiles < g_ws_grid ? a.ntiles : g_ws_grid; a.tile_stride = grid; }
   hipLaunchKernelGGL((layer_kernel_ws<EPI, KS, OUTF>), dim3(grid), dim3(WST), (WsCfg<EPI, KS>::LDS), st, a);
@@ -1053,6 +1055,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 9 && (value == 0 || value == 1)) { g_ws_interleave = value; return 0; }
   if (key == 10 && (value == 0 || value == 1)) { g_fused_interleave = value; return 0; }
   if (key == 11 && value >= 0 && value <= 31) { g_ws_aux_nt = value; return 0; }
+  if (key == 12 && (value == 0 || value == 1)) { g_ws_wide_store = value; return 0; }
   return -1;
 }
 

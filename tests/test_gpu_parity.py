@@ -408,13 +408,15 @@ def test_bf16_wgrad_kernels_agree(dev, R, S):
         _lib.check(_lib.lib().neat_set_tuning(6, 2), "neat_set_tuning")
         _lib.check(_lib.lib().neat_set_tuning(9, 0), "neat_set_tuning")      # contiguous tile ranges instead of interleaved tiles
         _lib.check(_lib.lib().neat_set_tuning(11, 0), "neat_set_tuning")     # no non-temporal fetches
-        batched["contiguous, temporal"] = grads(1)
+        _lib.check(_lib.lib().neat_set_tuning(12, 0), "neat_set_tuning")     # 8-byte output stores
+        batched["contiguous, temporal, narrow stores"] = grads(1)
     finally:
         _lib.lib().neat_set_tuning(1, 1)
         _lib.lib().neat_set_tuning(8, -1)
         _lib.lib().neat_set_tuning(6, 2)
         _lib.lib().neat_set_tuning(9, 1)
         _lib.lib().neat_set_tuning(11, 15)
+        _lib.lib().neat_set_tuning(12, 1)
     assert len(g3) >= 57
     batched[-1] = g3
     for nb, gb in batched.items():   # several problems per launch (1/nb of the splits each) vs separate launches: summation order only
