@@ -209,7 +209,7 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *   9 point tiles of the persistent streaming kernels: 1 = interleaved over the workgroups (default), 0 = one contiguous range each
  *  10 fused primal chain: batches interleaved over the workgroups (default 0)
  *  11 non-temporal accesses, bit mask (default 15): 1 / 2 = aux0 / aux1 fetch of the layer kernels, 4 = weight-gradient operands,
- *     8 = `in` fetch of the layer kernels, 16 = out1 (m_l) store
+ *     8 = `in` fetch of the layer kernels, 16 = out1 (m_l) store, 32 = out0 store (both stores measured neutral)
  *  12 layer kernels: 1 = 16-byte output stores through v_permlane32_swap (default; measured neutral), 0 = 8-byte stores */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);

@@ -567,8 +567,12 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
           typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
           const v2u_t s0 = __builtin_amdgcn_permlane32_swap(pk0[2 * j].x, pk0[2 * j + 1].x, false, false);
           const v2u_t s1 = __builtin_amdgcn_permlane32_swap(pk0[2 * j].y, pk0[2 * j + 1].y, false, false);
-          if (in_range && (EPI != EPI_REV || oct * 8 < ((a.n_split + 7) & ~7)))
-            *reinterpret_cast<uint4*>(a.out0 + oidx) = make_uint4(s0.x, s1.x, s0.y, s1.y);
+          if (in_range && (EPI != EPI_REV || oct * 8 < ((a.n_split + 7) & ~7))) {
+            typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+            const v4u_t v = {s0.x, s1.x, s0.y, s1.y};
+            if (a.aux_nt & 16) __builtin_nontemporal_store(v, reinterpret_cast<v4u_t*>(a.out0 + oidx));
+            else *reinterpret_cast<v4u_t*>(a.out0 + oidx) = v;
+          }
         }
         if (EPI == EPI_TAN || EPI == EPI_TAN_PF) {
           typedef unsigned v2u_t __attribute__((ext_vector_type(2)));

@@ -194,7 +194,7 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
   int grid = (a.ntiles + a.per_wg - 1) / a.per_wg;
   a.tile_stride = 1;
   a.wide_store = g_ws_wide_store;
-  a.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 12);      // key bits 3 / 4 -> kernel bits 2 / 3
+  a.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 28);      // key bits 3 / 4 / 5 -> kernel bits 2 / 3 / 4
   if (g_ws_interleave) { grid = a.ntiles < g_ws_grid ? a.ntiles : g_ws_grid; a.tile_stride = grid; }
   hipLaunchKernelGGL((layer_kernel_ws<EPI, KS, OUTF>), dim3(grid), dim3(WST), (WsCfg<EPI, KS>::LDS), st, a);
   return hipGetLastError();
@@ -1054,7 +1054,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
   if (key == 9 && (value == 0 || value == 1)) { g_ws_interleave = value; return 0; }
   if (key == 10 && (value == 0 || value == 1)) { g_fused_interleave = value; return 0; }
-  if (key == 11 && value >= 0 && value <= 31) { g_ws_aux_nt = value; return 0; }
+  if (key == 11 && value >= 0 && value <= 63) { g_ws_aux_nt = value; return 0; }
   if (key == 12 && (value == 0 || value == 1)) { g_ws_wide_store = value; return 0; }
   return -1;
 }
