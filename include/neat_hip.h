@@ -206,7 +206,8 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *   6 partial reduction: 2 = one launch, 16-byte loads (default), 0 = group sums + finish, 1 = one 16-wave pass
  *   7 interleave weight gradients with the reverse chain (default 0)
  *   8 same-shaped weight gradients per launch (-1 = by problem size (default), 0 = one layer per launch, 2, 3, 6)
- *   9 point tiles of the persistent streaming kernels: 1 = interleaved over the workgroups (default), 0 = one contiguous range each
+ *   9 point tiles of the persistent streaming kernels: 1 = interleaved over the workgroups (default), 2 = interleaved with an
+ *     XCD-contiguous slot order (measured neutral), 0 = one contiguous range each
  *  10 fused primal chain: batches interleaved over the workgroups (default 0)
  *  11 non-temporal accesses, bit mask (default 15): 1 / 2 = aux0 / aux1 fetch of the layer kernels, 4 = weight-gradient operands,
  *     8 = `in` fetch of the layer kernels, 16 = out1 (m_l) store, 32 = out0 store (both stores measured neutral)

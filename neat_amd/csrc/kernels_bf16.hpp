@@ -350,6 +350,7 @@ struct LayerArgsWS {
   float* out0f;                                          // OUTF variants: out0 is fp32 feature-major [N][ldp]
   int x_octs;                                            // KS = 20: valid octets of in2 (the rest of its 8-octet slot is zero weight)
   const u16* padfill;                                    // EPI_TAN_PF: octet-major array whose rows 0..6 fill rows N..N+6 of out0
+  int xcd_major;                                         // interleaved tiles: workgroup -> tile slot permuted so that an XCD owns a contiguous run
   int wide_store;                                        // 1: bf16 outputs leave as 16-byte stores (v_permlane32_swap), 0: 8-byte
   int aux_nt;                                            // non-temporal: bit 0 / 1 fetch of aux0 / aux1, bit 2 fetch of `in`, bit 3 store of out1
   int tile_stride;                                       // 1: workgroup w owns tiles [w per_wg, (w+1) per_wg); gridDim.x: tiles w, w + grid, ...
@@ -398,7 +399,9 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // tile of step tau: contiguous ranges (tile_stride 1) or interleaved over the workgroups (tile_stride = gridDim.x: at any
   // moment the machine works on one contiguous window of every array)
-  const int t_begin = a.tile_stride == 1 ? blockIdx.x * a.per_wg : blockIdx.x;
+  // (xcd_major: consecutive workgroups go to different XCDs; give each XCD a contiguous run of the interleaved tiles instead)
+  const int wq = (a.xcd_major && (gridDim.x & 7) == 0) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_begin = a.tile_stride == 1 ? blockIdx.x * a.per_wg : wq;
   const int T = a.tile_stride == 1 ? min(a.per_wg, a.ntiles - t_begin) : (a.ntiles - t_begin + a.tile_stride - 1) / a.tile_stride;
   if (T <= 0) return;
   const unsigned lds_base = (unsigned)(size_t)(lds_ptr)wslds;

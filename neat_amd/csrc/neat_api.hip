@@ -195,6 +195,7 @@ template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hi
   a.tile_stride = 1;
   a.wide_store = g_ws_wide_store;
   a.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 28);      // key bits 3 / 4 / 5 -> kernel bits 2 / 3 / 4
+  a.xcd_major = g_ws_interleave == 2;
   if (g_ws_interleave) { grid = a.ntiles < g_ws_grid ? a.ntiles : g_ws_grid; a.tile_stride = grid; }
   hipLaunchKernelGGL((layer_kernel_ws<EPI, KS, OUTF>), dim3(grid), dim3(WST), (WsCfg<EPI, KS>::LDS), st, a);
   return hipGetLastError();
@@ -633,7 +634,7 @@ hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob,
     }
   a.splitB = 32; a.octsB = 32; a.npairs = npairs; a.N = N; a.K = K; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
   a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.col_off = 0; a.bias_col = K;
-  a.nprob = nprob; a.prob_stride = region; a.interleave = g_ws_interleave; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
+  a.nprob = nprob; a.prob_stride = region; a.interleave = g_ws_interleave != 0; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
   ProfSlot* ps = prof_begin(c.st, 1, flops, bytes + (double)nprob * splits * N * (K + 1) * 4.0);
   hipLaunchKernelGGL(wgrad_kernel_h3, dim3(nprob, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
   prof_end(c.st, ps);
@@ -766,7 +767,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
         }
         a.octsB = (a.K + 7) / 8;
         a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-        a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.interleave = g_ws_interleave; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
+        a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.interleave = g_ws_interleave != 0; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
         hipLaunchKernelGGL(wgrad_kernel_h3, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
       }
       prof_end(c.st, ps);
@@ -1052,7 +1053,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 7 && (value == 0 || value == 1)) { g_wgrad_interleave = value; return 0; }
   if (key == 8 && (value == -1 || value == 0 || value == 2 || value == 3 || value == 6)) { g_wgrad_batch = value; return 0; }
   if (key == 5 && (value == 0 || (value >= 2 && value <= 4))) { g_fused_nt = value; return 0; }
-  if (key == 9 && (value == 0 || value == 1)) { g_ws_interleave = value; return 0; }
+  if (key == 9 && value >= 0 && value <= 2) { g_ws_interleave = value; return 0; }
   if (key == 10 && (value == 0 || value == 1)) { g_fused_interleave = value; return 0; }
   if (key == 11 && value >= 0 && value <= 63) { g_ws_aux_nt = value; return 0; }
   if (key == 12 && (value == 0 || value == 1)) { g_ws_wide_store = value; return 0; }
