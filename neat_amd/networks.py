@@ -541,7 +541,7 @@ class VolSDFNetwork(_HipModule):
         """Eikonal points: uniform in the bounding cube + one near-surface sample per ray (rend_a :515-527)."""
         r = self.scene_bounding_sphere
         eik = self._cpu_random("eik_uniform", lambda: torch.empty(n_rays, 3).uniform_(-r, r), ray_dirs.device)
-        eik = torch.cat([eik, cam_loc + z_eik * ray_dirs], 0)
+        eik = torch.cat([eik, torch.addcmul(cam_loc, z_eik, ray_dirs)], 0)       # o + z d in one launch
         if junctions is not None:
             eik = torch.cat([eik, junctions], 0)
         return eik
