@@ -45,19 +45,25 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ src, float* _
       case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
-    if (MODE != 2) asm volatile("s_barrier" ::: "memory");
-    if (tau + NS - 1 < T) issue(tau + NS - 1);
+    if (MODE != 2 && MODE != 8) asm volatile("s_barrier" ::: "memory");
+    if (MODE != 6 && tau + NS - 1 < T) issue(tau + NS - 1);
+    if (MODE == 7) {
+      float x = __uint_as_float(0x3f800000u + (unsigned)tau + lane);
+#pragma unroll
+      for (int it = 0; it < 128; ++it) x = fmaf(x, 1.0000001f, 1e-7f);      // ~128 dependent VALU ops
+      acc ^= __float_as_uint(x) ^ *reinterpret_cast<const unsigned*>(lds + (tau % NS) * (32 * WSP * 16) + tid * 4);
+    } else
     if (MODE >= 3) {
-      constexpr int NC = MODE == 3 ? 1 : (MODE == 4 ? 2 : 4);
+      constexpr int NC = MODE == 3 || MODE == 6 || MODE == 8 ? 1 : (MODE == 4 ? 2 : 4);
       f32x16 c[NC];
 #pragma unroll
       for (int j = 0; j < NC; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[j][r] = 0.0f;
-      const unsigned char* slot = lds + (tau % NS) * (32 * WSP * 16) + ((lane >> 5) * WSP + (lane & 31)) * 16;
+      const unsigned char* slot = lds + (tau % NS) * (32 * WSP * 16) + ((lane >> 5) * WSP + (lane & 31)) * 16 + (MODE == 8 ? 4 * wave * (WSP * 16) : 0);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const uint4 bv = *reinterpret_cast<const uint4*>(slot + ks * (2 * WSP * 16));
+        const uint4 bv = *reinterpret_cast<const uint4*>(slot + (MODE == 8 ? (ks & 1) : ks) * (2 * WSP * 16));
         uint4 av = make_uint4(0x3f803f80u + ks, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
         c[ks % NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&av), *reinterpret_cast<const bf16x8*>(&bv), c[ks % NC], 0, 0, 0);
       }
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ src, float* _
       for (int j = 0; j < NC; ++j) acc ^= __float_as_uint(c[j][0]) ^ __float_as_uint(c[j][7]);
     } else
     acc ^= *reinterpret_cast<const unsigned*>(lds + (tau % NS) * (32 * WSP * 16) + tid * 4);
+    if (MODE == 6 && tau + NS - 1 < T) issue(tau + NS - 1);
   }
   if (acc == 0x12345u) sink[tid] = 1.f;
 }
@@ -86,6 +93,9 @@ int main() {
   run<6, 0>(src, sink, "DMA ring + barrier"); run<8, 0>(src, sink, "DMA ring + barrier");
   run<4, 2>(src, sink, "DMA ring, no barrier"); run<8, 2>(src, sink, "DMA ring, no barrier");
   run<4, 3>(src, sink, "ring + 16 dependent MFMAs / stage"); run<8, 3>(src, sink, "ring + 16 dependent MFMAs / stage");
+  run<3, 3>(src, sink, "ring + 16 dependent MFMAs / stage"); run<6, 3>(src, sink, "ring + 16 dependent MFMAs / stage");
+  run<4, 6>(src, sink, "ring + MFMAs, issue AFTER compute"); run<4, 7>(src, sink, "ring + 128 dependent VALU ops");
+  run<4, 8>(src, sink, "ring + MFMAs on own octets, NO barrier");
   run<4, 4>(src, sink, "ring + 2 chains of 8 MFMAs"); run<4, 5>(src, sink, "ring + 4 chains of 4 MFMAs"); run<8, 5>(src, sink, "ring + 4 chains of 4 MFMAs");
   return 0;
 }
