@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ src, float* _
       acc ^= __float_as_uint(x) ^ *reinterpret_cast<const unsigned*>(lds + (tau % NS) * (32 * WSP * 16) + tid * 4);
     } else
     if (MODE >= 3) {
-      constexpr int NC = MODE == 3 || MODE == 6 || MODE == 8 ? 1 : (MODE == 4 ? 2 : 4);
+      constexpr int NC = MODE == 3 || MODE == 6 || MODE == 8 || MODE == 9 || MODE == 10 ? 1 : (MODE == 4 ? 2 : 4);
       f32x16 c[NC];
 #pragma unroll
       for (int j = 0; j < NC; ++j)
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ src, float* _
       const unsigned char* slot = lds + (tau % NS) * (32 * WSP * 16) + ((lane >> 5) * WSP + (lane & 31)) * 16 + (MODE == 8 ? 4 * wave * (WSP * 16) : 0);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
-        const uint4 bv = *reinterpret_cast<const uint4*>(slot + (MODE == 8 ? (ks & 1) : ks) * (2 * WSP * 16));
+        uint4 bv = make_uint4(0x3f803f80u, 0x3f803f80u + tau, 0x3f803f80u, 0x3f803f80u);
+        if (MODE != 9) bv = *reinterpret_cast<const uint4*>(slot + (MODE == 8 ? (ks & 1) : ks) * (2 * WSP * 16));
+        if (MODE == 10) { acc ^= bv.x ^ bv.y ^ bv.z ^ bv.w; continue; }
         uint4 av = make_uint4(0x3f803f80u + ks, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
         c[ks % NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&av), *reinterpret_cast<const bf16x8*>(&bv), c[ks % NC], 0, 0, 0);
       }
@@ -96,6 +98,7 @@ int main() {
   run<3, 3>(src, sink, "ring + 16 dependent MFMAs / stage"); run<6, 3>(src, sink, "ring + 16 dependent MFMAs / stage");
   run<4, 6>(src, sink, "ring + MFMAs, issue AFTER compute"); run<4, 7>(src, sink, "ring + 128 dependent VALU ops");
   run<4, 8>(src, sink, "ring + MFMAs on own octets, NO barrier");
+  run<4, 9>(src, sink, "ring + 16 MFMAs, operands in registers"); run<4, 10>(src, sink, "ring + 16 ds_read_b128, no MFMA");
   run<4, 4>(src, sink, "ring + 2 chains of 8 MFMAs"); run<4, 5>(src, sink, "ring + 4 chains of 4 MFMAs"); run<8, 5>(src, sink, "ring + 4 chains of 4 MFMAs");
   return 0;
 }
