@@ -1,0 +1,16 @@
+// Host-side launchers of the fused chain kernels (kernels_fused.hpp).  They live in their own translation unit
+// (neat_fused.hip), which is compiled with -mllvm -amdgpu-mfma-vgpr-form: these kernels run ONE wave per SIMD with
+// 512 registers, keep 256 registers of weight fragments and read every accumulator on the VALU (activation epilogue),
+// so the accumulators belong in the VGPR half and the weights in the AGPR half -- hipcc's default puts them the other
+// way round and pays one v_accvgpr_read per accumulator element.
+#pragma once
+#include "bf16_common.hpp"
+
+namespace neat {
+
+// fused SDF primal chain, 4 waves x 64 output rows, 128-point batches.  full: save h_1..h_8, PE, lin8 outputs for backward;
+// otherwise only the clamped sdf (sampler).  nwg persistent workgroups over ntiles 32-point tiles; interleave: batches
+// interleaved over the workgroups instead of one contiguous range each.
+hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave);
+
+}  // namespace neat

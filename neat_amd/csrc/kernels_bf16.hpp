@@ -11,52 +11,9 @@
 // (v_perm_b32) while staging, so a single HBM layout serves both consumers.
 #pragma once
 #include "kernels.hpp"
+#include "bf16_common.hpp"
 
 namespace neat {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16;
-
-constexpr int BMH = 128;         // point-stride granule of the bf16 build (ldp is a multiple of this)
-
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-// float -> bf16 round-to-nearest-even through the compiler's native conversion (v_cvt_pk_bf16_f32 on gfx950: one
-// instruction per PAIR; the hand-rolled add/shift form cost ~5 VALU per value and made the epilogues issue-bound)
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  f32x2_t v = {lo, hi};
-  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
-  return __builtin_bit_cast(unsigned, r);
-}
-__device__ __forceinline__ u16 f2bf(float f) { return (u16)(pack2(f, 0.0f) & 0xFFFFu); }
-__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
-
-// branch-free activation math for the bf16 build (hardware exp/log; absolute error ~1e-7, far below bf16 resolution)
-__device__ __forceinline__ float softplus100_fast(float a) {
-  // base-2 form on the raw v_exp_f32 / v_log_f32 (8 VALU ops; `__logf` expands to ~15 with its denormal and ln2 fix-ups):
-  // softplus_100(a) = ln2/100 * (max(u,0) + log2(1 + 2^-|u|)),  u = 100 a log2(e);  the log argument lies in [1, 2]
-  const float u = a * 144.26950408889634f;
-  const float y = __builtin_amdgcn_exp2f(-fabsf(u));
-  return (fmaxf(u, 0.0f) + __builtin_amdgcn_logf(1.0f + y)) * 0.0069314718055994531f;
-}
-// two activations at once on the packed fp32 ALU (v_pk_fma/add/mul_f32: two lanes of work per issue slot; exp2 / log2 and
-// max have no packed form): u = 100 log2(e) (acc + b) arrives as acc * C + b_scaled with the bias pre-scaled by C
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-constexpr float SOFTPLUS_C = 144.26950408889634f;
-__device__ __forceinline__ v2f_t softplus100_pk(v2f_t acc, v2f_t bias_scaled) {
-  const v2f_t cc = {SOFTPLUS_C, SOFTPLUS_C};
-  const v2f_t u = acc * cc + bias_scaled;
-  v2f_t y = {__builtin_amdgcn_exp2f(-fabsf(u.x)), __builtin_amdgcn_exp2f(-fabsf(u.y))};
-  const v2f_t one = {1.0f, 1.0f};
-  y = y + one;
-  const v2f_t lg = {__builtin_amdgcn_logf(y.x), __builtin_amdgcn_logf(y.y)};
-  const v2f_t m = {fmaxf(u.x, 0.0f), fmaxf(u.y, 0.0f)};
-  const v2f_t k = {0.0069314718055994531f, 0.0069314718055994531f};
-  return (m + lg) * k;
-}
-__device__ __forceinline__ float dphi_fast(float h) { return 1.0f - __expf(-100.0f * h); }
 
 // element (f, p) of an octet-major bf16 array
 __device__ __forceinline__ size_t oct_index(int f, int p, int ldp) { return ((size_t)(f >> 3) * ldp + p) * 8 + (f & 7); }
@@ -640,17 +597,6 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ s
 //   values mode : only the clamped sdf leaves the chip (the sampler's 128..640 queries per ray: no HBM round trips)
 //   save mode   : every post-activation h_l, the PE rows and the lin8 output are also written for the backward pass
 // ---------------------------------------------------------------------------------------------
-struct FusedArgs {
-  const float* x_fm; int P, ldp;
-  const uint4* Wp[9]; int KS[9]; const float* bias[9];
-  int save, values_only;
-  u16* h[9];                  // h[1..8], octet-major (save mode)
-  float* E;                   // [39][ldp] fp32 (save mode)
-  u16* feat; float* sdfraw;   // lin8 outputs (save mode): 256 feature rows (octet-major) + raw sdf row
-  float* sdf_out;             // values mode: clamped sdf, row-major [P]
-  float radius, scale;
-  int bias8_rot, bias8_n;     // lin8 rows are packed [feature | sdf]
-};
 
 template <int PT, bool VALUES>
 __global__ __launch_bounds__(WG, 2) void sdf_fused_kernel_h(FusedArgs a) {
