@@ -21,129 +21,230 @@
 
 namespace neat {
 
-constexpr int F6T = 256;
-template <int NT> struct F6Cfg {
+// NEAT_F6_ABLATE (probe builds only; results are WRONG): 1 = epilogue without the softplus math, 2 = no MFMAs, 3 = no B-fragment
+// LDS reads, 4 = no stage barriers, 5 = no epilogue LDS writes
+#ifndef NEAT_F6_ABLATE
+#define NEAT_F6_ABLATE 0
+#endif
+#ifndef NEAT_F6_SPLITK
+#define NEAT_F6_SPLITK 0    // RT = 1: k-steps alternate between two accumulator chains (measured neutral)
+#endif
+#ifndef NEAT_F6_GROUP
+#define NEAT_F6_GROUP 1     // k-steps whose MFMAs are issued back to back before their share of the epilogue
+#endif
+#ifndef NEAT_F6_RING
+#define NEAT_F6_RING 3      // B-fragment ring: registers (k-steps in flight + 1)
+#endif
+
+// RT = 32-row output tiles per wave: 2 -> four waves (one per SIMD, 512 registers), 1 -> eight waves (two per SIMD, 256 registers:
+// the two waves of a SIMD fill each other's matrix-pipe and VALU gaps)
+template <int NT, int RT = 2> struct F6Cfg {
+  static constexpr int NW = 8 / RT, THREADS = 64 * NW;
   static constexpr int BP = 32 * NT;
   static constexpr int XBYTES = 32 * BP * 16;            // one activation buffer [32 octets][BP][16 B]
-  static constexpr int PEBYTES = 8 * BP * 16;            // PE octets (K padded to 64); reused for the sdf partial sums
+  static constexpr int PEBYTES = 8 * BP * 16;            // PE octets (K padded to 64)
   static constexpr int BIAS_FLOATS = 9 * 256 + 8;
-  static constexpr int XA = 0, XB = XBYTES, PE = 2 * XBYTES, BIAS = 2 * XBYTES + PEBYTES;     // byte offsets in the LDS block
-  static constexpr int LDS = 2 * XBYTES + PEBYTES + BIAS_FLOATS * 4;
+  static constexpr int XA = 0, XB = XBYTES, PE = 2 * XBYTES, BIAS = 2 * XBYTES + PEBYTES, RED = BIAS + BIAS_FLOATS * 4;     // byte offsets
+  static constexpr int LDS = RED + NW * BP * 4;          // + partial sums of the sdf row [waves][BP]
 };
 
-// Per-lane base addresses of one wave; every access of the layer loop is  base + compile-time offset  that fits the
+// Per-lane base addresses of one wave; every access of the stage loop is  base + compile-time offset  that fits the
 // instruction's immediate field (ds: 16 bits, so one base per 64 KiB LDS region; global: wave-uniform SGPR base + 32-bit
 // per-lane offset + 12 bits), so nothing address-like is recomputed -- or hoisted out of the batch loop and spilled --
 // per quad, tile or layer.  The bases are made opaque (empty asm) so that the compiler does not re-derive them from one
 // another with constants that do not fit.
 struct F6Lane {
   const unsigned char* frag[3];   // B-fragment reads from XA / XB / PE:  region + (hi * BP + (lane & 31)) * 16
-  unsigned char* quad[2];         // accumulator-quad writes into XA / XB: region + ((8 wave) * BP + (lane & 31)) * 16 + 8 hi
+  unsigned char* quad[2];         // accumulator-quad writes into XA / XB: region + ((4 RT wave) * BP + (lane & 31)) * 16 + 8 hi
   const unsigned char* bias;      // bias float4 reads: BIAS + (64 wave + 4 hi) * 4
+  const unsigned char* pe0;       // PE octet 0 of this lane's point: PE + (lane & 31) * 16        (+ t * 512)
   unsigned gquad;                 // HBM quad store:   ((8 wave) * ldp + p0 + (lane & 31)) * 16 + 8 hi      (per batch)
   unsigned ldp16;                 // ldp * 16
 };
 
-// One layer for one wave: rows 64 wave .. 64 wave + 63 of  act(W src + b)  over the nt point tiles of the batch.
-//   ACT: softplus_100 -> LDS buffer DST (input of the next layer) and, if hout, HBM;  !ACT (lin8's feature rows): bias only,
-//   HBM only.  N = 217 (lin3) masks the rows the PE copy will occupy.  The epilogue of point tile t-1 is interleaved quad by
-//   quad with the 2 x KS MFMAs of point tile t.
-// FULL: all NT point tiles are valid (straight-line code, no per-tile guards); otherwise the first nt (last batch of a workgroup).
-template <int NT, bool FULL, int KS, int N, bool ACT, bool SAVE, int SRC, int DST, int BIASOFF>      // SRC: 0 = XA, 1 = XB, 2 = PE; DST: 0 = XA, 1 = XB
-__device__ __forceinline__ void f6_layer(const F6Lane& L, const uint4 (&wc)[2][16], int nt, u16* hout, int wave, int hi) {
-  typedef F6Cfg<NT> C;
+// ---------------------------------------------------------------------------------------------------------------
+// Stage pipeline.  A STAGE = the 2 x KS MFMAs of one (layer, point tile) interleaved, slot by slot, with the epilogue of
+// the PREVIOUS stage (which may belong to the previous layer): after every MFMA the wave issues one "half unit" of
+// epilogue work (~7 VALU instructions) -- with one wave per SIMD nothing else can fill the 32 cycles the matrix pipe
+// needs per MFMA.  One workgroup barrier per stage; layer l+1 starts on tile 0 while tile 3 of layer l is still in its
+// epilogue, so there is no bubble between layers.  Accumulators ping-pong between two register sets (static indices:
+// everything is unrolled).
+// ---------------------------------------------------------------------------------------------------------------
+struct F6EpiState { float m0, m1, w0, w1; unsigned lo; };       // what travels from half unit A to half unit B of a value pair
+
+// epilogue of one layer (compile-time description): activation, destination, row count, bias rows
+template <bool ACT_, bool SAVE_, int N_, int DST_, int BIASOFF_> struct F6EpiCfg {
+  static constexpr bool ACT = ACT_, SAVE = SAVE_, NONE = false;
+  static constexpr int N = N_, DST = DST_, BIASOFF = BIASOFF_;
+};
+struct F6NoEpi { static constexpr bool ACT = false, SAVE = false, NONE = true; static constexpr int N = 256, DST = 0, BIASOFF = 0; };
+
+// the bias rows of this lane for a layer: 8 quads x float4 (pre-scaled by SOFTPLUS_C for the activated layers)
+template <class E, int RT> __device__ __forceinline__ void f6_load_bias(const F6Lane& L, float4 (&bq)[4 * RT]) {
+#pragma unroll
+  for (int g = 0; g < 4 * RT; ++g) bq[g] = *reinterpret_cast<const float4*>(L.bias + (E::BIASOFF + (g >> 2) * 32 + 8 * (g & 3)) * 4);
+}
+
+// half unit h (0 = A: bias, exp2, max; 1 = B: log2, scale, pack, store) of value pair e (0..15): quad g = e >> 1 = (row tile
+// i = g >> 2, quad q = g & 3), pair e & 1 of the quad; t = point tile the accumulators `ae` belong to
+template <int NT, int RT, bool FULL, class E>
+__device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[RT], const float4 (&bq)[4 * RT], F6EpiState& st, int e, int h, int t,
+                                            int nt, u16* hout, int wave, int hi) {
+  typedef F6Cfg<NT, RT> C;
   constexpr int BP = C::BP;
-  const bool live1 = N == 256 || (2 * wave + 1) * 32 < N;      // lin3: row tile 7 (rows 224..255) is dead
-  f32x16 acc[2][2];
-  const unsigned char* fr = L.frag[SRC];
-  auto epi_quad = [&](const f32x16& ac, int t, int i, int q) {
-    if (N != 256 && (2 * wave + i) * 32 + 8 * q + 4 * hi >= N) return;
-    const float4 bb = *reinterpret_cast<const float4*>(L.bias + (BIASOFF + i * 32 + 8 * q) * 4);
-    float o[4];
-    if (ACT) {
-      const v2f_t o01 = softplus100_pk(v2f_t{ac[4 * q], ac[4 * q + 1]}, v2f_t{bb.x, bb.y});
-      const v2f_t o23 = softplus100_pk(v2f_t{ac[4 * q + 2], ac[4 * q + 3]}, v2f_t{bb.z, bb.w});
-      o[0] = o01.x; o[1] = o01.y; o[2] = o23.x; o[3] = o23.y;
+  if (NEAT_F6_ABLATE == 7 || NEAT_F6_ABLATE == 8) { if (e == 0 && h == 0) asm volatile("" :: "v"(ae[0][0])); return; }
+  const int g = e >> 1, i = g >> 2, q = g & 3, pr = e & 1;
+  const float x0 = ae[i][4 * q + 2 * pr], x1 = ae[i][4 * q + 2 * pr + 1];
+  const float b0 = pr ? bq[g].z : bq[g].x, b1 = pr ? bq[g].w : bq[g].y;
+  if (h == 0) {
+    if (E::ACT && NEAT_F6_ABLATE != 1) {
+      const float u0 = NEAT_F6_ABLATE == 6 ? x0 : fmaf(x0, SOFTPLUS_C, b0), u1 = NEAT_F6_ABLATE == 6 ? x1 : fmaf(x1, SOFTPLUS_C, b1);
+      st.w0 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u0));
+      st.w1 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u1));
+      st.m0 = fmaxf(u0, 0.0f); st.m1 = fmaxf(u1, 0.0f);
     } else {
-      o[0] = ac[4 * q] + bb.x; o[1] = ac[4 * q + 1] + bb.y; o[2] = ac[4 * q + 2] + bb.z; o[3] = ac[4 * q + 3] + bb.w;
+      st.m0 = x0 + b0; st.m1 = x1 + b1;
     }
-    unsigned char* lq = L.quad[DST] + ((i * 4 + q) * BP + t * 32) * 16;
-    if (N == 256 || (2 * wave + i) * 32 + 8 * q + 4 * hi + 3 < N) {
-      const uint2 pk = make_uint2(pack2(o[0], o[1]), pack2(o[2], o[3]));
-      if (ACT) *reinterpret_cast<uint2*>(lq) = pk;
-      if (SAVE)                                        // wave-uniform row base + per-lane 32-bit offset + immediate
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q) * L.ldp16) + t * 512) + (size_t)L.gquad) = pk;
-    } else {                                           // lin3: the quad holding row 216 (rows 217.. receive the PE copy)
-      const int n0 = (2 * wave + i) * 32 + 8 * q + 4 * hi;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n0 + e < N) reinterpret_cast<u16*>(lq)[e] = f2bf(o[e]);
+    return;
+  }
+  float r0 = st.m0, r1 = st.m1;
+  if (E::ACT && NEAT_F6_ABLATE != 1) {
+    r0 = (st.m0 + __builtin_amdgcn_logf(st.w0)) * (NEAT_F6_ABLATE == 6 ? 1.0f : 0.0069314718055994531f);
+    r1 = (st.m1 + __builtin_amdgcn_logf(st.w1)) * (NEAT_F6_ABLATE == 6 ? 1.0f : 0.0069314718055994531f);
+  }
+  const unsigned pk = pack2(r0, r1);
+  if (pr == 0) { st.lo = pk; return; }
+  uint2 v = make_uint2(st.lo, pk);
+  if (E::N == 217 && i == 0 && q == 3) {       // (row tile 6 is the first tile of its wave for RT = 1 and RT = 2)
+    // lin3, rows 216..223 (wave 3 only): [h216 | PE rows 0..6] -- what lin4 (skip connection, rend_a :87-88) and the saved h4
+    // expect in the last octet of the 217-row array.  (Row tile 7 holds don't-care values until the skip copy.)
+    if (RT * wave == 6) {
+      const uint4 w = *reinterpret_cast<const uint4*>(L.pe0 + t * 512);       // PE rows 0..7 of this point, bf16
+      if (hi == 0) v = make_uint2((st.lo & 0xFFFFu) | (w.x << 16), (w.x >> 16) | (w.y << 16));
+      else v = make_uint2((w.y >> 16) | (w.z << 16), (w.z >> 16) | (w.w << 16));
     }
-  };
+  }
+  if (E::ACT && NEAT_F6_ABLATE != 5) *reinterpret_cast<uint2*>(L.quad[E::DST] + ((i * 4 + q) * BP + t * 32) * 16) = v;
+  if (NEAT_F6_ABLATE == 5) asm volatile("" :: "v"(v.x), "v"(v.y));
+  if (E::SAVE && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
+    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q) * L.ldp16) + t * 512) + (size_t)L.gquad) = v;
+}
+
+// MMA = false: drain stage (epilogue only).  KS k-steps of layer input region SRC (0 = XA, 1 = XB, 2 = PE), tile t; the epilogue
+// E works on tile te of the accumulators `ae`.  B fragments travel through a ring of three registers, two k-steps ahead; the
+// first two fragments of the NEXT stage (base address nfr, or null) are requested during the last two k-steps, i.e. before the
+// barrier that ends the stage: they were written at least two barriers ago.  ROFF = ring slot of this stage's k-step 0
+// (every KS is 1 mod 3, so it advances by one per stage).  BAR: end the stage with the workgroup barrier.
+template <int NT, int RT, bool FULL, bool MMA, int KS, int SRC, class E, int ROFF, bool BAR>
+__device__ __forceinline__ void f6_stage(const F6Lane& L, const uint4 (&wc)[RT][16], int t, f32x16 (&am)[RT], const f32x16 (&ae)[RT],
+                                         const float4 (&bq)[4 * RT], int te, int nt, u16* hout, int wave, int hi, uint4 (&ring)[NEAT_F6_RING],
+                                         const unsigned char* nfr) {
+  typedef F6Cfg<NT, RT> C;
+  constexpr int STEP = 2 * C::BP * 16;                 // bytes between k-steps of a fragment column
+  constexpr int HU = 16 * RT;                          // epilogue half units of a tile: 8 RT value pairs x {A, B}
+  constexpr int SLOTS = MMA ? RT * KS : 1;
+  constexpr int UPS = E::NONE ? 0 : HU / SLOTS;        // epilogue half units per slot
+  constexpr int RD = NEAT_F6_RING, AH = RD - 1;       // ring size / k-steps of look-ahead
+  F6EpiState st{};
+  if (!MMA) {
+    if (nfr) {
 #pragma unroll
-  for (int t = 0; t <= NT; ++t) {
-    const bool mma_on = t < NT && (FULL || t < nt), epi_on = t >= 1 && (FULL || t - 1 < nt);
-    f32x16(&am)[2] = acc[t & 1];
-    const f32x16(&ae)[2] = acc[(t + 1) & 1];
-    if (mma_on) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { am[0][r] = 0.0f; am[1][r] = 0.0f; }
+      for (int j = 0; j < AH; ++j) ring[(ROFF + j) % RD] = *reinterpret_cast<const uint4*>(nfr + j * STEP);
     }
-    uint4 bv = make_uint4(0u, 0u, 0u, 0u);
-    if (mma_on) bv = *reinterpret_cast<const uint4*>(fr + t * 512);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (mma_on) {
-        const uint4 cur = bv;
-        if (ks + 1 < KS) bv = *reinterpret_cast<const uint4*>(fr + ((ks + 1) * 2 * BP * 16 + t * 512));
-        am[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wc[0][ks]), *reinterpret_cast<const bf16x8*>(&cur), am[0], 0, 0, 0);
-        if (live1) am[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wc[1][ks]), *reinterpret_cast<const bf16x8*>(&cur), am[1], 0, 0, 0);
+    for (int u = 0; u < HU; ++u) {
+      if (!E::NONE) f6_epi_half<NT, RT, FULL, E>(L, ae, bq, st, u >> 1, u & 1, te, nt, hout, wave, hi);
+      if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (BAR) __syncthreads();
+    return;
+  }
+  const unsigned char* fr = L.frag[SRC] + t * 512;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 odd = zero;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (NEAT_F6_ABLATE != 3 && NEAT_F6_ABLATE != 8) {
+      if (ks + AH < KS) ring[(ks + AH + ROFF) % RD] = *reinterpret_cast<const uint4*>(fr + (ks + AH) * STEP);
+      else if (nfr) ring[(ks + AH + ROFF) % RD] = *reinterpret_cast<const uint4*>(nfr + (ks + AH - KS) * STEP);
+    }
+    const uint4 cur = ring[(ks + ROFF) % RD];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      // RT = 1: the k-steps alternate between two accumulator chains (a chain of DEPENDENT 32x32x16 MFMAs with other instructions in
+      // between runs at ~75 cycles per MFMA instead of 32); they are summed after the last k-step
+      f32x16& dst = (NEAT_F6_SPLITK && RT == 1 && (ks & 1)) ? odd : am[i];
+      if (NEAT_F6_ABLATE != 2)
+        dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wc[i][ks]), *reinterpret_cast<const bf16x8*>(&cur), ks >= (NEAT_F6_SPLITK && RT == 1 ? 2 : 1) ? dst : zero, 0, 0, 0);
+      else if (ks == 0) { am[i] = zero; am[i][0] = __uint_as_float(cur.x ^ wc[i][ks].x); }
+      if (NEAT_F6_GROUP == 1) {
+#pragma unroll
+        for (int u = 0; u < UPS; ++u) {
+          const int hu = (RT * ks + i) * UPS + u;
+          f6_epi_half<NT, RT, FULL, E>(L, ae, bq, st, hu >> 1, hu & 1, te, nt, hout, wave, hi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (epi_on) {
+    }
+    if (NEAT_F6_GROUP > 1 && ((ks + 1) % NEAT_F6_GROUP == 0 || ks == KS - 1)) {
+      // coarse schedule: the MFMAs of the last GROUP k-steps are in the matrix pipe's queue; now their share of the epilogue
+      constexpr int G = NEAT_F6_GROUP;
+      const int ks0 = ks - (ks % G);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 8; ++g)
-          if (g >= (8 * ks) / KS && g < (8 * (ks + 1)) / KS) epi_quad(ae[g >> 2], t - 1, g >> 2, g & 3);
-      }
+      for (int hu = 0; hu < HU; ++hu)
+        if (hu >= ks0 * RT * UPS && hu < (ks + 1) * RT * UPS) {
+          f6_epi_half<NT, RT, FULL, E>(L, ae, bq, st, hu >> 1, hu & 1, te, nt, hout, wave, hi);
+          if ((hu & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
+  if (NEAT_F6_SPLITK && RT == 1 && NEAT_F6_ABLATE != 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) am[0][r] += odd[r];
+  }
+  if (BAR && NEAT_F6_ABLATE != 4) __syncthreads();
 }
 
-template <int NT, bool VALUES>
-__global__ __launch_bounds__(F6T, 1) void sdf_fused_w64_kernel(FusedArgs a, int ntiles, int nwg) {
-  typedef F6Cfg<NT> C;
-  constexpr int BP = C::BP;
+template <int NT, bool VALUES, int RT>
+__global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(FusedArgs a, int ntiles, int nwg) {
+  typedef F6Cfg<NT, RT> C;
+  constexpr int BP = C::BP, F6T = C::THREADS, NW = C::NW;
+  static_assert(NT == 4 && (RT == 1 || RT == 2), "the PE phase maps threads to (point of a 128-point batch, frequency group)");
   extern __shared__ __attribute__((aligned(16))) unsigned char f6lds[];
-  unsigned char* PE = f6lds + C::PE;
   float* biasl = reinterpret_cast<float*>(f6lds + C::BIAS);     // [l][256]; lin8 in packed row order
-  u16* pe16 = reinterpret_cast<u16*>(PE);
+  float* red = reinterpret_cast<float*>(f6lds + C::RED);        // [waves][BP]: partial sums of the sdf row
+  u16* pe16 = reinterpret_cast<u16*>(f6lds + C::PE);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool save = !VALUES && a.save;
+  constexpr bool SAVE = !VALUES;
 
   for (int idx = tid; idx < 8 * 256; idx += F6T) {
     const int l = idx >> 8, n = idx & 255;
     float v = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (l == k && n < (k == 3 ? 217 : 256)) v = a.bias[k][n];
-    biasl[idx] = v * SOFTPLUS_C;             // hidden layers: pre-scaled for softplus100_pk
+    biasl[idx] = v * SOFTPLUS_C;             // hidden layers: pre-scaled for the softplus epilogue
   }
   for (int n = tid; n < 257; n += F6T) {
     int bi = n + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
     biasl[8 * 256 + n] = VALUES ? (n == 0 ? a.bias[8][0] : 0.0f) : a.bias[8][bi];
   }
+  // PE rows 39..63 (octets 4..7; row 32..38 are rewritten per batch) stay zero for the whole launch
+  for (int idx = tid; idx < 4 * BP; idx += F6T) reinterpret_cast<uint4*>(f6lds + C::PE)[4 * BP + idx] = make_uint4(0u, 0u, 0u, 0u);
 
-  // two register sets for the weight slices (this layer / next layer); lin0's short slice (K = 64: 4 k-steps) and this wave's four
-  // k-steps of the sdf row of lin8 are re-fetched per batch into whichever set is idle
-  uint4 wA[2][16], wB[2][16];
-  auto load_w = [&](uint4 (&dst)[2][16], const uint4* Wl, int KS, int N) {
+  // two register sets for the weight slices (this layer / next layer); lin0's short slice (K = 64: 4 k-steps) and this wave's
+  // k-steps of the sdf row of lin8 are fetched per batch into whichever set is idle
+  uint4 wA[RT][16], wB[RT][16];
+  auto load_w = [&](uint4 (&dst)[RT][16], const uint4* Wl, int KS, int N) {
     // kernarg pointer (SGPR pair) + ONE 32-bit per-lane offset (made opaque: otherwise the fragment addresses of all layers are
     // loop-invariant 64-bit values that get hoisted out of the batch loop and spilled) + immediate.  Dead row tiles (lin3:
-    // rows >= 224) re-read a live one.
+    // rows >= 224) re-read a live one; their products are never used.
     const char* base = reinterpret_cast<const char*>(Wl);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int tile = (2 * wave + i) * 32 < N ? 2 * wave + i : 2 * wave;
+    for (int i = 0; i < RT; ++i) {
+      const int tile = (RT * wave + i) * 32 < N ? RT * wave + i : 0;
       unsigned voff = (unsigned)((tile * KS) * 64 + lane) * 16u;
       asm volatile("" : "+v"(voff));
 #pragma unroll
@@ -154,11 +255,12 @@ __global__ __launch_bounds__(F6T, 1) void sdf_fused_w64_kernel(FusedArgs a, int 
 
   F6Lane L;
   {
-    const unsigned fo = (unsigned)(hi * BP + (lane & 31)) * 16u, qo = (unsigned)((8 * wave) * BP + (lane & 31)) * 16u + 8u * hi;
-    unsigned b0 = fo, b1 = fo + C::XB, b2 = fo + C::PE, q0 = qo, q1 = qo + C::XB, bb = C::BIAS + (unsigned)(64 * wave + 4 * hi) * 4u;
-    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(q0), "+v"(q1), "+v"(bb));
+    const unsigned fo = (unsigned)(hi * BP + (lane & 31)) * 16u, qo = (unsigned)((4 * RT * wave) * BP + (lane & 31)) * 16u + 8u * hi;
+    unsigned b0 = fo, b1 = fo + C::XB, b2 = fo + C::PE, q0 = qo, q1 = qo + C::XB, bb = C::BIAS + (unsigned)(32 * RT * wave + 4 * hi) * 4u;
+    unsigned pz = C::PE + (unsigned)(lane & 31) * 16u;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(q0), "+v"(q1), "+v"(bb), "+v"(pz));
     L.frag[0] = f6lds + b0; L.frag[1] = f6lds + b1; L.frag[2] = f6lds + b2;
-    L.quad[0] = f6lds + q0; L.quad[1] = f6lds + q1; L.bias = f6lds + bb;
+    L.quad[0] = f6lds + q0; L.quad[1] = f6lds + q1; L.bias = f6lds + bb; L.pe0 = f6lds + pz;
   }
   L.ldp16 = (unsigned)a.ldp * 16u;
 
@@ -170,94 +272,153 @@ __global__ __launch_bounds__(F6T, 1) void sdf_fused_w64_kernel(FusedArgs a, int 
   for (int tile0 = t_begin; tile0 < t_end; tile0 += t_step) {
     const int p0 = tile0 * 32;
     const int nt = min(NT, t_end - tile0);
-    L.gquad = ((unsigned)(8 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
-    // ---- positional encoding (embedder.py:12-36) into the PE octets (rows 39..63 zero)
-    for (int idx = tid; idx < 64 * BP; idx += F6T) {
-      const int j = idx / BP, p = idx % BP;
-      float v = 0.0f;
-      if (j < 39 && p < nt * 32) {
-        const int c = j < 3 ? j : (j - 3) % 3;
-        const float xc = a.x_fm[(size_t)c * a.ldp + p0 + p];
-        if (j < 3) v = xc;
-        else {
-          const int k = (j - 3) / 6, is_cos = ((j - 3) % 6) >= 3;
-          const float f = (float)(1 << k);
-          v = is_cos ? __cosf(xc * f) : __sinf(xc * f);
-        }
-        if (save) a.E[(size_t)j * a.ldp + p0 + p] = v;
-      }
-      pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
-    }
-    __syncthreads();
+    L.gquad = ((unsigned)(4 * RT * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
 
-    float* red = reinterpret_cast<float*>(PE);               // [4 waves][BP]: partial sums of the sdf row
     auto chain = [&](auto full_tag) {
-      constexpr bool FULLB = decltype(full_tag)::value;
+      constexpr bool FULL = decltype(full_tag)::value;
+      // the slices of lin0 and lin1 travel while the positional encoding is computed
       load_w(wB, a.Wp[0], 4, 256);
       load_w(wA, a.Wp[1], 16, 256);
-      f6_layer<NT, FULLB, 4, 256, true, !VALUES, 2, 0, 0 * 256>(L, wB, nt, a.h[1], wave, hi);
-      load_w(wB, a.Wp[2], 16, 256);
-      f6_layer<NT, FULLB, 16, 256, true, !VALUES, 0, 1, 1 * 256>(L, wA, nt, a.h[2], wave, hi);
-      load_w(wA, a.Wp[3], 16, 217);
-      f6_layer<NT, FULLB, 16, 256, true, !VALUES, 1, 0, 2 * 256>(L, wB, nt, a.h[3], wave, hi);
-      load_w(wB, a.Wp[4], 16, 256);
-      f6_layer<NT, FULLB, 16, 217, true, false, 0, 1, 3 * 256>(L, wA, nt, nullptr, wave, hi);
-      // skip connection (rend_a :87-88): rows 217..255 of lin4's input are the 39 PE rows (1/sqrt2 folded into W4)
+      // ---- positional encoding (embedder.py:12-36): thread = (point, group of NFQ frequencies); rows 0..2 = x, then per frequency
+      // k: rows 3+6k.. = sin(2^k xyz), rows 6+6k.. = cos(2^k xyz)
       {
-        u16* xb16 = reinterpret_cast<u16*>(f6lds + C::XB);
-        for (int idx = tid; idx < 39 * BP; idx += F6T) {
-          const int j = idx / BP, p = idx % BP, row = 217 + j;
-          xb16[((row >> 3) * BP + p) * 8 + (row & 7)] = pe16[((j >> 3) * BP + p) * 8 + (j & 7)];
+        constexpr int NG = F6T / BP, NFQ = 6 / (NG < 6 ? (NG == 4 ? 3 : NG) : 6);     // 2 groups x 3 frequencies, or 3 (of 4) groups x 2
+        const int p = tid & (BP - 1), fg = tid / BP;
+        const bool ok = p < nt * 32;
+        float xc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xc[c] = ok ? a.x_fm[(size_t)c * a.ldp + p0 + p] : 0.0f;
+        auto put = [&](int j, float v) {
+          pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
+          if (SAVE && ok) a.E[(size_t)j * a.ldp + p0 + p] = v;
+        };
+        if (fg == NG - 1) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) put(c, xc[c]);
         }
-        __syncthreads();
-        if (save) {                                          // h4 as the unfused consumers expect it: 217 rows + PE[0..6] in the pad
-          for (int idx = tid; idx < 28 * nt * 32; idx += F6T) {
-            const int o8 = idx / (nt * 32), p = idx % (nt * 32);
-            reinterpret_cast<uint4*>(a.h[4])[(size_t)o8 * a.ldp + p0 + p] = reinterpret_cast<const uint4*>(f6lds + C::XB)[o8 * BP + p];
+        if (fg * NFQ < 6) {
+#pragma unroll
+          for (int kk = 0; kk < NFQ; ++kk) {
+            const int k = fg * NFQ + kk;
+            const float f = (float)(1 << k);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float arg = xc[c] * f;
+              put(3 + 6 * k + c, ok ? __sinf(arg) : 0.0f);
+              put(6 + 6 * k + c, ok ? __cosf(arg) : 0.0f);
+            }
           }
         }
       }
-      load_w(wA, a.Wp[5], 16, 256);
-      f6_layer<NT, FULLB, 16, 256, true, !VALUES, 1, 0, 4 * 256>(L, wB, nt, a.h[5], wave, hi);
-      load_w(wB, a.Wp[6], 16, 256);
-      f6_layer<NT, FULLB, 16, 256, true, !VALUES, 0, 1, 5 * 256>(L, wA, nt, a.h[6], wave, hi);
-      load_w(wA, a.Wp[7], 16, 256);
-      f6_layer<NT, FULLB, 16, 256, true, !VALUES, 1, 0, 6 * 256>(L, wB, nt, a.h[7], wave, hi);
-      if (!VALUES) load_w(wB, a.Wp[8], 16, 256);             // the 256 feature rows of lin8 (tiles 0..7 of the [feature | sdf] pack)
-      f6_layer<NT, FULLB, 16, 256, true, !VALUES, 0, 1, 7 * 256>(L, wA, nt, a.h[8], wave, hi);
+      __syncthreads();
 
+      typedef F6EpiCfg<true, SAVE, 256, 0, 0 * 256> E0;      // lin0 -> XA
+      typedef F6EpiCfg<true, SAVE, 256, 1, 1 * 256> E1;      // lin1 -> XB
+      typedef F6EpiCfg<true, SAVE, 256, 0, 2 * 256> E2;
+      typedef F6EpiCfg<true, SAVE, 217, 1, 3 * 256> E3;      // lin3 -> XB rows 0..216 (+ PE rows 0..6 in the last octet)
+      typedef F6EpiCfg<true, SAVE, 256, 0, 4 * 256> E4;
+      typedef F6EpiCfg<true, SAVE, 256, 1, 5 * 256> E5;
+      typedef F6EpiCfg<true, SAVE, 256, 0, 6 * 256> E6;
+      typedef F6EpiCfg<true, SAVE, 256, 1, 7 * 256> E7;
+      typedef F6EpiCfg<false, true, 256, 0, 8 * 256> E8;     // lin8 feature rows -> HBM only
+      f32x16 acc[2][RT];
+      float4 bq[4 * RT];
+      uint4 ring[NEAT_F6_RING];
+      constexpr int RD = NEAT_F6_RING;
+#define F6_KSUM(S_) ((S_) < 4 ? 4 * (S_) : ((S_) < 33 ? 16 * (S_) - 48 : 16 * (S_) - 64))      /* k-steps before stage S_ (stage 32 = drain) */
+      // skip connection (rend_a :87-88): rows 224..255 of lin4's input (octets 28..31 of XB) = PE rows 7..38 (the 1/sqrt2 is folded
+      // into W4).  One thread per (point of tile tc, octet): PE rows 7+8k .. 14+8k straddle PE octets k and k+1.
+      auto skip_copy = [&](int tc) {
+        if (tid < 128) {
+          const int pp = tc * 32 + (tid & 31), k = tid >> 5;
+          const uint4* pe = reinterpret_cast<const uint4*>(f6lds + C::PE);
+          const uint4 lo = pe[k * BP + pp], hi4 = pe[(k + 1) * BP + pp];
+          reinterpret_cast<uint4*>(f6lds + C::XB)[(28 + k) * BP + pp] =
+              make_uint4((lo.w >> 16) | (hi4.x << 16), (hi4.x >> 16) | (hi4.y << 16), (hi4.y >> 16) | (hi4.z << 16), (hi4.z >> 16) | (hi4.w << 16));
+        }
+      };
+      // One layer = NT stages.  S0_ = index of its first stage (accumulator set = stage & 1, ring offset = stage % 3); the last
+      // stage of a layer prefetches fragments of the next layer's input NSRC_ (3 = none).  A barrier ends every second stage
+      // (a tile written in stage w is read in stage w + 3) and every stage where ALLBAR_ says so.
+#define F6_STAGE(S_, T_, KS_, SRC_, WC_, E_, H_, TE_, NFR_, BAR_)                                                                   \
+      f6_stage<NT, RT, FULL, true, KS_, SRC_, E_, F6_KSUM(S_) % RD, BAR_>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], bq, TE_, nt, H_, wave, hi, ring, NFR_);
+#define F6_LAYER(S0_, KS_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, NSRC_, ALLBAR_, PRE_)                                              \
+      { PRE_(0) F6_STAGE((S0_) + 0, 0, KS_, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512, (ALLBAR_ || ((S0_) + 0) % 2 == 1))  \
+        f6_load_bias<ECUR_, RT>(L, bq);                                                                                          \
+        PRE_(1) F6_STAGE((S0_) + 1, 1, KS_, SRC_, WC_, ECUR_, HCUR_, 0, L.frag[SRC_] + 2 * 512, (ALLBAR_ || ((S0_) + 1) % 2 == 1))  \
+        PRE_(2) F6_STAGE((S0_) + 2, 2, KS_, SRC_, WC_, ECUR_, HCUR_, 1, L.frag[SRC_] + 3 * 512, (ALLBAR_ || ((S0_) + 2) % 2 == 1))  \
+        PRE_(3) F6_STAGE((S0_) + 3, 3, KS_, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 3 ? L.frag[(NSRC_) < 3 ? (NSRC_) : 0] : nullptr), (ALLBAR_ || ((S0_) + 3) % 2 == 1)) }
+#define F6_NOPRE(T_)
+#define F6_SKIPPRE(T_) skip_copy((T_) < 3 ? (T_) + 1 : 3);
+      // stage 0's first two fragments
+#pragma unroll
+      for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[2] + j * 2 * BP * 16);
+      F6_LAYER(0, 4, 2, wB, F6NoEpi, E0, nullptr, a.h[1], 0, false, F6_NOPRE)
+      load_w(wB, a.Wp[2], 16, 256);
+      F6_LAYER(4, 16, 0, wA, E0, E1, a.h[1], a.h[2], 1, false, F6_NOPRE)
+      load_w(wA, a.Wp[3], 16, 217);
+      F6_LAYER(8, 16, 1, wB, E1, E2, a.h[2], a.h[3], 0, false, F6_NOPRE)
+      load_w(wB, a.Wp[4], 16, 256);
+      // lin3 and lin4 keep a barrier per stage: lin4's tile t reads XB rows 224..255 of tile t, which the skip copy fills one to two
+      // stages earlier -- after lin3's epilogue of that tile has written its don't-care rows there
+      F6_LAYER(12, 16, 0, wA, E2, E3, a.h[3], a.h[4], 3, true, F6_NOPRE)
+      load_w(wA, a.Wp[5], 16, 256);
+      skip_copy(0);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RD - 1; ++j) ring[(F6_KSUM(16) + j) % RD] = *reinterpret_cast<const uint4*>(L.frag[1] + j * 2 * BP * 16);
+      F6_LAYER(16, 16, 1, wB, E3, E4, a.h[4], a.h[5], 0, true, F6_SKIPPRE)
+      load_w(wB, a.Wp[6], 16, 256);
+      F6_LAYER(20, 16, 0, wA, E4, E5, a.h[5], a.h[6], 1, false, F6_NOPRE)
+      load_w(wA, a.Wp[7], 16, 256);
+      F6_LAYER(24, 16, 1, wB, E5, E6, a.h[6], a.h[7], 0, false, F6_NOPRE)
+      if (!VALUES) load_w(wB, a.Wp[8], 16, 256);             // the 256 feature rows of lin8 (tiles 0..7 of the [feature | sdf] pack)
+      F6_LAYER(28, 16, 0, wA, E6, E7, a.h[7], a.h[8], 3, false, F6_NOPRE)
+      // drain: epilogue of lin7's last tile (h8 complete in XB after the barrier)
+      f6_stage<NT, RT, FULL, false, 16, 0, E7, 0, true>(L, wA, 0, acc[0], acc[1], bq, NT - 1, nt, a.h[8], wave, hi, ring, nullptr);
       // ---- lin8: the sdf row, split over the waves' k-steps and reduced through LDS; then (save mode) the 256 feature rows
       {
-        {                                                    // this wave's four k-steps of the sdf row -> the idle set wA
-          unsigned voff = (unsigned)((((VALUES ? 0 : 8) * 16 + 4 * wave) * 64 + lane) * 16);
+        constexpr int KW = 16 / NW;                          // k-steps of the sdf row per wave
+        {                                                    // -> the idle set wA
+          unsigned voff = (unsigned)((((VALUES ? 0 : 8) * 16 + KW * wave) * 64 + lane) * 16);
           asm volatile("" : "+v"(voff));
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wA[0][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[8]) + voff + j * 1024);
+          for (int j = 0; j < KW; ++j) wA[0][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[8]) + voff + j * 1024);
         }
-        const unsigned char* fr = L.frag[1] + (unsigned)(4 * wave) * (2 * BP * 16);
+        const unsigned char* fr = L.frag[1] + (unsigned)(KW * wave) * (2 * BP * 16);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (!FULLB && t >= nt) break;
           f32x16 accs;
 #pragma unroll
           for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < KW; ++j) {
             const uint4 bv = *reinterpret_cast<const uint4*>(fr + (j * 2 * BP * 16 + t * 512));
             accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wA[0][j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
           }
           if (hi == 0) red[wave * BP + t * 32 + lane] = accs[0];
         }
       }
-      if (!VALUES) f6_layer<NT, FULLB, 16, 256, false, true, 1, 0, 8 * 256>(L, wB, nt, a.feat, wave, hi);      // (ends with a barrier)
-      else __syncthreads();
+      if (!VALUES) {
+#pragma unroll
+        for (int j = 0; j < RD - 1; ++j) ring[(F6_KSUM(33) + j) % RD] = *reinterpret_cast<const uint4*>(L.frag[1] + j * 2 * BP * 16);
+        F6_LAYER(33, 16, 1, wB, F6NoEpi, E8, nullptr, a.feat, 3, false, F6_NOPRE)
+        f6_stage<NT, RT, FULL, false, 16, 0, E8, 0, true>(L, wB, 0, acc[37 & 1], acc[(37 + 1) & 1], bq, NT - 1, nt, a.feat, wave, hi, ring, nullptr);
+      } else {
+        __syncthreads();
+      }
+#undef F6_STAGE
+#undef F6_KSUM
+#undef F6_NOPRE
+#undef F6_SKIPPRE
+#undef F6_LAYER
     };
-    if (nt == NT) chain(std::true_type{});
+    if (VALUES || nt == NT) chain(std::true_type{});       // (values mode stores nothing per tile: the full-batch code serves every batch)
     else chain(std::false_type{});
     if (tid < nt * 32) {
       float sv = biasl[8 * 256 + (VALUES ? 0 : 256)];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) sv += red[w * BP + tid];
+      for (int w = 0; w < NW; ++w) sv += red[w * BP + tid];
       const int p = p0 + tid;
       if (VALUES) {
         if (a.radius > 0.0f) {

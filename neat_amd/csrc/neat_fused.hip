@@ -3,17 +3,22 @@
 
 namespace neat {
 
-hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave) {
+template <int RT> hipError_t launch_rt(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave) {
+  typedef F6Cfg<4, RT> C;
   static bool attr_done = false;      // not a stream operation: keep it out of graph capture
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_fused_w64_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, F6Cfg<4>::LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_fused_w64_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F6Cfg<4>::LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_fused_w64_kernel<4, false, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_fused_w64_kernel<4, true, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  if (full) hipLaunchKernelGGL((sdf_fused_w64_kernel<4, false>), dim3(nwg), dim3(F6T), F6Cfg<4>::LDS, st, a, ntiles, interleave ? -nwg : nwg);
-  else hipLaunchKernelGGL((sdf_fused_w64_kernel<4, true>), dim3(nwg), dim3(F6T), F6Cfg<4>::LDS, st, a, ntiles, interleave ? -nwg : nwg);
+  if (full) hipLaunchKernelGGL((sdf_fused_w64_kernel<4, false, RT>), dim3(nwg), dim3(C::THREADS), C::LDS, st, a, ntiles, interleave ? -nwg : nwg);
+  else hipLaunchKernelGGL((sdf_fused_w64_kernel<4, true, RT>), dim3(nwg), dim3(C::THREADS), C::LDS, st, a, ntiles, interleave ? -nwg : nwg);
   return hipGetLastError();
+}
+
+hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave, int rows_per_wave) {
+  return rows_per_wave == 64 ? launch_rt<2>(st, a, ntiles, nwg, full, interleave) : launch_rt<1>(st, a, ntiles, nwg, full, interleave);
 }
 
 }  // namespace neat
