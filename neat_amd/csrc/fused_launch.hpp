@@ -11,7 +11,8 @@ namespace neat {
 // fused SDF primal chain, 4 waves x 64 output rows, 128-point batches.  full: save h_1..h_8, PE, lin8 outputs for backward;
 // otherwise only the clamped sdf (sampler).  nwg persistent workgroups over ntiles 32-point tiles; interleave: batches
 // interleaved over the workgroups instead of one contiguous range each.
-// rows_per_wave: 64 (four waves, one per SIMD) or 32 (eight waves, two per SIMD).
+// rows_per_wave: 0 = phase-staggered kernel (sdf_fused_ph_kernel); 64 / 32 = stage-pipelined kernel with four waves (one per
+// SIMD) / eight waves (two per SIMD).
 hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave, int rows_per_wave);
 
 }  // namespace neat

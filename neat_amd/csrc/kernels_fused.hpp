@@ -434,4 +434,297 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
   }
 }
 
+// ===============================================================================================================
+// Phase-staggered fused primal chain (generation 4).
+//
+// What the ablations of the stage-pipelined kernel above showed (scripts/probe_fused_abl.py, values mode, P = 133 120):
+// MFMAs + B-fragment reads alone 81 us (4 waves x 64 rows) = the matrix-pipe time; the epilogue alone 74 us; both in one
+// instruction stream 236 us -- more than their sum, whatever the interleave (fine, per 2 / 4 / 16 k-steps), the fragment
+// ring depth, the accumulator register class or the barrier count.  A wave that mixes MFMAs with VALU / LDS work runs
+// both at a fraction of their rates; two such waves on one SIMD do not fix it, because they mix in lock step.
+// What does overlap on this machine is a wave in a DENSE matrix phase next to a wave in a DENSE vector phase on the same
+// SIMD ("matrix beside VALU", MI355X_MICROARCH.md, two waves per SIMD).  So here:
+//   * eight waves, wave w owns output rows 32 w .. 32 w + 31 (weights: 16 fragments, double-buffered = 128 registers);
+//   * waves 0..3 (role 0) and 4..7 (role 1) -- one of each per SIMD -- run the same sequence of phases one phase apart:
+//       phase 2t   : role 0 multiplies tile t (16 back-to-back MFMAs on one accumulator tile, B fragments through a ring),
+//                    role 1 runs the epilogue of ITS previous tile (bias, softplus, pack, LDS / HBM stores);
+//       phase 2t+1 : the other way round;
+//     one workgroup barrier per phase keeps the two roles in opposite phases;
+//   * layer l+1 follows layer l without a bubble (its tile 0 was finished six phases earlier).
+// ===============================================================================================================
+constexpr int PHT = 512;
+typedef F6Cfg<4, 1> PhCfg;
+
+// dense matrix phase: acc = W_slice (32 x 16 KS) x input tile t of region SRC.  The first RD-1 fragments are already in `ring`
+// (requested at the end of this wave's previous vector phase).
+template <int KS, int SRC>
+__device__ __forceinline__ void ph_mma(const F6Lane& L, const uint4 (&wc)[16], int t, f32x16& acc, uint4 (&ring)[4]) {
+  constexpr int STEP = 2 * PhCfg::BP * 16, RD = 4, AH = 3;
+  const unsigned char* fr = L.frag[SRC] + t * 512;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + AH < KS) ring[(ks + AH) % RD] = *reinterpret_cast<const uint4*>(fr + (ks + AH) * STEP);
+    const uint4 cur = ring[ks % RD];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wc[ks]), *reinterpret_cast<const bf16x8*>(&cur), ks ? acc : zero, 0, 0, 0);
+  }
+}
+// request the first fragments of the next matrix phase (tile t of region SRC; KS >= 3)
+template <int SRC> __device__ __forceinline__ void ph_prefetch(const F6Lane& L, int t, uint4 (&ring)[4]) {
+  constexpr int STEP = 2 * PhCfg::BP * 16;
+  const unsigned char* fr = L.frag[SRC] + t * 512;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) ring[j] = *reinterpret_cast<const uint4*>(fr + j * STEP);
+}
+
+// dense vector phase: epilogue E of the accumulator tile `acc` (point tile t)
+template <bool FULL, class E>
+__device__ __forceinline__ void ph_epi(const F6Lane& L, const f32x16& acc, const float4 (&bq)[4], int t, int nt, u16* hout, int wave, int hi) {
+  constexpr int BP = PhCfg::BP;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float b[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = acc[4 * q + e];
+      if (E::ACT) {
+        const float u = fmaf(x, SOFTPLUS_C, b[e]);
+        r[e] = (fmaxf(u, 0.0f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(u)))) * 0.0069314718055994531f;
+      } else {
+        r[e] = x + b[e];
+      }
+    }
+    uint2 v = make_uint2(pack2(r[0], r[1]), pack2(r[2], r[3]));
+    if (E::N == 217 && q == 3) {
+      // lin3, rows 216..223 (wave 6): [h216 | PE rows 0..6] -- what lin4 (skip connection, rend_a :87-88) and the saved h4 expect in
+      // the last octet of the 217-row array
+      if (wave == 6) {
+        const uint4 w = *reinterpret_cast<const uint4*>(L.pe0 + t * 512);       // PE rows 0..7 of this point, bf16
+        if (hi == 0) v = make_uint2((v.x & 0xFFFFu) | (w.x << 16), (w.x >> 16) | (w.y << 16));
+        else v = make_uint2((w.y >> 16) | (w.z << 16), (w.z >> 16) | (w.w << 16));
+      }
+    }
+    if (E::ACT) *reinterpret_cast<uint2*>(L.quad[E::DST] + (q * BP + t * 32) * 16) = v;
+    if (E::SAVE && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
+      *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((size_t)(q * L.ldp16) + t * 512) + (size_t)L.gquad) = v;
+  }
+}
+template <class E> __device__ __forceinline__ void ph_load_bias(const F6Lane& L, float4 (&bq)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(L.bias + (E::BIASOFF + 8 * q) * 4);
+}
+
+template <bool VALUES>
+__global__ __launch_bounds__(PHT, 2) void sdf_fused_ph_kernel(FusedArgs a, int ntiles, int nwg) {
+  typedef PhCfg C;
+  constexpr int BP = C::BP, NT = 4, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char f6lds[];
+  float* biasl = reinterpret_cast<float*>(f6lds + C::BIAS);     // [l][256]; lin8 in packed row order
+  float* red = reinterpret_cast<float*>(f6lds + C::RED);        // [waves][BP]: partial sums of the sdf row
+  u16* pe16 = reinterpret_cast<u16*>(f6lds + C::PE);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2;                  // waves w and w + 4 share a SIMD (round-robin placement): one of each role per SIMD
+  constexpr bool SAVE = !VALUES;
+
+  for (int idx = tid; idx < 8 * 256; idx += PHT) {
+    const int l = idx >> 8, n = idx & 255;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (l == k && n < (k == 3 ? 217 : 256)) v = a.bias[k][n];
+    biasl[idx] = v * SOFTPLUS_C;             // hidden layers: pre-scaled for the softplus epilogue
+  }
+  for (int n = tid; n < 257; n += PHT) {
+    int bi = n + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
+    biasl[8 * 256 + n] = VALUES ? (n == 0 ? a.bias[8][0] : 0.0f) : a.bias[8][bi];
+  }
+  // PE rows 39..63 (octets 4..7; rows 32..38 are rewritten per batch) stay zero for the whole launch
+  for (int idx = tid; idx < 4 * BP; idx += PHT) reinterpret_cast<uint4*>(f6lds + C::PE)[4 * BP + idx] = make_uint4(0u, 0u, 0u, 0u);
+
+  uint4 wA[16], wB[16];
+  auto load_w = [&](uint4 (&dst)[16], const uint4* Wl, int KS, int N) {
+    // kernarg pointer (SGPR pair) + ONE opaque 32-bit per-lane offset + immediate (see sdf_fused_w64_kernel).  The dead row tile
+    // of lin3 (rows 224..255) re-reads tile 0; it is never multiplied.
+    const char* base = reinterpret_cast<const char*>(Wl);
+    const int tile = wave * 32 < N ? wave : 0;
+    unsigned voff = (unsigned)((tile * KS) * 64 + lane) * 16u;
+    asm volatile("" : "+v"(voff));
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks < KS) dst[ks] = *reinterpret_cast<const uint4*>(base + voff + ks * 1024);
+  };
+
+  F6Lane L;
+  {
+    const unsigned fo = (unsigned)(hi * BP + (lane & 31)) * 16u, qo = (unsigned)((4 * wave) * BP + (lane & 31)) * 16u + 8u * hi;
+    unsigned b0 = fo, b1 = fo + C::XB, b2 = fo + C::PE, q0 = qo, q1 = qo + C::XB, bb = C::BIAS + (unsigned)(32 * wave + 4 * hi) * 4u;
+    unsigned pz = C::PE + (unsigned)(lane & 31) * 16u;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(q0), "+v"(q1), "+v"(bb), "+v"(pz));
+    L.frag[0] = f6lds + b0; L.frag[1] = f6lds + b1; L.frag[2] = f6lds + b2;
+    L.quad[0] = f6lds + q0; L.quad[1] = f6lds + q1; L.bias = f6lds + bb; L.pe0 = f6lds + pz;
+  }
+  L.ldp16 = (unsigned)a.ldp * 16u;
+
+  const bool inter = nwg < 0;
+  const int ng = inter ? -nwg : nwg;
+  const int t_begin = inter ? (int)blockIdx.x * NT : (int)(((long long)blockIdx.x * ntiles) / ng);
+  const int t_end = inter ? ntiles : (int)(((long long)(blockIdx.x + 1) * ntiles) / ng);
+  const int t_step = inter ? ng * NT : NT;
+  for (int tile0 = t_begin; tile0 < t_end; tile0 += t_step) {
+    const int p0 = tile0 * 32;
+    const int nt = min(NT, t_end - tile0);
+    L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
+
+    auto chain = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      load_w(wB, a.Wp[0], 4, 256);
+      load_w(wA, a.Wp[1], 16, 256);
+      // ---- positional encoding (embedder.py:12-36): thread = (point, group of 2 frequencies; the 4th group writes x itself)
+      {
+        const int p = tid & (BP - 1), fg = tid / BP;
+        const bool ok = p < nt * 32;
+        float xc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xc[c] = ok ? a.x_fm[(size_t)c * a.ldp + p0 + p] : 0.0f;
+        auto put = [&](int j, float v) {
+          pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
+          if (SAVE && ok) a.E[(size_t)j * a.ldp + p0 + p] = v;
+        };
+        if (fg == 3) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) put(c, xc[c]);
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int k = fg * 2 + kk;
+            const float f = (float)(1 << k);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float arg = xc[c] * f;
+              put(3 + 6 * k + c, ok ? __sinf(arg) : 0.0f);
+              put(6 + 6 * k + c, ok ? __cosf(arg) : 0.0f);
+            }
+          }
+        }
+      }
+      __syncthreads();
+
+      typedef F6EpiCfg<true, SAVE, 256, 0, 0 * 256> E0;      // lin0 -> XA
+      typedef F6EpiCfg<true, SAVE, 256, 1, 1 * 256> E1;      // lin1 -> XB
+      typedef F6EpiCfg<true, SAVE, 256, 0, 2 * 256> E2;
+      typedef F6EpiCfg<true, SAVE, 217, 1, 3 * 256> E3;      // lin3 -> XB rows 0..216 (+ PE rows 0..6 in the last octet)
+      typedef F6EpiCfg<true, SAVE, 256, 0, 4 * 256> E4;
+      typedef F6EpiCfg<true, SAVE, 256, 1, 5 * 256> E5;
+      typedef F6EpiCfg<true, SAVE, 256, 0, 6 * 256> E6;
+      typedef F6EpiCfg<true, SAVE, 256, 1, 7 * 256> E7;
+      typedef F6EpiCfg<false, true, 256, 0, 8 * 256> E8;     // lin8 feature rows -> HBM only
+      f32x16 acc;
+      float4 bq[4];
+      uint4 ring[4];
+      // One layer = 2 NT phases.  Role 0: phase 2t = matrix phase of tile t, phase 2t+1 = its epilogue.  Role 1 runs one phase
+      // behind: phase 2t = epilogue of its previous tile (tile t-1, or tile 3 of the previous layer: EPREV_ with the previous
+      // layer's bias still in bq), phase 2t+1 = matrix phase of tile t.  LIVE_ / LIVEPREV_: this wave's row tile exists in the layer /
+      // in the previous one.
+      // After a vector phase the wave requests the first fragments of its next matrix phase (NSRC_ = input region of the next layer).
+#define PH_LAYER(KS_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, NSRC_, LIVE_, LIVEPREV_)                                                     \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                          \
+        if (role == 0) {                                                                                                        \
+          if (LIVE_) ph_mma<KS_, SRC_>(L, WC_, t, acc, ring);                                                                   \
+          if (t == 0) ph_load_bias<ECUR_>(L, bq);                                                                               \
+        } else {                                                                                                                \
+          if (t == 0) { if (!EPREV_::NONE && (LIVEPREV_)) ph_epi<FULL, EPREV_>(L, acc, bq, NT - 1, nt, HPREV_, wave, hi); ph_load_bias<ECUR_>(L, bq); } \
+          else if (LIVE_) ph_epi<FULL, ECUR_>(L, acc, bq, t - 1, nt, HCUR_, wave, hi);                                          \
+          ph_prefetch<SRC_>(L, t, ring);                                                                                        \
+        }                                                                                                                       \
+        __syncthreads();                                                                                                        \
+        if (role == 0) {                                                                                                        \
+          if (LIVE_) ph_epi<FULL, ECUR_>(L, acc, bq, t, nt, HCUR_, wave, hi);                                                   \
+          if (t + 1 < NT) ph_prefetch<SRC_>(L, t + 1, ring); else if ((NSRC_) < 3) ph_prefetch<((NSRC_) < 3 ? (NSRC_) : 0)>(L, 0, ring); \
+        } else {                                                                                                                \
+          if (LIVE_) ph_mma<KS_, SRC_>(L, WC_, t, acc, ring);                                                                   \
+        }                                                                                                                       \
+        __syncthreads();                                                                                                        \
+      }
+      if (role == 0) ph_prefetch<2>(L, 0, ring);
+      PH_LAYER(4, 2, wB, F6NoEpi, E0, nullptr, a.h[1], 0, true, true)
+      load_w(wB, a.Wp[2], 16, 256);
+      PH_LAYER(16, 0, wA, E0, E1, a.h[1], a.h[2], 1, true, true)
+      load_w(wA, a.Wp[3], 16, 217);
+      PH_LAYER(16, 1, wB, E1, E2, a.h[2], a.h[3], 0, true, true)
+      load_w(wB, a.Wp[4], 16, 256);
+      // skip connection (rend_a :87-88): rows 224..255 of lin4's input (octets 28..31 of XB) = PE rows 7..38 (the 1/sqrt2 is folded
+      // into W4); nobody reads XB between lin2 (done) and lin4, and lin3 writes only rows 0..223 of it (its row tile 7 is dead).
+      // One thread per (point, octet): PE rows 7+8k .. 14+8k straddle PE octets k and k+1.
+      {
+        const int pp = tid & (BP - 1), k = tid >> 7;
+        const uint4* pe = reinterpret_cast<const uint4*>(f6lds + C::PE);
+        const uint4 lo = pe[k * BP + pp], hi4 = pe[(k + 1) * BP + pp];
+        reinterpret_cast<uint4*>(f6lds + C::XB)[(28 + k) * BP + pp] =
+            make_uint4((lo.w >> 16) | (hi4.x << 16), (hi4.x >> 16) | (hi4.y << 16), (hi4.y >> 16) | (hi4.z << 16), (hi4.z >> 16) | (hi4.w << 16));
+      }
+      PH_LAYER(16, 0, wA, E2, E3, a.h[3], a.h[4], 1, (wave != 7), true)
+      load_w(wA, a.Wp[5], 16, 256);
+      PH_LAYER(16, 1, wB, E3, E4, a.h[4], a.h[5], 0, true, (wave != 7))
+      load_w(wB, a.Wp[6], 16, 256);
+      PH_LAYER(16, 0, wA, E4, E5, a.h[5], a.h[6], 1, true, true)
+      load_w(wA, a.Wp[7], 16, 256);
+      PH_LAYER(16, 1, wB, E5, E6, a.h[6], a.h[7], 0, true, true)
+      if (!VALUES) load_w(wB, a.Wp[8], 16, 256);             // the 256 feature rows of lin8 (tiles 0..7 of the [feature | sdf] pack)
+      PH_LAYER(16, 0, wA, E6, E7, a.h[7], a.h[8], 3, true, true)
+      // role 1's last epilogue of lin7 (h8 complete in XB after the barrier)
+      if (role == 1) ph_epi<FULL, E7>(L, acc, bq, NT - 1, nt, a.h[8], wave, hi);
+      __syncthreads();
+      // ---- lin8: the sdf row, split over the waves' k-steps and reduced through LDS; then (save mode) the 256 feature rows
+      {
+        constexpr int KW = 16 / NW;                          // k-steps of the sdf row per wave
+        {                                                    // -> the idle set wA
+          unsigned voff = (unsigned)((((VALUES ? 0 : 8) * 16 + KW * wave) * 64 + lane) * 16);
+          asm volatile("" : "+v"(voff));
+#pragma unroll
+          for (int j = 0; j < KW; ++j) wA[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[8]) + voff + j * 1024);
+        }
+        const unsigned char* fr = L.frag[1] + (unsigned)(KW * wave) * (2 * BP * 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f32x16 accs;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
+#pragma unroll
+          for (int j = 0; j < KW; ++j) {
+            const uint4 bv = *reinterpret_cast<const uint4*>(fr + (j * 2 * BP * 16 + t * 512));
+            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wA[j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
+          }
+          if (hi == 0) red[wave * BP + t * 32 + lane] = accs[0];
+        }
+      }
+      if (!VALUES) {
+        if (role == 0) ph_prefetch<1>(L, 0, ring);
+        PH_LAYER(16, 1, wB, F6NoEpi, E8, nullptr, a.feat, 3, true, true)
+        if (role == 1) ph_epi<FULL, E8>(L, acc, bq, NT - 1, nt, a.feat, wave, hi);
+      }
+      __syncthreads();
+#undef PH_LAYER
+    };
+    if (VALUES || nt == NT) chain(std::true_type{});       // (values mode stores nothing per tile: the full-batch code serves every batch)
+    else chain(std::false_type{});
+    if (tid < nt * 32) {
+      float sv = biasl[8 * 256 + (VALUES ? 0 : 256)];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sv += red[w * BP + tid];
+      const int p = p0 + tid;
+      if (VALUES) {
+        if (a.radius > 0.0f) {
+          const float x0 = a.x_fm[p], x1 = a.x_fm[(size_t)a.ldp + p], x2 = a.x_fm[(size_t)2 * a.ldp + p];
+          sv = fminf(sv, a.scale * (a.radius - sqrtf(x0 * x0 + x1 * x1 + x2 * x2)));
+        }
+        if (p < a.P) a.sdf_out[p] = sv;
+      } else {
+        a.sdfraw[p] = sv;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace neat

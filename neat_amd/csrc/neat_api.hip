@@ -172,7 +172,8 @@ inline int wgrad_batch_size(int ldp) {
 int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
 int g_wreduce_direct = 2;   // bf16 weight-gradient reduction: 2 = one launch per layer / batch with 16-byte loads (wreduce_direct_kernel), 0 = group
                             // sums + finish (two launches, stage buffer), 1 = one 16-wave pass with 4-byte loads (slowest)
-int g_fused_ws = 3;         // fused primal chain: 3 / 2 = stage-pipelined kernel of kernels_fused.hpp with 8 waves x 32 rows / 4 waves x 64 rows,
+int g_fused_ws = 3;         // fused primal chain: 4 = phase-staggered kernel (sdf_fused_ph_kernel; measured slower: a matrix wave and a
+                            // vector wave on one SIMD do not overlap on this machine, scripts/probes/probe_roles.hip), 3 / 2 = stage-pipelined kernel of kernels_fused.hpp with 8 waves x 32 rows / 4 waves x 64 rows,
                             // 1 = first weight-stationary kernel (8 waves x 32 rows), 0 = sdf_fused_kernel_h
 int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
@@ -504,7 +505,7 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
       const int ntiles = c.ldp / 32;                 // ldp is a multiple of 64
       const int nwg = ntiles < g_ws_grid ? ntiles : g_ws_grid;
       if (g_fused_ws >= 2) {
-        hipError_t e6 = launch_sdf_fused_w64(c.st, a, ntiles, nwg, full, g_fused_interleave != 0, g_fused_ws == 2 ? 64 : 32);
+        hipError_t e6 = launch_sdf_fused_w64(c.st, a, ntiles, nwg, full, g_fused_interleave != 0, g_fused_ws == 2 ? 64 : (g_fused_ws == 3 ? 32 : 0));
         prof_end(c.st, ps);
         return e6;
       }
@@ -1055,7 +1056,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 1 && (value == 0 || value == 1)) { g_wgrad_h3 = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { g_layer_ws = value; return 0; }
   if (key == 3 && value >= 1 && value <= 4096) { g_ws_grid = value; return 0; }
-  if (key == 4 && value >= 0 && value <= 3) { g_fused_ws = value; return 0; }
+  if (key == 4 && value >= 0 && value <= 4) { g_fused_ws = value; return 0; }
   if (key == 6 && value >= 0 && value <= 2) { g_wreduce_direct = value; return 0; }
   if (key == 7 && (value == 0 || value == 1)) { g_wgrad_interleave = value; return 0; }
   if (key == 8 && (value == -1 || value == 0 || value == 2 || value == 3 || value == 6)) { g_wgrad_batch = value; return 0; }

@@ -17,7 +17,21 @@ template <int RT> hipError_t launch_rt(hipStream_t st, const FusedArgs& a, int n
   return hipGetLastError();
 }
 
+hipError_t launch_ph(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_fused_ph_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_fused_ph_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PhCfg::LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  if (full) hipLaunchKernelGGL((sdf_fused_ph_kernel<false>), dim3(nwg), dim3(PHT), PhCfg::LDS, st, a, ntiles, interleave ? -nwg : nwg);
+  else hipLaunchKernelGGL((sdf_fused_ph_kernel<true>), dim3(nwg), dim3(PHT), PhCfg::LDS, st, a, ntiles, interleave ? -nwg : nwg);
+  return hipGetLastError();
+}
+
 hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave, int rows_per_wave) {
+  if (rows_per_wave == 0) return launch_ph(st, a, ntiles, nwg, full, interleave);
   return rows_per_wave == 64 ? launch_rt<2>(st, a, ntiles, nwg, full, interleave) : launch_rt<1>(st, a, ntiles, nwg, full, interleave);
 }
 

@@ -31,7 +31,7 @@ def timeit(fn, n=20):
 
 
 res = {}
-for gen in (1, 2, 3):
+for gen in (1, 2, 3, 4):
     _lib.check(lib.neat_set_tuning(4, gen), "neat_set_tuning")
     with torch.no_grad():
         sdf = m.implicit_network.get_sdf_vals(x).clone()
@@ -40,7 +40,7 @@ for gen in (1, 2, 3):
         t_val = timeit(lambda: m.implicit_network.get_sdf_vals(x))
         t_out = timeit(lambda: m.implicit_network.get_outputs(x))
     print(f"generation {gen}: get_sdf_vals {t_val:8.1f} us   get_outputs (fused primal + adjoint chain + exports) {t_out:8.1f} us", flush=True)
-for gen in (2, 3):
+for gen in (2, 3, 4):
   for name, a, b in zip(("sdf(values)", "sdf", "feat", "grad"), res[1], res[gen]):
     d = float((a - b).abs().max())
     print(f"  {name:12s} max |gen{gen} - gen1| = {d:.3e}  (scale {float(a.abs().max()):.3e})")
