@@ -9,6 +9,23 @@ namespace neat {
 
 constexpr int SMAX = 1024;      // max samples per ray inside the sampler (reference: 128 * max_total_iters = 640)
 
+// fp64 wave scan / sum.  The reference runs on torch-CPU, whose cumsum accumulates float rows in double and rounds every output once
+// (at::acc_type<float, false> = double); an fp32 scan rounds at every step and moves CDF knots by a few 1e-8, enough to flip the
+// `denom < 1e-5` rule of the inverse-CDF step for bins whose mass sits at the threshold (every empty bin of `weights + 1e-5`).
+__device__ __forceinline__ double wave_incl_scan_d(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
@@ -32,7 +49,8 @@ __device__ __forceinline__ float interval_bound(float a, float d0, float d1) {
 
 // max_i of the opacity error bound for one beta (get_error_bound, :285-293); arrays in LDS, m = n-1 intervals
 __device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
-  float carryE = 0.0f, carryS = 0.0f, best = -INFINITY;
+  double carryE = 0.0, carryS = 0.0;
+  float best = -INFINITY;
   for (int c0 = 0; c0 < m; c0 += 64) {
     const int j = c0 + lane;
     const bool ok = j < m;
@@ -42,10 +60,10 @@ __device__ __forceinline__ float error_bound(const float* sdf, const float* dist
       e = d * laplace_sigma(sdf[j], beta);
       s = expf(-dstar[j] / beta) * (d * d) / (4.0f * beta * beta);
     }
-    const float inclE = wave_incl_scan(e, lane), inclS = wave_incl_scan(s, lane);
-    float exclE = __shfl_up(inclE, 1);
-    if (lane == 0) exclE = 0.0f;
-    if (ok) best = fmaxf(best, (fminf(expf(carryS + inclS), 1.0e6f) - 1.0f) * expf(-(carryE + exclE)));
+    const double inclE = wave_incl_scan_d((double)e, lane), inclS = wave_incl_scan_d((double)s, lane);
+    double exclE = __shfl_up(inclE, 1);
+    if (lane == 0) exclE = 0.0;
+    if (ok) best = fmaxf(best, (fminf(expf((float)(carryS + inclS)), 1.0e6f) - 1.0f) * expf(-(float)(carryE + exclE)));
     carryE += __shfl(inclE, 63);
     carryS += __shfl(inclS, 63);
   }
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
   for (int j = lane; j < n; j += 64) { sz[j] = a.z[(size_t)r * n + j]; ssdf[j] = a.sdf[(size_t)r * n + j]; }
   __syncthreads();
   // pdf over the n-1 intervals -> scdf[1..n-1] (unnormalised), total in `sum`
-  float carryE = 0.0f, carryS = 0.0f, sum = 0.0f;
+  double carryE = 0.0, carryS = 0.0, sum = 0.0;
   for (int c0 = 0; c0 < n; c0 += 64) {
     const int j = c0 + lane;
     const bool ok = j < n;
@@ -126,28 +144,30 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
       e = d * laplace_sigma(ssdf[j], beta);
       if (j < m) s = expf(-interval_bound(d, ssdf[j], ssdf[j + 1]) / beta) * (d * d) / (4.0f * beta * beta);
     }
-    const float inclE = wave_incl_scan(e, lane), inclS = wave_incl_scan(s, lane);
-    float exclE = __shfl_up(inclE, 1);
-    if (lane == 0) exclE = 0.0f;
-    const float T = expf(-(carryE + exclE));
+    const double inclE = wave_incl_scan_d((double)e, lane), inclS = wave_incl_scan_d((double)s, lane);
+    double exclE = __shfl_up(inclE, 1);
+    if (lane == 0) exclE = 0.0;
+    const float T = expf(-(float)(carryE + exclE));
     float pdf = 0.0f;
     if (j < m) {
-      if (a.refine) pdf = (fminf(expf(carryS + inclS), 1.0e6f) - 1.0f) * T + a.add_tiny;      // (:205-211)
+      if (a.refine) pdf = (fminf(expf((float)(carryS + inclS)), 1.0e6f) - 1.0f) * T + a.add_tiny;      // (:205-211)
       else pdf = (1.0f - expf(-e)) * T + 1e-5f;                                                  // (:220-222)
       scdf[j + 1] = pdf;
     }
-    sum += wave_sum(pdf);
+    sum += wave_sum_d((double)pdf);
     carryE += __shfl(inclE, 63);
     carryS += __shfl(inclS, 63);
   }
   __syncthreads();
-  // normalise, then inclusive cumsum -> cdf[0..n-1] with cdf[0] = 0
-  float carry = 0.0f;
+  // normalise (pdf / sum in fp32, like `pdf / torch.sum(pdf)`), then inclusive cumsum in fp64, each knot rounded once
+  // -> cdf[0..n-1] with cdf[0] = 0
+  const float sumf = (float)sum;
+  double carry = 0.0;
   for (int c0 = 0; c0 < m; c0 += 64) {
     const int j = c0 + lane;
-    const float p = (j < m) ? scdf[j + 1] / sum : 0.0f;
-    const float incl = wave_incl_scan(p, lane);
-    if (j < m) scdf[j + 1] = carry + incl;
+    const float p = (j < m) ? scdf[j + 1] / sumf : 0.0f;
+    const double incl = wave_incl_scan_d((double)p, lane);
+    if (j < m) scdf[j + 1] = (float)(carry + incl);
     carry += __shfl(incl, 63);
   }
   if (lane == 0) scdf[0] = 0.0f;

@@ -5,7 +5,14 @@ that the reference delegates to the un-vendored CUDA op `hawp.base._C.encodels` 
 
 PARITY UNPINNED at the encodels boundary: the hawp submodule is empty in the reference tree, so its exact tie-breaking
 cannot be checked; the semantics implemented are the ones the call sites depend on (see include/neat_hip.h) and are
-tested against a brute-force numpy oracle (oracle/attraction_oracle.py)."""
+tested against a brute-force numpy oracle (oracle/attraction_oracle.py).  One known difference: the reference multiplies
+the validity map `labels_onehot.max(dim=0)` that encodels returns into the support mask (blender_hawp_dataset.py:98,130);
+with at least one segment every pixel has a nearest segment, so that map is taken to be all ones here.
+
+`SceneDataset` is the DTU / BlendedMVS counterpart (code/datasets/scene_hawp_dataset.py): cameras come as projection
+matrices `world_mat_i @ scale_mat_i` and are decomposed into K and pose; the reference uses
+`cv2.decomposeProjectionMatrix` (opencv-python, unpinned in requirements.txt, absent here), restated below as an RQ
+decomposition with positive diagonal."""
 import ctypes
 import json
 import os
@@ -60,6 +67,31 @@ def compute_point_line_attraction(lines, img_res, distance=10.0):
     foot = torch.stack([lmap[0] + xs, lmap[1] + ys], -1).reshape(-1, 2)
     foot = torch.where(mask[:, None], foot, torch.zeros_like(foot))
     return mask.cpu(), labels.reshape(-1).cpu(), foot.float()
+
+
+def load_K_Rt_from_P(P):
+    """P [3,4] -> (intrinsics [4,4] with K / K[2,2], pose [4,4] camera-to-world)  (utils/rend_util.py:31-52, which calls
+    cv2.decomposeProjectionMatrix).  M = P[:, :3] = K R with K upper triangular, positive diagonal (RQ decomposition, signs
+    fixed the way OpenCV's RQDecomp3x3 fixes them), camera centre C = -M^-1 p4; pose = [R^T | C]."""
+    P = np.asarray(P, dtype=np.float64)
+    M = P[:3, :3]
+    # RQ via QR of the row-reversed transpose:  J M^T J... written out: M = K R  <=>  (J M)^T = (J R)^T (J K J)^T ...
+    J = np.eye(3)[::-1]
+    q, r = np.linalg.qr((J @ M).T)              # (J M)^T = q r  ->  M = J r^T q^T = (J r^T J) (J q^T)
+    K = J @ r.T @ J
+    R = J @ q.T
+    D = np.diag(np.where(np.diag(K) < 0, -1.0, 1.0))
+    K, R = K @ D, D @ R                         # positive diagonal; D D = I keeps the product
+    if np.linalg.det(R) < 0:                    # det(M) < 0: OpenCV leaves the sign in K[2,2]; keep R a rotation
+        R = -R
+        K = -K
+    C = -np.linalg.solve(M, P[:3, 3])
+    intrinsics = np.eye(4)
+    intrinsics[:3, :3] = K / K[2, 2]
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = R.T
+    pose[:3, 3] = C
+    return intrinsics, pose
 
 
 def load_rgb(path):
@@ -145,3 +177,67 @@ class BlenderDataset(torch.utils.data.Dataset):
 
     def get_scale_mat(self):
         return np.eye(4)
+
+
+class SceneDataset(BlenderDataset):
+    """DTU / BlendedMVS scans: <data_dir>/scan<id>/{image/*.png, cameras.npz (world_mat_i, scale_mat_i), <line_detector>/*.json}
+    (code/datasets/scene_hawp_dataset.py:16-223).  Differences from the ABC class, as in the reference: cameras from projection
+    matrices; wireframes of all images are kept (no empty-wireframe filter); rays of a step are drawn WITHOUT replacement from
+    the line support (`torch.randperm`, :182); `n_images` may cut the epoch length; default support distance 5 px."""
+
+    def __init__(self, data_dir, img_res, scan_id=0, n_images=-1, line_detector="hawp", distance_threshold=5.0, data_root="../data"):
+        self.instance_dir = os.path.join(data_root, data_dir, "scan{0}".format(scan_id))
+        assert os.path.exists(self.instance_dir), "Data directory is empty"
+        self.img_res = list(img_res)
+        self.total_pixels = img_res[0] * img_res[1]
+        self.sampling_idx = None
+        self.distance = distance_threshold
+        self.score_threshold = 0.05
+        paths = []
+        for ext in ("*.png", "*.jpg", "*.JPEG", "*.JPG"):
+            paths += glob(os.path.join(self.instance_dir, "image", ext))
+        paths = sorted(paths)
+        self.n_images = len(paths)
+        self.cam_file = os.path.join(self.instance_dir, "cameras.npz")
+        cams = np.load(self.cam_file)
+        self.intrinsics_all, self.pose_all = [], []
+        for i in range(self.n_images):
+            P = (cams["world_mat_%d" % i].astype(np.float32) @ cams["scale_mat_%d" % i].astype(np.float32))[:3, :4]
+            K, pose = load_K_Rt_from_P(P)
+            self.intrinsics_all.append(torch.from_numpy(K).float())
+            self.pose_all.append(torch.from_numpy(pose).float())
+        self.rgb_images, self.wireframes, self.lines = [], [], []
+        for path in paths:
+            self.rgb_images.append(torch.from_numpy(load_rgb(path).reshape(3, -1).transpose(1, 0).copy()).float())
+            wf = WireframeGraph.load_json(os.path.join(self.instance_dir, line_detector, os.path.splitext(os.path.basename(path))[0] + ".json"))
+            assert wf.frame_height == img_res[0] and wf.frame_width == img_res[1]
+            self.wireframes.append(wf)
+            self.lines.append(wf.line_segments(self.score_threshold))
+        if n_images > 0:
+            self.n_images = n_images
+        self.masks, self.labels, self.att_points = [], [], []
+        for lines in self.lines:
+            m, l, a = compute_point_line_attraction(lines, self.img_res, self.distance)
+            self.masks.append(m)
+            self.labels.append(l)
+            self.att_points.append(a)
+
+    def __getitem__(self, idx):
+        H, W = self.img_res
+        ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        uv = torch.stack([xs, ys], -1).reshape(-1, 2).float()
+        lines, mask, labels = self.lines[idx], self.masks[idx], self.labels[idx]
+        sample = {"uv": uv, "uv_proj": self.att_points[idx], "juncs2d": self.wireframes[idx].vertices,
+                  "intrinsics": self.intrinsics_all[idx], "pose": self.pose_all[idx], "wireframe": self.wireframes[idx],
+                  "mask": mask, "labels": labels, "lines": lines[labels], "lines_uniq": lines}
+        gt = {"rgb": self.rgb_images[idx]}
+        if self.sampling_idx is not None:      # rays inside the line support, without replacement (:179-182)
+            pool = mask.nonzero().flatten()
+            pick = pool[torch.randperm(pool.numel())[:len(self.sampling_idx)]]
+            gt["rgb"] = self.rgb_images[idx][pick, :]
+            gt["lines2d"] = lines[labels[pick]]
+            sample.update(lines=lines[labels[pick]], labels=labels[pick], uv=uv[pick, :], uv_proj=self.att_points[idx][pick.to(self.att_points[idx].device)])
+        return idx, sample, gt
+
+    def get_scale_mat(self):
+        return np.load(self.cam_file)["scale_mat_0"]

@@ -16,7 +16,7 @@ from torch import nn
 from . import ops, rend_util
 from .conf import ConfTree, from_dict
 from .density import LaplaceDensity
-from .ray_sampler import ErrorBoundSampler
+from .ray_sampler import ErrorBoundSampler, HierarchicalSampler
 
 
 def _wn_linear(in_dim, out_dim, weight_norm=True):
@@ -251,6 +251,11 @@ class VolSDFNetwork(_HipModule):
         self.attraction_network = AttractionFieldNetwork(self.feature_vector_size, **conf.get_config("attraction_network"))
         self.density = LaplaceDensity(**conf.get_config("density"))
         self.ray_sampler = ErrorBoundSampler(self.scene_bounding_sphere, **conf.get_config("ray_sampler"))
+        if conf.get_string("hip_sampler", default="error_bound") == "hierarchical":      # new optional key: BASELINE config C5
+            rs = conf.get_config("ray_sampler")
+            self.ray_sampler = HierarchicalSampler(self.scene_bounding_sphere, rs.get_float("near", default=0.0),
+                                                   conf.get_int("hip_sampler_coarse", default=rs.get_int("N_samples")),
+                                                   conf.get_int("hip_sampler_fine", default=rs.get_int("N_samples")))
         # global junction MLP on learnable latents (rend_a :272-303)
         cj = conf.get_config("global_junctions", default=ConfTree())
         hidden, depth = cj.get_int("dim_hidden", default=256), cj.get_int("num_layers", default=2)

@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, current stream, autograd graph); all P-
 happens in neat_amd/csrc.  Every op requires CUDA float32 tensors and raises if the library is absent.
 """
 import ctypes
+import warnings
 
 import torch
 
@@ -118,6 +119,11 @@ class SdfOutputsFn(torch.autograd.Function):
     def forward(ctx, handle, x, radius, scale, *params):
         lib = _lib.lib()
         ctx.set_materialize_grads(False)
+        if x.requires_grad and torch.is_grad_enabled():
+            # the reference's get_outputs is differentiable in x (rend_a :429: points3d = sum(w p) carries the weights' graph);
+            # loss_wfr never uses that path, and this op does not implement d/dx -- say so instead of dropping it silently
+            warnings.warn("neat_amd: sdf_outputs treats its input points as constants; gradients do not flow through x "
+                          "(INTEGRATION.md, 'Restrictions')", stacklevel=3)
         x = _f32c(x.detach())
         P = x.shape[0]
         packed, netp = handle.packed()

@@ -48,6 +48,7 @@ class FlatAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         group = self.param_groups[0]
+        self._realias()
         ptrs = (ctypes.c_void_p * len(self._params))()
         keep = []                                  # non-contiguous / non-fp32 gradients are normalised first (not the usual case)
         for i, p in enumerate(self._params):
@@ -69,6 +70,20 @@ class FlatAdam(torch.optim.Optimizer):
         for i, p in enumerate(self._params):
             self.state[p]["step"] = torch.tensor(float(self._steps[i]))
         return loss
+
+    def _realias(self):
+        """The kernel updates `flat_param`; the module reads its parameters.  They are the same memory as long as nobody rebinds
+        a parameter's storage (model.to(), load_state_dict(assign=True), deepcopy ...): if that happened, adopt the new values
+        and point the parameter back into the flat buffer instead of silently training a buffer the model no longer reads."""
+        base = self.flat_param.data_ptr()
+        for i, p in enumerate(self._params):
+            off, n = self._offsets[i], p.numel()
+            if p.data_ptr() != base + 4 * off:
+                if p.device != self.flat_param.device or p.dtype != torch.float32:
+                    raise RuntimeError("FlatAdam: a parameter was moved off the optimizer's device / dtype after construction")
+                view = self.flat_param[off:off + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

@@ -81,6 +81,33 @@ class UniformSampler(RaySampler):
         return torch.sort(torch.cat([z_vals, fine], -1), -1)[0]
 
 
+class HierarchicalSampler(RaySampler):
+    """BASELINE config C5: NeRF-style hierarchical sampling, N_coarse stratified depths + N_fine importance samples, feeding the
+    main pass.  The reference ships the two pieces (`UniformSampler.get_z_vals`, `get_z_vals_fine` / `sample_pdf`,
+    ray_sampler.py:16-106) but no model calls them; they are composed here the way SURVEY 8(d) defines C5 and the way
+    tests/golden/make_golden.py composes the reference's own functions for fixture G12:
+        coarse depths -> no-grad SDF values (fused HIP chain) -> volume_rendering weights (HIP scan) -> fine depths by inverse CDF
+        (`det = model.training`, the reference's inverted flag) -> sorted union; z_eik = one of the depths per ray (randint).
+    CPU random draws in the reference's order: rand [R, N_coarse] (training only), randint (drawn and dropped by get_z_vals),
+    [rand [R, N_fine] in eval mode], randint (eikonal index).  Selected with the optional conf key model.hip_sampler = hierarchical."""
+
+    def __init__(self, scene_bounding_sphere, near, N_coarse, N_fine):
+        super().__init__(near, 2.0 * scene_bounding_sphere)
+        self.uniform_sampler = UniformSampler(scene_bounding_sphere, near, N_coarse, N_important=N_fine)
+        self.N_samples, self.N_fine = N_coarse, N_fine
+        self.last_rounds = 0
+
+    def get_z_vals(self, ray_dirs, cam_loc, model):
+        zc = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
+        pts = cam_loc.unsqueeze(1) + zc.unsqueeze(2) * ray_dirs.unsqueeze(1)
+        with torch.no_grad():
+            sdf = model.implicit_network.get_sdf_vals(pts.reshape(-1, 3))
+            w = model.volume_rendering(zc, sdf)
+        z = self.uniform_sampler.get_z_vals_fine(zc, w, model)
+        idx = torch.randint(z.shape[-1], (z.shape[0],)).to(z.device)
+        return z, torch.gather(z, 1, idx.unsqueeze(-1))
+
+
 class ErrorBoundSampler(RaySampler):
     def __init__(self, scene_bounding_sphere, near, N_samples, N_samples_eval, N_samples_extra, eps, beta_iters,
                  max_total_iters, inverse_sphere_bg=False, N_samples_inverse_sphere=0, add_tiny=0.0):

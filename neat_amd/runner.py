@@ -7,19 +7,29 @@ the open3d dumps of the reference runner are out of scope.
     python -m neat_amd.runner --conf /path/to/confs/abc-neat-a.conf --data_root /path/to/data --nepoch 2000
 
 Class paths in the conf that name the reference's dataset / model / loss are mapped to their neat_amd counterparts (the
-conf may also name neat_amd classes directly, which is all the reference's own runner needs)."""
+conf may also name neat_amd classes directly, which is all the reference's own runner needs).
+
+Data parallel (new: the reference pins one GPU, volsdf_train.py:130-131):  `python -m neat_amd.runner --gpus N ...` re-executes
+itself under torch.distributed.run, one rank per GPU.  Every rank renders its OWN view per iteration (the model's forward is
+hard-wired to one view: `[0]` indexing at rend_a :427-439) with train.num_pixels / N rays, seed 42 + rank for everything it
+draws; the model starts from rank 0's weights; after backward ONE flat all-reduce averages the 1 219 274 gradients
+(neat_amd/dp.py), then every rank takes the same Adam step.  Checkpoints and the log come from rank 0."""
 import argparse
 import os
+import random
+import sys
 import time
 
+import numpy as np
 import torch
 
 from . import conf as conf_mod
-from . import rend_util
+from . import dp, rend_util
 from .general import get_class
 
 CLASS_MAP = {
     "datasets.blender_hawp_dataset.BlenderDataset": "neat_amd.datasets.BlenderDataset",
+    "datasets.scene_hawp_dataset.SceneDataset": "neat_amd.datasets.SceneDataset",
     "model.networks.neat_wfr_rend_a.VolSDFNetwork": "neat_amd.networks.VolSDFNetwork",
     "model.networks.loss_wfr.VolSDFLoss": "neat_amd.loss.VolSDFLoss",
 }
@@ -28,18 +38,20 @@ SUBDIRS = ("ModelParameters", "OptimizerParameters", "SchedulerParameters")
 
 class TrainRunner:
     def __init__(self, conf, nepochs, exps_folder="exps", expname="", scan_id=-1, data_root="../data", device="cuda:0",
-                 timestamp=None, precision=None, log_freq=50):
+                 timestamp=None, precision=None, log_freq=50, rank=0, world=1):
         self.conf = conf_mod.parse_file(conf) if isinstance(conf, str) else conf
         self.nepochs = nepochs
         self.device = torch.device(device)
+        self.rank, self.world = rank, world
         self.expname = self.conf.get_string("train.expname") + expname
         if scan_id != -1:
             self.expname += f"/{scan_id}"
         self.timestamp = timestamp or time.strftime("%Y_%m_%d_%H_%M_%S")
         self.expdir = os.path.join(exps_folder, self.expname)
         self.checkpoints_path = os.path.join(self.expdir, self.timestamp, "checkpoints")
-        for sub in SUBDIRS:
-            os.makedirs(os.path.join(self.checkpoints_path, sub), exist_ok=True)
+        if self.rank == 0:
+            for sub in SUBDIRS:
+                os.makedirs(os.path.join(self.checkpoints_path, sub), exist_ok=True)
         cls = lambda key: get_class(CLASS_MAP.get(self.conf.get_string(key), self.conf.get_string(key)))
         dataset_conf = dict(self.conf.get_config("dataset").items())
         if scan_id != -1:
@@ -48,7 +60,9 @@ class TrainRunner:
         if ds_cls.__module__.startswith("neat_amd"):
             dataset_conf["data_root"] = data_root
         self.train_dataset = ds_cls(**dataset_conf)
-        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=True,
+        gen = torch.Generator()
+        gen.manual_seed(dp.rank_seed(42, self.rank))      # each rank walks the views in its own order (one view per rank and step)
+        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=1, shuffle=True, generator=gen,
                                                             collate_fn=self.train_dataset.collate_fn)
         self.model = cls("train.model_class")(conf=self.conf.get_config("model")).to(self.device)
         if precision is not None and hasattr(self.model, "set_precision"):
@@ -63,7 +77,16 @@ class TrainRunner:
         decay_rate = self.conf.get_float("train.sched_decay_rate", default=0.1)
         decay_steps = self.nepochs * len(self.train_dataset)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, decay_rate ** (1.0 / decay_steps))
-        self.num_pixels = self.conf.get_int("train.num_pixels")
+        self.num_pixels = dp.shard_rays(self.conf.get_int("train.num_pixels"), self.world)      # C4: 4096 rays / 8 ranks = 512 per rank
+        self.bucket = dp.FlatGradBucket(self.model.parameters())
+        if self.world > 1:                                 # every rank starts from rank 0's weights
+            import torch.distributed as dist
+            flat = getattr(self.optimizer, "flat_param", None)
+            if flat is not None:
+                dist.broadcast(flat, src=0)
+            else:
+                for p in self.model.parameters():
+                    dist.broadcast(p.data, src=0)
         self.checkpoint_freq = self.conf.get_int("train.checkpoint_freq", default=100)
         self.start_epoch = 0
         self.log_freq = log_freq
@@ -75,6 +98,8 @@ class TrainRunner:
         self.start_epoch = state["epoch"]
 
     def save_checkpoints(self, epoch):
+        if self.rank != 0:
+            return
         payload = (("model_state_dict", self.model.state_dict()), ("optimizer_state_dict", self.optimizer.state_dict()),
                    ("scheduler_state_dict", self.scheduler.state_dict()))
         for sub, (key, sd) in zip(SUBDIRS, payload):
@@ -94,8 +119,9 @@ class TrainRunner:
                     model_input[k] = model_input[k].to(self.device)
                 outputs = self.model(model_input)
                 losses = self.loss(outputs, ground_truth)
-                self.optimizer.zero_grad()
+                self.optimizer.zero_grad(set_to_none=True)
                 losses["loss"].backward()
+                self.bucket.all_reduce_mean()              # world > 1: ONE flat all-reduce of all gradients; no-op on one GPU
                 self.optimizer.step()
                 self.train_dataset.change_sampling_idx(self.num_pixels)
                 self.scheduler.step()
@@ -103,8 +129,9 @@ class TrainRunner:
                     with torch.no_grad():
                         psnr = rend_util.get_psnr(outputs["rgb_values"], ground_truth["rgb"].to(self.device).reshape(-1, 3))
                     history.append((epoch, it, float(losses["loss"].detach()), float(psnr)))
-                    print(f"{self.expname}/{self.timestamp} [{epoch}] ({it}/{len(self.train_dataloader)}): "
-                          f"loss = {history[-1][2]:.4f}, psnr = {history[-1][3]:.3f}", flush=True)
+                    if self.rank == 0:
+                        print(f"{self.expname}/{self.timestamp} [{epoch}] ({it}/{len(self.train_dataloader)}): "
+                              f"loss = {history[-1][2]:.4f}, psnr = {history[-1][3]:.3f}", flush=True)
         self.save_checkpoints(epoch)
         return history
 
@@ -120,12 +147,35 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=None)
     ap.add_argument("--is_continue", default=None, help="checkpoints directory of the run to continue")
     ap.add_argument("--checkpoint", default="latest")
+    ap.add_argument("--gpus", type=int, default=1, help="data-parallel ranks (one per GPU); > 1 re-executes under torch.distributed.run")
+    ap.add_argument("--timestamp", default=None)
     args = ap.parse_args()
-    torch.manual_seed(42)              # exp_runner.py:36,49-51
-    runner = TrainRunner(args.conf, args.nepoch, args.exps_folder, args.expname, args.scan_id, args.data_root, precision=args.precision)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        stamp = args.timestamp or time.strftime("%Y_%m_%d_%H_%M_%S")      # one run directory for all ranks
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "neat_amd.runner"] + sys.argv[1:] + ["--timestamp", stamp]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    seed = dp.rank_seed(42, rank)      # exp_runner.py:36,49-51 seeds torch / random / numpy with 42; rank r uses 42 + r
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    runner = TrainRunner(args.conf, args.nepoch, args.exps_folder, args.expname, args.scan_id, args.data_root, device=f"cuda:{local}",
+                         timestamp=args.timestamp, precision=args.precision, rank=rank, world=world)
     if args.is_continue:
         runner.load_checkpoints(args.is_continue, args.checkpoint)
     runner.run()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

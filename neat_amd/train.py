@@ -24,7 +24,6 @@ class Trainer:
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.1 ** (1.0 / decay_steps))
         self.bucket = FlatGradBucket(self.model.parameters())
         self._graph, self._captured, self._ring_pos, self.capture_error = None, None, 0, None
-        self._seen = {}
 
     def step(self, model_input, ground_truth):
         if self._graph is not None:
@@ -54,11 +53,9 @@ class Trainer:
         self._static_gt = dict(ground_truth)
         for k in tensor_keys:
             self._static_in[k] = model_input[k].clone()
-            self._seen[(id(self._static_in), k)] = (model_input[k].data_ptr(), model_input[k]._version)
         for k, v in ground_truth.items():
             if isinstance(v, torch.Tensor):
                 self._static_gt[k] = v.to(self.device).clone()
-                self._seen[(id(self._static_gt), k)] = (v.data_ptr(), v._version)
         self.model.static_randoms = {}
         self.loss.nan_check = "off"
         try:
@@ -149,15 +146,13 @@ class Trainer:
     def _replay(self, model_input, ground_truth):
         if not self._same_batch_layout(model_input, ground_truth):
             return self.step_eager(model_input, ground_truth)      # another view / batch size: this graph does not apply
-        # inputs that changed since the last step are copied into the captured tensors (same object, same version: skip)
+        # every tensor of the fresh batch is copied into the captured tensors (a few KB per step).  No "unchanged?" shortcut on
+        # (data_ptr, _version): a new batch uploaded with .to(device) usually lands on the block the allocator just freed, with
+        # version 0, and would be mistaken for the previous one.
         for static, fresh in ((self._static_in, model_input), (self._static_gt, ground_truth)):
             for k, v in fresh.items():
-                if not isinstance(v, torch.Tensor) or v is static[k]:
-                    continue
-                tag = (v.data_ptr(), v._version)
-                if self._seen.get((id(static), k)) != tag:
+                if isinstance(v, torch.Tensor) and v is not static[k]:
                     static[k].copy_(v, non_blocking=True)
-                    self._seen[(id(static), k)] = tag
         self._refill_randoms()
         self._finish_step()
         return self._captured

@@ -117,11 +117,11 @@ class RngTape:
         torch.Tensor.uniform_ = self._orig["uniform_"]
 
 
-def build_model(variant, seed=42):
+def build_model(variant, seed=42, conf=None, num_junctions=64):
     from model.networks.neat_wfr_rend_a import VolSDFNetwork
     torch.manual_seed(0)
-    net = VolSDFNetwork(to_tree(synth.ABC_NEAT_A_MODEL_CONF))
-    sd = {k: torch.tensor(v) for k, v in synth.synth_state_dict(seed, variant).items()}
+    net = VolSDFNetwork(to_tree(conf or synth.ABC_NEAT_A_MODEL_CONF))
+    sd = {k: torch.tensor(v) for k, v in synth.synth_state_dict(seed, variant, num_junctions=num_junctions).items()}
     net.load_state_dict(sd, strict=True)
     return net
 
@@ -144,6 +144,118 @@ def save(name, **arrs):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrs)
     print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+class DupRows:
+    """While active, per-ray random draws (first dimension = rays) are made identical for rays r and r + R/2."""
+
+    def __enter__(self):
+        self._rand, self._randint, self._uni = torch.rand, torch.randint, torch.Tensor.uniform_
+
+        def dup(t):
+            if t.dim() >= 1 and t.shape[0] % 2 == 0 and t.shape[0] >= 2:
+                h = t.shape[0] // 2
+                t[h:] = t[:h]
+            return t
+        torch.rand = lambda *a, **k: dup(self._rand(*a, **k))
+        torch.randint = lambda *a, **k: dup(self._randint(*a, **k))
+        uni = self._uni
+        torch.Tensor.uniform_ = lambda t, *a, **k: dup(uni(t, *a, **k))
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randint, torch.Tensor.uniform_ = self._rand, self._randint, self._uni
+
+
+def train_step_arrays(net, sc, inp, gt, tape_names, loss_conf=None):
+    """One reference train step (forward + VolSDFLoss + backward) with its random draws recorded: inputs, draws, outputs, the loss
+    scalars and a strided subsample + norm of every gradient."""
+    from model.networks.loss_wfr import VolSDFLoss
+    loss_fn = VolSDFLoss(**(loss_conf or synth.ABC_NEAT_A_LOSS_CONF))
+    with RngTape() as tp:
+        out = net(inp)
+    names = [n for n, _ in tp.tape]
+    assert names == tape_names, names
+    lo = loss_fn(out, gt)
+    lo["loss"].backward()
+    arrs = {k: sc[k] for k in ("uv", "uv_proj", "pose", "intrinsics", "wf_vertices", "wf_vconf", "wf_edges",
+                               "wf_weights", "gt_rgb", "gt_lines2d")}
+    for k in ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "lines2d", "sdf",
+              "grad_theta", "j3d_local", "j2d_local", "j2d_local_calib", "j3d_global", "j2d_global",
+              "j2d_global_calib", "median"):
+        if k in out:
+            arrs["out_" + k] = np_(out[k])
+    for k, v in lo.items():
+        arrs["loss_" + k] = np_(torch.as_tensor(v).float())
+    for k, prm in net.named_parameters():
+        if prm.grad is None:
+            continue
+        gflat = np_(prm.grad).reshape(-1)
+        arrs["grad_" + k] = gflat[::GRAD_STRIDE].copy()
+        arrs["gradnorm_" + k] = np.array([np.sqrt((gflat.astype(np.float64) ** 2).sum()), gflat.astype(np.float64).sum()])
+    return arrs, tp.tape
+
+
+def extra_goldens():
+    """G11 / G12 (round 2): the DTU / BlendedMVS model switches and the hierarchical 64 + 64 sampler as train steps of the reference."""
+    install_shims()
+    torch.set_default_dtype(torch.float32)
+    from model import ray_sampler as ref_rs
+    WG = load_wireframe_cls()
+
+    # ---------------- G11: dtu.conf / bmvs.conf model switches (dbscan_enabled = True, use_median = False, 1024 latents;
+    # rend_a :333-342,460,475-482), train step, rough weights.  32 distinct rays, each twice: DBSCAN(eps = 0.01, min_samples = 2)
+    # then finds one cluster per line end point (a random batch has no two end points within 1 cm and the reference would stop
+    # on an empty candidate set).
+    conf = dict(synth.ABC_NEAT_A_MODEL_CONF)
+    conf.update(dbscan_enabled=True, use_median=False)
+    conf["global_junctions"] = dict(conf["global_junctions"], num_junctions=1024)
+    net = build_model("rough", conf=conf, num_junctions=1024)
+    net.train()
+    sc, inp, gt = scene_inputs(WG, seed=21, n_rays=32, view=2)
+    for k in ("uv", "uv_proj", "gt_rgb", "gt_lines2d"):
+        sc[k] = np.concatenate([sc[k], sc[k]], axis=1)
+    inp["uv"], inp["uv_proj"] = torch.tensor(sc["uv"]), torch.tensor(sc["uv_proj"])
+    gt = {"rgb": torch.tensor(sc["gt_rgb"]), "lines2d": torch.tensor(sc["gt_lines2d"])}
+    # the sampler's draws are per ray: the two copies of a ray get identical draws, so their samples and line end points coincide
+    # exactly and the clustering does not hinge on distances near eps
+    rec = {}
+    inner = net.ray_sampler.get_z_vals
+
+    def recording(*a, _inner=inner, _rec=rec, **k):
+        _rec["z"], _rec["z_eik"] = _inner(*a, **k)
+        return _rec["z"], _rec["z_eik"]
+    net.ray_sampler.get_z_vals = recording
+    with DupRows():
+        arrs, tape = train_step_arrays(net, sc, inp, gt, ["rand", "randint", "rand", "randperm", "randint", "uniform_"])
+    arrs.update(z_vals=np_(rec["z"]), z_eik=np_(rec["z_eik"]))
+    arrs.update(t_rand=np_(tape[0][1]), u_final=np_(tape[2][1]), perm=np_(tape[3][1]), eik_idx=np_(tape[4][1]), eik_uniform=np_(tape[5][1]))
+    save("g11_train_step_dtu_switches", **arrs)
+
+    # ---------------- G12: C5 = hierarchical sampling 64 coarse + 64 fine feeding the main pass.  The reference ships the pieces
+    # (UniformSampler.get_z_vals, get_z_vals_fine / sample_pdf, ray_sampler.py:16-106) but no model calls them; composed here exactly
+    # as SURVEY 8(d) defines C5: coarse depths -> no-grad SDF -> volume_rendering weights -> fine depths -> sorted union, z_eik by randint.
+    net = build_model("rough")
+    net.train()
+    sc, inp, gt = scene_inputs(WG, seed=23, n_rays=64, view=1)
+    us = ref_rs.UniformSampler(net.scene_bounding_sphere, 0.0, 64, N_important=64)
+
+    def hierarchical(ray_dirs, cam_loc, model):
+        zc = us.get_z_vals(ray_dirs, cam_loc, model)
+        pts = cam_loc.unsqueeze(1) + zc.unsqueeze(2) * ray_dirs.unsqueeze(1)
+        with torch.no_grad():
+            sdf = model.implicit_network.get_sdf_vals(pts.reshape(-1, 3))
+            w = model.volume_rendering(zc, sdf)
+        z = us.get_z_vals_fine(zc, w, model)
+        idx = torch.randint(z.shape[-1], (z.shape[0],))
+        rec["z"], rec["z_coarse"], rec["w_coarse"] = z, zc, w
+        return z, torch.gather(z, 1, idx.unsqueeze(-1))
+    rec = {}
+    net.ray_sampler.get_z_vals = hierarchical
+    arrs, tape = train_step_arrays(net, sc, inp, gt, ["rand", "randint", "randint", "uniform_"])
+    arrs.update(t_rand=np_(tape[0][1]), eik_idx=np_(tape[2][1]), eik_uniform=np_(tape[3][1]), z_vals=np_(rec["z"]),
+                z_coarse=np_(rec["z_coarse"]), w_coarse=np_(rec["w_coarse"]))
+    save("g12_train_step_hierarchical", **arrs)
 
 
 def main():
@@ -294,4 +406,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":      # only the round-2 fixtures (G11, G12); the others are left untouched
+        extra_goldens()
+    else:
+        main()
+        extra_goldens()

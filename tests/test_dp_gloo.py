@@ -31,16 +31,36 @@ def _worker(rank, world, port, out_dir):
     assert bucket.numel == 15 + 7 + 1
     bucket.all_reduce_mean()
     torch.save([p.grad for p in params], os.path.join(out_dir, f"grads{rank}.pt"))
-    # gradients that are views of one flat allocation (what the HIP backward returns) are reduced in place
+    # Several steps in which the ranks' gradient memory behaves DIFFERENTLY (rank 0 gets fresh allocations every step, rank 1 keeps
+    # writing into the same tensors, and from step 2 on into the bucket's own views): every rank must still issue exactly one
+    # collective of the same size per step -- the bucket's decisions may not depend on this rank's addresses (dp.py).
     q = [torch.nn.Parameter(torch.zeros(4, 2)), torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))]
-    flat = torch.arange(11, dtype=torch.float32) * (rank + 1)
-    q[0].grad, q[1].grad = flat[:8].view(4, 2), flat[8:11]
-    q[2].grad = torch.full((2,), float(rank))
     b2 = dp.FlatGradBucket(q)
-    b2.all_reduce_mean()
-    assert b2._plan == [(0, 1)]
-    assert torch.allclose(flat, torch.arange(11, dtype=torch.float32) * 1.5) and q[0].grad.data_ptr() == flat.data_ptr()
-    assert torch.allclose(q[2].grad, torch.full((2,), 0.5))
+    keep = [torch.zeros(4, 2), torch.zeros(3), torch.zeros(2)]
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(tuple(t.shape)), orig(t, *a, **k))[1]
+    try:
+        for step in range(4):
+            vals = [torch.full(s.shape, float((rank + 1) * (step + 1) * (i + 1))) for i, s in enumerate(keep)]
+            for i, prm in enumerate(q):
+                if rank == 0:
+                    prm.grad = vals[i].clone()                      # fresh allocation: new address every step
+                elif step < 2:
+                    keep[i].copy_(vals[i]); prm.grad = keep[i]       # same tensors every step
+                else:
+                    prm.grad.copy_(vals[i])                          # in place, into the views the bucket installed
+            if step == 3 and rank == 1:
+                q[1].grad = None                                     # a parameter without gradient on one rank only
+            b2.all_reduce_mean()
+            for i, prm in enumerate(q):
+                expect = 1.5 * (step + 1) * (i + 1)
+                if step == 3 and i == 1:
+                    expect = 0.5 * 1 * (step + 1) * (i + 1)         # rank 1 contributed zeros
+                assert torch.allclose(prm.grad, torch.full(keep[i].shape, expect)), (rank, step, i, prm.grad, expect)
+    finally:
+        dist.all_reduce = orig
+    assert calls == [(13,)] * 4, calls                               # one flat all-reduce of all 8 + 3 + 2 elements per step, on every rank
     scal = dp.all_reduce_scalars({"loss": torch.tensor(float(rank + 1))})
     assert abs(float(scal["loss"]) - 1.5) < 1e-6
     assert dp.shard_rays(4096, world) == 2048 and dp.rank_seed(42, rank) == 42 + rank

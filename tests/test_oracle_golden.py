@@ -150,3 +150,48 @@ def test_train_step(golden):
         assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
         assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - nrm) <= 2e-4 * nrm + 1e-7, k
     print("worst relative grad err", worst)
+
+
+def _check_train_step(g, p, out, lo, keys):
+    for k in keys:
+        close(out[k], g["out_" + k], 5e-5, k)
+    for k in ("loss", "rgb_loss", "eikonal_loss", "line_loss", "j3d_loss", "j2d_loss"):
+        close(lo[k].float(), g["loss_" + k], 2e-5, "loss " + k)
+    assert int(lo["count"]) == int(g["loss_count"]) and int(lo["jcount"]) == int(g["loss_jcount"])
+    lo["loss"].backward()
+    from tests.golden.make_golden import GRAD_STRIDE
+    for k, v in p.items():
+        if "grad_" + k not in g:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+            continue
+        gr = v.grad.reshape(-1).numpy()
+        ref, (nrm, _) = g["grad_" + k], g["gradnorm_" + k]
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(gr[::GRAD_STRIDE] - ref).max() <= 2e-4 * scale + 1e-7, k
+        assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - nrm) <= 2e-4 * nrm + 1e-7, k
+
+
+def test_train_step_dtu_switches(golden):
+    """G11: dbscan_enabled = True, use_median = False, 1024 junction latents (confs/dtu.conf, bmvs.conf; rend_a :333-342,460,475-482)."""
+    g = golden("g11_train_step_dtu_switches")
+    p = O.params_from_numpy(synth.synth_state_dict(42, "rough", num_junctions=1024), requires_grad=True)
+    lines, verts = _wf(g)
+    rand = {k: T(g[k]) for k in ("t_rand", "u_final", "perm", "eik_idx", "eik_uniform")}
+    out = O.full_forward(p, _inp(g), lines, verts, training=True, rand=rand, use_median=False, dbscan_enabled=True)
+    assert "median" not in out and out["j3d_global"].shape == (1024, 3)
+    lo = O.neat_loss(out, T(g["gt_rgb"]), T(g["gt_lines2d"]))
+    _check_train_step(g, p, out, lo, ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+                                      "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib"))
+
+
+def test_train_step_hierarchical(golden):
+    """G12: C5, hierarchical 64 coarse + 64 fine depths feeding the main pass."""
+    g = golden("g12_train_step_hierarchical")
+    p = params("rough", grad=True)
+    lines, verts = _wf(g)
+    rand = {k: T(g[k]) for k in ("t_rand", "eik_idx", "eik_uniform")}
+    out = O.full_forward(p, _inp(g), lines, verts, training=True, rand=rand, sampler="hierarchical")
+    close(out["z_vals"], g["z_vals"], 2e-5, "z_vals")
+    lo = O.neat_loss(out, T(g["gt_rgb"]), T(g["gt_lines2d"]))
+    _check_train_step(g, p, out, lo, ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+                                      "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median"))

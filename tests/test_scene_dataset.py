@@ -1,0 +1,106 @@
+"""SURVEY 8f-1 / VERDICT r1 missing #2: the DTU / BlendedMVS dataset class (reference: code/datasets/scene_hawp_dataset.py).
+CPU part: the projection-matrix decomposition against the numpy oracle (Givens RQ, OpenCV's published algorithm) and against
+K, R, C -> P -> K, R, C round trips.  GPU part: the dataset on a synthetic DTU-style scan directory, and the runner on it."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+
+def _random_camera(rng):
+    K = np.array([[rng.uniform(500, 3000), rng.uniform(-2, 2), rng.uniform(300, 900)], [0, rng.uniform(500, 3000), rng.uniform(200, 700)], [0, 0, 1.0]])
+    A = rng.normal(size=(3, 3))
+    R, _ = np.linalg.qr(A)
+    if np.linalg.det(R) < 0:
+        R[:, 0] = -R[:, 0]
+    C = rng.uniform(-3, 3, 3)
+    return K, R, C
+
+
+def test_projection_decomposition_round_trip_and_oracle():
+    from neat_amd.datasets import load_K_Rt_from_P
+    from oracle import camera_oracle
+    rng = np.random.default_rng(0)
+    for i in range(50):
+        K, R, C = _random_camera(rng)
+        P = K @ np.concatenate([R, (-R @ C)[:, None]], 1) * rng.uniform(0.1, 10.0)          # arbitrary positive scale
+        intr, pose = load_K_Rt_from_P(P)
+        assert np.allclose(intr[:3, :3], K, rtol=1e-9, atol=1e-7), i
+        assert np.allclose(pose[:3, :3], R.T, atol=1e-6) and np.allclose(pose[:3, 3], C, atol=1e-5), i
+        o_intr, o_pose = camera_oracle.load_K_Rt_from_P(P)
+        assert np.allclose(intr, o_intr, rtol=1e-8, atol=1e-6) and np.allclose(pose, o_pose, atol=1e-5), i
+    # a DTU-style pair: world_mat (K [R|t] padded to 4x4) times scale_mat (uniform scale + shift), float32 like the dataset loads it
+    K, R, C = _random_camera(rng)
+    world = np.eye(4); world[:3] = K @ np.concatenate([R, (-R @ C)[:, None]], 1)
+    scale = np.eye(4); scale[:3, :3] *= 250.0; scale[:3, 3] = [10.0, -20.0, 600.0]
+    P = (world.astype(np.float32) @ scale.astype(np.float32))[:3, :4]
+    intr, pose = load_K_Rt_from_P(P)
+    o_intr, o_pose = camera_oracle.load_K_Rt_from_P(P)
+    assert np.allclose(intr, o_intr, rtol=1e-5, atol=1e-3) and np.allclose(pose, o_pose, atol=1e-4)
+    assert np.allclose(intr[:3, :3], K, rtol=1e-4, atol=1e-2)          # scaling the world does not change K
+    assert np.allclose(pose[:3, 3], (C - scale[:3, 3]) / 250.0, atol=1e-3)
+
+
+def _toy_scan(root, res=(48, 64), n_views=3):
+    from PIL import Image
+    scan = root / "DTU" / "scan7"
+    (scan / "image").mkdir(parents=True)
+    (scan / "hawp").mkdir()
+    rng = np.random.default_rng(1)
+    cams = {}
+    H, W = res
+    for v in range(n_views):
+        ang = 0.7 * v
+        C = np.array([2.2 * np.cos(ang), 2.2 * np.sin(ang), 0.4])
+        z = -C / np.linalg.norm(C)
+        x = np.cross([0, 0, 1.0], z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])                                    # world -> camera
+        K = np.array([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]])
+        world = np.eye(4); world[:3] = K @ np.concatenate([R, (-R @ C)[:, None]], 1)
+        cams[f"world_mat_{v}"] = world
+        cams[f"scale_mat_{v}"] = np.eye(4)
+        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(scan / "image" / f"{v:06d}.png")
+        verts = np.stack([rng.uniform(6, W - 6, 8), rng.uniform(6, H - 6, 8)], 1).round(2).tolist()
+        edges = [[0, 1], [1, 2], [2, 3], [3, 0], [4, 5], [5, 6]]
+        json.dump({"vertices": verts, "vertices-score": [0.9] * 8, "edges": edges, "edges-weights": [0.99] * len(edges),
+                   "height": H, "width": W}, open(scan / "hawp" / f"{v:06d}.json", "w"))
+    np.savez(scan / "cameras.npz", **cams)
+    return cams
+
+
+@pytest.mark.gpu
+def test_scene_dataset_and_runner(tmp_path):
+    from neat_amd import synth
+    from neat_amd.datasets import SceneDataset
+    from neat_amd.runner import TrainRunner
+    from tests.test_runner import _hocon
+    cams = _toy_scan(tmp_path / "data")
+    ds = SceneDataset("DTU", [48, 64], scan_id=7, data_root=str(tmp_path / "data"))
+    assert len(ds) == 3 and ds.total_pixels == 48 * 64
+    idx, sample, gt = ds[1]
+    assert sample["uv"].shape == (48 * 64, 2) and sample["intrinsics"].shape == (4, 4) and sample["pose"].shape == (4, 4)
+    assert torch.allclose(sample["intrinsics"][:3, :3], torch.tensor([[60.0, 0, 32], [0, 60.0, 24], [0, 0, 1]]), atol=1e-3)
+    assert abs(float(sample["pose"][:3, 3].norm()) - np.sqrt(2.2 ** 2 + 0.4 ** 2)) < 1e-3
+    ds.change_sampling_idx(96)
+    _, s2, g2 = ds[1]
+    assert s2["uv"].shape == (96, 2) and g2["rgb"].shape == (96, 3) and g2["lines2d"].shape[0] == 96
+    pix = (s2["uv"][:, 1] * 64 + s2["uv"][:, 0]).long()
+    assert pix.unique().numel() == 96 and bool(ds.masks[1][pix].all())          # without replacement, inside the line support
+    assert np.allclose(ds.get_scale_mat(), cams["scale_mat_0"])
+    # the reference's dtu.conf names this dataset class; the runner maps it and trains on the scan
+    model_conf = dict(synth.ABC_NEAT_A_MODEL_CONF)
+    model_conf.update(dbscan_enabled=True, use_median=False)
+    conf = {"train": {"expname": "toy_dtu", "dataset_class": "datasets.scene_hawp_dataset.SceneDataset",
+                      "model_class": "model.networks.neat_wfr_rend_a.VolSDFNetwork", "loss_class": "model.networks.loss_wfr.VolSDFLoss",
+                      "learning_rate": 5.0e-4, "num_pixels": 64, "checkpoint_freq": 1},
+            "loss": dict(synth.ABC_NEAT_A_LOSS_CONF),
+            "dataset": {"data_dir": "DTU", "img_res": [48, 64], "scan_id": 7},
+            "model": model_conf}
+    path = tmp_path / "toy_dtu.conf"
+    path.write_text(_hocon(conf))
+    runner = TrainRunner(str(path), nepochs=1, exps_folder=str(tmp_path / "exps"), data_root=str(tmp_path / "data"), log_freq=1)
+    assert type(runner.train_dataset).__name__ == "SceneDataset"
+    hist = runner.run()
+    assert len(hist) >= 3 and all(np.isfinite(h[2]) for h in hist)
