@@ -24,7 +24,10 @@ def _lerp_inverse_cdf(bins, cdf, u):
 
 def _pdf_to_cdf(pdf):
     pdf = pdf / pdf.sum(-1, keepdim=True)
-    return torch.cat([torch.zeros_like(pdf[:, :1]), pdf.cumsum(-1)], -1)
+    # torch-CPU (where the reference's sampler math was defined) accumulates a float cumsum in double and rounds each knot once;
+    # do the same on the device -- an fp32 scan moves knots by a few 1e-8, enough to flip the `denom < 1e-5` rule below for the
+    # empty bins of `weights + 1e-5` (see tests/test_oracle_golden.py::test_sampler_is_ill_conditioned)
+    return torch.cat([torch.zeros_like(pdf[:, :1]), pdf.double().cumsum(-1).float()], -1)
 
 
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False):

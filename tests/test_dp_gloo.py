@@ -87,3 +87,69 @@ def test_single_process_is_a_no_op():
     p.grad = torch.full((3,), 2.0)
     dp.FlatGradBucket([p]).all_reduce_mean()
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def _grad_worker(rank, world, port, out_dir):
+    """C4 arithmetic: each rank differentiates the mean-reduced losses of ITS rays (oracle on CPU = the reference's math), the bucket
+    averages; must equal the gradient of the same losses over the concatenated batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neat_amd import dp, synth
+    from oracle import neat_oracle as O
+    dp.init_from_env(backend="gloo")
+    R, S = 16, 24
+    p, full = _dp_problem(R, S)
+    sl = slice(rank * R // world, (rank + 1) * R // world)
+    loss = _dp_loss(O, p, full, sl)
+    loss.backward()
+    params = list(p.values())
+    for q in params:
+        q.requires_grad_(True)
+    bucket = dp.FlatGradBucket(params)
+    bucket.all_reduce_mean()
+    torch.save({k: v.grad.clone() for k, v in p.items() if v.grad is not None}, os.path.join(out_dir, f"dpgrads{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _dp_problem(R, S):
+    from neat_amd import synth
+    from oracle import neat_oracle as O
+    sd = synth.synth_state_dict(5, "rough")
+    p = O.params_from_numpy(sd, requires_grad=True)
+    sc = synth.synth_scene(seed=5, n_rays=R, view=0)
+    z = torch.tensor(synth.synth_z_vals(5, R, S))
+    gen = torch.Generator().manual_seed(5)
+    eik = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
+    return p, (sc, z, eik)
+
+
+def _dp_loss(O, p, full, sl):
+    """rgb L1 (mean over rays) + 0.1 eikonal (mean over points): the ray-decomposable part of VolSDFLoss (loss_wfr.py:60-75)."""
+    sc, z, eik = full
+    T = torch.tensor
+    dirs, origin = O.camera_rays(T(sc["uv"])[:, sl], T(sc["pose"]), T(sc["intrinsics"]))
+    dirs = dirs.reshape(-1, 3)
+    o = origin[:, None, :].expand(1, dirs.shape[0], 3).reshape(-1, 3)
+    out = O.render_rays(p, o, dirs, z[sl])
+    rgb_l = (out["rgb_values"] - T(sc["gt_rgb"])[0, sl]).abs().mean()
+    gth = O.sdf_gradient(p, eik[sl])
+    return rgb_l + 0.1 * ((gth.norm(2, dim=1) - 1) ** 2).mean()
+
+
+def test_two_rank_average_equals_full_batch_gradient(tmp_path):
+    from oracle import neat_oracle as O
+    world, port = 2, _free_port()
+    mp.spawn(_grad_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g0 = torch.load(tmp_path / "dpgrads0.pt")
+    g1 = torch.load(tmp_path / "dpgrads1.pt")
+    p, full = _dp_problem(16, 24)
+    _dp_loss(O, p, full, slice(0, 16)).backward()
+    checked = 0
+    for k, v in p.items():
+        if v.grad is None:
+            continue
+        scale = float(v.grad.abs().max()) + 1e-12
+        assert torch.allclose(g0[k], g1[k]), k                                  # both ranks hold the same averaged gradient
+        assert float((g0[k] - v.grad).abs().max()) <= 2e-5 * scale + 1e-9, k      # = gradient of the full-batch mean losses
+        checked += 1
+    assert checked == 43          # 27 SDF + 15 rendering-head tensors + density.beta (the attraction head and the junction MLP see neither loss)

@@ -79,7 +79,7 @@ def test_volume_rendering_and_camera_golden(dev, golden):
         close(c, g["cam" + tag], tol=0, what="cam" + tag)
 
 
-def close_sampler(z, ref, what):
+def close_sampler(z, ref, what, max_frac=0.003):
     """The inverse-CDF step is discontinuous: a sample with u at a CDF knot (notably u = 1.0, the last linspace
     value, against cdf[-1] = 1 +- 1ulp) lands one coarse bin away when the cumsum rounds differently (device scan
     vs the CPU's sequential sum).  Everything else must agree to 2e-4; at most 0.5% of the samples may sit one bin
@@ -87,7 +87,10 @@ def close_sampler(z, ref, what):
     err = np.abs(z.detach().cpu().numpy() - ref)
     assert err.shape == ref.shape
     frac = float((err > 2e-4).mean())
-    assert frac <= 0.005, f"{what}: {frac:.4%} of samples differ by more than 2e-4"
+    # Measured with the fp64 CDF scans of sampler_resample_kernel: 0 .. 0.18 % (scripts/sampler_flips.py).  The flips are not a
+    # summation-order artefact: tests/test_oracle_golden.py::test_sampler_is_ill_conditioned shows that the reference algorithm
+    # itself moves a sample by a whole bin when ONE ulp of noise is put on the SDF values it reads.
+    assert frac <= max_frac, f"{what}: {frac:.4%} of samples differ by more than 2e-4"
     # a flipped sample moves by one bin of the *current* grid: <= 2 * 6/127 with stratified jitter (training)
     assert float(err.max()) <= 2 * 6.0 / 127 + 1e-3, f"{what}: max err {err.max():.3e} exceeds one coarse bin"
 
@@ -230,7 +233,9 @@ def test_train_step_hierarchical_vs_reference_golden(dev, golden):
     with RngReplay([("rand", T(g["t_rand"])), ("randint", None), ("randint", T(g["eik_idx"]))]):
         z, z_eik = m.ray_sampler.get_z_vals(d, c, m)
     assert z.shape == (64, 128)
-    close_sampler(z, g["z_vals"], what="hierarchical z_vals")
+    # (every fine sample of the hierarchical scheme is drawn from `weights + 1e-5` with mostly empty bins, the worst case of the
+    # ill-conditioned rule: measured 0.33 %)
+    close_sampler(z, g["z_vals"], what="hierarchical z_vals", max_frac=0.005)
     # (ii) everything downstream of the depths, on the reference's depths
     m.z_vals_override = T(g["z_vals"]).to(dev)
     with RngReplay([("randint", T(g["eik_idx"])), ("uniform_", T(g["eik_uniform"]))]):
@@ -330,13 +335,162 @@ def test_full_size_properties(dev):
     assert float((g2 - 2 * g_full).abs().max()) <= 1e-4 * scale
 
 
+def _dtu_conf():
+    import copy
+    conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+    conf.update(dbscan_enabled=True, use_median=False)
+    conf["global_junctions"] = dict(conf["global_junctions"], num_junctions=1024)
+    return conf
+
+
+def test_c3_dtu_switches_vs_oracle_small(dev):
+    """C3's model (dtu.conf switches) on seeded inputs against the oracle: 48 distinct rays, each twice (so that DBSCAN finds the
+    line end points as clusters), 128 samples, depths given; outputs, loss and all gradients, fp32 build."""
+    from neat_amd import networks
+    from neat_amd.loss import VolSDFLoss
+    from neat_amd.wireframe import WireframeGraph
+    from oracle import neat_oracle as O
+    from tests.util_replay import RngReplay
+    R, S, seed = 96, 128, 6
+    sd = synth.synth_state_dict(seed, "rough", num_junctions=1024)
+    sc = synth.synth_scene(seed=seed, n_rays=R // 2, view=1)
+    for k in ("uv", "uv_proj", "gt_rgb", "gt_lines2d"):
+        sc[k] = np.concatenate([sc[k], sc[k]], axis=1)
+    zh = synth.synth_z_vals(seed, R // 2, S)
+    z = T(np.concatenate([zh, zh], 0))
+    gen = torch.Generator().manual_seed(seed)
+    eik_idx = torch.randint(S, (R,), generator=gen)
+    eik_uniform = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
+    p = O.params_from_numpy(sd, requires_grad=True)
+    wf = WireframeGraph(T(sc["wf_vertices"]), T(sc["wf_vconf"]), T(sc["wf_edges"]), T(sc["wf_weights"]), 512, 512)
+    ref = O.full_forward(p, {k: T(sc[k]) for k in ("intrinsics", "pose", "uv", "uv_proj")}, wf.line_segments(), wf.vertices, training=True,
+                         rand={"eik_idx": eik_idx, "eik_uniform": eik_uniform}, z_vals=z, use_median=False, dbscan_enabled=True)
+    ref_lo = O.neat_loss(ref, T(sc["gt_rgb"]), T(sc["gt_lines2d"]))
+    ref_lo["loss"].backward()
+    m = networks.VolSDFNetwork(_dtu_conf())
+    m.load_state_dict({k: T(v) for k, v in sd.items()})
+    m.to(dev).train()
+    m.z_vals_override = z.to(dev)
+    with RngReplay([("randint", eik_idx), ("uniform_", eik_uniform)]):
+        out = m(scene_inputs(sc, dev))
+    assert ref["j3d_local"].shape[0] > 0
+    for k in ("rgb_values", "lines3d", "depth", "xyz", "grad_theta", "lines2d_calib", "sdf", "j3d_local", "j2d_local_calib", "j3d_global"):
+        close(out[k], ref[k], what=k)
+    lo = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)(out, {"rgb": T(sc["gt_rgb"]).to(dev), "lines2d": T(sc["gt_lines2d"]).to(dev)})
+    for k in ("loss", "rgb_loss", "eikonal_loss", "line_loss", "j3d_loss", "j2d_loss"):
+        close(lo[k].reshape(()), ref_lo[k].reshape(()), what="loss " + k)
+    lo["loss"].backward()
+    for k, prm in m.named_parameters():
+        r = p[k].grad
+        if r is None:
+            continue
+        scale = max(float(r.abs().max()), 1e-6)
+        assert float((prm.grad.cpu() - r).abs().max()) <= 2e-3 * scale + 1e-7, k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_c3_full_size_dtu_step(dev, precision):
+    """BASELINE config 3 at full size: 2048 rays x 128 samples, DTU model switches (device DBSCAN + matching, 1024 junction latents),
+    full losses (rgb + eikonal + line + junction), whole train step through Trainer (forward, loss, backward, Adam).  No oracle
+    run at 262 144 points: size-independent properties -- determinism of the step, finiteness, loss decreases under Adam on a fixed
+    batch, the step's parameters equal those of the same step replayed from a HIP graph."""
+    from neat_amd.train import Trainer, synthetic_batch
+    R, S = 2048, 128
+    sd = {k: T(v) for k, v in synth.synth_state_dict(42, "rough", num_junctions=1024).items()}
+
+    def fresh():
+        tr = Trainer(model_conf=_dtu_conf(), device=dev, state_dict=sd)
+        tr.model.set_precision(precision)
+        tr.model.z_vals_override = T(synth.synth_z_vals(42, R, S)).to(dev)
+        return tr
+    _, inp, gt = synthetic_batch(42, R, dev, view=0)
+
+    def run(tr, n):
+        torch.manual_seed(7)
+        hist = []
+        for _ in range(n):
+            out, lo = tr.step(inp, gt)
+            hist.append({k: float(v.detach()) for k, v in lo.items() if v.numel() == 1})
+        return hist, torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])
+    h1, p1 = run(fresh(), 3)
+    h2, p2 = run(fresh(), 3)
+    assert h1 == h2 and torch.equal(p1, p2)                     # run-to-run determinism of the whole step (no atomics on the path)
+    assert all(np.isfinite(list(h.values())).all() for h in h1) and torch.isfinite(p1).all()
+    assert {"loss", "rgb_loss", "eikonal_loss", "line_loss", "l2d_loss", "count", "j3d_loss", "j2d_loss", "j2d_stat", "jcount"} <= set(h1[0])
+    assert h1[0]["count"] > 0
+    assert h1[-1]["loss"] < h1[0]["loss"]                          # three Adam steps on a fixed batch reduce its loss
+    tr = fresh()
+    assert tr.capture(inp, gt), tr.capture_error                # the C3 step has no host synchronisation: it captures into a HIP graph
+    _, lo_g = tr.step(inp, gt)
+    tr.check_nan()
+    assert np.isfinite(float(lo_g["loss"]))
+
+
+def test_c4_rank_shape_step_vs_oracle(dev):
+    """BASELINE config 4 = 4096 rays per step over 8 ranks: a rank renders 512 rays of its own view and the only exchange is the flat
+    gradient all-reduce (neat_amd/dp.py; its two-rank arithmetic runs under gloo in tests/test_dp_gloo.py).  Here the per-rank
+    part on one GPU: (i) Trainer.step = forward + loss + backward + FlatGradBucket (world 1: no-op) + FlatAdam against the oracle
+    + torch.optim.Adam for ONE step at a small size: every parameter that has a gradient moves by the same amount;
+    (ii) the 512 x 128 rank shape runs, is deterministic and finite."""
+    from neat_amd.train import Trainer, synthetic_batch
+    from tests.util_replay import RngReplay
+    R, S, seed = 40, 128, 8
+    sdn = synth.synth_state_dict(seed, "rough")
+    sc = synth.synth_scene(seed=seed, n_rays=R, view=2)
+    z = T(synth.synth_z_vals(seed, R, S))
+    gen = torch.Generator().manual_seed(seed)
+    eik_idx = torch.randint(S, (R,), generator=gen)
+    eik_uniform = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
+    p, ref, ref_lo = oracle_train_step(sdn, sc, z, eik_idx, eik_uniform)
+    before = {k: v.detach().clone() for k, v in p.items()}
+    torch.optim.Adam([v for v in p.values()], lr=5e-4).step()
+    tr = Trainer(device=dev, state_dict={k: T(v) for k, v in sdn.items()})
+    tr.model.z_vals_override = z.to(dev)
+    inp = scene_inputs(sc, dev)
+    gt = {"rgb": T(sc["gt_rgb"]).to(dev), "lines2d": T(sc["gt_lines2d"]).to(dev)}
+    with RngReplay([("randint", eik_idx), ("uniform_", eik_uniform)]):
+        _, lo = tr.step(inp, gt)
+    close(lo["loss"].reshape(()), ref_lo["loss"].reshape(()), what="loss")
+    lr = 5e-4
+    for k, prm in tr.model.named_parameters():
+        g = p[k].grad
+        if g is None:
+            assert torch.equal(prm.detach().cpu(), before[k]), k
+            continue
+        d_ref = (p[k].detach() - before[k])
+        d_our = prm.detach().cpu() - before[k]
+        sure = g.abs() > 1e-3 * g.abs().max()                   # Adam's first step is -lr g / (|g| + eps): +-lr wherever g is not ~0
+        assert float((d_our - d_ref)[sure].abs().max()) <= 0.02 * lr, k
+        assert float(d_our.abs().max()) <= lr * 1.0001
+    # (ii) the rank shape of C4
+    R4 = 512
+    sd = {k: T(v) for k, v in synth.synth_state_dict(42, "rough").items()}
+    outs = []
+    for _ in range(2):
+        tr = Trainer(device=dev, state_dict=sd)
+        tr.model.set_precision("bf16")
+        tr.model.z_vals_override = T(synth.synth_z_vals(1, R4, 128)).to(dev)
+        _, inp4, gt4 = synthetic_batch(1, R4, dev, view=1)
+        torch.manual_seed(3)
+        hist = [float(tr.step(inp4, gt4)[1]["loss"].detach()) for _ in range(3)]
+        outs.append((hist, torch.cat([q.detach().reshape(-1) for q in tr.model.parameters()])))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and np.isfinite(outs[0][0]).all()
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # bf16 build (BASELINE config 2: "bf16").  bf16 has an 8-bit mantissa, so it cannot meet the 1e-4 fp32 tolerance --
 # that is what the fp32 build above is for.  Here the bar is bf16-grade agreement with the SAME oracle on the same
-# inputs: rendered outputs within 5e-3 of scale, normals within 3e-2, every gradient tensor within 0.99 cosine of the
-# fp32 truth and the loss within 5e-3; plus the same structural properties (determinism, finiteness).
+# inputs.  Measured on MI355X (scripts/bf16_error_table.py; fp32 build in brackets), max error relative to the tensor's scale:
+# rgb 2.5e-4 (2e-7), lines3d 1.7e-3 (2e-6), depth / xyz 1.8e-3 (2e-6), sdf 3e-3 (5e-5), eikonal normals 1.9e-2 (8e-6), loss 1e-3
+# (2e-7); per gradient tensor, relative L2 error  |g - g_ref|_2 / |g_ref|_2  at most 8.4e-2 (1.1e-5), worst on the heads' input
+# layers, which read the normals (a nine-layer bf16 adjoint chain).  The test bounds are those numbers with ~1.5x head room:
+# outputs 5e-3, sdf 1e-2, normals 3e-2, loss 5e-3, every gradient tensor 0.12 relative L2 (a cosine of 0.99 -- the previous
+# criterion -- allows 0.14 and says nothing about the length).
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("R,S,seed", [(96, 128, 1), (33, 50, 2)])
+BF16_GRAD_REL_L2 = 0.12
+
+
+@pytest.mark.parametrize("R,S,seed", [(96, 128, 1), (33, 50, 2), (256, 128, 3)])
 def test_bf16_build_vs_oracle(dev, R, S, seed):
     from neat_amd.loss import VolSDFLoss
     from neat_amd import networks
@@ -365,8 +519,8 @@ def test_bf16_build_vs_oracle(dev, R, S, seed):
             continue
         g = prm.grad.detach().cpu().flatten()
         assert torch.isfinite(g).all(), k
-        cos = float(g @ r.flatten() / (g.norm() * r.norm() + 1e-30))
-        assert cos > 0.99, (k, cos)
+        rel = float((g - r.flatten()).norm() / (r.norm() + 1e-30))
+        assert rel <= BF16_GRAD_REL_L2, (k, rel)
 
 
 def test_bf16_full_size_properties(dev):
