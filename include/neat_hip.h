@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 3 */
+int neat_abi_version(void);      /* 4 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -101,6 +101,16 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
                          const float* z, int R, int S, int E, int precision, const float* beta,
                          const float* d_rgb, const float* d_lines3d, const float* d_depth, const float* d_xyz,
                          const float* d_eik_grad, const neat_net_grads* grads, float* dbeta_ray, void* stream);
+
+/* Forward-only variant for eval / inference callers (code/neat-final-parsing.py:203-218 drives `model(s)` in 2048-ray chunks under
+ * model.eval(); training/volsdf_train.py:312-320 renders validation images the same way): same arguments and results as
+ * neat_render_forward with E = 0, but the workspace keeps nothing for a backward pass (hidden activations of the adjoint chain and
+ * of the two heads ping-pong between two buffers): about a quarter of neat_render_ws_floats. */
+size_t neat_render_eval_ws_floats(int R, int S, int precision);
+int neat_render_forward_eval(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
+                             const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                             float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
+                             float* xyz, float* normal_map, void* stream);
 
 /* ---- a3: ErrorBoundSampler bookkeeping (model/ray_sampler.py:130-293), one wavefront per ray --------------------
  * One round of Algorithm 1 = neat_sdf_forward(mode 0) on the new samples, then:

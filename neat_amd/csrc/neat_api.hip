@@ -420,6 +420,15 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
   if (mode == 0) {
     Arr a = big(256), b = big(256);
     for (int l = 1; l <= 8; ++l) w.h[l] = (l & 1) ? a : b;
+  } else if (mode == 2) {
+    // forward only (eval / inference, neat-final-parsing.py:203-218): h_1..h_8 are kept for the adjoint chain (the normals feed both
+    // heads and the normal map), the adjoint's u_l ping-pong between two buffers, nothing is kept for a backward pass
+    for (int l = 1; l <= 8; ++l) w.h[l] = big(256);
+    if (prec) w.feat = big(256);
+    else { float* out8 = take(257); w.sdfraw = out8; w.feat = F(out8 + ldp); }
+    Arr a = big(256), b = big(256);
+    for (int l = 0; l < 8; ++l) w.u[l] = (l & 1) ? a : b;
+    w.e0 = take(PE_ROWS); w.es = take(PE_ROWS);
   } else {
     for (int l = 1; l <= 8; ++l) w.h[l] = big(256);
     if (prec) w.feat = big(256);
@@ -444,12 +453,20 @@ struct HeadWs {
   Arr smallbf_r, smallbf_a, topbf_r, topbf_a;                           // bf16 build: octet-major copies of small_* / zrgb / dlin
   size_t total;
 };
-HeadWs head_ws(float* base, int ldp, int prec) {
+HeadWs head_ws(float* base, int ldp, int prec, bool fwd_only = false) {
   HeadWs w{};
   size_t off = 0;
   auto take = [&](int rows) { float* p = base ? base + off : nullptr; off += (size_t)rows * ldp; return p; };
   auto big = [&](int rows) { Arr a; a.p = take(rows); a.bf16 = prec; return a; };
   w.small_r = take(SMALL_R); w.small_a = take(SMALL_A);
+  if (fwd_only) {      // hidden activations of both heads ping-pong between two buffers; no cotangent arrays
+    Arr a = big(256), b = big(256);
+    for (int l = 1; l <= 4; ++l) { w.hr[l] = (l & 1) ? a : b; w.ha[l] = (l & 1) ? a : b; }
+    w.rgb = take(3); w.lin = take(6);
+    if (prec) { w.smallbf_r = big(20); w.smallbf_a = big(8); }
+    w.total = off;
+    return w;
+  }
   for (int l = 1; l <= 4; ++l) { w.hr[l] = big(256); w.ha[l] = big(256); }
   w.rgb = take(3); w.lin = take(6);
   w.zrgb = take(3); w.dlin = take(6);
@@ -1049,7 +1066,7 @@ bool bad_prec(int p) { return p != F32 && p != BF16; }
 // ================================================================================================
 extern "C" {
 
-int neat_abi_version(void) { return 3; }
+int neat_abi_version(void) { return 4; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
   if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
@@ -1198,17 +1215,17 @@ size_t neat_render_ws_floats(int R, int S, int E, int precision) {
   return sdf_ws(nullptr, ldp, 1, precision).total + head_ws(nullptr, ldp, precision).total;
 }
 
-int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                        const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
-                        float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
-                        float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream) {
+static int render_forward_impl(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
+                               const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                               float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
+                               float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream, bool fwd_only) {
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !origins || !dirs || !z || !rgb || !lines3d || !depth || !xyz || bad_prec(precision)) return -1;
   if (E < 0 || (E > 0 && (!eik_points || !eik_grad))) return -1;
   const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
-  SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
-  HeadWs h = head_ws(ws + w.total, c.ldp, precision);
+  SdfWs w = sdf_ws(ws, c.ldp, fwd_only ? 2 : 1, precision);
+  HeadWs h = head_ws(ws + w.total, c.ldp, precision, fwd_only);
   hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points, eik_points, E);
   NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w));
@@ -1223,6 +1240,28 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
   ca.weights = weights; ca.rgb = rgb; ca.lines3d = lines3d; ca.depth = depth; ca.xyz = xyz; ca.normal_map = normal_map;
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, ca);
   return (int)hipGetLastError();
+}
+
+int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
+                        const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                        float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
+                        float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream) {
+  return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d,
+                             depth, xyz, normal_map, eik_points, E, eik_grad, stream, false);
+}
+
+size_t neat_render_eval_ws_floats(int R, int S, int precision) {
+  if (bad_prec(precision)) return 0;
+  const int ldp = round_ldp(R * S, precision);
+  return sdf_ws(nullptr, ldp, 2, precision).total + head_ws(nullptr, ldp, precision, true).total;
+}
+
+int neat_render_forward_eval(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
+                             const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                             float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
+                             float* xyz, float* normal_map, void* stream) {
+  return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d,
+                             depth, xyz, normal_map, nullptr, 0, nullptr, stream, true);
 }
 
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs, const float* z,

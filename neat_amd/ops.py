@@ -241,10 +241,35 @@ class RenderRaysFn(torch.autograd.Function):
         return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, None, *views)
 
 
+def render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False):
+    """Forward-only main pass (no autograd graph, no backward workspace): what eval / inference callers run
+    (neat-final-parsing.py:203-218, 2048-ray chunks).  Same results as render_rays."""
+    lib = _lib.lib()
+    origins, dirs, z = (_f32c(t.detach()) for t in (origins, dirs, z))
+    beta_d = _f32c(beta.detach().reshape(1))
+    R, S = z.shape
+    dev = z.device
+    packed, netp = handle.packed()
+    prec = handle.precision
+    ws = torch.empty(lib.neat_render_eval_ws_floats(R, S, prec), device=dev, dtype=torch.float32)
+    points, weights, sdf = torch.empty(R, S, 3, device=dev), torch.empty(R, S, device=dev), torch.empty(R, S, device=dev)
+    rgb, lines3d = torch.empty(R, 3, device=dev), torch.empty(R, 2, 3, device=dev)
+    depth, xyz = torch.empty(R, device=dev), torch.empty(R, 3, device=dev)
+    nmap = torch.empty(R, 3, device=dev) if want_normal_map else None
+    _lib.check(lib.neat_render_forward_eval(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, _p(beta_d),
+                                            float(radius), float(scale), _p(ws), _p(points), _p(weights), _p(sdf), _p(rgb),
+                                            _p(lines3d), _p(depth), _p(xyz), _p(nmap), _stream()), "neat_render_forward_eval")
+    if nmap is None:
+        nmap = torch.empty(0, device=dev)
+    return rgb, lines3d, depth, xyz, torch.empty(0, 3, device=dev), weights, sdf, points, nmap
+
+
 def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False, eik_points=None):
     """-> rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], eik_grad [E,3], weights, sdf, points, normal_map"""
     if not handle.has_heads():
         raise RuntimeError("render_rays needs the SDF network and both heads attached to the NetHandle")
+    if not torch.is_grad_enabled() and eik_points is None:
+        return render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map)
     return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, *handle.tensors())
 
 

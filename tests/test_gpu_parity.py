@@ -244,6 +244,58 @@ def test_train_step_hierarchical_vs_reference_golden(dev, golden):
                                               "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median", "l3d"))
 
 
+@pytest.mark.parametrize("variant", ["init", "rough"])
+def test_eval_chunks_like_final_parsing(dev, golden, variant):
+    """the inference caller (code/neat-final-parsing.py:203-218) splits a view into chunks with utils.split_input,
+    runs `model(s)` under eval() / no_grad per chunk and merges `lines3d`, `lines2d`, `l3d` with utils.merge_output.  Same flow here
+    on fixture G7 (made by the reference in one piece), at two chunk sizes; the chunks run on the forward-only chain
+    (neat_render_forward_eval: no backward workspace), which must also equal the training chain bit for bit."""
+    from tests.util_replay import RngReplay
+    from neat_amd.general import split_input, merge_output
+    from neat_amd import _lib, ops
+    g = golden(f"g7_forward_eval_{variant}")
+    m = build_model(dev, variant)
+    inp = scene_inputs(g, dev)
+    z = T(g["z_vals"]).to(dev)
+    total = z.shape[0]
+    keys = ("lines3d", "lines2d", "l3d", "rgb_values", "depth", "xyz", "normal_map", "lines2d_calib", "sdf")
+    calls = {"eval": 0}
+    inner = ops.render_rays_eval
+
+    def counting(*a, **k):
+        calls["eval"] += 1
+        return inner(*a, **k)
+    ops.render_rays_eval = counting
+    try:
+        for chunk in (16, 40):
+            res, off = [], 0
+            for s in split_input(inp, total, n_pixels=chunk):
+                n = s["uv"].shape[1]
+                m.z_vals_override = z[off:off + n].contiguous()
+                off += n
+                with torch.no_grad(), RngReplay([("randint", None)]):
+                    out = m(s)
+                res.append({k: out[k].detach() for k in keys})
+            merged = merge_output(res, total, 1)
+            for k in keys:
+                ref = g["out_" + k].reshape(total, -1) if g["out_" + k].ndim > 1 else g["out_" + k]
+                close(merged[k], ref, tol=3e-4 if k == "l3d" else TOL, what=f"chunk {chunk}: {k}")
+        assert calls["eval"] == 4 + 2                      # every chunk went through the forward-only entry point
+    finally:
+        ops.render_rays_eval = inner
+    # forward-only chain == training chain (same kernels, smaller workspace), and the workspace really is smaller
+    m.z_vals_override = z
+    with torch.no_grad(), RngReplay([("randint", None)]):
+        a = m(inp)
+    with RngReplay([("randint", None)]):
+        b = m(inp)                                          # grad enabled: the training entry point (saves the backward workspace)
+    for k in keys:
+        assert torch.equal(a[k], b[k].detach()), k
+    lib = _lib.lib()
+    for prec in (0, 1):
+        assert lib.neat_render_eval_ws_floats(2048, 98, prec) * 3 < lib.neat_render_ws_floats(2048, 98, 0, prec)
+
+
 def oracle_train_step(sd, sc, z, eik_idx, eik_uniform):
     from oracle import neat_oracle as O
     from neat_amd.wireframe import WireframeGraph
