@@ -74,7 +74,9 @@ def cpu_baseline(seed):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    cores = min(avail, CPU_BASELINE_THREADS)
+    import neat_amd
+    quota = neat_amd.cpu_quota()                  # the container's cgroup CPU quota (16 on the MI355X boxes of this pool)
+    cores = min(quota, CPU_BASELINE_THREADS)
     before = torch.get_num_threads()
     v_all = run(cores)
     v_one = run(1)
@@ -91,8 +93,8 @@ def cpu_baseline(seed):
     return {"value": v_all, "unit": "ray-samples/s", "cores": cores, "kind": "port",
             "sample": f"oracle (own torch-CPU fp32 restatement of the reference path, pinned to reference goldens) train step on "
                       f"{R} rays x {S} samples of the C2 workload, median of {TIMED} after {WARM} warm-up, {cores} threads",
-            "value_1thread": v_one, "cpu_model": model, "host_cpus": avail,
-            "threads_note": f"{cores} of {avail} host CPUs: a {R * S}-point batch of 256-wide GEMMs stops scaling in torch-CPU beyond "
+            "value_1thread": v_one, "cpu_model": model, "host_cpus": avail, "cpu_quota": quota,
+            "threads_note": f"{cores} threads = the container's CPU quota ({quota} of {avail} host CPUs): a {R * S}-point batch of 256-wide GEMMs stops scaling in torch-CPU beyond "
                             "a few tens of threads; the 1-thread figure is the reference runner's own configuration"}
 
 

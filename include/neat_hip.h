@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 4 */
+int neat_abi_version(void);      /* 5 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -130,6 +130,34 @@ int neat_sampler_resample(const float* z, const float* sdf, int n, int R, const 
                           const float* u, int u_stride, int N, float* samples, float* z_merged, int* order, void* stream);
 int neat_sampler_finish(const float* samples, int N, const float* z, int n, const int* pick, int n_extra, float near, float far,
                         int R, const int* eik_idx, float* z_vals, float* z_eik, void* stream);
+
+/* ---- a3 without host synchronisation (HIP-graph capturable) -----------------------------------------------------
+ * The reference reads `beta.max() > beta0` on the host once per round (:200).  Here the rounds are a FIXED sequence of max_rounds
+ * launches and the decision lives in device memory: int32 open[max_rounds] (zero-initialised; the bound kernel of round k ORs into
+ * open[k]) and int32 cont[max_rounds] (the resample launch of round k writes 1 = "refined, go on" or 2 = "final samples drawn").
+ * A launch of round k > 0 does nothing unless cont[k-1] == 1, so the rounds after the final one cost only their launch.
+ *  neat_sdf_values_gated     : neat_sdf_forward(mode 0) that returns at once unless *gate == gate_value (gate = &cont[k-1], 1).
+ *  neat_sampler_bound_dev    : neat_sampler_bound with `open` = &open[k] and the same gate.
+ *  neat_sampler_resample_dev : decides refine = *open && round + 1 < max_rounds on the device.  refine: N_refine samples at u_refine
+ *                              (shared by the rays), merged grid and order, as neat_sampler_resample(refine=1).  Otherwise the N_final
+ *                              output samples at u_final (stride u_final_stride), a copy of this round's grid into z_final
+ *                              [R, ld_final] and its size into *n_final.
+ *  neat_sampler_finish_dev   : picks the n_extra grid points on the device (sizes come from *n_final): keys == NULL ->
+ *                              linspace(0, n-1, n_extra).long() (:266, eval); keys [>= n] -> the indices of the n_extra smallest
+ *                              keys, a uniformly random subset like randperm(n)[:n_extra] (:264, training); then as
+ *                              neat_sampler_finish.  `pick` [n_extra] receives the indices. */
+int neat_sdf_values_gated(const float* packed, const neat_net_params* net, const float* x, int P, int precision, float radius,
+                          float scale, float* ws, float* sdf, const int* gate, int gate_value, void* stream);
+int neat_sampler_bound_dev(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
+                           const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out,
+                           int* open, const int* gate, int gate_value, void* stream);
+int neat_sampler_resample_dev(const float* z, const float* sdf, int n, int R, const float* beta, float add_tiny,
+                              const float* u_refine, int N_refine, float* samples_refine, float* z_merged, int* order,
+                              const float* u_final, int u_final_stride, int N_final, float* samples_final, float* z_final, int ld_final,
+                              int* n_final, const int* open, int* cont, int round, int max_rounds, void* stream);
+int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, int ld_final, const int* n_final, const float* keys,
+                            int n_extra, int* pick, float near, float far, int R, const int* eik_idx, float* z_vals, float* z_eik,
+                            void* stream);
 
 /* ---- 8f-1 (next row): dataset attraction field, replacement for the un-vendored hawp.base._C.encodels ------------
  * (datasets/blender_hawp_dataset.py:96, scene_hawp_dataset.py:95).  lines [N,4] = (x1,y1,x2,y2) in pixels;

@@ -1,0 +1,34 @@
+"""neat_amd: the NEAT hot path (rays -> depth samples -> SDF/heads -> compositing -> junction block -> loss -> Adam) on MI355X."""
+import os
+
+
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup-v2 quota (cpu.max) if there is one, else the affinity mask."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            avail = min(avail, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def _cap_host_threads():
+    """torch sizes its intra-op pool by the machine's core count (128 on the MI355X hosts), not by the container's CPU quota (16).
+    The host side of the hot path only draws a few hundred KB of CPU randoms per step; with a 128-thread pool every such draw leaves
+    OpenMP workers spinning, the cgroup runs out of quota and the kernel parks the whole process -- including the thread that feeds
+    the GPU -- for the rest of the 100 ms period (measured: every other train step with the sampler on took 90 ms instead of 6).
+    Unless OMP_NUM_THREADS says otherwise, keep the pool at a quarter of the quota (at most 8 threads)."""
+    if "OMP_NUM_THREADS" in os.environ:
+        return
+    import torch
+    want = max(1, min(8, cpu_quota() // 4))
+    if torch.get_num_threads() > want:
+        torch.set_num_threads(want)
+
+
+_cap_host_threads()

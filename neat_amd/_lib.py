@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 4
+ABI_VERSION = 5
 PRECISIONS = {"fp32": 0, "bf16": 1}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libneat_hip.so")
@@ -51,6 +51,16 @@ _SIGNATURES = {
                                              c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_sampler_finish": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "neat_sdf_values_gated": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                             ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
+    "neat_sampler_bound_dev": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp,
+                                              ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
+    "neat_sampler_resample_dev": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_float,
+                                                 c_fp, ctypes.c_int, c_fp, c_fp, c_fp,
+                                                 c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
+                                                 c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
+    "neat_sampler_finish_dev": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_float,
+                                               ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_ffn_forward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 10),
     "neat_ffn_backward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 15),

@@ -64,6 +64,7 @@ struct FusedArgs {
   float* sdf_out;             // values mode: clamped sdf, row-major [P]
   float radius, scale;
   int bias8_rot, bias8_n;     // lin8 rows are packed [feature | sdf]
+  const int* gate; int gate_value;      // device-side gate (sync-free sampler): the launch does nothing unless *gate == gate_value (null: run)
 };
 
 }  // namespace neat

@@ -601,6 +601,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ s
 template <int PT, bool VALUES>
 __global__ __launch_bounds__(WG, 2) void sdf_fused_kernel_h(FusedArgs a) {
   constexpr int BMT = 32 * PT;
+  if (a.gate && *a.gate != a.gate_value) return;
   extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];        // tile [32][BMT] | PE octets [8][BMT] (K padded to 64)
   uint4* tile = ldsq;
   uint4* pe = ldsq + 32 * BMT;
@@ -798,6 +799,7 @@ template <int NT, bool VALUES>
 __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int ntiles, int nwg) {
   typedef FwsCfg<NT> C;
   constexpr int BP = C::BP;
+  if (a.gate && *a.gate != a.gate_value) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char fws[];
   unsigned char* XA = fws;
   unsigned char* XB = fws + C::XBYTES;

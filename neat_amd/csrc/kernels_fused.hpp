@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
   typedef F6Cfg<NT, RT> C;
   constexpr int BP = C::BP, F6T = C::THREADS, NW = C::NW;
   static_assert(NT == 4 && (RT == 1 || RT == 2), "the PE phase maps threads to (point of a 128-point batch, frequency group)");
+  if (a.gate && *a.gate != a.gate_value) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char f6lds[];
   float* biasl = reinterpret_cast<float*>(f6lds + C::BIAS);     // [l][256]; lin8 in packed row order
   float* red = reinterpret_cast<float*>(f6lds + C::RED);        // [waves][BP]: partial sums of the sdf row
@@ -519,6 +520,7 @@ template <bool VALUES>
 __global__ __launch_bounds__(PHT, 2) void sdf_fused_ph_kernel(FusedArgs a, int ntiles, int nwg) {
   typedef PhCfg C;
   constexpr int BP = C::BP, NT = 4, NW = 8;
+  if (a.gate && *a.gate != a.gate_value) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char f6lds[];
   float* biasl = reinterpret_cast<float*>(f6lds + C::BIAS);     // [l][256]; lin8 in packed row order
   float* red = reinterpret_cast<float*>(f6lds + C::RED);        // [waves][BP]: partial sums of the sdf row

@@ -76,10 +76,12 @@ struct SamplerBoundArgs {
   const float* beta_in; const float* beta0;  // [R], device scalar
   float eps; int iters;
   float* sdf_out; float* beta_out; int* flag;   // merged sdf [R,n], new beta [R], flag |= (beta > beta0)
+  const int* gate; int gate_value;              // device-decided rounds (sync-free sampler): run only if *gate == gate_value (null: always)
 };
 
 __global__ __launch_bounds__(64) void sampler_bound_kernel(SamplerBoundArgs a) {
   __shared__ float ssdf[SMAX], sdist[SMAX], sdstar[SMAX];
+  if (a.gate && *a.gate != a.gate_value) return;
   const int r = blockIdx.x, lane = threadIdx.x, n = a.n;
   const float* z = a.z + (size_t)r * n;
   for (int j = lane; j < n; j += 64) {
@@ -124,15 +126,36 @@ struct SamplerResampleArgs {
   const float* u; int u_stride; int N;          // u [N] (stride 0) or [R,N]
   float* samples;                               // [R,N]
   float* z_merged; int* order;                  // refine: [R,n+N] sorted union and its source index into cat[z, samples]
+  // ---- device-decided mode (sync-free sampler; all null / 0 in the host-decided mode) -------------------------------------------
+  // The batch-global test of ray_sampler.py:200 (`beta.max() > beta0`) is read from *open instead of by the host: refine iff *open and
+  // round + 1 < max_rounds.  Both outcomes have their own u / N / output: refine -> (u, N, samples, z_merged, order) above; final ->
+  // (u_final, N_final, samples_final) plus a copy of the grid into z_final [R, ld_final] and its size into *n_final.  cont[round] <- 1
+  // (refined) or 2 (finalised); the launch runs only if round == 0 or cont[round - 1] == 1.
+  const int* open; int* cont; int round, max_rounds;
+  const float* u_final; int u_final_stride, N_final; float* samples_final;
+  float* z_final; int ld_final; int* n_final;
 };
 
 __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArgs a) {
   __shared__ float sz[SMAX], scdf[SMAX], ssmp[SMAX];
   __shared__ float ssdf[SMAX];
   const int r = blockIdx.x, lane = threadIdx.x, n = a.n, m = n - 1;
+  bool refine = a.refine != 0;
+  const float* uptr = a.u; int ustride = a.u_stride, N = a.N;
+  float* samples = a.samples;
+  if (a.cont) {                                   // device-decided round
+    if (a.round > 0 && a.cont[a.round - 1] != 1) return;
+    refine = (*a.open != 0) && (a.round + 1 < a.max_rounds);
+    if (!refine) { uptr = a.u_final; ustride = a.u_final_stride; N = a.N_final; samples = a.samples_final; }
+  }
   const float beta = a.beta[r];
   for (int j = lane; j < n; j += 64) { sz[j] = a.z[(size_t)r * n + j]; ssdf[j] = a.sdf[(size_t)r * n + j]; }
   __syncthreads();
+  if (a.cont && !refine) {                        // the grid of the final round is what the tail of Algorithm 1 picks its extra samples from
+    for (int j = lane; j < n; j += 64) a.z_final[(size_t)r * a.ld_final + j] = sz[j];
+    if (r == 0 && lane == 0) { *a.n_final = n; }
+  }
+  if (a.cont && lane == 0) a.cont[a.round] = refine ? 1 : 2;      // (every ray writes the same value; read by later launches only)
   // pdf over the n-1 intervals -> scdf[1..n-1] (unnormalised), total in `sum`
   double carryE = 0.0, carryS = 0.0, sum = 0.0;
   for (int c0 = 0; c0 < n; c0 += 64) {
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
     const float T = expf(-(float)(carryE + exclE));
     float pdf = 0.0f;
     if (j < m) {
-      if (a.refine) pdf = (fminf(expf((float)(carryS + inclS)), 1.0e6f) - 1.0f) * T + a.add_tiny;      // (:205-211)
+      if (refine) pdf = (fminf(expf((float)(carryS + inclS)), 1.0e6f) - 1.0f) * T + a.add_tiny;      // (:205-211)
       else pdf = (1.0f - expf(-e)) * T + 1e-5f;                                                  // (:220-222)
       scdf[j + 1] = pdf;
     }
@@ -173,8 +196,8 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
   if (lane == 0) scdf[0] = 0.0f;
   __syncthreads();
   // inverse CDF (:237-249): searchsorted(right) + lerp with the 1e-5 denominator guard
-  for (int k = lane; k < a.N; k += 64) {
-    const float u = a.u[(size_t)r * a.u_stride + k];
+  for (int k = lane; k < N; k += 64) {
+    const float u = uptr[(size_t)r * ustride + k];
     int lo = 0, hi = n;                          // first index with cdf[idx] > u
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (scdf[mid] > u) hi = mid; else lo = mid + 1; }
     const int below = max(lo - 1, 0), above = min(lo, n - 1);
@@ -183,25 +206,51 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
     const float t = (u - scdf[below]) / den;
     const float smp = sz[below] + t * (sz[above] - sz[below]);
     ssmp[k] = smp;
-    a.samples[(size_t)r * a.N + k] = smp;
+    samples[(size_t)r * N + k] = smp;
   }
-  if (!a.refine) return;
+  if (!refine) return;
   __syncthreads();
   // sorted union of z (sorted) and the new samples (sorted: u is increasing): rank by binary search, old first on ties
-  const int tot = n + a.N;
+  const int tot = n + N;
   for (int j = lane; j < n; j += 64) {
     const float v = sz[j];
-    int lo = 0, hi = a.N;                        // #samples < v
+    int lo = 0, hi = N;                          // #samples < v
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (ssmp[mid] < v) lo = mid + 1; else hi = mid; }
     a.z_merged[(size_t)r * tot + j + lo] = v;
     a.order[(size_t)r * tot + j + lo] = j;
   }
-  for (int k = lane; k < a.N; k += 64) {
+  for (int k = lane; k < N; k += 64) {
     const float v = ssmp[k];
     int lo = 0, hi = n;                          // #z <= v
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (sz[mid] <= v) lo = mid + 1; else hi = mid; }
     a.z_merged[(size_t)r * tot + k + lo] = v;
     a.order[(size_t)r * tot + k + lo] = n + k;
+  }
+}
+
+// Which samples of the final grid join the output (ray_sampler.py:263-268), decided on the device from the grid size n:
+//   eval : torch.linspace(0, n - 1, n_extra).long()            (the reference's formula, fp32, symmetric around the middle)
+//   train: a uniformly random n_extra-subset without replacement (the reference: torch.randperm(n)[:n_extra]) = the n_extra smallest
+//          of n random keys (drawn on the CPU generator), in key order.  One workgroup.
+__global__ __launch_bounds__(256) void sampler_pick_kernel(const int* __restrict__ n_ptr, const float* __restrict__ keys, int n_extra,
+                                                           int* __restrict__ pick) {
+  __shared__ float sk[SMAX];
+  const int n = *n_ptr, tid = threadIdx.x;
+  if (!keys) {
+    const float start = 0.0f, end = (float)(n - 1), step = (end - start) / (float)(n_extra - 1);
+    for (int j = tid; j < n_extra; j += 256) {
+      const float v = j < n_extra / 2 ? start + step * (float)j : end - step * (float)(n_extra - 1 - j);
+      pick[j] = (int)v;
+    }
+    return;
+  }
+  for (int i = tid; i < n; i += 256) sk[i] = keys[i];
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const float x = sk[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (sk[j] < x) || (sk[j] == x && j < i);
+    if (rank < n_extra) pick[rank] = i;
   }
 }
 
@@ -212,6 +261,7 @@ struct SamplerFinishArgs {
   float near, far; int R;
   const int* eik_idx;                 // [R] index into the output row (:275-276)
   float* z_vals; float* z_eik;        // [R, N+2+n_extra] sorted, [R]
+  int ld_z;                           // row stride of the grid (= n in the host-decided mode)
 };
 
 __global__ __launch_bounds__(64) void sampler_finish_kernel(SamplerFinishArgs a) {
@@ -223,7 +273,7 @@ __global__ __launch_bounds__(64) void sampler_finish_kernel(SamplerFinishArgs a)
     if (k < a.N) x = a.samples[(size_t)r * a.N + k];
     else if (k == a.N) x = a.near;
     else if (k == a.N + 1) x = a.far;
-    else x = a.z[(size_t)r * a.n + a.pick[k - a.N - 2]];
+    else x = a.z[(size_t)r * a.ld_z + a.pick[k - a.N - 2]];
     v[k] = x;
   }
   __syncthreads();

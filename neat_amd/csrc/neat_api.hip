@@ -181,6 +181,7 @@ int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per
 int g_ws_aux_nt = 15;       // non-temporal accesses (tuning key 11): bit 0 / 1 = fetch of aux0 / aux1 of the streaming layer kernels, bit 2 =
                             // weight-gradient operands, bit 3 = `in` of the layer kernels, bit 4 = store of out1 (m_l)
 int g_ws_wide_store = 1;    // streaming layer kernels: 16-byte output stores (tuning key 12)
+const int* g_gate = nullptr; int g_gate_value = 0;      // set around one neat_sdf_forward call by neat_sdf_values_gated
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
@@ -500,6 +501,7 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
     a.save = full; a.values_only = !full;
     a.E = w.E; a.feat = reinterpret_cast<u16*>(w.feat.p); a.sdfraw = w.sdfraw; a.sdf_out = sdf_out;
     a.radius = radius; a.scale = scale; a.bias8_rot = 1; a.bias8_n = 257;
+    a.gate = g_gate; a.gate_value = g_gate_value;
     constexpr int PT = 2;
     const size_t lds = (size_t)(32 + 8) * (32 * PT) * 16;
     double fl = 0.0;
@@ -1066,7 +1068,7 @@ bool bad_prec(int p) { return p != F32 && p != BF16; }
 // ================================================================================================
 extern "C" {
 
-int neat_abi_version(void) { return 4; }
+int neat_abi_version(void) { return 5; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
   if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
@@ -1165,6 +1167,16 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
                      w.sdf, w.g, w.mask, sdf, grad, P, (float*)nullptr);
   export_out8(c, w, out257, feat);
   return (int)hipGetLastError();
+}
+
+int neat_sdf_values_gated(const float* packed, const neat_net_params* net, const float* x, int P, int precision, float radius,
+                          float scale, float* ws, float* sdf, const int* gate, int gate_value, void* stream) {
+  if (P <= 0) return 0;
+  if (!packed || !net || !x || !ws || !sdf || bad_prec(precision)) return -1;
+  g_gate = gate; g_gate_value = gate_value;
+  const int rc = neat_sdf_forward(packed, net, x, P, 0, precision, radius, scale, ws, nullptr, sdf, nullptr, nullptr, stream);
+  g_gate = nullptr;
+  return rc;
 }
 
 int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P, int precision,
@@ -1297,7 +1309,7 @@ int neat_sampler_bound(const float* z, int n, int R, const float* sdf_old, const
                        int* flag, void* stream) {
   if (R <= 0) return 0;
   if (n < 2 || n > SMAX || !z || !sdf_new || !beta_in || !beta0 || !sdf_out || !beta_out || !flag) return -1;
-  SamplerBoundArgs a{z, n, R, sdf_old, sdf_new, order, n_old, beta_in, beta0, eps, iters, sdf_out, beta_out, flag};
+  SamplerBoundArgs a{z, n, R, sdf_old, sdf_new, order, n_old, beta_in, beta0, eps, iters, sdf_out, beta_out, flag, nullptr, 0};
   hipLaunchKernelGGL(sampler_bound_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -1306,7 +1318,9 @@ int neat_sampler_resample(const float* z, const float* sdf, int n, int R, const 
                           const float* u, int u_stride, int N, float* samples, float* z_merged, int* order, void* stream) {
   if (R <= 0) return 0;
   if (n < 2 || n > SMAX || N < 1 || N > SMAX || !z || !sdf || !beta || !u || !samples || (refine && (!z_merged || !order))) return -1;
-  SamplerResampleArgs a{z, sdf, n, R, beta, refine, add_tiny, u, u_stride, N, samples, z_merged, order};
+  SamplerResampleArgs a{};
+  a.z = z; a.sdf = sdf; a.n = n; a.R = R; a.beta = beta; a.refine = refine; a.add_tiny = add_tiny; a.u = u; a.u_stride = u_stride; a.N = N;
+  a.samples = samples; a.z_merged = z_merged; a.order = order;
   hipLaunchKernelGGL(sampler_resample_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -1315,7 +1329,47 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
                         int R, const int* eik_idx, float* z_vals, float* z_eik, void* stream) {
   if (R <= 0) return 0;
   if (N + 2 + n_extra > SMAX || !samples || !z || (n_extra > 0 && !pick) || !eik_idx || !z_vals || !z_eik) return -1;
-  SamplerFinishArgs a{samples, N, z, n, pick, n_extra, near, far, R, eik_idx, z_vals, z_eik};
+  SamplerFinishArgs a{samples, N, z, n, pick, n_extra, near, far, R, eik_idx, z_vals, z_eik, n};
+  hipLaunchKernelGGL(sampler_finish_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_bound_dev(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
+                           const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out,
+                           int* open, const int* gate, int gate_value, void* stream) {
+  if (R <= 0) return 0;
+  if (n < 2 || n > SMAX || !z || !sdf_new || !beta_in || !beta0 || !sdf_out || !beta_out || !open) return -1;
+  SamplerBoundArgs a{z, n, R, sdf_old, sdf_new, order, n_old, beta_in, beta0, eps, iters, sdf_out, beta_out, open, gate, gate_value};
+  hipLaunchKernelGGL(sampler_bound_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_resample_dev(const float* z, const float* sdf, int n, int R, const float* beta, float add_tiny,
+                              const float* u_refine, int N_refine, float* samples_refine, float* z_merged, int* order,
+                              const float* u_final, int u_final_stride, int N_final, float* samples_final, float* z_final, int ld_final,
+                              int* n_final, const int* open, int* cont, int round, int max_rounds, void* stream) {
+  if (R <= 0) return 0;
+  if (n < 2 || n > SMAX || N_refine < 1 || N_final < 1 || n + N_refine > SMAX || ld_final < n || !z || !sdf || !beta || !u_refine || !u_final ||
+      !samples_refine || !z_merged || !order || !samples_final || !z_final || !n_final || !open || !cont || round < 0 || round >= max_rounds)
+    return -1;
+  SamplerResampleArgs a{};
+  a.z = z; a.sdf = sdf; a.n = n; a.R = R; a.beta = beta; a.refine = 1; a.add_tiny = add_tiny;
+  a.u = u_refine; a.u_stride = 0; a.N = N_refine; a.samples = samples_refine; a.z_merged = z_merged; a.order = order;
+  a.open = open; a.cont = cont; a.round = round; a.max_rounds = max_rounds;
+  a.u_final = u_final; a.u_final_stride = u_final_stride; a.N_final = N_final; a.samples_final = samples_final;
+  a.z_final = z_final; a.ld_final = ld_final; a.n_final = n_final;
+  hipLaunchKernelGGL(sampler_resample_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, int ld_final, const int* n_final, const float* keys,
+                            int n_extra, int* pick, float near, float far, int R, const int* eik_idx, float* z_vals, float* z_eik,
+                            void* stream) {
+  if (R <= 0) return 0;
+  if (N + 2 + n_extra > SMAX || ld_final > SMAX || !samples || !z_final || !n_final || (n_extra > 0 && !pick) || n_extra == 1 || !eik_idx ||
+      !z_vals || !z_eik) return -1;
+  if (n_extra > 0) hipLaunchKernelGGL(sampler_pick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_final, keys, n_extra, pick);
+  SamplerFinishArgs a{samples, N, z_final, 0, pick, n_extra, near, far, R, eik_idx, z_vals, z_eik, ld_final};
   hipLaunchKernelGGL(sampler_finish_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

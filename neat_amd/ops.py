@@ -157,8 +157,9 @@ def sdf_outputs(handle, x, radius, scale):
     return SdfOutputsFn.apply(handle, x, radius, scale, *handle.tensors(0, N_SDF))
 
 
-def sdf_values(handle, x, radius, scale):
-    """get_sdf_vals without autograd (sampler path): primal chain only, nothing saved."""
+def sdf_values(handle, x, radius, scale, gate=None):
+    """get_sdf_vals without autograd (sampler path): primal chain only, nothing saved.
+    gate = (int32 tensor, index, value): the launch does nothing unless tensor[index] == value on the device (sync-free sampler)."""
     lib = _lib.lib()
     x = _f32c(x.detach())
     P = x.shape[0]
@@ -167,6 +168,12 @@ def sdf_values(handle, x, radius, scale):
         return sdf
     packed, netp = handle.packed()
     ws = torch.empty(lib.neat_sdf_ws_floats(P, 0, handle.precision), device=x.device, dtype=torch.float32)
+    if gate is not None:
+        ctl, idx, val = gate
+        _lib.check(lib.neat_sdf_values_gated(_p(packed), ctypes.byref(netp), _p(x), P, handle.precision, float(radius), float(scale), _p(ws),
+                                             _p(sdf), ctypes.c_void_p(ctl.data_ptr() + 4 * idx), int(val), _stream()),
+                   "neat_sdf_values_gated")
+        return sdf
     _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 0, handle.precision, float(radius), float(scale), _p(ws),
                                     None, _p(sdf), None, None, _stream()), "neat_sdf_forward(values)")
     return sdf
@@ -343,6 +350,52 @@ def sampler_finish(samples, z, pick, near, far, eik_idx):
     _lib.check(lib.neat_sampler_finish(_p(samples), N, _p(z), z.shape[1], _p(pick), n_extra, float(near), float(far), R,
                                        _p(eik_idx), _p(out), _p(zeik), _stream()), "neat_sampler_finish")
     return out, zeik
+
+
+# ---- the same rounds with the control flow on the device (no host sync; see include/neat_hip.h) ------------------------------------
+def _ip(t, idx):
+    return ctypes.c_void_p(t.data_ptr() + 4 * idx)
+
+
+def sampler_round_dev(z, sdf_old, sdf_new, order, beta_in, beta0, eps, iters, add_tiny, u_refine, u_final, samples_final, z_final, ctl,
+                      rnd, max_rounds):
+    """Round `rnd` of Algorithm 1 with the refine/finish decision taken on the device.
+    ctl int32 [2*max_rounds + 1] = open[max_rounds] | cont[max_rounds] | n_final (zero-initialised by the caller).
+    -> (merged sdf [R,n], beta [R], refine samples [R,Ne], merged grid [R,n+Ne], order) -- garbage once the sampler has finished."""
+    lib = _lib.lib()
+    z, sdf_new = _f32c(z), _f32c(sdf_new)
+    R, n = z.shape
+    n_old = 0
+    if order is not None:
+        sdf_old, n_old = _f32c(sdf_old), sdf_old.shape[1]
+    dev = z.device
+    sdf_out, beta_out = torch.empty(R, n, device=dev), torch.empty(R, device=dev)
+    gate = _ip(ctl, max_rounds + rnd - 1) if rnd > 0 else None
+    _lib.check(lib.neat_sampler_bound_dev(_p(z), n, R, _p(sdf_old) if order is not None else None, _p(sdf_new), _p(order), n_old,
+                                          _p(_f32c(beta_in)), _p(_f32c(beta0.reshape(1))), float(eps), int(iters), _p(sdf_out),
+                                          _p(beta_out), _ip(ctl, rnd), gate, 1, _stream()), "neat_sampler_bound_dev")
+    Ne, N = u_refine.shape[-1], u_final.shape[-1]
+    fresh = torch.empty(R, Ne, device=dev)
+    zm = torch.empty(R, n + Ne, device=dev)
+    order_out = torch.empty(R, n + Ne, device=dev, dtype=torch.int32)
+    _lib.check(lib.neat_sampler_resample_dev(_p(z), _p(sdf_out), n, R, _p(beta_out), float(add_tiny), _p(u_refine), Ne, _p(fresh), _p(zm),
+                                             _p(order_out), _p(u_final), N if u_final.dim() == 2 else 0, N, _p(samples_final),
+                                             _p(z_final), z_final.shape[1], _ip(ctl, 2 * max_rounds), _ip(ctl, rnd),
+                                             _ip(ctl, max_rounds), rnd, max_rounds, _stream()), "neat_sampler_resample_dev")
+    return sdf_out, beta_out, fresh, zm, order_out
+
+
+def sampler_finish_dev(samples_final, z_final, ctl, max_rounds, keys, n_extra, near, far, eik_idx):
+    """-> z_vals [R, N+2+n_extra] sorted, z_eik [R,1], pick [n_extra] (device-chosen grid indices)."""
+    lib = _lib.lib()
+    R, N = samples_final.shape
+    dev = samples_final.device
+    out, zeik = torch.empty(R, N + 2 + n_extra, device=dev), torch.empty(R, 1, device=dev)
+    pick = torch.empty(max(n_extra, 1), device=dev, dtype=torch.int32)
+    _lib.check(lib.neat_sampler_finish_dev(_p(samples_final), N, _p(z_final), z_final.shape[1], _ip(ctl, 2 * max_rounds),
+                                           _p(_f32c(keys)) if keys is not None else None, n_extra, _p(pick), float(near), float(far), R,
+                                           _p(eik_idx), _p(out), _p(zeik), _stream()), "neat_sampler_finish_dev")
+    return out, zeik, pick[:n_extra]
 
 
 def linear_sum_assignment(cost, row_mask=None, col_mask=None):

@@ -43,6 +43,13 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
     return _lerp_inverse_cdf(bins, cdf, u.contiguous().to(weights.device))
 
 
+def _draw(model, name, fn, dev):
+    """A CPU draw moved to the device; through the model's draw-site registry when it has one (HIP-graph replay refills the
+    persistent device tensor of every site, networks.VolSDFNetwork._cpu_random)."""
+    hook = getattr(model, "_cpu_random", None)
+    return hook(name, fn, dev) if hook is not None else fn().to(dev)
+
+
 class RaySampler:
     def __init__(self, near, far):
         self.near, self.far = near, far
@@ -73,8 +80,13 @@ class UniformSampler(RaySampler):
             mid = 0.5 * (z[:, 1:] + z[:, :-1])
             hi = torch.cat([mid, z[:, -1:]], -1)
             lo = torch.cat([z[:, :1], mid], -1)
-            z = lo + (hi - lo) * torch.rand(z.shape).to(dev)
-        torch.randint(z.shape[-1], (R,))                     # the reference draws (and discards) an index here (:91)
+            shape = z.shape
+            z = lo + (hi - lo) * _draw(model, "uniform_jitter", lambda: torch.rand(shape), dev)
+        if getattr(model, "static_randoms", None) is None:
+            torch.randint(z.shape[-1], (R,))                 # the reference draws (and discards) an index here (:91)
+        else:                                                # graph replay: keep the draw in the refill sequence
+            n = z.shape[-1]
+            _draw(model, "uniform_dropped_idx", lambda: torch.randint(n, (R,)), dev)
         return z
 
     def get_z_vals_fine(self, z_vals, weights, model):
@@ -123,6 +135,11 @@ class ErrorBoundSampler(RaySampler):
         self.inverse_sphere_bg = False
         self.uniform_sampler = UniformSampler(scene_bounding_sphere, near, N_samples_eval)
         self.last_rounds = 0          # refinement rounds taken by the last call (reported by bench.py)
+        # (1 / (4 log(1 + eps))) of the initial beta (:143), evaluated once in fp32 on the host: a device-side torch.tensor(eps + 1)
+        # would be a pageable upload per call (a sync, and not capturable)
+        self._beta_c = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
+        self.sync_free = False        # True: get_z_vals_device (control flow on the device, HIP-graph capturable)
+        self._ctl = None              # device control words of the last sync-free call
 
     # ----- pieces of Algorithm 1 --------------------------------------------------------------
     @staticmethod
@@ -146,16 +163,61 @@ class ErrorBoundSampler(RaySampler):
         err = (torch.exp(-d_star / beta) * dists ** 2.0 / (4.0 * beta ** 2)).cumsum(-1)
         return ((torch.exp(err).clamp(max=1.0e6) - 1.0) * torch.exp(-opt_depth[:, :-1])).max(-1)[0]
 
+    def get_z_vals_device(self, ray_dirs, cam_loc, model):
+        """Algorithm 1 without host synchronisation: always `max_total_iters` rounds of launches, the batch-global test of :200 kept
+        in device memory (include/neat_hip.h "a3 without host synchronisation"); the launches after the final round return at once.
+        Same arithmetic as get_z_vals.  Differences, all in the random draws: the final u [R, N] is drawn before the rounds instead of
+        in the last one (same position in the CPU stream: the refine rounds draw nothing), and the training-mode
+        `randperm(n)[:N_extra]` -- whose n is only known on the device -- becomes "the N_extra smallest of n uniform keys", the same
+        distribution from a different stretch of the stream.  Eval mode draws nothing here and is bit-identical to get_z_vals."""
+        from . import ops
+        dev, R = ray_dirs.device, ray_dirs.shape[0]
+        K, Ne, N = self.max_total_iters, self.N_samples_eval, self.N_samples
+        beta0 = model.density.get_beta().detach()
+        z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
+        gap = z[:, 1:] - z[:, :-1]
+        beta = torch.sqrt(self._beta_c * (gap ** 2.0).sum(-1))
+        ctl = torch.zeros(2 * K + 1, dtype=torch.int32, device=dev)
+        u_refine = torch.linspace(0.0, 1.0, Ne, device=dev)
+        u_final = _draw(model, "sampler_u", lambda: torch.rand(R, N), dev) if model.training else torch.linspace(0.0, 1.0, N, device=dev)
+        samples, z_final = torch.empty(R, N, device=dev), torch.empty(R, Ne * K, device=dev)
+        fresh, order, sdf = z, None, None
+        cam, dirs = cam_loc.unsqueeze(1), ray_dirs.unsqueeze(1)
+        for k in range(K):
+            pts = torch.addcmul(cam, fresh.unsqueeze(2), dirs).reshape(-1, 3)
+            with torch.no_grad():
+                new_sdf = model.implicit_network.get_sdf_vals(pts, gate=(ctl, K + k - 1, 1) if k > 0 else None).reshape(R, -1)
+            sdf, beta, fresh, z_next, order_next = ops.sampler_round_dev(z, sdf, new_sdf, order, beta, beta0, self.eps, self.beta_iters,
+                                                                         self.add_tiny, u_refine, u_final, samples, z_final, ctl, k, K)
+            z, order = z_next, order_next
+        self._ctl = ctl
+        self.last_rounds = None                              # read lazily: rounds_taken()
+        n_extra = max(self.N_samples_extra, 0)
+        keys = _draw(model, "sampler_keys", lambda: torch.rand(Ne * K), dev) if (n_extra and model.training) else None
+        n_out = N + 2 + n_extra
+        eik_idx = _draw(model, "sampler_eik_idx", lambda: torch.randint(n_out, (R,)).to(torch.int32), dev)
+        z_vals, z_eik, self.last_pick = ops.sampler_finish_dev(samples, z_final, ctl, K, keys, n_extra, self.near, self.far, eik_idx)
+        return z_vals, z_eik
+
+    def rounds_taken(self):
+        """Rounds of Algorithm 1 the last call ran (one device read when the last call was sync-free)."""
+        if self.last_rounds is None and self._ctl is not None:
+            K = self.max_total_iters
+            self.last_rounds = int((self._ctl[K:2 * K] != 0).sum().item())
+        return self.last_rounds
+
     def get_z_vals(self, ray_dirs, cam_loc, model):
         """Algorithm 1 with the per-ray work in HIP (neat_sampler_* kernels, one wavefront per ray) and the MLP queries in
         the SDF kernels.  Control flow, the one host sync per round and the CPU random draws follow the reference."""
         from . import ops
+        if self.sync_free and ray_dirs.is_cuda:
+            return self.get_z_vals_device(ray_dirs, cam_loc, model)
         dev, R = ray_dirs.device, ray_dirs.shape[0]
         beta0 = model.density.get_beta().detach()
         z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
         fresh, order, sdf = z, None, None
         gap = z[:, 1:] - z[:, :-1]
-        beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0, device=dev)))) * (gap ** 2.0).sum(-1))
+        beta = torch.sqrt(self._beta_c * (gap ** 2.0).sum(-1))
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         rounds, open_ = 0, True
         while open_ and rounds < self.max_total_iters:
@@ -171,7 +233,7 @@ class ErrorBoundSampler(RaySampler):
             if refine or not model.training:
                 u = torch.linspace(0.0, 1.0, n, device=dev)
             else:
-                u = torch.rand(R, n).to(dev)
+                u = _draw(model, "sampler_u", lambda: torch.rand(R, n), dev)
             fresh, zm, order = ops.sampler_resample(z, sdf, beta, u, refine, self.add_tiny)
             if refine:
                 z = zm
@@ -182,9 +244,9 @@ class ErrorBoundSampler(RaySampler):
                 pick = torch.randperm(z.shape[1])[:self.N_samples_extra]
             else:
                 pick = torch.linspace(0, z.shape[1] - 1, self.N_samples_extra).long()
-            pick = pick.to(torch.int32).to(dev)
+            pick = _draw(model, "sampler_pick", lambda: pick.to(torch.int32), dev)
         n_out = self.N_samples + 2 + (self.N_samples_extra if self.N_samples_extra > 0 else 0)
-        eik_idx = torch.randint(n_out, (R,)).to(torch.int32).to(dev)
+        eik_idx = _draw(model, "sampler_eik_idx", lambda: torch.randint(n_out, (R,)).to(torch.int32), dev)
         return ops.sampler_finish(fresh, z, pick, self.near, self.far, eik_idx)
 
     # ---- torch-on-device formulation of the same algorithm (kept for cross-checking the kernels in the gpu tests) ----

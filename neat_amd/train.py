@@ -58,6 +58,10 @@ class Trainer:
                 self._static_gt[k] = v.to(self.device).clone()
         self.model.static_randoms = {}
         self.loss.nan_check = "off"
+        sampler = getattr(self.model, "ray_sampler", None)
+        was_sync_free = getattr(sampler, "sync_free", None)
+        if was_sync_free is not None:
+            sampler.sync_free = True                        # Algorithm 1 with its control flow on the device: no .item() per round
         try:
             if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up runs on a side stream on purpose
@@ -83,6 +87,8 @@ class Trainer:
         except Exception as exc:                            # a sync inside the step, an uncapturable op ...
             self.model.static_randoms = None
             self.loss.nan_check = "deferred"
+            if was_sync_free is not None:
+                sampler.sync_free = was_sync_free
             self._graph = None
             self.capture_error = exc
             torch.cuda.synchronize()

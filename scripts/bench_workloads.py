@@ -11,23 +11,38 @@ from neat_amd.train import Trainer, synthetic_batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--only-sampler", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
 tr = Trainer(device=dev, state_dict={k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()})
 tr.model.set_precision(args.precision)
 _, inp, gt = synthetic_batch(42, 1024, dev)
-for _ in range(3):
-    tr.step(inp, gt)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(args.steps):
-    out, lo = tr.step(inp, gt)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / args.steps
-S = out["points"].shape[0] // 1024 if out["points"].dim() == 2 else out["points"].shape[1]
-print(json.dumps({"workload": "train step with ErrorBoundSampler, 1024 rays, conf-default sampler", "ms_per_step": 1e3 * dt,
-                  "samples_per_ray": S, "ray_samples_per_s": 1024 * S / dt, "rays_per_s": 1024 / dt, "precision": args.precision}))
+def timed_steps(label):
+    for _ in range(3):
+        tr.step(inp, gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, lo = tr.step(inp, gt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    S = out["points"].shape[0] // 1024 if out["points"].dim() == 2 else out["points"].shape[1]
+    print(json.dumps({"workload": "train step with ErrorBoundSampler, 1024 rays, conf-default sampler", "sampler": label,
+                      "rounds": tr.model.ray_sampler.rounds_taken(), "ms_per_step": 1e3 * dt, "samples_per_ray": S,
+                      "ray_samples_per_s": 1024 * S / dt, "rays_per_s": 1024 / dt, "precision": args.precision}), flush=True)
+
+
+timed_steps("host decides (one sync per round), eager")
+tr.model.ray_sampler.sync_free = True
+timed_steps("device decides (no sync), eager")
+graphed = tr.capture(inp, gt)
+timed_steps("device decides (no sync), HIP graph" if graphed else f"capture failed: {tr.capture_error!r}")
+tr.model.static_randoms = None
+tr._graph = None
+tr.model.ray_sampler.sync_free = False
+if args.only_sampler:
+    sys.exit(0)
 tr.model.eval()
 _, inp2, _ = synthetic_batch(43, 2048, dev)
 with torch.no_grad():

@@ -735,6 +735,103 @@ def test_sampler_kernels_match_torch_formulation(dev, golden, variant, train):
     assert float(z1.min()) >= 0.0 and float(z1.max()) <= 6.0 + 1e-5
 
 
+@pytest.mark.parametrize("variant,train", [("rough", False), ("init", False), ("rough", True), ("init", True)])
+def test_sampler_device_control_flow_equals_host(dev, golden, variant, train):
+    """Algorithm 1 with the `beta.max() > beta0` decision kept on the device (fixed max_total_iters rounds, gated
+    launches, no .item()) against the host-synchronised path: same round count and BIT-identical depths.  In training the device
+    path picks the extra grid points from random keys; the host path is replayed with a permutation that starts with that pick."""
+    from tests.util_replay import RngReplay
+    from neat_amd import rend_util
+    m = build_model(dev, variant, train=train)
+    smp = m.ray_sampler
+    g = golden(f"g6_sampler_{'train' if train else 'eval'}_{variant}")
+    d, c = rend_util.get_camera_params(T(g["uv"]).to(dev), T(g["pose"]).to(dev), T(g["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(d.shape[0], 3).contiguous()
+    if train:
+        dev_draws = [("rand", T(g["t_rand"])), ("randint", None), ("rand", T(g["u_final"])), ("rand", None), ("randint", T(g["eik_idx"]))]
+    else:
+        dev_draws = [("randint", None), ("randint", T(g["eik_idx"]))]
+    smp.sync_free = True
+    with RngReplay(list(dev_draws)):
+        z_dev, e_dev = smp.get_z_vals(d, c, m)
+    rounds_dev = smp.rounds_taken()
+    K = smp.max_total_iters
+    ctl = smp._ctl.cpu()
+    n_final = int(ctl[2 * K])
+    assert n_final == smp.N_samples_eval * rounds_dev
+    cont = ctl[K:2 * K].tolist()
+    assert cont[:rounds_dev] == [1] * (rounds_dev - 1) + [2] and not any(cont[rounds_dev:])
+    pick = smp.last_pick.cpu().long()
+    assert len(set(pick.tolist())) == smp.N_samples_extra and int(pick.max()) < n_final and int(pick.min()) >= 0
+    smp.sync_free = False
+    if train:
+        rest = torch.tensor([i for i in range(n_final) if i not in set(pick.tolist())], dtype=torch.long)
+        host_draws = [("rand", T(g["t_rand"])), ("randint", None), ("rand", T(g["u_final"])), ("randperm", torch.cat([pick, rest])),
+                      ("randint", T(g["eik_idx"]))]
+    else:
+        host_draws = dev_draws
+    with RngReplay(list(host_draws)):
+        z_host, e_host = smp.get_z_vals(d, c, m)
+    assert smp.last_rounds == rounds_dev
+    assert torch.equal(z_dev, z_host) and torch.equal(e_dev, e_host)
+
+
+def test_sampler_device_pick_is_a_uniform_subset(dev):
+    """The key-ranking pick of neat_sampler_finish_dev: N_extra distinct grid indices below n, every index equally likely."""
+    from neat_amd import ops
+    K, Ne, n_extra, R, N = 5, 128, 32, 4, 64
+    counts = torch.zeros(3 * Ne)
+    gen = torch.Generator().manual_seed(5)
+    ctl = torch.zeros(2 * K + 1, dtype=torch.int32, device=dev)
+    ctl[2 * K] = 3 * Ne                                            # grid of the third round
+    z_final = torch.rand(R, Ne * K, generator=gen).sort(-1)[0].to(dev)
+    samples = torch.rand(R, N, generator=gen).sort(-1)[0].to(dev)
+    eik = torch.zeros(R, dtype=torch.int32, device=dev)
+    for _ in range(200):
+        keys = torch.rand(Ne * K, generator=gen)
+        z, _, pick = ops.sampler_finish_dev(samples, z_final, ctl, K, keys.to(dev), n_extra, 0.0, 6.0, eik)
+        pick = pick.cpu().long()
+        want = torch.argsort(keys[:3 * Ne], stable=True)[:n_extra]
+        assert torch.equal(pick, want)
+        counts[pick] += 1
+        assert (z[:, 1:] >= z[:, :-1]).all()
+    # 200 * 32 / 384 = 16.7 expected hits per index; binomial sd about 3.9
+    assert float(counts.min()) >= 3 and float(counts.max()) <= 36
+    # eval rule: torch.linspace(0, n - 1, n_extra).long()
+    for n in (128, 256, 384, 512, 640):
+        ctl[2 * K] = n
+        _, _, pick = ops.sampler_finish_dev(samples, z_final, ctl, K, None, n_extra, 0.0, 6.0, eik)
+        assert torch.equal(pick.cpu().long(), torch.linspace(0, n - 1, n_extra).long()), n
+
+
+def test_graph_replay_with_sampler_equals_eager(dev):
+    """The REAL training step (ErrorBoundSampler on, no given depths) captures into a HIP graph once the sampler keeps its control
+    flow on the device, and the replayed trajectory equals the eager one of the same sync-free sampler (same CPU random stream)."""
+    from neat_amd.train import Trainer, synthetic_batch
+
+    def run(graph):
+        torch.manual_seed(9)
+        tr = Trainer(device=dev, state_dict={k: T(v) for k, v in synth.synth_state_dict(11, "rough").items()})
+        tr.model.ray_sampler.sync_free = True
+        _, inp, gt = synthetic_batch(11, 96, dev)
+        losses = []
+        if graph:
+            assert tr.capture(inp, gt, warmup=2), repr(tr.capture_error)      # = 3 optimizer steps
+        for _ in range(3 if graph else 6):
+            _, lo = tr.step(inp, gt)
+            losses.append(float(lo["loss"]))
+        assert tr.model.ray_sampler.rounds_taken() >= 1
+        return {k: p.detach().clone() for k, p in tr.model.named_parameters()}, losses
+
+    p_e, l_e = run(False)
+    p_g, l_g = run(True)
+    assert abs(l_e[-1] - l_g[-1]) <= 1e-5 * abs(l_e[-1])
+    for k in p_e:
+        err = float((p_e[k] - p_g[k]).abs().max())
+        assert err <= 1e-5 * max(1.0, float(p_e[k].abs().max())), (k, err)
+
+
 def test_hierarchical_sampler_on_device(dev, golden):
     """a2 + a13 (BASELINE config 5: 64 coarse + 64 fine): UniformSampler / sample_pdf / get_z_vals_fine on the device
     against the reference's golden vectors (det = linspace u, and recorded random u)."""
@@ -924,8 +1021,12 @@ def test_graph_falls_back_for_other_batches(dev):
     _, inp, gt = synthetic_batch(5, 64, dev)
     _, inp2, gt2 = synthetic_batch(6, 64, dev, view=1)
     _, inp3, gt3 = synthetic_batch(7, 32, dev)
-    # depth samples come from the sampler here (host syncs): capture must fail cleanly and leave an eager trainer
+    # a step with a host synchronisation in it: capture must fail cleanly and leave an eager trainer
+    real_forward = tr.model.forward
+    tr.model.forward = lambda batch: (lambda out: (float(out["rgb_values"].sum().item()), out)[1])(real_forward(batch))
     assert not tr.capture(inp, gt) and tr.capture_error is not None
+    tr.model.forward = real_forward
+    assert tr.model.ray_sampler.sync_free is False and tr.model.static_randoms is None
     tr.step(inp, gt)
     tr.model.z_vals_override = T(synth.synth_z_vals(5, 64, 40)).to(dev)
     assert tr.capture(inp, gt), repr(tr.capture_error)
