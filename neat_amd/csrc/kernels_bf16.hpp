@@ -1275,6 +1275,10 @@ __global__ void oct_pack_kernel(OctPackArgs a) {
 //    (`__syncthreads()` would drain the DMA queue); nothing else in the loop uses the vector-memory counter.
 // Bias gradient = row sums of pair 0's A, taken from the A fragments on the VALU by the waves of column half 0.
 // ---------------------------------------------------------------------------------------------
+// NEAT_W3_ABLATE (probe builds only; results are WRONG): 1 = no MFMAs, 2 = no LDS fragment reads, 3 = no partial-tile stores, 4 = no DMA
+#ifndef NEAT_W3_ABLATE
+#define NEAT_W3_ABLATE 0
+#endif
 constexpr int W3T = 512, W3P = 32, W3NS = 4;
 constexpr int W3_STAGE = 2 * 256 * W3P * 2;          // bytes per stage: A | B, each 8 quads x 32 points x 64 B
 constexpr int W3_LDS_BYTES = W3NS * W3_STAGE;
@@ -1344,6 +1348,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   auto issue = [&](int tau) {
     const int q = tau >= nsteps ? 1 : 0;
     const int st = tau - q * nsteps;
+    if (NEAT_W3_ABLATE == 4) return;
     const unsigned short* base = q ? opbase[1] : opbase[0];
     const unsigned short* base2 = q ? opbase2[1] : opbase2[0];
     const int maxoct = q ? opmax[1] : opmax[0];
@@ -1394,6 +1399,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       uint4 av[2], bv[4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
+        if (NEAT_W3_ABLATE == 2) { av[i] = make_uint4(lane, tau, i, s2); continue; }
         const unsigned char* ap = slot + ((wr >> 5) + i) * 2048 + s2 * 1024 + frag_off;
         const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ap));
         const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(ap + 256));
@@ -1401,6 +1407,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (NEAT_W3_ABLATE == 2) { bv[j] = make_uint4(lane, tau, j, s2); continue; }
         const unsigned char* bp = slot + W3_STAGE / 2 + ((wc >> 5) + j) * 2048 + s2 * 1024 + frag_off;
         const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(bp));
         const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(bp + 256));
@@ -1437,12 +1444,18 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
         if (!liveR[i]) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (liveC[j])
+          if (liveC[j]) {
+            if (NEAT_W3_ABLATE == 1) { asm volatile("" :: "v"(av[i].x), "v"(av[i].w), "v"(bv[j].x), "v"(bv[j].w)); continue; }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
+          }
       }
     }
   }
   float* dstp = a.partial + (size_t)prob * a.prob_stride + (size_t)blockIdx.y * a.split_stride;
+  auto put = [&](float* q, float v) {
+    if (NEAT_W3_ABLATE == 3 && v != 123.0f) return;
+    *q = v;
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (!liveR[i]) continue;
@@ -1453,7 +1466,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = wc + 32 * j + (lane & 31);
-        if (liveC[j] && k < a.K) dstp[(size_t)n * a.row_stride + a.col_off + k] = acc[i][j][r];
+        if (liveC[j] && k < a.K) put(dstp + (size_t)n * a.row_stride + a.col_off + k, acc[i][j][r]);
       }
     }
   }
@@ -1463,7 +1476,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       float v = rsum[i];
       v += __shfl_xor(v, 32);
       const int n = wr + 32 * i + (lane & 31);
-      if (lane < 32 && n < a.N) dstp[(size_t)n * a.row_stride + a.bias_col] = v;
+      if (lane < 32 && n < a.N) put(dstp + (size_t)n * a.row_stride + a.bias_col, v);
     }
   }
 }

@@ -22,7 +22,7 @@
 namespace neat {
 
 // NEAT_F6_ABLATE (probe builds only; results are WRONG): 1 = epilogue without the softplus math, 2 = no MFMAs, 3 = no B-fragment
-// LDS reads, 4 = no stage barriers, 5 = no epilogue LDS writes
+// LDS reads, 4 = no stage barriers, 5 = no epilogue LDS writes, 9 = no HBM stores of the hidden activations (save mode)
 #ifndef NEAT_F6_ABLATE
 #define NEAT_F6_ABLATE 0
 #endif
@@ -126,7 +126,7 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
   }
   if (E::ACT && NEAT_F6_ABLATE != 5) *reinterpret_cast<uint2*>(L.quad[E::DST] + ((i * 4 + q) * BP + t * 32) * 16) = v;
   if (NEAT_F6_ABLATE == 5) asm volatile("" :: "v"(v.x), "v"(v.y));
-  if (E::SAVE && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
+  if (E::SAVE && NEAT_F6_ABLATE != 9 && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q) * L.ldp16) + t * 512) + (size_t)L.gquad) = v;
 }
 
@@ -284,14 +284,21 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       // k: rows 3+6k.. = sin(2^k xyz), rows 6+6k.. = cos(2^k xyz)
       {
         constexpr int NG = F6T / BP, NFQ = 6 / (NG < 6 ? (NG == 4 ? 3 : NG) : 6);     // 2 groups x 3 frequencies, or 3 (of 4) groups x 2
-        const int p = tid & (BP - 1), fg = tid / BP;
+        const int p = tid & (BP - 1), fg = __builtin_amdgcn_readfirstlane(tid / BP);      // (BP >= 64: the group is wave-uniform)
         const bool ok = p < nt * 32;
         float xc[3];
+        // rows of x_fm / E: kernarg base (SGPR pair) + ONE 32-bit per-lane byte offset computed where it is used from an opaque
+        // copy of ldp.  (With 64-bit row addresses the 13 row pointers of a thread -- its rows depend on its frequency group --
+        // were hoisted out of the batch loop and spilled, and every reload carried an s_waitcnt vmcnt(0) that serialised the E
+        // stores: +75 us per launch in save mode.)
+        unsigned pvo = (unsigned)(p0 + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
+        asm volatile("" : "+v"(pvo), "+v"(ldp4));
 #pragma unroll
-        for (int c = 0; c < 3; ++c) xc[c] = ok ? a.x_fm[(size_t)c * a.ldp + p0 + p] : 0.0f;
+        for (int c = 0; c < 3; ++c)
+          xc[c] = ok ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_fm) + ((unsigned)c * ldp4 + pvo)) : 0.0f;
         auto put = [&](int j, float v) {
           pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
-          if (SAVE && ok) a.E[(size_t)j * a.ldp + p0 + p] = v;
+          if (SAVE && ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo)) = v;
         };
         if (fg == NG - 1) {
 #pragma unroll
@@ -507,7 +514,7 @@ __device__ __forceinline__ void ph_epi(const F6Lane& L, const f32x16& acc, const
       }
     }
     if (E::ACT) *reinterpret_cast<uint2*>(L.quad[E::DST] + (q * BP + t * 32) * 16) = v;
-    if (E::SAVE && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
+    if (E::SAVE && NEAT_F6_ABLATE != 9 && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
       *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((size_t)(q * L.ldp16) + t * 512) + (size_t)L.gquad) = v;
   }
 }
@@ -584,14 +591,21 @@ __global__ __launch_bounds__(PHT, 2) void sdf_fused_ph_kernel(FusedArgs a, int n
       load_w(wA, a.Wp[1], 16, 256);
       // ---- positional encoding (embedder.py:12-36): thread = (point, group of 2 frequencies; the 4th group writes x itself)
       {
-        const int p = tid & (BP - 1), fg = tid / BP;
+        const int p = tid & (BP - 1), fg = __builtin_amdgcn_readfirstlane(tid / BP);      // (BP >= 64: the group is wave-uniform)
         const bool ok = p < nt * 32;
         float xc[3];
+        // rows of x_fm / E: kernarg base (SGPR pair) + ONE 32-bit per-lane byte offset computed where it is used from an opaque
+        // copy of ldp.  (With 64-bit row addresses the 13 row pointers of a thread -- its rows depend on its frequency group --
+        // were hoisted out of the batch loop and spilled, and every reload carried an s_waitcnt vmcnt(0) that serialised the E
+        // stores: +75 us per launch in save mode.)
+        unsigned pvo = (unsigned)(p0 + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
+        asm volatile("" : "+v"(pvo), "+v"(ldp4));
 #pragma unroll
-        for (int c = 0; c < 3; ++c) xc[c] = ok ? a.x_fm[(size_t)c * a.ldp + p0 + p] : 0.0f;
+        for (int c = 0; c < 3; ++c)
+          xc[c] = ok ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_fm) + ((unsigned)c * ldp4 + pvo)) : 0.0f;
         auto put = [&](int j, float v) {
           pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
-          if (SAVE && ok) a.E[(size_t)j * a.ldp + p0 + p] = v;
+          if (SAVE && ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo)) = v;
         };
         if (fg == 3) {
 #pragma unroll

@@ -47,27 +47,69 @@ __device__ __forceinline__ float interval_bound(float a, float d0, float d1) {
   return (sg1 * sg0 == 1.0f) ? ds : 0.0f;
 }
 
-// max_i of the opacity error bound for one beta (get_error_bound, :285-293); arrays in LDS, m = n-1 intervals
-__device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
-  double carryE = 0.0, carryS = 0.0;
+// max_i of the opacity error bound for one beta (get_error_bound, :285-293); arrays in LDS, m = n-1 intervals.
+// Lane l owns the PER consecutive intervals [l*PER, (l+1)*PER) (PER odd: conflict-free LDS stride): it sums its terms in fp64, one
+// wave scan of the 64 lane totals gives each lane its offset, a second pass over the lane's registers applies it.  PER is a template
+// parameter so that the PER element chains (three expf and two IEEE divisions each) are unrolled and overlap: with one wave per SIMD
+// (1024 rays = 1024 waves) the kernel is bound by dependent-instruction latency, not by the scans.
+template <int PER>
+__device__ __forceinline__ float error_bound_t(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
+  const int j0 = lane * PER;
+  const float q = 4.0f * beta * beta;
+  float e[PER], sv[PER];
+  double te = 0.0, ts = 0.0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const bool ok = j0 + k < m;
+    const int j = min(j0 + k, m - 1);
+    const float d = dist[j];
+    e[k] = ok ? d * laplace_sigma(sdf[j], beta) : 0.0f;
+    sv[k] = ok ? expf(-dstar[j] / beta) * (d * d) / q : 0.0f;
+    te += (double)e[k];
+    ts += (double)sv[k];
+  }
+  double re = wave_incl_scan_d(te, lane) - te, rs = wave_incl_scan_d(ts, lane) - ts;      // exclusive offsets of this lane
   float best = -INFINITY;
-  for (int c0 = 0; c0 < m; c0 += 64) {
-    const int j = c0 + lane;
-    const bool ok = j < m;
-    float e = 0.0f, s = 0.0f;
-    if (ok) {
-      const float d = dist[j];
-      e = d * laplace_sigma(sdf[j], beta);
-      s = expf(-dstar[j] / beta) * (d * d) / (4.0f * beta * beta);
-    }
-    const double inclE = wave_incl_scan_d((double)e, lane), inclS = wave_incl_scan_d((double)s, lane);
-    double exclE = __shfl_up(inclE, 1);
-    if (lane == 0) exclE = 0.0;
-    if (ok) best = fmaxf(best, (fminf(expf((float)(carryS + inclS)), 1.0e6f) - 1.0f) * expf(-(float)(carryE + exclE)));
-    carryE += __shfl(inclE, 63);
-    carryS += __shfl(inclS, 63);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    rs += (double)sv[k];
+    const float b = (fminf(expf((float)rs), 1.0e6f) - 1.0f) * expf(-(float)re);
+    if (j0 + k < m) best = fmaxf(best, b);
+    re += (double)e[k];
   }
   return wave_max(best);
+}
+
+__device__ __forceinline__ float error_bound_loop(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
+  const int per = ((m + 63) >> 6) | 1;
+  const int j0 = lane * per, j1 = min(m, j0 + per);
+  const float q = 4.0f * beta * beta;
+  double te = 0.0, ts = 0.0;
+  for (int j = j0; j < j1; ++j) {
+    const float d = dist[j];
+    te += (double)(d * laplace_sigma(sdf[j], beta));
+    ts += (double)(expf(-dstar[j] / beta) * (d * d) / q);
+  }
+  double re = wave_incl_scan_d(te, lane) - te, rs = wave_incl_scan_d(ts, lane) - ts;
+  float best = -INFINITY;
+  for (int j = j0; j < j1; ++j) {
+    const float d = dist[j];
+    rs += (double)(expf(-dstar[j] / beta) * (d * d) / q);
+    best = fmaxf(best, (fminf(expf((float)rs), 1.0e6f) - 1.0f) * expf(-(float)re));
+    re += (double)(d * laplace_sigma(sdf[j], beta));
+  }
+  return wave_max(best);
+}
+
+__device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
+  switch (((m + 63) >> 6) | 1) {      // n = 128 k samples (the reference's grids) -> PER = 3, 5, 7, 9, 11
+    case 3: return error_bound_t<3>(sdf, dist, dstar, m, beta, lane);
+    case 5: return error_bound_t<5>(sdf, dist, dstar, m, beta, lane);
+    case 7: return error_bound_t<7>(sdf, dist, dstar, m, beta, lane);
+    case 9: return error_bound_t<9>(sdf, dist, dstar, m, beta, lane);
+    case 11: return error_bound_t<11>(sdf, dist, dstar, m, beta, lane);
+    default: return error_bound_loop(sdf, dist, dstar, m, beta, lane);
+  }
 }
 
 struct SamplerBoundArgs {
@@ -232,26 +274,35 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
 //   eval : torch.linspace(0, n - 1, n_extra).long()            (the reference's formula, fp32, symmetric around the middle)
 //   train: a uniformly random n_extra-subset without replacement (the reference: torch.randperm(n)[:n_extra]) = the n_extra smallest
 //          of n random keys (drawn on the CPU generator), in key order.  One workgroup.
-__global__ __launch_bounds__(256) void sampler_pick_kernel(const int* __restrict__ n_ptr, const float* __restrict__ keys, int n_extra,
+__global__ __launch_bounds__(1024) void sampler_pick_kernel(const int* __restrict__ n_ptr, const float* __restrict__ keys, int n_extra,
                                                            int* __restrict__ pick) {
-  __shared__ float sk[SMAX];
+  __shared__ __attribute__((aligned(16))) float sk[SMAX];
   const int n = *n_ptr, tid = threadIdx.x;
   if (!keys) {
     const float start = 0.0f, end = (float)(n - 1), step = (end - start) / (float)(n_extra - 1);
-    for (int j = tid; j < n_extra; j += 256) {
+    for (int j = tid; j < n_extra; j += 1024) {
       const float v = j < n_extra / 2 ? start + step * (float)j : end - step * (float)(n_extra - 1 - j);
       pick[j] = (int)v;
     }
     return;
   }
-  for (int i = tid; i < n; i += 256) sk[i] = keys[i];
+  for (int i = tid; i < SMAX; i += 1024) sk[i] = i < n ? keys[i] : INFINITY;      // padding never ranks below a key
   __syncthreads();
-  for (int i = tid; i < n; i += 256) {
-    const float x = sk[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += (sk[j] < x) || (sk[j] == x && j < i);
-    if (rank < n_extra) pick[rank] = i;
+  const float4* sk4 = (const float4*)sk;
+  const int n4 = (n + 3) >> 2, i = tid;
+  if (i >= n) return;
+  const float x = sk[i];
+  int lt = 0, le = 0;
+#pragma unroll 4
+  for (int j = 0; j < n4; ++j) {                // (one broadcast ds_read_b128 per four keys)
+    const float4 k = sk4[j];
+    lt += (k.x < x) + (k.y < x) + (k.z < x) + (k.w < x);
+    le += (k.x <= x) + (k.y <= x) + (k.z <= x) + (k.w <= x);
   }
+  int rank = lt;
+  if (le - lt > 1)                               // equal keys (24-bit uniforms: about 1 call in 80 has a pair): the lower index first
+    for (int j = 0; j < i; ++j) rank += sk[j] == x;
+  if (rank < n_extra) pick[rank] = i;
 }
 
 struct SamplerFinishArgs {

@@ -1368,7 +1368,7 @@ int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, i
   if (R <= 0) return 0;
   if (N + 2 + n_extra > SMAX || ld_final > SMAX || !samples || !z_final || !n_final || (n_extra > 0 && !pick) || n_extra == 1 || !eik_idx ||
       !z_vals || !z_eik) return -1;
-  if (n_extra > 0) hipLaunchKernelGGL(sampler_pick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_final, keys, n_extra, pick);
+  if (n_extra > 0) hipLaunchKernelGGL(sampler_pick_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_final, keys, n_extra, pick);
   SamplerFinishArgs a{samples, N, z_final, 0, pick, n_extra, near, far, R, eik_idx, z_vals, z_eik, ld_final};
   hipLaunchKernelGGL(sampler_finish_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
