@@ -252,6 +252,11 @@ class JunctionOutputs(dict):
     def items(self):
         return [(k, self[k]) for k in self.keys()]
 
+    def detached(self):
+        """The same outputs without their autograd history (what a trainer hands back after it has run backward itself)."""
+        det = lambda v: v.detach() if isinstance(v, torch.Tensor) else v
+        return JunctionOutputs({k: det(v) for k, v in dict.items(self)}, det(self.good), {k: det(v) for k, v in self.padded.items()})
+
 
 class VolSDFNetwork(_HipModule):
     def __init__(self, conf):

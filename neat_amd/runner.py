@@ -87,6 +87,12 @@ class TrainRunner:
             else:
                 for p in self.model.parameters():
                     dist.broadcast(p.data, src=0)
+        # the step itself: eager the first time a view comes up, from then on replayed from that view's HIP graph (train.Trainer).
+        # New optional conf key train.hip_graphs (default: on for CUDA); the reference loop is the eager path.
+        from .train import Trainer
+        self.trainer = Trainer(device=self.device, parts=(self.model, self.loss, self.optimizer, self.scheduler, self.bucket))
+        if self.device.type == "cuda" and self.conf.get_bool("train.hip_graphs", default=True):
+            self.trainer.auto_capture = 1
         self.checkpoint_freq = self.conf.get_int("train.checkpoint_freq", default=100)
         self.start_epoch = 0
         self.log_freq = log_freq
@@ -117,14 +123,9 @@ class TrainRunner:
             for it, (indices, model_input, ground_truth) in enumerate(self.train_dataloader):
                 for k in ("intrinsics", "uv", "pose", "uv_proj"):
                     model_input[k] = model_input[k].to(self.device)
-                outputs = self.model(model_input)
-                losses = self.loss(outputs, ground_truth)
-                self.optimizer.zero_grad(set_to_none=True)
-                losses["loss"].backward()
-                self.bucket.all_reduce_mean()              # world > 1: ONE flat all-reduce of all gradients; no-op on one GPU
-                self.optimizer.step()
+                # forward, loss, backward, [ONE flat all-reduce of all gradients when world > 1], Adam, scheduler
+                outputs, losses = self.trainer.step(model_input, ground_truth)
                 self.train_dataset.change_sampling_idx(self.num_pixels)
-                self.scheduler.step()
                 if (it + 1) % self.log_freq == 0 or it + 1 == len(self.train_dataloader):
                     with torch.no_grad():
                         psnr = rend_util.get_psnr(outputs["rgb_values"], ground_truth["rgb"].to(self.device).reshape(-1, 3))

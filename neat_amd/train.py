@@ -8,26 +8,44 @@ from .loss import VolSDFLoss
 from .wireframe import WireframeGraph
 
 
+GT_KEYS = ("rgb", "lines2d")      # what VolSDFLoss reads from the ground truth (loss_wfr.py:92-110)
+
+
 class Trainer:
-    def __init__(self, model_conf=None, loss_conf=None, lr=5.0e-4, decay_steps=200000, device="cuda:0", state_dict=None):
+    def __init__(self, model_conf=None, loss_conf=None, lr=5.0e-4, decay_steps=200000, device="cuda:0", state_dict=None, parts=None):
         self.device = torch.device(device)
-        self.model = networks.VolSDFNetwork(model_conf or synth.ABC_NEAT_A_MODEL_CONF)
-        if state_dict is not None:
-            self.model.load_state_dict(state_dict)
-        self.model.to(self.device).train()
-        self.loss = VolSDFLoss(**(loss_conf or synth.ABC_NEAT_A_LOSS_CONF))
-        if self.device.type == "cuda":
-            from .optim import FlatAdam
-            self.optimizer = FlatAdam(self.model.parameters(), lr=lr)      # torch.optim.Adam semantics, one HIP launch
+        if parts is not None:              # an already built model / loss / optimizer / scheduler / bucket (neat_amd.runner)
+            self.model, self.loss, self.optimizer, self.scheduler, self.bucket = parts
         else:
-            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)
-        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.1 ** (1.0 / decay_steps))
-        self.bucket = FlatGradBucket(self.model.parameters())
-        self._graph, self._captured, self._ring_pos, self.capture_error = None, None, 0, None
+            self.model = networks.VolSDFNetwork(model_conf or synth.ABC_NEAT_A_MODEL_CONF)
+            if state_dict is not None:
+                self.model.load_state_dict(state_dict)
+            self.model.to(self.device).train()
+            self.loss = VolSDFLoss(**(loss_conf or synth.ABC_NEAT_A_LOSS_CONF))
+            if self.device.type == "cuda":
+                from .optim import FlatAdam
+                self.optimizer = FlatAdam(self.model.parameters(), lr=lr)      # torch.optim.Adam semantics, one HIP launch
+            else:
+                self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)
+            self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.1 ** (1.0 / decay_steps))
+            self.bucket = FlatGradBucket(self.model.parameters())
+        self._graphs, self._pool, self._ring_pos, self.capture_error = {}, None, 0, None
+        self.auto_capture = 0             # > 0: a batch layout seen this many times eagerly is captured on its next visit
+        self._visits, self._uncapturable, self._last = {}, set(), None
+        self.replays = self.eager_steps = 0
 
     def step(self, model_input, ground_truth):
-        if self._graph is not None:
-            return self._replay(model_input, ground_truth)
+        if self._graphs or self.auto_capture:
+            key = self._layout_key(model_input, ground_truth)
+            entry = self._graphs.get(key)
+            if entry is not None:
+                return self._replay(entry, model_input, ground_truth)
+            if self.auto_capture and self.device.type == "cuda":
+                n = self._visits[key] = self._visits.get(key, 0) + 1
+                if n > self.auto_capture and self.capture(model_input, ground_truth, warmup=0):
+                    return self._graphs[key].outputs          # (capture() ends with one replayed step)
+        self.eager_steps += 1
+        self._last = None
         return self.step_eager(model_input, ground_truth)
 
     def step_eager(self, model_input, ground_truth):
@@ -38,83 +56,145 @@ class Trainer:
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         self.scheduler.step()
-        return out, losses
+        return _detached(out), _detached(losses)
 
-    # ---- HIP-graph mode: forward + loss + backward are captured once and replayed; the gradient all-reduce, the Adam
-    # launch and the scheduler stay outside (their arguments change every step).  Valid while the batch keeps its shapes
-    # and its wireframe (one graph per view in a real run); the step must be free of host synchronisation, which the
-    # hot path is when the depth samples are given or come from a sync-free sampler.
+    # ---- HIP-graph mode: forward + loss + backward are captured once PER BATCH LAYOUT and replayed; the gradient all-reduce, the
+    # Adam launch and the scheduler stay outside (their arguments change every step).  A layout = the tensor shapes of the batch, its
+    # wireframe object (the vertex count shapes the matching and its device tensors are baked into the graph) and the model switches
+    # that change what the forward launches.  A real run walks over the views of a scene (volsdf_train.py:361 draws a view per
+    # iteration): every view gets its own graph (auto_capture), all graphs share one memory pool -- they never run concurrently, so the
+    # 6.6 GB of per-step workspace exists once, not once per view.  The step must be free of host synchronisation: it is when the depth
+    # samples are given, or come from the sync-free sampler (ray_sampler.ErrorBoundSampler.get_z_vals_device).
+    @property
+    def _graph(self):
+        """Any captured graph (kept for callers that only ask "is the step replayed?")."""
+        return next(iter(self._graphs.values())).graph if self._graphs else None
+
+    def _layout_key(self, model_input, ground_truth):
+        key = []
+        for tag, batch in (("in", model_input), ("gt", ground_truth)):
+            for k in sorted(batch):
+                v = batch[k]
+                if isinstance(v, torch.Tensor):
+                    key.append((tag, k, tuple(v.shape), str(v.dtype)))
+                elif isinstance(v, (list, tuple)):
+                    key.append((tag, k, tuple(id(x) for x in v)))
+                else:
+                    key.append((tag, k, v if isinstance(v, (int, float, str, bool, type(None))) else id(v)))
+        zo = getattr(self.model, "z_vals_override", None)
+        key.append(("z_vals_override", None if zo is None else tuple(zo.shape)))
+        key.append(("training", self.model.training))
+        return tuple(key)
+
     def capture(self, model_input, ground_truth, warmup=2):
-        """Returns True if the step is now replayed from a HIP graph, False if capture was not possible (stays eager)."""
-        if self.device.type != "cuda" or self._graph is not None:
-            return self._graph is not None
-        tensor_keys = [k for k, v in model_input.items() if isinstance(v, torch.Tensor)]
-        self._static_in = dict(model_input)
-        self._static_gt = dict(ground_truth)
-        for k in tensor_keys:
-            self._static_in[k] = model_input[k].clone()
+        """Capture the step for this batch layout.  Returns True if it is now replayed from a HIP graph, False if capture was not
+        possible (the layout stays eager; `capture_error` holds the reason).  `warmup` eager optimizer steps on this batch run first
+        (lazy initialisations; 0 when the layout has already been stepped eagerly)."""
+        if self.device.type != "cuda":
+            return False
+        key = self._layout_key(model_input, ground_truth)
+        if key in self._graphs:
+            return True
+        if key in self._uncapturable:
+            return False
+        entry = _Captured()
+        entry.static_in, entry.static_gt = dict(model_input), dict(ground_truth)
+        for k, v in model_input.items():      # (host-side entries of a dataset sample -- masks, labels ... -- are not read by the forward)
+            if isinstance(v, torch.Tensor) and v.device == self.device:
+                entry.static_in[k] = v.clone()
         for k, v in ground_truth.items():
-            if isinstance(v, torch.Tensor):
-                self._static_gt[k] = v.to(self.device).clone()
-        self.model.static_randoms = {}
-        self.loss.nan_check = "off"
+            if isinstance(v, torch.Tensor) and k in GT_KEYS:
+                entry.static_gt[k] = v.to(self.device).clone()
+        # given depth samples are one more static input (the graph reads THIS tensor; a caller may assign another one later)
+        zo = getattr(self.model, "z_vals_override", None)
+        entry.static_z = None if zo is None else zo.clone()
+        entry.randoms = {}
+        # what the captured forward needs from the model, for the duration of the capture only -- eager steps of other layouts keep
+        # drawing fresh randoms, checking NaNs their way and using the sampler they were configured with
         sampler = getattr(self.model, "ray_sampler", None)
-        was_sync_free = getattr(sampler, "sync_free", None)
-        if was_sync_free is not None:
+        eager = (self.loss.nan_check, getattr(sampler, "sync_free", None))
+        self.model.static_randoms = entry.randoms          # persistent device tensor per draw site, refilled before every replay
+        self.loss.nan_check = "off"                         # the NaN flag stays on the device: check_nan()
+        if eager[1] is not None:
             sampler.sync_free = True                        # Algorithm 1 with its control flow on the device: no .item() per round
+        if entry.static_z is not None:
+            self.model.z_vals_override = entry.static_z
+        ok = False
+        torch.cuda.synchronize()                            # (captures are rare: start from an idle device)
         try:
             if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up runs on a side stream on purpose
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                   # warm-up on the side stream: lazy inits, allocator, draw sites
-                for _ in range(warmup):
-                    self._refill_randoms()
-                    self._fwd_bwd()
-                    self._finish_step()
+                for _ in range(warmup):                     # (real optimizer steps on this batch)
+                    self._refill_randoms(entry)
+                    self._fwd_bwd(entry)
+                    self._finish_step(None)
+                if not entry.randoms:                       # no warm-up step ran (auto-capture of a layout that already ran eagerly):
+                    rng = torch.get_rng_state()             # one forward registers the draw sites, without consuming the CPU stream
+                    with torch.no_grad():
+                        self.model(entry.static_in)
+                    torch.set_rng_state(rng)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self._refill_randoms()
+            self._refill_randoms(entry)
             self.optimizer.zero_grad(set_to_none=True)
+            # whatever the model caches per parameter version (the packed weights, ops.NetHandle.packed) must be rebuilt INSIDE the
+            # graph: a cache filled by the forward just above would be read, never refreshed, by every replay
+            torch._C._increment_version(list(self.model.parameters()))
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
             graph = torch.cuda.CUDAGraph()
             # thread_local: a NCCL/RCCL watchdog thread may touch the runtime while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                self._captured = self._fwd_bwd(zero=False)
-            self._graph = graph
-            self._static_grads = [(p, p.grad) for p in self.model.parameters()]
-            self._finish_step()                             # the capture pass itself does not execute: replay it once
-            return True
+            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+                out, losses = self._fwd_bwd(entry, zero=False)
+                entry.outputs = (_detached(out), _detached(losses))
+                del out, losses
+            entry.graph = graph
+            entry.static_grads = [(p, p.grad) for p in self.model.parameters()]
+            entry.nan_flag = self.loss.nan_flag
+            ok = True
         except Exception as exc:                            # a sync inside the step, an uncapturable op ...
-            self.model.static_randoms = None
-            self.loss.nan_check = "deferred"
-            if was_sync_free is not None:
-                sampler.sync_free = was_sync_free
-            self._graph = None
             self.capture_error = exc
+            self._uncapturable.add(key)
             torch.cuda.synchronize()
-            return False
+        finally:
+            self.model.static_randoms = None
+            self.loss.nan_check = eager[0]
+            if eager[1] is not None:
+                sampler.sync_free = eager[1]
+            if entry.static_z is not None:
+                self.model.z_vals_override = zo
+        if ok:
+            self._graphs[key] = entry
+            self._load_batch(entry, model_input, ground_truth)      # (same values; loads the multi-tensor copy kernel outside any timed step)
+            self._finish_step(entry)                        # the capture pass itself does not execute: replay it once
+            self.replays += 1
+            self._last = entry
+        return ok
 
-    def _fwd_bwd(self, zero=True):
-        out = self.model(self._static_in)
-        losses = self.loss(out, self._static_gt)
+    def _fwd_bwd(self, entry, zero=True):
+        out = self.model(entry.static_in)
+        losses = self.loss(out, entry.static_gt)
         if zero:
             self.optimizer.zero_grad(set_to_none=True)
         losses["loss"].backward()
         return out, losses
 
-    def _finish_step(self):
-        if self._graph is not None:
-            for p, g in self._static_grads:                 # an eager step in between re-pointed .grad: the graph writes the captured tensors
+    def _finish_step(self, entry):
+        if entry is not None:
+            for p, g in entry.static_grads:                 # another graph or an eager step re-pointed .grad: this graph writes ITS tensors
                 if p.grad is not g:
                     p.grad = g
-            self._graph.replay()
+            entry.graph.replay()
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         self.scheduler.step()
 
-    def _refill_randoms(self):
-        """Fresh CPU draws, in the forward's draw order, into the persistent device tensors (pinned staging ring)."""
-        slots = sorted(self.model.static_randoms.values(), key=lambda s: s["order"])
+    def _refill_randoms(self, entry):
+        """Fresh CPU draws, in the forward's draw order, into the layout's persistent device tensors (pinned staging ring)."""
+        slots = sorted(entry.randoms.values(), key=lambda s: s["order"])
         for slot in slots:
             ring = slot.setdefault("ring", [])
             if len(ring) < 4:
@@ -126,42 +206,52 @@ class Trainer:
             ev.record()
         self._ring_pos += 1
 
-    def _same_batch_layout(self, model_input, ground_truth):
-        """The captured graph is valid for batches with the captured tensor shapes and the captured non-tensor entries
-        (the wireframe of the view: its vertex count shapes the matching)."""
-        for static, fresh in ((self._static_in, model_input), (self._static_gt, ground_truth)):
-            if set(static) != set(fresh):
-                return False
-            for k, v in fresh.items():
-                if isinstance(v, torch.Tensor):
-                    if v.shape != static[k].shape or v.dtype != static[k].dtype:
-                        return False
-                elif isinstance(v, (list, tuple)):
-                    if len(v) != len(static[k]) or any(a is not b for a, b in zip(v, static[k])):
-                        return False
-                elif v is not static[k] and v != static[k]:
-                    return False
-        return True
-
     def check_nan(self):
         """Graph mode keeps the line-loss NaN flag on the device (loss.nan_check == "off"); this reads it (one sync)."""
-        flag = self.loss.nan_flag
+        flag = self._last.nan_flag if self._last is not None else self.loss.nan_flag
         if flag is not None and bool(flag.item()):
             raise FloatingPointError("line loss is NaN (the reference drops into pdb here, loss_wfr.py:66-67)")
 
-    def _replay(self, model_input, ground_truth):
-        if not self._same_batch_layout(model_input, ground_truth):
-            return self.step_eager(model_input, ground_truth)      # another view / batch size: this graph does not apply
-        # every tensor of the fresh batch is copied into the captured tensors (a few KB per step).  No "unchanged?" shortcut on
-        # (data_ptr, _version): a new batch uploaded with .to(device) usually lands on the block the allocator just freed, with
-        # version 0, and would be mistaken for the previous one.
-        for static, fresh in ((self._static_in, model_input), (self._static_gt, ground_truth)):
+    def _load_batch(self, entry, model_input, ground_truth):
+        """Every tensor of the fresh batch is copied into the captured tensors, in ONE multi-tensor launch (a few KB per step).  No
+        "unchanged?" shortcut on (data_ptr, _version): a new batch uploaded with .to(device) usually lands on the block the allocator
+        just freed, with version 0, and would be mistaken for the previous one."""
+        dst, src = [], []
+        for static, fresh, keys in ((entry.static_in, model_input, None), (entry.static_gt, ground_truth, GT_KEYS)):
             for k, v in fresh.items():
-                if isinstance(v, torch.Tensor) and v is not static[k]:
+                if not isinstance(v, torch.Tensor) or v is static[k] or static[k].device != self.device or (keys and k not in keys):
+                    continue
+                if v.device == self.device and v.dtype == static[k].dtype:
+                    dst.append(static[k]); src.append(v)
+                else:
                     static[k].copy_(v, non_blocking=True)
-        self._refill_randoms()
-        self._finish_step()
-        return self._captured
+        zo = getattr(self.model, "z_vals_override", None)
+        if entry.static_z is not None and zo is not entry.static_z:
+            dst.append(entry.static_z); src.append(zo)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def _replay(self, entry, model_input, ground_truth):
+        self._load_batch(entry, model_input, ground_truth)
+        self._refill_randoms(entry)
+        self._finish_step(entry)
+        self._last = entry
+        self.replays += 1
+        return entry.outputs
+
+
+def _detached(d):
+    """Outputs / losses without autograd history.  The step has already run backward; a caller that kept the previous step's
+    graph alive through them would also keep its AccumulateGrad nodes (bound to the stream of that step) alive, and a later
+    capture on the capture stream then records a wait on that other stream: hipStreamEndCapture dies on the unjoined fork."""
+    if hasattr(d, "detached"):
+        return d.detached()
+    return type(d)((k, v.detach() if isinstance(v, torch.Tensor) else v) for k, v in d.items())
+
+
+class _Captured:
+    """One captured batch layout: the graph, its static input tensors, its outputs and the gradient tensors it writes."""
+    graph = static_in = static_gt = static_z = outputs = static_grads = randoms = nan_flag = None
 
 
 def synthetic_batch(seed, n_rays, device, view=0):

@@ -38,8 +38,7 @@ tr.model.ray_sampler.sync_free = True
 timed_steps("device decides (no sync), eager")
 graphed = tr.capture(inp, gt)
 timed_steps("device decides (no sync), HIP graph" if graphed else f"capture failed: {tr.capture_error!r}")
-tr.model.static_randoms = None
-tr._graph = None
+tr._graphs.clear()
 tr.model.ray_sampler.sync_free = False
 if args.only_sampler:
     sys.exit(0)

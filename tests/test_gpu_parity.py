@@ -1012,6 +1012,37 @@ def test_ffn_kernels_vs_torch(dev, J):
         close(a, b, tol=2e-5, what="ffn backward")
 
 
+def test_graph_per_view_cache_equals_eager(dev):
+    """A real run draws another view every iteration (volsdf_train.py:361): with auto_capture every view gets its own HIP graph
+    (shared memory pool) the second time it comes up.  Three views, sampler on: the trajectory equals the eager one."""
+    from neat_amd.train import Trainer, synthetic_batch
+
+    def run(auto):
+        torch.manual_seed(13)
+        tr = Trainer(device=dev, state_dict={k: T(v) for k, v in synth.synth_state_dict(3, "rough").items()})
+        tr.model.ray_sampler.sync_free = True
+        tr.auto_capture = auto
+        views = [synthetic_batch(20 + v, 64, dev, view=v)[1:] for v in range(3)]
+        losses = []
+        for it in range(12):
+            inp, gt = views[(it * 2) % 3] if it % 4 else views[0]
+            _, lo = tr.step(inp, gt)
+            losses.append(float(lo["loss"].detach()))
+        return tr, {k: p.detach().clone() for k, p in tr.model.named_parameters()}, losses
+
+    tr_e, p_e, l_e = run(0)
+    tr_g, p_g, l_g = run(1)
+    assert tr_e.replays == 0 and tr_e.eager_steps == 12
+    assert len(tr_g._graphs) == 3 and tr_g.replays >= 8 and tr_g.capture_error is None
+    assert tr_g.model.static_randoms is None and tr_g.model.ray_sampler.sync_free is True
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_g)
+    for k in p_e:
+        err = float((p_e[k] - p_g[k]).abs().max())
+        assert err <= 1e-5 * max(1.0, float(p_e[k].abs().max())), (k, err)
+    tr_g.check_nan()
+
+
 def test_graph_falls_back_for_other_batches(dev):
     """A captured step only replays for batches with the captured layout; another view (other wireframe object) or another
     ray count runs eagerly, and the next matching batch replays again."""

@@ -61,6 +61,8 @@ def test_runner_trains_and_checkpoints(tmp_path):
     assert type(runner.model).__module__ == "neat_amd.networks" and type(runner.train_dataset).__module__ == "neat_amd.datasets"
     hist = runner.run()
     assert len(hist) == 2 * 3 and all(np.isfinite(h[2]) for h in hist)
+    # epoch 0 steps every view eagerly, epoch 1 captures each view's HIP graph on its second visit and runs from it
+    assert runner.trainer.capture_error is None and runner.trainer.eager_steps == 3 and runner.trainer.replays == 3
     ck = runner.checkpoints_path
     for sub, key in (("ModelParameters", "model_state_dict"), ("OptimizerParameters", "optimizer_state_dict"),
                      ("SchedulerParameters", "scheduler_state_dict")):
