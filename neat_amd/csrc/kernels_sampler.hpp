@@ -12,24 +12,42 @@ constexpr int SMAX = 1024;      // max samples per ray inside the sampler (refer
 // fp64 wave scan / sum.  The reference runs on torch-CPU, whose cumsum accumulates float rows in double and rounds every output once
 // (at::acc_type<float, false> = double); an fp32 scan rounds at every step and moves CDF knots by a few 1e-8, enough to flip the
 // `denom < 1e-5` rule of the inverse-CDF step for bins whose mass sits at the threshold (every empty bin of `weights + 1e-5`).
-__device__ __forceinline__ double wave_incl_scan_d(double v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double t = __shfl_up(v, off);
-    if (lane >= off) v += t;
-  }
+// The scans run on the DPP network (row shifts inside 16-lane rows, then the two row broadcasts), two 32-bit moves per fp64 step:
+// a __shfl_up of a double is two ds_bpermute round trips through the LDS crossbar per step, and with one to four waves per SIMD
+// (a ray per workgroup) that latency was most of the bound kernel's time.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_zero_d(double v) {      // lanes without a source (or outside ROW_MASK) receive 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_incl_scan_d(double v, int /*lane*/) {
+  v += dpp_zero_d<0x111, 0xf>(v);      // row_shr:1
+  v += dpp_zero_d<0x112, 0xf>(v);      // row_shr:2
+  v += dpp_zero_d<0x114, 0xf>(v);      // row_shr:4
+  v += dpp_zero_d<0x118, 0xf>(v);      // row_shr:8   -> inclusive scan inside every row of 16 lanes
+  v += dpp_zero_d<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v += dpp_zero_d<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
   return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v = wave_incl_scan_d(v, 0);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_f(float v) {         // lanes without a source keep their own value
+  const int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return fmaxf(v, __int_as_float(t));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
+  v = dpp_max_f<0x111, 0xf>(v);
+  v = dpp_max_f<0x112, 0xf>(v);
+  v = dpp_max_f<0x114, 0xf>(v);
+  v = dpp_max_f<0x118, 0xf>(v);
+  v = dpp_max_f<0x142, 0xa>(v);
+  v = dpp_max_f<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // d* of Theorem 1 per interval (:161-173)
@@ -47,68 +65,66 @@ __device__ __forceinline__ float interval_bound(float a, float d0, float d1) {
   return (sg1 * sg0 == 1.0f) ? ds : 0.0f;
 }
 
-// max_i of the opacity error bound for one beta (get_error_bound, :285-293); arrays in LDS, m = n-1 intervals.
-// Lane l owns the PER consecutive intervals [l*PER, (l+1)*PER) (PER odd: conflict-free LDS stride): it sums its terms in fp64, one
-// wave scan of the 64 lane totals gives each lane its offset, a second pass over the lane's registers applies it.  PER is a template
-// parameter so that the PER element chains (three expf and two IEEE divisions each) are unrolled and overlap: with one wave per SIMD
-// (1024 rays = 1024 waves) the kernel is bound by dependent-instruction latency, not by the scans.
+// max_i of the opacity error bound for one beta (get_error_bound, :285-293); arrays in LDS, m = n-1 intervals.  One workgroup of
+// BOUND_T threads per ray: thread t owns the PER consecutive intervals [t*PER, (t+1)*PER): it sums its terms in fp64, a wave scan
+// plus the totals of the lower waves (through LDS) give its offset, a second pass over the thread's registers applies it.  PER is
+// a template parameter so that the element chains (three expf and two IEEE divisions each) are unrolled and overlap.  History: one
+// wave per ray scanning 64-interval chunks took 105 us per launch at n = 640 (1024 rays = one wave per SIMD, everything exposed
+// latency); lane-blocked with unrolled chains 76 us; four waves per ray ... see DESIGN.md.
+constexpr int BOUND_T = 256;
+struct BoundScratch { double e[BOUND_T / 64], s[BOUND_T / 64]; float mx[BOUND_T / 64]; };
+
 template <int PER>
-__device__ __forceinline__ float error_bound_t(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
-  const int j0 = lane * PER;
-  const float q = 4.0f * beta * beta;
+__device__ __forceinline__ float error_bound_t(const float* sdf, const float* dist, const float* dstar, int m, float beta, int tid,
+                                               BoundScratch* sc) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j0 = tid * PER;
+  // The bisection only compares this bound with eps, so its terms use the hardware exp2 / reciprocal forms (each within ~2 ulp of
+  // the library functions, 1 or 2 instructions instead of 15 .. 40): the kernel is VALU-bound -- 11 evaluations x n intervals x
+  // 1024 rays -- and the exact expf / expm1f / IEEE-division sequences were 5/6 of its instructions.  The pdf the samples are
+  // drawn from (sampler_resample_kernel) keeps the exact functions.
+  const float inv_b = 1.0f / beta, inv_q = 1.0f / (4.0f * beta * beta);
   float e[PER], sv[PER];
   double te = 0.0, ts = 0.0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const bool ok = j0 + k < m;
     const int j = min(j0 + k, m - 1);
-    const float d = dist[j];
-    e[k] = ok ? d * laplace_sigma(sdf[j], beta) : 0.0f;
-    sv[k] = ok ? expf(-dstar[j] / beta) * (d * d) / q : 0.0f;
+    const float d = dist[j], sd = sdf[j];
+    const float sg = (sd > 0.0f) ? 0.5f : ((sd < 0.0f) ? -0.5f : 0.0f);
+    e[k] = ok ? d * inv_b * (0.5f + sg * (__expf(-fabsf(sd) * inv_b) - 1.0f)) : 0.0f;      // d * laplace_sigma(sd, beta)
+    sv[k] = ok ? __expf(-dstar[j] * inv_b) * (d * d) * inv_q : 0.0f;
     te += (double)e[k];
     ts += (double)sv[k];
   }
-  double re = wave_incl_scan_d(te, lane) - te, rs = wave_incl_scan_d(ts, lane) - ts;      // exclusive offsets of this lane
+  const double ie = wave_incl_scan_d(te, lane), is = wave_incl_scan_d(ts, lane);
+  if (lane == 63) { sc->e[wave] = ie; sc->s[wave] = is; }
+  __syncthreads();
+  double re = ie - te, rs = is - ts;                       // exclusive offsets of this thread
+#pragma unroll
+  for (int w = 0; w < BOUND_T / 64; ++w)
+    if (w < wave) { re += sc->e[w]; rs += sc->s[w]; }
   float best = -INFINITY;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     rs += (double)sv[k];
-    const float b = (fminf(expf((float)rs), 1.0e6f) - 1.0f) * expf(-(float)re);
+    const float b = (fminf(__expf((float)rs), 1.0e6f) - 1.0f) * __expf(-(float)re);
     if (j0 + k < m) best = fmaxf(best, b);
     re += (double)e[k];
   }
-  return wave_max(best);
+  best = wave_max(best);
+  if (lane == 0) sc->mx[wave] = best;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < BOUND_T / 64; ++w) best = fmaxf(best, sc->mx[w]);
+  return best;                                             // (the next evaluation's first barrier orders the reuse of *sc)
 }
 
-__device__ __forceinline__ float error_bound_loop(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
-  const int per = ((m + 63) >> 6) | 1;
-  const int j0 = lane * per, j1 = min(m, j0 + per);
-  const float q = 4.0f * beta * beta;
-  double te = 0.0, ts = 0.0;
-  for (int j = j0; j < j1; ++j) {
-    const float d = dist[j];
-    te += (double)(d * laplace_sigma(sdf[j], beta));
-    ts += (double)(expf(-dstar[j] / beta) * (d * d) / q);
-  }
-  double re = wave_incl_scan_d(te, lane) - te, rs = wave_incl_scan_d(ts, lane) - ts;
-  float best = -INFINITY;
-  for (int j = j0; j < j1; ++j) {
-    const float d = dist[j];
-    rs += (double)(expf(-dstar[j] / beta) * (d * d) / q);
-    best = fmaxf(best, (fminf(expf((float)rs), 1.0e6f) - 1.0f) * expf(-(float)re));
-    re += (double)(d * laplace_sigma(sdf[j], beta));
-  }
-  return wave_max(best);
-}
-
-__device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int lane) {
-  switch (((m + 63) >> 6) | 1) {      // n = 128 k samples (the reference's grids) -> PER = 3, 5, 7, 9, 11
-    case 3: return error_bound_t<3>(sdf, dist, dstar, m, beta, lane);
-    case 5: return error_bound_t<5>(sdf, dist, dstar, m, beta, lane);
-    case 7: return error_bound_t<7>(sdf, dist, dstar, m, beta, lane);
-    case 9: return error_bound_t<9>(sdf, dist, dstar, m, beta, lane);
-    case 11: return error_bound_t<11>(sdf, dist, dstar, m, beta, lane);
-    default: return error_bound_loop(sdf, dist, dstar, m, beta, lane);
+__device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int tid, BoundScratch* sc) {
+  switch (((m + BOUND_T - 1) / BOUND_T) | 1) {      // n = 128 k samples (the reference's grids): PER = 1 (n <= 256) or 3; SMAX = 1024 -> 5
+    case 1: return error_bound_t<1>(sdf, dist, dstar, m, beta, tid, sc);
+    case 3: return error_bound_t<3>(sdf, dist, dstar, m, beta, tid, sc);
+    default: return error_bound_t<5>(sdf, dist, dstar, m, beta, tid, sc);
   }
 }
 
@@ -121,12 +137,13 @@ struct SamplerBoundArgs {
   const int* gate; int gate_value;              // device-decided rounds (sync-free sampler): run only if *gate == gate_value (null: always)
 };
 
-__global__ __launch_bounds__(64) void sampler_bound_kernel(SamplerBoundArgs a) {
+__global__ __launch_bounds__(BOUND_T) void sampler_bound_kernel(SamplerBoundArgs a) {
   __shared__ float ssdf[SMAX], sdist[SMAX], sdstar[SMAX];
+  __shared__ BoundScratch sc;
   if (a.gate && *a.gate != a.gate_value) return;
-  const int r = blockIdx.x, lane = threadIdx.x, n = a.n;
+  const int r = blockIdx.x, tid = threadIdx.x, n = a.n;
   const float* z = a.z + (size_t)r * n;
-  for (int j = lane; j < n; j += 64) {
+  for (int j = tid; j < n; j += BOUND_T) {
     float v;
     if (a.order) {
       const int o = a.order[(size_t)r * n + j];
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(64) void sampler_bound_kernel(SamplerBoundArgs a) {
   }
   __syncthreads();
   const int m = n - 1;
-  for (int j = lane; j < m; j += 64) {
+  for (int j = tid; j < m; j += BOUND_T) {
     const float d = z[j + 1] - z[j];
     sdist[j] = d;
     sdstar[j] = interval_bound(d, ssdf[j], ssdf[j + 1]);
@@ -147,15 +164,15 @@ __global__ __launch_bounds__(64) void sampler_bound_kernel(SamplerBoundArgs a) {
   __syncthreads();
   const float beta0 = *a.beta0;
   float hi = a.beta_in[r];
-  if (error_bound(ssdf, sdist, sdstar, m, beta0, lane) <= a.eps) hi = beta0;      // (:177-178)
+  if (error_bound(ssdf, sdist, sdstar, m, beta0, tid, &sc) <= a.eps) hi = beta0;      // (:177-178)
   float lo = beta0;
-  for (int it = 0; it < a.iters; ++it) {                                           // bisection (:179-185)
+  for (int it = 0; it < a.iters; ++it) {                                                // bisection (:179-185); every thread holds the same lo / hi
     const float mid = (lo + hi) / 2.0f;
-    const float err = error_bound(ssdf, sdist, sdstar, m, mid, lane);
+    const float err = error_bound(ssdf, sdist, sdstar, m, mid, tid, &sc);
     if (err <= a.eps) hi = mid;
     if (err > a.eps) lo = mid;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     a.beta_out[r] = hi;
     if (hi > beta0) atomicOr(a.flag, 1);
   }

@@ -1310,7 +1310,7 @@ int neat_sampler_bound(const float* z, int n, int R, const float* sdf_old, const
   if (R <= 0) return 0;
   if (n < 2 || n > SMAX || !z || !sdf_new || !beta_in || !beta0 || !sdf_out || !beta_out || !flag) return -1;
   SamplerBoundArgs a{z, n, R, sdf_old, sdf_new, order, n_old, beta_in, beta0, eps, iters, sdf_out, beta_out, flag, nullptr, 0};
-  hipLaunchKernelGGL(sampler_bound_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sampler_bound_kernel, dim3(R), dim3(BOUND_T), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1340,7 +1340,7 @@ int neat_sampler_bound_dev(const float* z, int n, int R, const float* sdf_old, c
   if (R <= 0) return 0;
   if (n < 2 || n > SMAX || !z || !sdf_new || !beta_in || !beta0 || !sdf_out || !beta_out || !open) return -1;
   SamplerBoundArgs a{z, n, R, sdf_old, sdf_new, order, n_old, beta_in, beta0, eps, iters, sdf_out, beta_out, open, gate, gate_value};
-  hipLaunchKernelGGL(sampler_bound_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sampler_bound_kernel, dim3(R), dim3(BOUND_T), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
