@@ -202,6 +202,12 @@ int neat_project2d(const float* K, const float* w2c, const float* X, int N, floa
 int neat_project2d_backward(const float* K, const float* w2c, const float* X, int N, const float* d_uv, float* d_X, void* stream);
 int neat_line_loss(const float* pred, const float* gt, const float* weight, int R, float threshold, float* out2, float* per_line,
                    float* d_pred, void* stream);
+/* Both line terms of VolSDFLoss.forward (loss_wfr.py:52-65) in one launch: pred_px / pred_calib [R,4] = the projected 3-D lines in
+ * pixel and in calibrated coordinates, gt5 [R,5] = (x1, y1, x2, y2, weight), K [3,3].  out3 = (l2d pixel term, calibrated line
+ * loss, #segments the pixel term accepts); the ground-truth end points are calibrated with K^-1 inside; d_pred_calib [R,4] =
+ * d out3[1] / d pred_calib.  Same arithmetic as neat_line_loss + neat_inv_small + neat_project2d on the same inputs. */
+int neat_line_losses(const float* pred_px, const float* pred_calib, const float* gt5, const float* K, int R, float threshold, float* out3,
+                     float* d_pred_calib, void* stream);
 
 /* ---- a16: Adam step over one flat fp32 parameter buffer = torch.optim.Adam(lr) as the reference trainer builds it
  * (training/volsdf_train.py:177; no weight decay, no amsgrad).  The parameters and both moments are flat [n]; the

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "neat_project2d": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d_backward": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_line_loss": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, c_fp, c_fp]),
+    "neat_line_losses": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, c_fp]),
     "neat_adam_step": (ctypes.c_int, [c_fp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int),
                                       ctypes.c_int, c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp]),
     "neat_lsap_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

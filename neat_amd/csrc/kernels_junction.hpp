@@ -395,6 +395,90 @@ __device__ __forceinline__ void inv_small_body(const float* sA, float* __restric
     for (int j = 0; j < NN; ++j) out[i * NN + j] = a[i][NN + j];
 }
 
+// Both line losses of VolSDFLoss.forward in one launch (loss_wfr.py:52-65): the gated pixel-space term on the (detached) 2-D lines,
+// the count of segments it accepts, the K^-1 calibration of the ground-truth end points (:59-63) and the differentiable calibrated
+// term whose weights are masked by the first term's gate.  gt5 [R,5] = (x1, y1, x2, y2, weight) as the dataset delivers it.
+//   out[0] = l2d (pixel term), out[1] = line loss (calibrated term), out[2] = #{per_line_px < thr};  d_pred_c [R,4] = d out[1] / d pred_c.
+// Same arithmetic and summation order as line_loss_kernel / inv_small_kernel / project2d_kernel, which it replaces on this path
+// (eleven launches: two slices, compare, ones, cat, inverse, projection, mask product, two line losses, sum).
+__global__ __launch_bounds__(1024) void line_losses_kernel(const float* __restrict__ pred_u, const float* __restrict__ pred_c,
+                                                           const float* __restrict__ gt5, const float* __restrict__ K, int R, float thr,
+                                                           float* __restrict__ out, float* __restrict__ d_pred_c) {
+  __shared__ float s_acc[4][16];
+  __shared__ float s_kinv[9], s_k[9];
+  __shared__ float s_inv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 9) s_k[tid] = K[tid];
+  __syncthreads();
+  if (tid == 0) inv_small_body<3>(s_k, s_kinv);
+  __syncthreads();
+  auto terms = [&](int r, float& lu, float& lc, float& w, float (&dsign)[4]) {
+    float pu[4], pc[4], g[4], gc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pu[c] = pred_u[4 * r + c]; pc[c] = pred_c[4 * r + c]; g[c] = gt5[5 * r + c]; }
+    w = gt5[5 * r + 4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {            // K^-1 (x, y, 1), divided by its third component (project2d with w2c = [I | 0])
+      const float x[3] = {g[2 * e], g[2 * e + 1], 1.0f};
+      float cam[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) cam[i] = s_kinv[3 * i] * x[0] + s_kinv[3 * i + 1] * x[1] + s_kinv[3 * i + 2] * x[2];
+      float ww = cam[2];
+      if (fabsf(ww) < 1e-8f) ww += (ww >= 0.0f) ? 1e-8f : -1e-8f;
+      gc[2 * e] = cam[0] / ww; gc[2 * e + 1] = cam[1] / ww;
+    }
+    auto one = [&](const float (&p)[4], const float (&t)[4], float* sg) {
+      float ds = 0.0f, df = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float a = p[c] - t[c], b = p[c] - t[c ^ 2]; ds += a * a; df += b * b; }
+      const bool straight = ds < df;
+      float l = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = p[c] - (straight ? t[c] : t[c ^ 2]);
+        l += fabsf(d);
+        if (sg) sg[c] = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+      }
+      return l * 0.25f;
+    };
+    lu = one(pu, g, nullptr);
+    lc = one(pc, gc, dsign);
+  };
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // sum / count of the pixel term, sum / count of the calibrated term
+  for (int r = tid; r < R; r += blockDim.x) {
+    float lu, lc, w, sg[4];
+    terms(r, lu, lc, w, sg);
+    const bool close = lu < thr;
+    if (close) { acc[0] += lu * w; acc[1] += 1.0f; }
+    if (lc < thr) { acc[2] += lc * (w * (close ? 1.0f : 0.0f)); acc[3] += 1.0f; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc[k] = wave_sum(acc[k]);
+    if (lane == 0) s_acc[k][wave] = acc[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] += s_acc[k][w];
+    out[0] = t[0] / fmaxf(t[1], 1.0f); out[2] = t[1];
+    const float den = fmaxf(t[3], 1.0f);
+    out[1] = t[2] / den;
+    s_inv = 1.0f / den;
+  }
+  __syncthreads();
+  const float inv = s_inv;
+  for (int r = tid; r < R; r += blockDim.x) {
+    float lu, lc, w, sg[4];
+    terms(r, lu, lc, w, sg);
+    const float coef = (lc < thr) ? (w * (lu < thr ? 1.0f : 0.0f)) * inv * 0.25f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d_pred_c[4 * r + c] = coef * sg[c];
+  }
+}
+
 __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, float* __restrict__ out) {
   __shared__ float sA[16];
   if (threadIdx.x < n * n) sA[threadIdx.x] = A[(threadIdx.x / n) * lda + threadIdx.x % n];      // one parallel fetch, not 16 dependent ones

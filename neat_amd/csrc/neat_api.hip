@@ -1515,6 +1515,13 @@ int neat_line_loss(const float* pred, const float* gt, const float* weight, int 
   return (int)hipGetLastError();
 }
 
+int neat_line_losses(const float* pred_px, const float* pred_calib, const float* gt5, const float* K, int R, float threshold, float* out3,
+                     float* d_pred_calib, void* stream) {
+  if (R <= 0 || !pred_px || !pred_calib || !gt5 || !K || !out3 || !d_pred_calib) return -1;
+  hipLaunchKernelGGL(line_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred_px, pred_calib, gt5, K, R, threshold, out3, d_pred_calib);
+  return (int)hipGetLastError();
+}
+
 size_t neat_lsap_ws_bytes(int nr, int nc) {
   const size_t mx = (size_t)(nr > nc ? nr : nc), mn = (size_t)(nr < nc ? nr : nc);
   return (mn + 2 * mx) * sizeof(double) + ((size_t)nr + (size_t)nc + 5 * mx + 2 * mn) * sizeof(int);

@@ -84,24 +84,32 @@ class VolSDFLoss(nn.Module):
     def forward(self, model_outputs, ground_truth):
         self.steps += 1
         dev = model_outputs["rgb_values"].device
-        seg_gt, seg_w = ground_truth["lines2d"][0].to(dev).split(4, dim=-1)
-        if dev.type == "cuda":      # column slices of [R,5]: one copy each here instead of one per consumer (two line losses, the reshape below)
-            seg_gt, seg_w = seg_gt.contiguous(), seg_w.contiguous()
-        if "labels" in ground_truth:
-            seg_w = seg_w * ground_truth["labels"][0, :, None].to(dev)
-        l2d_uncalib, per_line = self.get_line_loss(model_outputs["lines2d"].reshape(-1, 4), seg_gt, seg_w)
-        close = per_line < 100
-        # bring the GT segments into calibrated (K^-1) coordinates for the differentiable term (:59-65)
-        ends = seg_gt.reshape(-1, 2)
-        ends_1 = torch.cat([ends, torch.ones_like(ends[:, :1])], -1)
-        if ends.is_cuda:          # K^-1 [x, y, 1] and the division by its third component = one projection launch
+        gt5 = ground_truth["lines2d"][0].to(dev)
+        if dev.type == "cuda" and "labels" not in ground_truth and gt5.shape[-1] == 5:
+            # both line terms, the K^-1 calibration of the ground truth between them and the count: one launch
             from . import ops
-            seg_gt_calib = ops.project2d(_inv3(model_outputs["K"]), _identity34(ends.device), ends_1).reshape(-1, 4)
+            l2d_uncalib, line_loss, count = ops.line_losses(model_outputs["lines2d"].reshape(-1, 4), model_outputs["lines2d_calib"].reshape(-1, 4),
+                                                            gt5, model_outputs["K"], 100.0)
         else:
-            ends_h = (_inv3(model_outputs["K"]) @ ends_1.t()).t()
-            seg_gt_calib = (ends_h[:, :2] / ends_h[:, 2, None]).reshape(-1, 4)
-        line_loss, _ = self.get_line_loss(model_outputs["lines2d_calib"].reshape(-1, 4), seg_gt_calib,
-                                          seg_w * close.reshape(-1, 1))
+            seg_gt, seg_w = gt5.split(4, dim=-1)
+            if dev.type == "cuda":      # column slices of [R,5]: one copy each here instead of one per consumer
+                seg_gt, seg_w = seg_gt.contiguous(), seg_w.contiguous()
+            if "labels" in ground_truth:
+                seg_w = seg_w * ground_truth["labels"][0, :, None].to(dev)
+            l2d_uncalib, per_line = self.get_line_loss(model_outputs["lines2d"].reshape(-1, 4), seg_gt, seg_w)
+            close = per_line < 100
+            # bring the GT segments into calibrated (K^-1) coordinates for the differentiable term (:59-65)
+            ends = seg_gt.reshape(-1, 2)
+            ends_1 = torch.cat([ends, torch.ones_like(ends[:, :1])], -1)
+            if ends.is_cuda:          # K^-1 [x, y, 1] and the division by its third component = one projection launch
+                from . import ops
+                seg_gt_calib = ops.project2d(_inv3(model_outputs["K"]), _identity34(ends.device), ends_1).reshape(-1, 4)
+            else:
+                ends_h = (_inv3(model_outputs["K"]) @ ends_1.t()).t()
+                seg_gt_calib = (ends_h[:, :2] / ends_h[:, 2, None]).reshape(-1, 4)
+            line_loss, _ = self.get_line_loss(model_outputs["lines2d_calib"].reshape(-1, 4), seg_gt_calib,
+                                              seg_w * close.reshape(-1, 1))
+            count = close.sum()
         self._check_deferred()
         self._defer_nan_check(line_loss)
         padded = getattr(model_outputs, "padded", None)
@@ -121,7 +129,7 @@ class VolSDFLoss(nn.Module):
                                        loc3 if have_junctions else None, loc2c if have_junctions else None,
                                        loc2 if have_junctions else None, glo[2], good, self.eikonal_weight, self.line_weight,
                                        self.junction_3d_weight, self.junction_2d_weight)
-            out = {"rgb_loss": scal[0], "eikonal_loss": scal[1], "line_loss": line_loss, "l2d_loss": l2d_uncalib, "count": close.sum(),
+            out = {"rgb_loss": scal[0], "eikonal_loss": scal[1], "line_loss": line_loss, "l2d_loss": l2d_uncalib, "count": count,
                    "j3d_loss": scal[2], "j2d_loss": scal[3], "j2d_stat": scal[4], "jcount": scal[5], "loss": loss}
             if "median" in model_outputs:
                 out["median"] = model_outputs["median"]
@@ -131,7 +139,7 @@ class VolSDFLoss(nn.Module):
         eikonal = self.get_eikonal_loss(model_outputs["grad_theta"]) if "grad_theta" in model_outputs else zero
         loss = rgb_loss + self.eikonal_weight * eikonal + self.line_weight * line_loss
         out = {"rgb_loss": rgb_loss, "eikonal_loss": eikonal, "line_loss": line_loss, "l2d_loss": l2d_uncalib,
-               "count": close.sum(), "j3d_loss": zero, "j2d_loss": zero, "j2d_stat": zero, "jcount": zero}
+               "count": count, "j3d_loss": zero, "j2d_loss": zero, "j2d_stat": zero, "jcount": zero}
         if have_junctions:
             from . import ops
             glo3, glo2c = model_outputs["j3d_global"], model_outputs["j2d_global_calib"]

@@ -473,6 +473,35 @@ def line_loss(pred, gt, weight, threshold=100.0):
     return LineLossFn.apply(pred, gt, weight, threshold)
 
 
+class LineLossesFn(torch.autograd.Function):
+    """The two line terms of VolSDFLoss.forward in one launch (neat_line_losses): -> (l2d pixel term, calibrated line loss, count)."""
+
+    @staticmethod
+    def forward(ctx, pred_px, pred_calib, gt5, K, threshold):
+        pu, pc, g, Kc = _f32c(pred_px.detach()), _f32c(pred_calib.detach()), _f32c(gt5.detach()), _f32c(K.detach())
+        R = pc.shape[0]
+        if pu.shape != (R, 4) or pc.shape != (R, 4) or g.shape != (R, 5) or Kc.numel() != 9:
+            raise RuntimeError("line_losses: pred [R,4] x2, gt [R,5], K [3,3]")
+        out3 = torch.empty(3, device=pc.device)
+        d_pred = torch.empty(R, 4, device=pc.device)
+        _lib.check(_lib.lib().neat_line_losses(_p(pu), _p(pc), _p(g), _p(Kc), R, float(threshold), _p(out3), _p(d_pred), _stream()),
+                   "neat_line_losses")
+        ctx.save_for_backward(d_pred)
+        ctx.set_materialize_grads(False)
+        l2d, count = out3[0], out3[2]
+        ctx.mark_non_differentiable(l2d, count)
+        return l2d, out3[1], count
+
+    @staticmethod
+    def backward(ctx, g_l2d, g_loss, g_count):
+        (d_pred,) = ctx.saved_tensors
+        return None, (None if g_loss is None else g_loss * d_pred), None, None, None
+
+
+def line_losses(pred_px, pred_calib, gt5, K, threshold=100.0):
+    return LineLossesFn.apply(pred_px, pred_calib, gt5, K, threshold)
+
+
 def inv_small(A):
     """Inverse of one [n,n] matrix, n <= 4, in one launch (no host-side singularity check, no sync); no gradient."""
     A = A.detach()

@@ -1,4 +1,5 @@
-"""Where a replayed step spends its time: the HIP graph alone, graph + Adam, the whole Trainer.step.  python scripts/replay_phases.py"""
+"""Where a replayed step spends its time: the HIP graph alone, graph + Adam, the whole Trainer.step.
+    python scripts/replay_phases.py [sampler]      (sampler: depths from the ErrorBoundSampler instead of given depths)"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from neat_amd import synth
@@ -8,7 +9,8 @@ torch.manual_seed(42)
 tr = Trainer(device=dev, state_dict={k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()})
 tr.model.set_precision("bf16")
 _, inp, gt = synthetic_batch(42, 1024, dev)
-tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(42, 1024, 128)).to(dev)
+if "sampler" not in sys.argv[1:]:
+    tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(42, 1024, 128)).to(dev)
 for _ in range(3):
     tr.step(inp, gt)
 assert tr.capture(inp, gt), tr.capture_error
@@ -30,3 +32,13 @@ print("graph.replay() only      : %.3f ms" % timed(entry.graph.replay))
 print("replay + Adam + scheduler: %.3f ms" % timed(lambda: tr._finish_step(entry)))
 print("refill + replay + Adam   : %.3f ms" % timed(lambda: (tr._refill_randoms(entry), tr._finish_step(entry))))
 print("Trainer.step             : %.3f ms" % timed(lambda: tr.step(inp, gt)))
+
+# host cost of one launch (the call returns when the graph is enqueued)
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    t0 = time.perf_counter()
+    entry.graph.replay()
+    ts.append(1e3 * (time.perf_counter() - t0))
+    torch.cuda.synchronize()
+print("host time of graph.replay() with an idle device: " + " ".join("%.2f" % t for t in ts) + " ms")

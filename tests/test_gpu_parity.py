@@ -990,6 +990,39 @@ def test_project2d_and_line_loss_kernels_vs_torch(dev):
         close(pb.grad, 2.0 * pa.grad, tol=1e-5, what="line loss backward")
 
 
+def test_fused_line_losses_equal_the_separate_launches(dev):
+    """neat_line_losses (both line terms of the loss, the K^-1 calibration between them, the count) against the composition
+    of line loss / small inverse / projection launches it replaces: same values and the same gradient."""
+    from neat_amd import ops
+    from neat_amd.loss import _identity34
+    gen = torch.Generator().manual_seed(11)
+    R = 1500
+    K = torch.tensor([[560.0, 0.3, 256.0], [0.0, 555.0, 250.0], [0.0, 0.0, 1.0]]).to(dev)
+    gt = torch.rand(R, 4, generator=gen) * 512
+    w = torch.rand(R, 1, generator=gen)
+    w[::5] = 0.0
+    pred_px = gt.clone()
+    pred_px[::2] = pred_px[::2][:, [2, 3, 0, 1]]
+    pred_px = pred_px + torch.randn(R, 4, generator=gen) * 3
+    pred_px[::7] += 400.0                                     # beyond the 100 px gate: masked out of the calibrated term
+    gt5 = torch.cat([gt, w], -1).to(dev)
+    Kinv = ops.inv_small(K)
+    ends1 = torch.cat([gt5[:, :4].reshape(-1, 2), torch.ones(2 * R, 1, device=dev)], -1)
+    gt_cal = ops.project2d(Kinv, _identity34(dev), ends1).reshape(-1, 4)
+    pred_cal = (gt_cal + torch.randn(R, 4, generator=gen).to(dev) * 0.01)
+    pa = pred_cal.clone().requires_grad_(True)
+    l2d_ref, per_line, _ = ops.line_loss(pred_px.to(dev), gt5[:, :4].contiguous(), gt5[:, 4].contiguous(), 100.0)
+    close_ = per_line < 100
+    ll_ref, _, _ = ops.line_loss(pa, gt_cal, gt5[:, 4] * close_, 100.0)
+    (3.0 * ll_ref).backward()
+    pb = pred_cal.clone().requires_grad_(True)
+    l2d, ll, count = ops.line_losses(pred_px.to(dev), pb, gt5, K, 100.0)
+    (3.0 * ll).backward()
+    assert int(count) == int(close_.sum()) and 0 < int(count) < R
+    assert torch.equal(l2d, l2d_ref) and torch.equal(ll.detach(), ll_ref.detach())
+    assert torch.equal(pb.grad, pa.grad)
+
+
 @pytest.mark.parametrize("J", [64, 100, 1024])
 def test_ffn_kernels_vs_torch(dev, J):
     """ffn(latents) through the three HIP launches against the torch modules (values and every gradient)."""
