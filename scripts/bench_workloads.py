@@ -1,6 +1,8 @@
 """Secondary workloads of SURVEY 8d (not the headline): (1) the full train step WITH the error-bound sampler (conf default
 N_samples = 64 -> 98 samples per ray), (2) eval-mode forward in 2048-ray chunks as neat-final-parsing.py drives the model.
 Prints one JSON line each.  (3) C3-style: 2048 rays x 128 given samples with the DTU conf switches (dbscan_enabled, 1024 global junctions), eager.
+(4) C4's per-rank shape: 512 rays x 128 given samples with the DTU switches (one of eight data-parallel ranks; world size 1 here).
+(5) C5-style: 1024 rays, hierarchical 64 coarse + 64 fine depths (HierarchicalSampler), abc model.
 Prints one JSON line each.  usage: python scripts/bench_workloads.py [--precision bf16]"""
 import argparse, json, sys, time
 import torch
@@ -81,3 +83,40 @@ for dbscan in (True, False):
     print(json.dumps({"workload": f"C3-style train step: 2048 rays x 128 given samples, 1024 junction latents, dbscan_enabled={dbscan}",
                       "launch": "hip graph" if graphed else "eager", "ms_per_step": 1e3 * dt, "ray_samples_per_s": 2048 * 128 / dt,
                       "rays_per_s": 2048 / dt, "precision": args.precision}))
+
+# ---- C4 per-rank shape and C5-style hierarchical step
+conf["dbscan_enabled"] = True
+tr4 = Trainer(model_conf=conf, device=dev, state_dict={k: torch.tensor(v) for k, v in sd.items()})
+tr4.model.set_precision(args.precision)
+_, inp4, gt4 = synthetic_batch(42, 512, dev)
+tr4.model.z_vals_override = torch.tensor(synth.synth_z_vals(42, 512, 128)).to(dev)
+for _ in range(3):
+    tr4.step(inp4, gt4)
+graphed = tr4.capture(inp4, gt4)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    tr4.step(inp4, gt4)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+print(json.dumps({"workload": "C4 per-rank shape: 512 rays x 128 given samples, DTU switches (1024 junction latents, device DBSCAN), world size 1",
+                  "launch": "hip graph" if graphed else "eager", "ms_per_step": 1e3 * dt, "ray_samples_per_s": 512 * 128 / dt,
+                  "rays_per_s": 512 / dt, "precision": args.precision}), flush=True)
+
+conf5 = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+conf5.update(hip_sampler="hierarchical", hip_sampler_coarse=64, hip_sampler_fine=64)
+tr5 = Trainer(model_conf=conf5, device=dev, state_dict={k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()})
+tr5.model.set_precision(args.precision)
+_, inp5, gt5 = synthetic_batch(42, 1024, dev)
+for _ in range(3):
+    tr5.step(inp5, gt5)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    out5, _ = tr5.step(inp5, gt5)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+S5 = out5["points"].shape[0] // 1024 if out5["points"].dim() == 2 else out5["points"].shape[1]
+print(json.dumps({"workload": "C5-style train step: 1024 rays, hierarchical 64 coarse + 64 fine depths (HierarchicalSampler), abc model",
+                  "launch": "eager (the torch-op sampler uploads its draws synchronously)", "ms_per_step": 1e3 * dt, "samples_per_ray": S5,
+                  "ray_samples_per_s": 1024 * S5 / dt, "rays_per_s": 1024 / dt, "precision": args.precision}), flush=True)
