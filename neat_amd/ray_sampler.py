@@ -199,6 +199,17 @@ class ErrorBoundSampler(RaySampler):
         z_vals, z_eik, self.last_pick = ops.sampler_finish_dev(samples, z_final, ctl, K, keys, n_extra, self.near, self.far, eik_idx)
         return z_vals, z_eik
 
+    @staticmethod
+    def _eval_on_device(model):
+        """Inference takes the device-decided rounds by default: in eval mode they draw nothing and are bit-identical to the
+        host-decided ones, minus one host round trip per round.  (bf16 build only: the fp32 build's SDF kernels are not gated, a
+        sampler that converged early would still evaluate all rounds.)"""
+        if model.training:
+            return False
+        net = getattr(model, "implicit_network", None)
+        handle = getattr(net, "handle", None)
+        return handle is not None and handle().precision == 1
+
     def rounds_taken(self):
         """Rounds of Algorithm 1 the last call ran (one device read when the last call was sync-free)."""
         if self.last_rounds is None and self._ctl is not None:
@@ -210,7 +221,7 @@ class ErrorBoundSampler(RaySampler):
         """Algorithm 1 with the per-ray work in HIP (neat_sampler_* kernels, one wavefront per ray) and the MLP queries in
         the SDF kernels.  Control flow, the one host sync per round and the CPU random draws follow the reference."""
         from . import ops
-        if self.sync_free and ray_dirs.is_cuda:
+        if ray_dirs.is_cuda and (self.sync_free or self._eval_on_device(model)):
             return self.get_z_vals_device(ray_dirs, cam_loc, model)
         dev, R = ray_dirs.device, ray_dirs.shape[0]
         beta0 = model.density.get_beta().detach()
