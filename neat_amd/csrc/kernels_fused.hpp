@@ -270,13 +270,19 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
   const int t_begin = inter ? (int)blockIdx.x * NT : (int)(((long long)blockIdx.x * ntiles) / ng);
   const int t_end = inter ? ntiles : (int)(((long long)(blockIdx.x + 1) * ntiles) / ng);
   const int t_step = inter ? ng * NT : NT;
+  // A batch = NT tiles through the stage pipeline.  What is left of a workgroup's range (1 .. NT-1 tiles: the ragged end of a big
+  // launch, or everything a workgroup gets in a small one -- get_outputs on the R junction points) goes tile by tile through the
+  // SINGLE path: one tile per layer, MFMAs then epilogue then barrier, no pipeline.  A pipeline batch costs its full latency
+  // (~45 us for nine layers) whatever it holds; a single tile costs ~1/6 of that.
   for (int tile0 = t_begin; tile0 < t_end; tile0 += t_step) {
-    const int p0 = tile0 * 32;
-    const int nt = min(NT, t_end - tile0);
+   const int ntb = min(NT, t_end - tile0);
+   for (int sub = 0; sub < (ntb == NT ? 1 : ntb); ++sub) {
+    const int p0 = (tile0 + sub) * 32;
+    const int nt = ntb == NT ? NT : 1;
     L.gquad = ((unsigned)(4 * RT * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
 
-    auto chain = [&](auto full_tag) {
-      constexpr bool FULL = decltype(full_tag)::value;
+    auto chain = [&](auto single_tag) {
+      constexpr bool FULL = true, SINGLE = decltype(single_tag)::value;
       // the slices of lin0 and lin1 travel while the positional encoding is computed
       load_w(wB, a.Wp[0], 4, 256);
       load_w(wA, a.Wp[1], 16, 256);
@@ -358,6 +364,57 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
         PRE_(3) F6_STAGE((S0_) + 3, 3, KS_, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 3 ? L.frag[(NSRC_) < 3 ? (NSRC_) : 0] : nullptr), (ALLBAR_ || ((S0_) + 3) % 2 == 1)) }
 #define F6_NOPRE(T_)
 #define F6_SKIPPRE(T_) skip_copy((T_) < 3 ? (T_) + 1 : 3);
+      if constexpr (SINGLE) {
+        // ---- one tile: per layer the 16 (4) k-steps, then the whole epilogue, then the barrier that publishes the tile
+#define F6_RING0(SRC_)                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[SRC_] + j * 2 * BP * 16);
+#define F6_LAYER1(KS_, SRC_, WC_, ECUR_, HCUR_)                                                                                     \
+        { F6_RING0(SRC_)                                                                                                            \
+          f6_stage<NT, RT, true, true, KS_, SRC_, F6NoEpi, 0, false>(L, WC_, 0, acc[0], acc[1], bq, 0, 1, nullptr, wave, hi, ring, nullptr); \
+          f6_load_bias<ECUR_, RT>(L, bq);                                                                                           \
+          f6_stage<NT, RT, true, false, 16, 0, ECUR_, 0, true>(L, WC_, 0, acc[1], acc[0], bq, 0, 1, HCUR_, wave, hi, ring, nullptr); }
+        F6_LAYER1(4, 2, wB, E0, a.h[1])
+        load_w(wB, a.Wp[2], 16, 256);
+        F6_LAYER1(16, 0, wA, E1, a.h[2])
+        load_w(wA, a.Wp[3], 16, 217);
+        F6_LAYER1(16, 1, wB, E2, a.h[3])
+        load_w(wB, a.Wp[4], 16, 256);
+        F6_LAYER1(16, 0, wA, E3, a.h[4])
+        load_w(wA, a.Wp[5], 16, 256);
+        skip_copy(0);
+        __syncthreads();
+        F6_LAYER1(16, 1, wB, E4, a.h[5])
+        load_w(wB, a.Wp[6], 16, 256);
+        F6_LAYER1(16, 0, wA, E5, a.h[6])
+        load_w(wA, a.Wp[7], 16, 256);
+        F6_LAYER1(16, 1, wB, E6, a.h[7])
+        if (!VALUES) load_w(wB, a.Wp[8], 16, 256);
+        F6_LAYER1(16, 0, wA, E7, a.h[8])
+        {                                                    // lin8's sdf row for tile 0: split over the waves' k-steps, reduced through LDS
+          constexpr int KW = 16 / NW;
+          unsigned voff = (unsigned)((((VALUES ? 0 : 8) * 16 + KW * wave) * 64 + lane) * 16);
+          asm volatile("" : "+v"(voff));
+#pragma unroll
+          for (int j = 0; j < KW; ++j) wA[0][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp[8]) + voff + j * 1024);
+          const unsigned char* fr = L.frag[1] + (unsigned)(KW * wave) * (2 * BP * 16);
+          f32x16 accs;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
+#pragma unroll
+          for (int j = 0; j < KW; ++j) {
+            const uint4 bv = *reinterpret_cast<const uint4*>(fr + j * 2 * BP * 16);
+            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wA[0][j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
+          }
+          if (hi == 0) red[wave * BP + lane] = accs[0];
+        }
+        if (!VALUES) {
+          F6_LAYER1(16, 1, wB, E8, a.feat)
+        } else {
+          __syncthreads();
+        }
+#undef F6_LAYER1
+#undef F6_RING0
+      } else {
       // stage 0's first two fragments
 #pragma unroll
       for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[2] + j * 2 * BP * 16);
@@ -415,14 +472,15 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       } else {
         __syncthreads();
       }
+      }
 #undef F6_STAGE
 #undef F6_KSUM
 #undef F6_NOPRE
 #undef F6_SKIPPRE
 #undef F6_LAYER
     };
-    if (VALUES || nt == NT) chain(std::true_type{});       // (values mode stores nothing per tile: the full-batch code serves every batch)
-    else chain(std::false_type{});
+    if (nt == NT) chain(std::false_type{});
+    else chain(std::true_type{});
     if (tid < nt * 32) {
       float sv = biasl[8 * 256 + (VALUES ? 0 : 256)];
 #pragma unroll
@@ -439,6 +497,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       }
     }
     __syncthreads();
+   }
   }
 }
 
