@@ -22,11 +22,12 @@ def _cap_host_threads():
     The host side of the hot path only draws a few hundred KB of CPU randoms per step; with a 128-thread pool every such draw leaves
     OpenMP workers spinning, the cgroup runs out of quota and the kernel parks the whole process -- including the thread that feeds
     the GPU -- for the rest of the 100 ms period (measured: every other train step with the sampler on took 90 ms instead of 6).
-    Unless OMP_NUM_THREADS says otherwise, keep the pool at a quarter of the quota (at most 8 threads)."""
+    Unless OMP_NUM_THREADS says otherwise, keep the pool at a quarter of this rank's share of the quota (at most 8 threads)."""
     if "OMP_NUM_THREADS" in os.environ:
         return
     import torch
-    want = max(1, min(8, cpu_quota() // 4))
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))      # torchrun: the ranks of this node share the quota
+    want = max(1, min(8, cpu_quota() // (4 * ranks)))
     if torch.get_num_threads() > want:
         torch.set_num_threads(want)
 
