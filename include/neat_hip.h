@@ -42,9 +42,13 @@ int neat_abi_version(void);      /* 5 */
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
  *   NEAT_BF16 (1): bf16 MFMA with fp32 accumulate, bf16 hidden activations -- throughput build
+ *   NEAT_BF16X3 (2): the NEAT_F32 build (same layouts, workspaces, packed weights, kernels) whose two GEMM kernels evaluate every
+ *                    product as three bf16 MFMAs on hi/lo splits of both operands, fp32 accumulate (~2^-17 relative per product):
+ *                    fp32-grade parity at a multiple of the f32-MFMA rate
  * Packed weights, workspaces and forward/backward calls of one pass must use the same value. */
 #define NEAT_F32 0
 #define NEAT_BF16 1
+#define NEAT_BF16X3 2
 
 /* ---- a15: weight norm + packing (replaces the per-call `_weight_norm` pre-hook) -------------------
  * Computes W = g * v/|v| for all 19 layers once per step and stores W and W^T in MFMA-fragment order. */

@@ -7,7 +7,7 @@ import os
 
 NUM_LAYERS = 19
 ABI_VERSION = 5
-PRECISIONS = {"fp32": 0, "bf16": 1}
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/abl_build.sh)
 

@@ -10,10 +10,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "bf16_common.hpp"
 
 namespace neat {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 64;          // points per workgroup tile
 constexpr int WG = 256;         // threads per workgroup (4 waves, one per SIMD)
@@ -49,6 +48,7 @@ struct LayerArgs {
   int ldp;                              // point stride of every array (multiple of 64)
   float* out0; float* out1; int n_split; int accumulate;
   const float* aux0; const float* aux1;
+  int x3;                               // 1: the contraction runs as three bf16 MFMAs on hi/lo splits of both operands (NEAT_BF16X3)
 };
 
 template <int NTW>
@@ -73,6 +73,74 @@ __device__ __forceinline__ void mma_rows(f32x16 (&acc)[3][2], const float* __res
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NEAT_BF16X3: fp32 storage, fp32 accumulation, every product x*y evaluated as  hi(x) hi(y) + hi(x) lo(y) + lo(x) hi(y)  with
+// hi = bf16(x), lo = bf16(x - hi): three v_mfma_f32_32x32x16_bf16 (16 k per 32 cycles each) instead of eight
+// v_mfma_f32_32x32x2_f32 (2 k per 64 cycles).  The dropped lo*lo term and the rounding of lo are ~2^-17 relative per product;
+// everything else of the fp32 build (layouts, epilogues, every other kernel) is shared.  Operands are split in registers on
+// the fly: the fp32 weight pack and the fp32 LDS tile are read in the k-order the bf16 fragment wants (8 consecutive k per lane).
+// ---------------------------------------------------------------------------------------------
+struct X3Frag { bf16x8 hi, lo; };
+__device__ __forceinline__ X3Frag x3_split(const float (&f)[8]) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = pack2(f[2 * j], f[2 * j + 1]);
+    l[j] = pack2(f[2 * j] - bf_lo(h[j]), f[2 * j + 1] - bf_hi(h[j]));
+  }
+  X3Frag r;
+  const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]), lv = make_uint4(l[0], l[1], l[2], l[3]);
+  r.hi = *reinterpret_cast<const bf16x8*>(&hv);
+  r.lo = *reinterpret_cast<const bf16x8*>(&lv);
+  return r;
+}
+__device__ __forceinline__ void x3_mfma(f32x16& acc, const X3Frag& A, const X3Frag& B) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, B.hi, acc, 0, 0, 0);      // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc, 0, 0, 0);
+}
+
+// wbase: this wave's first tile of the fp32 pack [tile][Kpad/2][64] (element (s, lane) = W[lane & 31][2 s + (lane >> 5)]);
+// tile: the fp32 LDS input tile [Kpad][BM].  16-k chunks go through the split product, a remaining 8-k chunk through the f32 MFMA.
+template <int NTW>
+__device__ __forceinline__ void mma_rows_x3(f32x16 (&acc)[3][2], const float* __restrict__ wbase, int tile_stride,
+                                            const float* __restrict__ tile, int KS) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int SF = KS >> 3;
+  // the weight floats of chunk S+1 are requested before chunk S is multiplied: one L2 round trip per chunk was most of the kernel
+  const float* wl = wbase + (4 * h) * 64 + r;
+  float fa[NTW][8], fn[NTW][8];
+  auto fetch = [&](float (&dst)[NTW][8], int S) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[i][e] = wl[(size_t)i * tile_stride + (8 * S + (e >> 1)) * 64 + 32 * (e & 1)];
+  };
+  if (SF > 0) fetch(fn, 0);
+  for (int S = 0; S < SF; ++S) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fa[i][e] = fn[i][e];
+    if (S + 1 < SF) fetch(fn, S + 1);
+    X3Frag B[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = tile[(16 * S + 8 * h + e) * BM + r + 32 * q];
+      B[q] = x3_split(f);
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const X3Frag A = x3_split(fa[i]);
+      x3_mfma(acc[i][0], A, B[0]);
+      x3_mfma(acc[i][1], A, B[1]);
+    }
+  }
+  if (8 * SF < KS) mma_rows<NTW>(acc, wbase + lane, tile_stride, tile + h * BM + r, 8 * SF, KS);
 }
 
 template <int EPI>
@@ -145,7 +213,12 @@ __global__ __launch_bounds__(WG, 2) void layer_kernel(LayerArgs a) {
     const int ntw = (a.NT - wave + 3) >> 2;          // tiles owned (wave-uniform, 1..3 here)
     const float* wp0 = a.Wp + (size_t)wave * KS * 64 + lane;
     const int tstride = 4 * KS * 64;
-    if (ntw >= 3) mma_rows<3>(acc, wp0, tstride, bl, 0, KS);
+    if (a.x3) {
+      const float* wb = a.Wp + (size_t)wave * KS * 64;
+      if (ntw >= 3) mma_rows_x3<3>(acc, wb, tstride, lds, KS);
+      else if (ntw == 2) mma_rows_x3<2>(acc, wb, tstride, lds, KS);
+      else if (ntw == 1) mma_rows_x3<1>(acc, wb, tstride, lds, KS);
+    } else if (ntw >= 3) mma_rows<3>(acc, wp0, tstride, bl, 0, KS);
     else if (ntw == 2) mma_rows<2>(acc, wp0, tstride, bl, 0, KS);
     else if (ntw == 1) mma_rows<1>(acc, wp0, tstride, bl, 0, KS);
 #pragma unroll
@@ -202,6 +275,7 @@ struct WgradArgs {
   int P, ldp, chunk;         // points per grid.y slice (multiple of 32)
   float* partial;            // element (split, n, k) at n*row_stride + split*split_stride + k
   size_t row_stride, split_stride; int ktiles;
+  int x3;                    // NEAT_BF16X3: split-bf16 products (see x3_mfma)
 };
 
 constexpr int WBP = 32;      // points per staging step
@@ -259,6 +333,29 @@ __global__ __launch_bounds__(WG) void wgrad_kernel(WgradArgs a) {
         db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
       }
       __syncthreads();
+      if (a.x3) {
+#pragma unroll
+        for (int S = 0; S < WBP / 16; ++S) {
+          X3Frag A[2], B[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float fa[8], fb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              fa[e] = As[(wr + 32 * i + (lane & 31)) * WLD + 16 * S + 8 * (lane >> 5) + e];
+              fb[e] = Bs[(wc + 32 * i + (lane & 31)) * WLD + 16 * S + 8 * (lane >> 5) + e];
+            }
+            A[i] = x3_split(fa); B[i] = x3_split(fb);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (live[i][j]) x3_mfma(acc[i][j], A[i], B[j]);
+        }
+        __syncthreads();
+        continue;
+      }
       const float* ap = As + (wr + (lane & 31)) * WLD + (lane >> 5);
       const float* bp = Bs + (wc + (lane & 31)) * WLD + (lane >> 5);
 #pragma unroll

@@ -24,7 +24,10 @@ constexpr int L_REND = 9, L_ATTR = 14;
 const int kO[NLAYERS] = {256, 256, 256, 217, 256, 256, 256, 256, 257, 256, 256, 256, 256, 3, 256, 256, 256, 256, 6};
 const int kI[NLAYERS] = {39, 256, 256, 256, 256, 256, 256, 256, 256, 289, 256, 256, 256, 256, 265, 256, 256, 256, 256};
 constexpr int PE_ROWS = 39, SMALL_R = 33, SMALL_A = 9;
-enum { F32 = 0, BF16 = 1 };
+enum { F32 = 0, BF16 = 1, BF16X3 = 2 };
+// BF16X3 = the F32 build (layouts, kernels, workspaces) with split-bf16 products in its two GEMM kernels: every entry point maps it
+// to F32 + Ctx::x3 (take_x3)
+inline int take_x3(int& precision) { if (precision == BF16X3) { precision = F32; return 1; } return 0; }
 
 inline int padk(int k, int prec) { return prec ? (k + 63) & ~63 : (k + 7) & ~7; }   // bf16: k-steps of 16, unrolled by 4
 inline int pad8(int k) { return (k + 7) & ~7; }
@@ -303,6 +306,7 @@ struct Ctx {
   const float* packed;
   const neat_net_params* net;
   int P, ldp, prec;
+  int x3 = 0;                // NEAT_BF16X3: fp32 layouts, split-bf16 products (kernels.hpp, x3_mfma)
   const PackLayout& L() const { return pack_layout(prec); }
   const float* rowscale(int l) const { return packed + L().rowscale_off + L().row_off[l]; }
 };
@@ -349,7 +353,7 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
     a.Kpad = d.Kpad; a.Wp = wp; a.bias = bias;
     a.N = N; a.NT = tiles32(N); a.ldp = c.ldp;
     a.out0 = out0.f(); a.out1 = out1.f(); a.n_split = n_split; a.accumulate = accumulate;
-    a.aux0 = aux0.f(); a.aux1 = aux1.f();
+    a.aux0 = aux0.f(); a.aux1 = aux1.f(); a.x3 = c.x3;
     e = dispatch_f(c.st, epi, a, c.ldp / BM);
   } else {
     LayerArgsH a;
@@ -738,7 +742,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       for (int s = 0; s < 3; ++s) { a.pair[q].B[s] = pairs[q].B[s].f(); a.pair[q].rowsB[s] = pairs[q].rowsB[s]; }
     }
     a.npairs = npairs; a.N = N; a.Kt = Kt; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
-    a.partial = w.partial; a.row_stride = (size_t)splits * WLDK; a.split_stride = WLDK; a.ktiles = ktiles;
+    a.partial = w.partial; a.row_stride = (size_t)splits * WLDK; a.split_stride = WLDK; a.ktiles = ktiles; a.x3 = c.x3;
     ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * Kt * 4.0);
     hipLaunchKernelGGL(wgrad_kernel, dim3(ntile * ktiles, splits), dim3(WG), 0, c.st, a);
     prof_end(c.st, ps);
@@ -1059,7 +1063,7 @@ void export_out8(const Ctx& c, const SdfWs& w, float* out257, float* feat) {
   }
 }
 
-bool bad_prec(int p) { return p != F32 && p != BF16; }
+bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3; }
 
 }  // namespace
 
@@ -1112,9 +1116,11 @@ int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launc
   return 0;
 }
 
-size_t neat_packed_floats(int precision) { return bad_prec(precision) ? 0 : pack_layout(precision).total; }
+size_t neat_packed_floats(int precision) {
+  const int x3 = take_x3(precision); (void)x3; return bad_prec(precision) ? 0 : pack_layout(precision).total; }
 
 int neat_pack_weights(const neat_net_params* net, float* packed, int precision, void* stream) {
+  const int x3 = take_x3(precision); (void)x3;
   if (!net || !packed || bad_prec(precision)) return -1;
   hipStream_t st = (hipStream_t)stream;
   const PackLayout& L = pack_layout(precision);
@@ -1139,15 +1145,18 @@ int neat_camera_rays(const float* uv, const float* pose, const float* K, int kst
 }
 
 size_t neat_sdf_ws_floats(int P, int mode, int precision) {
+  const int x3 = take_x3(precision); (void)x3;
   return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision).total;
 }
 
 int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
                      float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad,
                      void* stream) {
+  const int x3 = take_x3(precision); (void)x3;
   if (P <= 0) return 0;
   if (!packed || !net || !x || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  c.x3 = x3;
   SdfWs w = sdf_ws(ws, c.ldp, mode, precision);
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
   if (mode == 0 && precision) {
@@ -1182,9 +1191,11 @@ int neat_sdf_values_gated(const float* packed, const neat_net_params* net, const
 int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P, int precision,
                       const float* d_out257, const float* d_sdf, const float* d_feat, const float* d_grad,
                       const neat_net_grads* grads, void* stream) {
+  const int x3 = take_x3(precision); (void)x3;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  c.x3 = x3;
   SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
   hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8);
   if (precision) oct_pack(c, {{w.abar8 + c.ldp, 256, w.featc}});
@@ -1195,6 +1206,7 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
 }
 
 size_t neat_heads_ws_floats(int P, int precision) {
+  const int x3 = take_x3(precision); (void)x3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(P, precision);
   return head_ws(nullptr, ldp, precision).total + (size_t)(3 + 3 + 256) * ldp;
@@ -1203,9 +1215,11 @@ size_t neat_heads_ws_floats(int P, int precision) {
 int neat_heads_forward(const float* packed, const neat_net_params* net, const float* points, const float* normals,
                        const float* view_dirs, const float* feats, int P, int precision, float* ws, float* rgb, float* lines,
                        void* stream) {
+  const int x3 = take_x3(precision); (void)x3;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  c.x3 = x3;
   HeadWs h = head_ws(ws, c.ldp, precision);
   float* x_fm = ws + h.total; float* g_fm = x_fm + 3 * (size_t)c.ldp; float* f_fm = g_fm + 3 * (size_t)c.ldp;
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, points, P, 3, c.ldp, x_fm);
@@ -1222,6 +1236,7 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
 }
 
 size_t neat_render_ws_floats(int R, int S, int E, int precision) {
+  const int x3 = take_x3(precision); (void)x3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S + E, precision);
   return sdf_ws(nullptr, ldp, 1, precision).total + head_ws(nullptr, ldp, precision).total;
@@ -1231,11 +1246,13 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
                                const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
                                float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                                float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream, bool fwd_only) {
+  const int x3 = take_x3(precision); (void)x3;
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !origins || !dirs || !z || !rgb || !lines3d || !depth || !xyz || bad_prec(precision)) return -1;
   if (E < 0 || (E > 0 && (!eik_points || !eik_grad))) return -1;
   const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  c.x3 = x3;
   SdfWs w = sdf_ws(ws, c.ldp, fwd_only ? 2 : 1, precision);
   HeadWs h = head_ws(ws + w.total, c.ldp, precision, fwd_only);
   hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points, eik_points, E);
@@ -1263,6 +1280,7 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
 }
 
 size_t neat_render_eval_ws_floats(int R, int S, int precision) {
+  const int x3 = take_x3(precision); (void)x3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S, precision);
   return sdf_ws(nullptr, ldp, 2, precision).total + head_ws(nullptr, ldp, precision, true).total;
@@ -1280,10 +1298,12 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
                          int R, int S, int E, int precision, const float* beta, const float* d_rgb, const float* d_lines3d,
                          const float* d_depth, const float* d_xyz, const float* d_eik_grad, const neat_net_grads* grads,
                          float* dbeta_ray, void* stream) {
+  const int x3 = take_x3(precision); (void)x3;
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision) || E < 0) return -1;
   const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
+  c.x3 = x3;
   SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
   HeadWs h = head_ws(ws + w.total, c.ldp, precision);
   CompositeBwdArgs cb;

@@ -21,12 +21,20 @@ def dev():
     return torch.device("cuda:0")
 
 
-def build_model(dev, variant, seed=42, train=False):
+def build_model(dev, variant, seed=42, train=False, precision="fp32"):
     from neat_amd import networks
     m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
     m.load_state_dict({k: T(v) for k, v in synth.synth_state_dict(seed, variant).items()}, strict=True)
     m.to(dev)
+    m.set_precision(precision)
     return m.train() if train else m.eval()
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def prec(request):
+    """The two builds that claim the fp32 parity bars (1e-4 outputs, 2e-3 gradients vs the reference's goldens): exact-f32 MFMA and
+    the split-bf16 products of NEAT_BF16X3."""
+    return request.param
 
 
 def close(a, b, tol=TOL, what=""):
@@ -43,9 +51,9 @@ def close(a, b, tol=TOL, what=""):
 
 
 @pytest.mark.parametrize("variant", ["init", "rough"])
-def test_implicit_network_vs_reference_golden(dev, golden, variant):
+def test_implicit_network_vs_reference_golden(dev, golden, variant, prec):
     g = golden(f"g2g3_networks_{variant}")
-    m = build_model(dev, variant)
+    m = build_model(dev, variant, precision=prec)
     x = T(g["x"]).to(dev)
     with torch.no_grad():
         close(m.implicit_network(x), g["forward"], what="forward")
@@ -58,9 +66,9 @@ def test_implicit_network_vs_reference_golden(dev, golden, variant):
 
 
 @pytest.mark.parametrize("variant", ["init", "rough"])
-def test_heads_vs_reference_golden(dev, golden, variant):
+def test_heads_vs_reference_golden(dev, golden, variant, prec):
     g = golden(f"g2g3_networks_{variant}")
-    m = build_model(dev, variant)
+    m = build_model(dev, variant, precision=prec)
     args = [T(g[k]).to(dev) for k in ("x", "out_grad", "view", "out_feat")]
     with torch.no_grad():
         close(m.rendering_network(*args), g["rgb"], what="rgb")
@@ -124,25 +132,27 @@ def test_sampler_vs_reference_golden(dev, golden, variant):
 
 
 @pytest.mark.parametrize("variant", ["init", "rough"])
-def test_full_forward_eval_vs_reference_golden(dev, golden, variant):
+def test_full_forward_eval_vs_reference_golden(dev, golden, variant, prec):
     from tests.util_replay import RngReplay
     g = golden(f"g7_forward_eval_{variant}")
-    m = build_model(dev, variant)
+    m = build_model(dev, variant, precision=prec)
     m.z_vals_override = T(g["z_vals"]).to(dev)        # the sampler has its own test; feed the reference's depths
     with torch.no_grad(), RngReplay([("randint", None)]):
         out = m(scene_inputs(g, dev))
+    # l3d = a ray / tangent-plane intersection, a quotient that amplifies the error of the normals: 3e-4 for exact f32 products, 1e-3 for
+    # the 17-bit products of bf16x3 (measured 5.1e-4)
     for k in ("points", "rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "normal_map"):
-        close(out[k], g["out_" + k], tol=3e-4 if k in ("l3d",) else TOL, what=k)
+        close(out[k], g["out_" + k], tol=(1e-3 if prec == "bf16x3" else 3e-4) if k in ("l3d",) else TOL, what=k)
     close(out["lines2d"], g["out_lines2d"], tol=1e-4, what="lines2d (pixels, relative to 512)")
 
 
-def test_train_step_vs_reference_golden(dev, golden):
+def test_train_step_vs_reference_golden(dev, golden, prec):
     """forward + loss + backward on the reference's own recorded random draws: outputs, 11 loss scalars, all 65 grads."""
     from tests.util_replay import RngReplay
     from tests.golden.make_golden import GRAD_STRIDE
     from neat_amd.loss import VolSDFLoss
     g = golden("g8_train_step_rough")
-    m = build_model(dev, "rough", train=True)
+    m = build_model(dev, "rough", train=True, precision=prec)
     draws = [("rand", T(g["t_rand"])), ("randint", None), ("rand", T(g["u_final"])), ("randperm", T(g["perm"])),
              ("randint", T(g["eik_idx"])), ("uniform_", T(g["eik_uniform"]))]
     with RngReplay(draws):
@@ -150,7 +160,7 @@ def test_train_step_vs_reference_golden(dev, golden):
     for k in ("rgb_values", "depth", "xyz", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
               "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median"):
         close(out[k], g["out_" + k], what=k)
-    close(out["l3d"], g["out_l3d"], tol=3e-4, what="l3d")
+    close(out["l3d"], g["out_l3d"], tol=1e-3 if prec == "bf16x3" else 3e-4, what="l3d")
     lo = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)(out, {"rgb": T(g["gt_rgb"]).to(dev), "lines2d": T(g["gt_lines2d"]).to(dev)})
     for k in ("loss", "rgb_loss", "eikonal_loss", "line_loss", "l2d_loss", "j3d_loss", "j2d_loss", "j2d_stat"):
         close(lo[k].float().reshape(()), g["loss_" + k].reshape(()), what="loss " + k)
@@ -169,11 +179,11 @@ def test_train_step_vs_reference_golden(dev, golden):
     print("worst relative grad error vs reference:", worst)
 
 
-def _check_golden_train_step(m, g, dev, out, keys, loss_conf=None):
+def _check_golden_train_step(m, g, dev, out, keys, loss_conf=None, l3d_tol=3e-4):
     from tests.golden.make_golden import GRAD_STRIDE
     from neat_amd.loss import VolSDFLoss
     for k in keys:
-        close(out[k], g["out_" + k], tol=3e-4 if k == "l3d" else TOL, what=k)
+        close(out[k], g["out_" + k], tol=l3d_tol if k == "l3d" else TOL, what=k)
     lo = VolSDFLoss(**(loss_conf or synth.ABC_NEAT_A_LOSS_CONF))(out, {"rgb": T(g["gt_rgb"]).to(dev), "lines2d": T(g["gt_lines2d"]).to(dev)})
     for k in ("loss", "rgb_loss", "eikonal_loss", "line_loss", "l2d_loss", "j3d_loss", "j2d_loss", "j2d_stat"):
         close(lo[k].float().reshape(()), g["loss_" + k].reshape(()), what="loss " + k)
@@ -190,7 +200,7 @@ def _check_golden_train_step(m, g, dev, out, keys, loss_conf=None):
         assert abs(float(np.sqrt((gr.astype(np.float64) ** 2).sum())) - nrm) <= 2e-3 * nrm + 1e-7, k
 
 
-def test_train_step_dtu_switches_vs_reference_golden(dev, golden):
+def test_train_step_dtu_switches_vs_reference_golden(dev, golden, prec):
     """C3's model switches (confs/dtu.conf, bmvs.conf: dbscan_enabled = True, use_median = False, 1024 junction latents;
     rend_a :333-342,460,475-482) as a full train step against fixture G11 made by the reference: device DBSCAN + Hungarian, all
     outputs, loss scalars and gradients."""
@@ -202,7 +212,7 @@ def test_train_step_dtu_switches_vs_reference_golden(dev, golden):
     conf["global_junctions"] = dict(conf["global_junctions"], num_junctions=1024)
     m = networks.VolSDFNetwork(conf)
     m.load_state_dict({k: T(v) for k, v in synth.synth_state_dict(42, "rough", num_junctions=1024).items()}, strict=True)
-    m.to(dev).train()
+    m.to(dev).train().set_precision(prec)
     # the reference's depth samples are fed in (the sampler has its own golden tests: its inverse-CDF step is ill-conditioned, see
     # test_sampler_vs_reference_golden); what is tested here is everything downstream of them
     m.z_vals_override = T(g["z_vals"]).to(dev)
@@ -210,10 +220,11 @@ def test_train_step_dtu_switches_vs_reference_golden(dev, golden):
         out = m(scene_inputs(g, dev))
     assert "median" not in out and out["j3d_global"].shape == (1024, 3)
     _check_golden_train_step(m, g, dev, out, ("rgb_values", "depth", "xyz", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
-                                              "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "l3d"))
+                                              "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "l3d"),
+                             l3d_tol=1e-3 if prec == "bf16x3" else 3e-4)
 
 
-def test_train_step_hierarchical_vs_reference_golden(dev, golden):
+def test_train_step_hierarchical_vs_reference_golden(dev, golden, prec):
     """C5: hierarchical 64 coarse + 64 fine depths feeding the main pass (model.hip_sampler = hierarchical), a full train step
     against fixture G12 in which the reference's own UniformSampler / get_z_vals_fine / get_sdf_vals / volume_rendering were composed."""
     from tests.util_replay import RngReplay
@@ -223,7 +234,7 @@ def test_train_step_hierarchical_vs_reference_golden(dev, golden):
     conf["hip_sampler"] = "hierarchical"
     m = networks.VolSDFNetwork(conf)
     m.load_state_dict({k: T(v) for k, v in synth.synth_state_dict(42, "rough").items()}, strict=True)
-    m.to(dev).train()
+    m.to(dev).train().set_precision(prec)
     assert type(m.ray_sampler).__name__ == "HierarchicalSampler"
     # (i) the sampler itself on the reference's draws (inverse-CDF sampling is ill-conditioned: close_sampler)
     from neat_amd import rend_util
@@ -241,7 +252,8 @@ def test_train_step_hierarchical_vs_reference_golden(dev, golden):
     with RngReplay([("randint", T(g["eik_idx"])), ("uniform_", T(g["eik_uniform"]))]):
         out = m(scene_inputs(g, dev))
     _check_golden_train_step(m, g, dev, out, ("rgb_values", "depth", "xyz", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
-                                              "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median", "l3d"))
+                                              "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median", "l3d"),
+                             l3d_tol=1e-3 if prec == "bf16x3" else 3e-4)
 
 
 @pytest.mark.parametrize("variant", ["init", "rough"])
