@@ -116,6 +116,12 @@ int neat_render_forward_eval(const float* packed, const neat_net_params* net, co
                              float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                              float* xyz, float* normal_map, void* stream);
 
+/* ---- a2: UniformSampler.get_z_vals (model/ray_sampler.py:61-95): N depths per ray between near and far (per ray [R] if the pointer
+ * is given, else the scalar), stratified jitter with rnd [R,N] in training (NULL: the plain grid).  t [N] = the linspace(0, 1, N)
+ * grid.  Operations rounded one by one like the reference's elementwise ops: bit-identical to them. */
+int neat_uniform_depths(const float* near_r, float near_s, const float* far_r, float far_s, const float* t, const float* rnd, int R, int N,
+                        float* z, void* stream);
+
 /* ---- a3: ErrorBoundSampler bookkeeping (model/ray_sampler.py:130-293), one wavefront per ray --------------------
  * One round of Algorithm 1 = neat_sdf_forward(mode 0) on the new samples, then:
  *  neat_sampler_bound    : merge the sdf values (order from the previous round, :152-157), d* per interval (:161-173),

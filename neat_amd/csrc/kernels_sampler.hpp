@@ -322,6 +322,28 @@ __global__ __launch_bounds__(1024) void sampler_pick_kernel(const int* __restric
   if (rank < n_extra) pick[rank] = i;
 }
 
+// a2: UniformSampler.get_z_vals (ray_sampler.py:61-95) in one launch.  t = torch.linspace(0, 1, N) is passed in (made once per N by
+// the caller), every operation is rounded separately like the reference's chain of elementwise torch ops (no fma contraction):
+//   z0 = near (1 - t) + far t;   training: mid = 0.5 (z0[j+1] + z0[j]), upper = [mid | z0[N-1]], lower = [z0[0] | mid],
+//   z = lower + (upper - lower) rand.      near / far: per ray (pointer) or one value for all rays.
+__device__ __forceinline__ float rounded(float x) { asm volatile("" : "+v"(x)); return x; }      // a product the compiler may not fuse into an fma
+__global__ void uniform_depths_kernel(const float* __restrict__ near_r, float near_s, const float* __restrict__ far_r, float far_s,
+                                      const float* __restrict__ t, const float* __restrict__ rnd, int R, int N, float* __restrict__ z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * N) return;
+  const int r = i / N, j = i - r * N;
+  const float nr = near_r ? near_r[r] : near_s, fr = far_r ? far_r[r] : far_s;
+  // (HIP's __fmul_rn / __fadd_rn are plain operators and get contracted; every product goes through rounded())
+  auto z0 = [&](int k) { return rounded(nr * rounded(1.0f - t[k])) + rounded(fr * t[k]); };
+  float v = rounded(z0(j));
+  if (rnd) {
+    const float up = j + 1 < N ? rounded(0.5f * rounded(rounded(z0(j + 1)) + v)) : v;
+    const float lo = j > 0 ? rounded(0.5f * rounded(v + rounded(z0(j - 1)))) : v;
+    v = lo + rounded(rounded(up - lo) * rnd[i]);
+  }
+  z[i] = v;
+}
+
 struct SamplerFinishArgs {
   const float* samples; int N;        // [R,N] final samples
   const float* z; int n;              // [R,n] sampler grid

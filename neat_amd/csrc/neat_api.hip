@@ -1354,6 +1354,14 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
   return (int)hipGetLastError();
 }
 
+int neat_uniform_depths(const float* near_r, float near_s, const float* far_r, float far_s, const float* t, const float* rnd, int R, int N,
+                        float* z, void* stream) {
+  if (R <= 0 || N <= 0) return 0;
+  if (!t || !z) return -1;
+  hipLaunchKernelGGL(uniform_depths_kernel, dim3((R * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, near_r, near_s, far_r, far_s, t, rnd, R, N, z);
+  return (int)hipGetLastError();
+}
+
 int neat_sampler_bound_dev(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
                            const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out,
                            int* open, const int* gate, int gate_value, void* stream) {

@@ -352,6 +352,24 @@ def sampler_finish(samples, z, pick, near, far, eik_idx):
     return out, zeik
 
 
+_LINSPACE = {}
+
+
+def uniform_depths(R, N, near, far, rnd, device):
+    """UniformSampler.get_z_vals in one launch: near / far floats or [R] / [R,1] tensors, rnd [R,N] (training jitter) or None."""
+    key = (N, str(device))
+    t = _LINSPACE.get(key)
+    if t is None:
+        t = _LINSPACE[key] = torch.linspace(0.0, 1.0, N, device=device)
+    z = torch.empty(R, N, device=device)
+    nt = _f32c(near.reshape(-1)) if isinstance(near, torch.Tensor) else None
+    ft = _f32c(far.reshape(-1)) if isinstance(far, torch.Tensor) else None
+    _lib.check(_lib.lib().neat_uniform_depths(_p(nt), 0.0 if nt is not None else float(near), _p(ft), 0.0 if ft is not None else float(far),
+                                              _p(t), _p(_f32c(rnd)) if rnd is not None else None, R, N, _p(z), _stream()),
+               "neat_uniform_depths")
+    return z
+
+
 # ---- the same rounds with the control flow on the device (no host sync; see include/neat_hip.h) ------------------------------------
 def _ip(t, idx):
     return ctypes.c_void_p(t.data_ptr() + 4 * idx)

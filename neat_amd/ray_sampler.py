@@ -68,20 +68,28 @@ class UniformSampler(RaySampler):
 
     def get_z_vals(self, ray_dirs, cam_loc, model):
         dev, R = ray_dirs.device, ray_dirs.shape[0]
-        near = torch.full((R, 1), float(self.near), device=dev)
+        far = None
         if self.take_sphere_intersection:
             from . import rend_util
             far = rend_util.get_sphere_intersections(cam_loc, ray_dirs, r=self.scene_bounding_sphere)[:, 1:]
-        else:
-            far = torch.full((R, 1), float(self.far), device=dev)
-        t = torch.linspace(0.0, 1.0, self.N_samples, device=dev)
-        z = near * (1.0 - t) + far * t
+        rnd = None
         if model.training:                                   # stratified jitter inside each bin (:81-89)
-            mid = 0.5 * (z[:, 1:] + z[:, :-1])
-            hi = torch.cat([mid, z[:, -1:]], -1)
-            lo = torch.cat([z[:, :1], mid], -1)
-            shape = z.shape
-            z = lo + (hi - lo) * _draw(model, "uniform_jitter", lambda: torch.rand(shape), dev)
+            shape = (R, self.N_samples)
+            rnd = _draw(model, "uniform_jitter", lambda: torch.rand(shape), dev)
+        if ray_dirs.is_cuda:                                 # one launch (neat_uniform_depths), bit-identical to the op chain below
+            from . import ops
+            z = ops.uniform_depths(R, self.N_samples, float(self.near), far if far is not None else float(self.far), rnd, dev)
+        else:
+            near = torch.full((R, 1), float(self.near), device=dev)
+            if far is None:
+                far = torch.full((R, 1), float(self.far), device=dev)
+            t = torch.linspace(0.0, 1.0, self.N_samples, device=dev)
+            z = near * (1.0 - t) + far * t
+            if rnd is not None:
+                mid = 0.5 * (z[:, 1:] + z[:, :-1])
+                hi = torch.cat([mid, z[:, -1:]], -1)
+                lo = torch.cat([z[:, :1], mid], -1)
+                z = lo + (hi - lo) * rnd
         if getattr(model, "static_randoms", None) is None:
             torch.randint(z.shape[-1], (R,))                 # the reference draws (and discards) an index here (:91)
         else:                                                # graph replay: keep the draw in the refill sequence

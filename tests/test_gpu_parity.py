@@ -844,6 +844,27 @@ def test_graph_replay_with_sampler_equals_eager(dev):
         assert err <= 1e-5 * max(1.0, float(p_e[k].abs().max())), (k, err)
 
 
+@pytest.mark.parametrize("N,per_ray_far", [(128, False), (64, True), (7, False)])
+def test_uniform_depths_kernel_equals_the_op_chain(dev, N, per_ray_far):
+    """a2: neat_uniform_depths against the reference's chain of elementwise torch ops (ray_sampler.py:61-95), bit for bit, plain and
+    jittered, scalar and per-ray far."""
+    from neat_amd import ops
+    gen = torch.Generator().manual_seed(N)
+    R = 333
+    near = 0.0
+    far = (torch.rand(R, 1, generator=gen) * 4 + 1).to(dev) if per_ray_far else 6.0
+    rnd = torch.rand(R, N, generator=gen).to(dev)
+    nr = torch.full((R, 1), near, device=dev)
+    fr = far if per_ray_far else torch.full((R, 1), far, device=dev)
+    t = torch.linspace(0.0, 1.0, N, device=dev)
+    z0 = nr * (1.0 - t) + fr * t
+    mid = 0.5 * (z0[:, 1:] + z0[:, :-1])
+    hi, lo = torch.cat([mid, z0[:, -1:]], -1), torch.cat([z0[:, :1], mid], -1)
+    z1 = lo + (hi - lo) * rnd
+    assert torch.equal(ops.uniform_depths(R, N, near, far, None, dev), z0)
+    assert torch.equal(ops.uniform_depths(R, N, near, far, rnd, dev), z1)
+
+
 def test_hierarchical_sampler_on_device(dev, golden):
     """a2 + a13 (BASELINE config 5: 64 coarse + 64 fine): UniformSampler / sample_pdf / get_z_vals_fine on the device
     against the reference's golden vectors (det = linspace u, and recorded random u)."""
