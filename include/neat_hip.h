@@ -122,6 +122,12 @@ int neat_render_forward_eval(const float* packed, const neat_net_params* net, co
 int neat_uniform_depths(const float* near_r, float near_s, const float* far_r, float far_s, const float* t, const float* rnd, int R, int N,
                         float* z, void* stream);
 
+/* ---- a13: sample_pdf (model/ray_sampler.py:16-59) and the sort of UniformSampler.get_z_vals_fine (:97-106), one wavefront per ray:
+ * bins [R,nb], weights [R,nb-1] (the caller passes weights[..., 1:-1] and the interval mid points), u [N] (u_stride 0) or [R,N]
+ * -> samples [R,N]; z_merge [R,nz] given: z_out [R,nz+N] = sort(cat[z_merge, samples]).  fp64 CDF rounded once per knot. */
+int neat_sample_pdf(const float* bins, const float* weights, int nb, int R, const float* u, int u_stride, int N, float* samples,
+                    const float* z_merge, int nz, float* z_out, void* stream);
+
 /* ---- a3: ErrorBoundSampler bookkeeping (model/ray_sampler.py:130-293), one wavefront per ray --------------------
  * One round of Algorithm 1 = neat_sdf_forward(mode 0) on the new samples, then:
  *  neat_sampler_bound    : merge the sdf values (order from the previous round, :152-157), d* per interval (:161-173),

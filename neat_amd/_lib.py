@@ -51,6 +51,7 @@ _SIGNATURES = {
                                              c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_sampler_finish": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "neat_sample_pdf": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_uniform_depths": (ctypes.c_int, [c_fp, ctypes.c_float, c_fp, ctypes.c_float, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "neat_sdf_values_gated": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                              ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),

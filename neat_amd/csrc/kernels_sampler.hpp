@@ -322,6 +322,63 @@ __global__ __launch_bounds__(1024) void sampler_pick_kernel(const int* __restric
   if (rank < n_extra) pick[rank] = i;
 }
 
+// a13: sample_pdf (ray_sampler.py:16-59) and the sort of get_z_vals_fine (:97-106), one wavefront per ray.
+//   pdf = (weights + 1e-5) / sum;  cdf = [0, cumsum(pdf)] (fp64 accumulation, every knot rounded once: torch-CPU's cumsum);
+//   inverse CDF at u with the `denom < 1e-5 -> 1` rule;  then (z_merge given) the sorted union of z_merge and the samples.
+struct SamplePdfArgs {
+  const float* bins; const float* weights; int nb, R;      // bins [R,nb], weights [R,nb-1]
+  const float* u; int u_stride, N;                         // u [N] (stride 0) or [R,N]
+  float* samples;                                          // [R,N]
+  const float* z_merge; int nz; float* z_out;              // [R,nz] -> z_out [R,nz+N] sorted (null: samples only)
+};
+__global__ __launch_bounds__(64) void sample_pdf_kernel(SamplePdfArgs a) {
+  __shared__ float sb[SMAX], scdf[SMAX], sall[SMAX];
+  const int r = blockIdx.x, lane = threadIdx.x, nb = a.nb, m = nb - 1;
+  for (int j = lane; j < nb; j += 64) sb[j] = a.bins[(size_t)r * nb + j];
+  double sum = 0.0;
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + lane;
+    float p = 0.0f;
+    if (j < m) { p = a.weights[(size_t)r * m + j] + 1e-5f; scdf[j + 1] = p; }
+    sum += wave_sum_d((double)p);
+  }
+  __syncthreads();
+  const float sumf = (float)sum;
+  double carry = 0.0;
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + lane;
+    const float p = (j < m) ? scdf[j + 1] / sumf : 0.0f;
+    const double incl = wave_incl_scan_d((double)p, lane);
+    if (j < m) scdf[j + 1] = (float)(carry + incl);
+    carry += __shfl(incl, 63);
+  }
+  if (lane == 0) scdf[0] = 0.0f;
+  __syncthreads();
+  const int nz = a.z_merge ? a.nz : 0;
+  for (int k = lane; k < a.N; k += 64) {
+    const float u = a.u[(size_t)r * a.u_stride + k];
+    int lo = 0, hi = nb;                          // first index with cdf[idx] > u  (searchsorted, right = True)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (scdf[mid] > u) hi = mid; else lo = mid + 1; }
+    const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+    float den = scdf[above] - scdf[below];
+    if (den < 1e-5f) den = 1.0f;
+    const float t = (u - scdf[below]) / den;
+    const float smp = sb[below] + t * (sb[above] - sb[below]);
+    a.samples[(size_t)r * a.N + k] = smp;
+    sall[nz + k] = smp;
+  }
+  if (!a.z_merge) return;
+  for (int j = lane; j < nz; j += 64) sall[j] = a.z_merge[(size_t)r * nz + j];
+  __syncthreads();
+  const int tot = nz + a.N;                       // rank of every element of [z_merge | samples] (the samples need not be sorted: eval mode draws u)
+  for (int i = lane; i < tot; i += 64) {
+    const float x = sall[i];
+    int rank = 0;
+    for (int j = 0; j < tot; ++j) rank += (sall[j] < x) || (sall[j] == x && j < i);
+    a.z_out[(size_t)r * tot + rank] = x;
+  }
+}
+
 // a2: UniformSampler.get_z_vals (ray_sampler.py:61-95) in one launch.  t = torch.linspace(0, 1, N) is passed in (made once per N by
 // the caller), every operation is rounded separately like the reference's chain of elementwise torch ops (no fma contraction):
 //   z0 = near (1 - t) + far t;   training: mid = 0.5 (z0[j+1] + z0[j]), upper = [mid | z0[N-1]], lower = [z0[0] | mid],

@@ -1354,6 +1354,15 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
   return (int)hipGetLastError();
 }
 
+int neat_sample_pdf(const float* bins, const float* weights, int nb, int R, const float* u, int u_stride, int N, float* samples,
+                    const float* z_merge, int nz, float* z_out, void* stream) {
+  if (R <= 0) return 0;
+  if (nb < 2 || nb > SMAX || N < 1 || N > SMAX || !bins || !weights || !u || !samples || (z_merge && (!z_out || nz < 0 || nz + N > SMAX))) return -1;
+  SamplePdfArgs a{bins, weights, nb, R, u, u_stride, N, samples, z_merge, nz, z_out};
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 int neat_uniform_depths(const float* near_r, float near_s, const float* far_r, float far_s, const float* t, const float* rnd, int R, int N,
                         float* z, void* stream) {
   if (R <= 0 || N <= 0) return 0;

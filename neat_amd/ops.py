@@ -352,6 +352,22 @@ def sampler_finish(samples, z, pick, near, far, eik_idx):
     return out, zeik
 
 
+def sample_pdf(bins, weights, u, z_merge=None):
+    """sample_pdf on the device in one launch: bins [R,nb], weights [R,nb-1], u [N] or [R,N] -> samples [R,N]
+    (and, with z_merge [R,nz], the sorted union [R,nz+N] of get_z_vals_fine)."""
+    bins, weights, u = _f32c(bins.detach()), _f32c(weights.detach()), _f32c(u)
+    R, nb = bins.shape
+    N = u.shape[-1]
+    if weights.shape != (R, nb - 1):
+        raise RuntimeError("sample_pdf: weights must be [R, nb - 1]")
+    samples = torch.empty(R, N, device=bins.device)
+    zm = _f32c(z_merge.detach()) if z_merge is not None else None
+    z_out = torch.empty(R, zm.shape[1] + N, device=bins.device) if zm is not None else None
+    _lib.check(_lib.lib().neat_sample_pdf(_p(bins), _p(weights), nb, R, _p(u), N if u.dim() == 2 else 0, N, _p(samples), _p(zm),
+                                          zm.shape[1] if zm is not None else 0, _p(z_out), _stream()), "neat_sample_pdf")
+    return samples, z_out
+
+
 _LINSPACE = {}
 
 

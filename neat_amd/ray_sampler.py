@@ -30,23 +30,38 @@ def _pdf_to_cdf(pdf):
     return torch.cat([torch.zeros_like(pdf[:, :1]), pdf.double().cumsum(-1).float()], -1)
 
 
-def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
-    """NeRF inverse-CDF sampling (ray_sampler.py:16-59)."""
+_DET_U = {}
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False, merge_with=None, model=None):
+    """NeRF inverse-CDF sampling (ray_sampler.py:16-59).  CUDA tensors: one HIP launch (neat_sample_pdf), which also produces the
+    sorted union with `merge_with` (get_z_vals_fine); returns samples, or (samples, sorted union) when merge_with is given."""
     if pytest:
         raise NotImplementedError("the reference's pytest branch is broken (NameError on np); not reproduced")
+    shape = list(weights.shape[:-1]) + [N_samples]
+    if weights.is_cuda:
+        from . import ops
+        if det:                       # the CPU linspace of the reference, uploaded once per (N, device)
+            key = (N_samples, str(weights.device))
+            if key not in _DET_U:
+                _DET_U[key] = torch.linspace(0.0, 1.0, N_samples).to(weights.device)
+            u = _DET_U[key]
+        else:
+            u = _draw(model, "sample_pdf_u", lambda: torch.rand(shape), weights.device)
+        samples, merged = ops.sample_pdf(bins, weights, u, merge_with)
+        return samples if merge_with is None else (samples, merged)
+    u = torch.linspace(0.0, 1.0, N_samples) if det else torch.rand(shape)
     cdf = _pdf_to_cdf(weights + 1e-5)
-    shape = list(cdf.shape[:-1]) + [N_samples]
-    if det:
-        u = torch.linspace(0.0, 1.0, N_samples).expand(shape)
-    else:
-        u = torch.rand(shape)
-    return _lerp_inverse_cdf(bins, cdf, u.contiguous().to(weights.device))
+    samples = _lerp_inverse_cdf(bins, cdf, u.expand(shape).contiguous().to(weights.device))
+    if merge_with is None:
+        return samples
+    return samples, torch.sort(torch.cat([merge_with, samples], -1), -1)[0]
 
 
 def _draw(model, name, fn, dev):
     """A CPU draw moved to the device; through the model's draw-site registry when it has one (HIP-graph replay refills the
     persistent device tensor of every site, networks.VolSDFNetwork._cpu_random)."""
-    hook = getattr(model, "_cpu_random", None)
+    hook = getattr(model, "_cpu_random", None) if model is not None else None
     return hook(name, fn, dev) if hook is not None else fn().to(dev)
 
 
@@ -100,8 +115,8 @@ class UniformSampler(RaySampler):
     def get_z_vals_fine(self, z_vals, weights, model):
         assert self.N_important > 0
         mid = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        fine = sample_pdf(mid, weights[..., 1:-1], self.N_important, det=model.training).detach()   # det is inverted vs NeRF
-        return torch.sort(torch.cat([z_vals, fine], -1), -1)[0]
+        _, merged = sample_pdf(mid, weights[..., 1:-1], self.N_important, det=model.training, merge_with=z_vals, model=model)   # det is inverted vs NeRF
+        return merged.detach()
 
 
 class HierarchicalSampler(RaySampler):
@@ -127,7 +142,8 @@ class HierarchicalSampler(RaySampler):
             sdf = model.implicit_network.get_sdf_vals(pts.reshape(-1, 3))
             w = model.volume_rendering(zc, sdf)
         z = self.uniform_sampler.get_z_vals_fine(zc, w, model)
-        idx = torch.randint(z.shape[-1], (z.shape[0],)).to(z.device)
+        n, R = z.shape[-1], z.shape[0]
+        idx = _draw(model, "eik_idx", lambda: torch.randint(n, (R,)), z.device)
         return z, torch.gather(z, 1, idx.unsqueeze(-1))
 
 

@@ -110,6 +110,7 @@ tr5.model.set_precision(args.precision)
 _, inp5, gt5 = synthetic_batch(42, 1024, dev)
 for _ in range(3):
     tr5.step(inp5, gt5)
+graphed5 = tr5.capture(inp5, gt5)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(args.steps):
@@ -118,5 +119,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 S5 = out5["points"].shape[0] // 1024 if out5["points"].dim() == 2 else out5["points"].shape[1]
 print(json.dumps({"workload": "C5-style train step: 1024 rays, hierarchical 64 coarse + 64 fine depths (HierarchicalSampler), abc model",
-                  "launch": "eager (the torch-op sampler uploads its draws synchronously)", "ms_per_step": 1e3 * dt, "samples_per_ray": S5,
+                  "launch": "hip graph" if graphed5 else "eager", "ms_per_step": 1e3 * dt, "samples_per_ray": S5,
                   "ray_samples_per_s": 1024 * S5 / dt, "rays_per_s": 1024 / dt, "precision": args.precision}), flush=True)

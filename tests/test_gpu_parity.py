@@ -865,6 +865,28 @@ def test_uniform_depths_kernel_equals_the_op_chain(dev, N, per_ray_far):
     assert torch.equal(ops.uniform_depths(R, N, near, far, rnd, dev), z1)
 
 
+@pytest.mark.parametrize("det", [True, False])
+def test_sample_pdf_kernel_vs_torch_formulation(dev, det):
+    """a13: neat_sample_pdf (inverse-CDF samples + the sorted union of get_z_vals_fine) against the torch formulation of the same
+    reference lines run on the CPU, on dense weights (no bin near the `denom < 1e-5` threshold: the comparison is tight)."""
+    from tests.util_replay import RngReplay
+    from neat_amd.ray_sampler import sample_pdf
+    gen = torch.Generator().manual_seed(4)
+    R, nb, N = 257, 63, 64
+    z = (torch.rand(R, nb + 1, generator=gen) * 6).sort(-1)[0]
+    bins = 0.5 * (z[:, 1:] + z[:, :-1])
+    w = torch.rand(R, nb - 1, generator=gen) + 0.05
+    u = torch.rand(R, N, generator=gen)
+    draws = [] if det else [("rand", u)]
+    with RngReplay(list(draws)):
+        s_ref, m_ref = sample_pdf(bins, w, N, det=det, merge_with=z)
+    with RngReplay(list(draws)):
+        s_dev, m_dev = sample_pdf(bins.to(dev), w.to(dev), N, det=det, merge_with=z.to(dev))
+    close(s_dev, s_ref, tol=2e-6, what="samples")
+    close(m_dev, m_ref, tol=2e-6, what="sorted union")
+    assert (m_dev[:, 1:] >= m_dev[:, :-1]).all() and m_dev.shape == (R, nb + 1 + N)
+
+
 def test_hierarchical_sampler_on_device(dev, golden):
     """a2 + a13 (BASELINE config 5: 64 coarse + 64 fine): UniformSampler / sample_pdf / get_z_vals_fine on the device
     against the reference's golden vectors (det = linspace u, and recorded random u)."""
