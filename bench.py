@@ -175,11 +175,20 @@ def main():
     import torch.distributed as dist
 
     t_start = time.perf_counter()
-    rank, world, local = dp.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # NEAT_DIST_BACKEND=gloo: a functional check of the multi-process path on fewer GPUs than ranks (ranks share devices, the gradient
+    # all-reduce goes through the host).  Never a measurement: RCCL needs one GPU per rank and is the default.
+    backend = os.environ.get("NEAT_DIST_BACKEND") or None
+    ndev = torch.cuda.device_count()
+    want_local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend != "gloo" and want_local >= ndev:
+        raise SystemExit(f"rank {want_local} of this node has no GPU of its own ({ndev} visible): RCCL needs one GPU per rank")
+    torch.cuda.set_device(want_local % ndev)
+    rank, world, local = dp.init_from_env(backend=backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.lib()
@@ -289,10 +298,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "C2: abc-neat-a networks, 1024 rays x 128 samples per GPU, depth samples given, "
-                                   "train step = forward + loss + backward + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
+                                   "train step = forward + loss + backward + Adam" +
+                                   ((" + RCCL grad all-reduce" if dist.get_backend() == "nccl" else " + gloo grad all-reduce (functional check)") if world > 1 else ""),
                        "rays_per_gpu": R_RAYS, "samples_per_ray": S_SAMPLES, "global_rays": world * R_RAYS,
                        "parallelism": f"dp{world}", "weights": "synthetic 'rough' (seed 42)",
-                       "launch": "hip graph replay (forward+loss+backward) + eager all-reduce/Adam" if graphed else "eager"},
+                       "launch": "hip graph replay (forward+loss+backward) + eager all-reduce/Adam" if graphed else "eager",
+                       "dist_backend": (dist.get_backend() if world > 1 else None)},
             "rays_per_s": world * R_RAYS * args.steps / elapsed,
             "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,
             "step_frac_of_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (peak * world),
