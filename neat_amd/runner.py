@@ -170,6 +170,7 @@ def main():
     torch.manual_seed(seed)
     random.seed(seed)
     np.random.seed(seed)
+    local = local % max(torch.cuda.device_count(), 1)      # (more ranks than GPUs only under NEAT_DIST_BACKEND=gloo: functional checks)
     runner = TrainRunner(args.conf, args.nepoch, args.exps_folder, args.expname, args.scan_id, args.data_root, device=f"cuda:{local}",
                          timestamp=args.timestamp, precision=args.precision, rank=rank, world=world)
     if args.is_continue:
