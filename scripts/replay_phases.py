@@ -32,6 +32,11 @@ print("graph.replay() only      : %.3f ms" % timed(entry.graph.replay))
 print("replay + Adam + scheduler: %.3f ms" % timed(lambda: tr._finish_step(entry)))
 print("refill + replay + Adam   : %.3f ms" % timed(lambda: (tr._refill_randoms(entry), tr._finish_step(entry))))
 print("Trainer.step             : %.3f ms" % timed(lambda: tr.step(inp, gt)))
+lr = tr.optimizer.param_groups[0]["lr"]
+tr.optimizer.param_groups[0]["lr"] = 0.0
+tr.scheduler.base_lrs = [0.0]
+print("replay + Adam (lr = 0: the weights stay put, same GPU work every step): %.3f ms" % timed(lambda: (entry.graph.replay(), tr.optimizer.step())))
+tr.optimizer.param_groups[0]["lr"] = lr
 
 # host cost of one launch (the call returns when the graph is enqueued)
 torch.cuda.synchronize()
