@@ -1,6 +1,8 @@
-"""Two ranks on ONE GPU over gloo (RCCL refuses two ranks per device): HIP-graph train step + flat-bucket all-reduce.
-Checks that ranks with different rays end every step with identical parameters.  Launch:
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 scripts/dp_graph_check.py"""
+"""Two ranks: HIP-graph train step + ONE flat gradient all-reduce + Adam per step.  Ranks render different views with different rays
+and must end every step with identical parameters.  On a box with fewer GPUs than ranks the ranks share a device and the
+all-reduce goes through gloo (RCCL refuses two ranks per device); with a GPU per rank it is RCCL.  Launch:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 scripts/dp_graph_check.py
+(tests/test_dp_gpu.py does)"""
 import os, sys
 import torch
 import torch.distributed as dist
@@ -8,9 +10,11 @@ sys.path.insert(0, '.')
 from neat_amd import dp, synth
 from neat_amd.train import Trainer, synthetic_batch
 
-rank, world, _ = dp.init_from_env(backend="gloo")
-dev = torch.device("cuda:0")
-torch.cuda.set_device(0)
+ndev = torch.cuda.device_count()
+backend = "nccl" if ndev >= int(os.environ.get("WORLD_SIZE", "1")) else "gloo"
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
+rank, world, local = dp.init_from_env(backend=backend)
+dev = torch.device("cuda", local % ndev)
 torch.manual_seed(dp.rank_seed(42, rank))
 tr = Trainer(device=dev, state_dict={k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()})
 _, inp, gt = synthetic_batch(dp.rank_seed(42, rank), 128, dev, view=rank)
@@ -26,7 +30,7 @@ gathered = [torch.empty_like(flat) for _ in range(world)]
 dist.all_gather(gathered, flat)
 diff = max(float((g - gathered[0]).abs().max()) for g in gathered)
 if rank == 0:
-    print("in-place all-reduce groups:", [len(g) for g in tr.bucket._plan], "of", len(tr.bucket.params), "tensors")
-    print(f"graph captured: {ok} ({tr.capture_error!r}); loss {float(lo['loss']):.5f}; max parameter difference across ranks: {diff:.3e}")
-    assert diff == 0.0
+    print(f"backend {backend}; graph captured: {ok} ({tr.capture_error!r}); replays {tr.replays}; loss {float(lo['loss'].detach()):.5f}; "
+          f"max parameter difference across ranks: {diff:.3e}", flush=True)
+    assert ok and tr.replays >= 4 and diff == 0.0 and torch.isfinite(lo["loss"]).all()
 dist.destroy_process_group()
