@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 5 */
+int neat_abi_version(void);      /* 6 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -57,7 +57,12 @@ int neat_pack_weights(const neat_net_params* net, float* packed, int precision, 
 
 /* ---- a1: pixel -> unit ray directions (utils/rend_util.py:55-81 get_camera_params, :95-108 lift) --
  * uv [R,2], pose [4,4] cam-to-world, K row stride `kstride` (3 or 4).  dirs [R,3].  Origin = pose[:3,3]. */
-int neat_camera_rays(const float* uv, const float* pose, const float* K, int kstride, int R, float* dirs, void* stream);
+int neat_camera_rays(const float* uv, const float* pose, const float* K, int kstride, int R, float* dirs, float* origins /* [R,3] or NULL: the camera centre per ray */,
+                     void* stream);
+/* a12: the eikonal points of a training step (neat_wfr_rend_a.py:515-527) as one array [2R + J, 3]:
+ * [uniform [R,3] (drawn by the caller) | origins + z_eik dirs | extra [J,3] (the global junctions, J may be 0)]. */
+int neat_eik_points(const float* uniform, const float* origins, const float* dirs, const float* z_eik, const float* extra, int R, int J,
+                    float* out, void* stream);
 
 /* ---- a4+a5: SDF / implicit network (neat_wfr_rend_a.py:78-137) -----------------------------------
  * mode 0: values only  -> sdf[P] = get_sdf_vals(x)            (:131-137), nothing saved

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/abl_build.sh)
@@ -26,7 +26,8 @@ _SIGNATURES = {
     "neat_abi_version": (ctypes.c_int, []),
     "neat_packed_floats": (ctypes.c_size_t, [ctypes.c_int]),
     "neat_pack_weights": (ctypes.c_int, [ctypes.POINTER(NetParams), c_fp, ctypes.c_int, c_fp]),
-    "neat_camera_rays": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "neat_eik_points": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "neat_camera_rays": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_sdf_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "neat_sdf_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),

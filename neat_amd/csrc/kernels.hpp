@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
 
 // pixel -> ray (rend_util.py:55-81,95-108)
 __global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ Kin,
-                                   int kstride, int R, float* __restrict__ dirs) {
+                                   int kstride, int R, float* __restrict__ dirs, float* __restrict__ origins) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float fx = Kin[0], sk = Kin[1], cx = Kin[2], fy = Kin[kstride + 1], cy = Kin[kstride + 2];
@@ -1020,6 +1020,25 @@ __global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __
   }
   const float n = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);
   dirs[r * 3 + 0] = w[0] / n; dirs[r * 3 + 1] = w[1] / n; dirs[r * 3 + 2] = w[2] / n;
+  if (origins) {          // the camera centre once per ray (the callers' `cam_loc.unsqueeze(1).repeat(1, R, 1)`, rend_a :395)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) origins[r * 3 + c] = pose[c * 4 + 3];
+  }
+}
+
+// eikonal points of a training step (rend_a :515-527): [uniform draws in the bounding cube | one point per ray at its drawn depth
+// o + z d | optional extra points (the global junctions)] as one [2R + J, 3] array, one launch instead of addcmul + cat (+ cat)
+__global__ void eik_points_kernel(const float* __restrict__ uniform, const float* __restrict__ o, const float* __restrict__ d,
+                                  const float* __restrict__ z_eik, const float* __restrict__ extra, int R, int J, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = (2 * R + J) * 3;
+  if (i >= n) return;
+  const int p = i / 3, c = i - 3 * p;
+  float v;
+  if (p < R) v = uniform[i];
+  else if (p < 2 * R) { const int r = p - R; v = fmaf(z_eik[r], d[3 * r + c], o[3 * r + c]); }
+  else v = extra[i - 6 * R];
+  out[i] = v;
 }
 
 }  // namespace neat

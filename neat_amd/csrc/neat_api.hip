@@ -1072,7 +1072,7 @@ bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3; }
 // ================================================================================================
 extern "C" {
 
-int neat_abi_version(void) { return 5; }
+int neat_abi_version(void) { return 6; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
   if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
@@ -1138,9 +1138,17 @@ int neat_pack_weights(const neat_net_params* net, float* packed, int precision, 
   return (int)hipGetLastError();
 }
 
-int neat_camera_rays(const float* uv, const float* pose, const float* K, int kstride, int R, float* dirs, void* stream) {
+int neat_camera_rays(const float* uv, const float* pose, const float* K, int kstride, int R, float* dirs, float* origins, void* stream) {
   if (R <= 0) return 0;
-  hipLaunchKernelGGL(camera_rays_kernel, grid1(R), dim3(256), 0, (hipStream_t)stream, uv, pose, K, kstride, R, dirs);
+  hipLaunchKernelGGL(camera_rays_kernel, grid1(R), dim3(256), 0, (hipStream_t)stream, uv, pose, K, kstride, R, dirs, origins);
+  return (int)hipGetLastError();
+}
+
+int neat_eik_points(const float* uniform, const float* origins, const float* dirs, const float* z_eik, const float* extra, int R, int J,
+                    float* out, void* stream) {
+  if (R <= 0 || J < 0) return R == 0 && J == 0 ? 0 : -1;
+  if (!uniform || !origins || !dirs || !z_eik || !out || (J > 0 && !extra)) return -1;
+  hipLaunchKernelGGL(eik_points_kernel, grid1((2 * R + J) * 3), dim3(256), 0, (hipStream_t)stream, uniform, origins, dirs, z_eik, extra, R, J, out);
   return (int)hipGetLastError();
 }
 

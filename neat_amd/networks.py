@@ -352,6 +352,9 @@ class VolSDFNetwork(_HipModule):
         return ops.volume_weights(z_vals, sdf, self.density.get_beta())
 
     def _rays(self, input, key="uv"):
+        if input[key].is_cuda and input["pose"].shape[1:] == (4, 4):      # directions and the per-ray camera centre in one launch
+            dirs, _, origins = ops.camera_rays(input[key], input["pose"], input["intrinsics"], with_origins=True)
+            return dirs.reshape(-1, 3), origins
         dirs, cam = rend_util.get_camera_params(input[key], input["pose"], input["intrinsics"])
         n = dirs.shape[1]
         return dirs.reshape(-1, 3), cam.unsqueeze(1).repeat(1, n, 1).reshape(-1, 3)
@@ -571,7 +574,9 @@ class VolSDFNetwork(_HipModule):
         """Eikonal points: uniform in the bounding cube + one near-surface sample per ray (rend_a :515-527)."""
         r = self.scene_bounding_sphere
         eik = self._cpu_random("eik_uniform", lambda: torch.empty(n_rays, 3).uniform_(-r, r), ray_dirs.device)
-        eik = torch.cat([eik, torch.addcmul(cam_loc, z_eik, ray_dirs)], 0)       # o + z d in one launch
+        if eik.is_cuda:
+            return ops.eik_points(eik, cam_loc, ray_dirs, z_eik, junctions)       # [uniform | o + z d | junctions]: one launch
+        eik = torch.cat([eik, torch.addcmul(cam_loc, z_eik, ray_dirs)], 0)
         if junctions is not None:
             eik = torch.cat([eik, junctions], 0)
         return eik

@@ -280,8 +280,9 @@ def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=F
     return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, *handle.tensors())
 
 
-def camera_rays(uv, pose, intrinsics):
-    """rend_util.get_camera_params for pose matrices: uv [1,R,2], pose [1,4,4], K [1,3|4,3|4] -> dirs [1,R,3], cam [1,3]."""
+def camera_rays(uv, pose, intrinsics, with_origins=False):
+    """rend_util.get_camera_params for pose matrices: uv [1,R,2], pose [1,4,4], K [1,3|4,3|4] -> dirs [1,R,3], cam [1,3]
+    (with_origins: also the camera centre repeated per ray, [R,3], written by the same launch)."""
     lib = _lib.lib()
     if pose.shape[0] != 1 or pose.shape[1:] != (4, 4):
         raise NotImplementedError("camera_rays: one 4x4 pose per call (the reference forward is single-view; "
@@ -289,8 +290,23 @@ def camera_rays(uv, pose, intrinsics):
     uv_c, pose_c, K_c = _f32c(uv.detach()), _f32c(pose.detach()), _f32c(intrinsics.detach())
     R = uv_c.shape[1]
     dirs = torch.empty(1, R, 3, device=uv_c.device)
-    _lib.check(lib.neat_camera_rays(_p(uv_c), _p(pose_c), _p(K_c), int(K_c.shape[-1]), R, _p(dirs), _stream()), "neat_camera_rays")
+    origins = torch.empty(R, 3, device=uv_c.device) if with_origins else None
+    _lib.check(lib.neat_camera_rays(_p(uv_c), _p(pose_c), _p(K_c), int(K_c.shape[-1]), R, _p(dirs), _p(origins), _stream()),
+               "neat_camera_rays")
+    if with_origins:
+        return dirs, pose_c[:, :3, 3], origins
     return dirs, pose_c[:, :3, 3]
+
+
+def eik_points(uniform, origins, dirs, z_eik, extra=None):
+    """[uniform | origins + z_eik dirs | extra] -> [2R + J, 3] in one launch (no gradient: the inputs are draws and detached depths)."""
+    uniform, origins, dirs, z_eik = (_f32c(t.detach()) for t in (uniform, origins, dirs, z_eik.reshape(-1)))
+    R = uniform.shape[0]
+    ex = _f32c(extra.detach()) if extra is not None and extra.shape[0] > 0 else None
+    J = ex.shape[0] if ex is not None else 0
+    out = torch.empty(2 * R + J, 3, device=uniform.device)
+    _lib.check(_lib.lib().neat_eik_points(_p(uniform), _p(origins), _p(dirs), _p(z_eik), _p(ex), R, J, _p(out), _stream()), "neat_eik_points")
+    return out
 
 
 def volume_weights(z, sdf, beta):
