@@ -1,8 +1,10 @@
 """Depth samplers with the reference's names (code/model/ray_sampler.py).
 
-ErrorBoundSampler = VolSDF Algorithm 1.  The MLP evaluations (the dominant cost: 128..640 SDF queries per
-ray) run in the HIP SDF kernels via model.implicit_network.get_sdf_vals; the per-ray bookkeeping below is
-R x <=640 sized torch-on-device work (a per-ray HIP kernel is the next step).
+UniformSampler, sample_pdf / get_z_vals_fine and the ErrorBoundSampler (VolSDF Algorithm 1) run in HIP on CUDA tensors:
+neat_uniform_depths, neat_sample_pdf, and for Algorithm 1 the fused SDF values kernel (128..640 SDF queries per ray, the dominant
+cost) plus the per-ray bound / resample / finish kernels (neat_sampler_*), driven either with the reference's control flow
+(one host sync per round) or with the decision kept on the device (get_z_vals_device).  The torch formulations in this file are
+the CPU path and the cross-checks of the gpu tests.
 Random draws are made on the CPU generator in the reference's order and moved to the device,
 so a seeded run consumes the RNG stream exactly as the reference does.
 """
