@@ -1,5 +1,7 @@
-// Second-generation fused chains of the bf16 build: FOUR waves per workgroup, one workgroup per CU, each wave owns
-// 64 output rows of every 256-wide layer.
+// Fused primal chain of the bf16 build, generations 2-4 (generation 1 = sdf_fused_ws_kernel in kernels_bf16.hpp):
+//   sdf_fused_w64_kernel<NT = 4, VALUES, RT>: stage pipeline; RT = 2 -> four waves x 64 output rows, RT = 1 (default, tuning key 4 = 3)
+//   -> eight waves x 32 rows, two per SIMD;  sdf_fused_ph_kernel: phase-staggered matrix / vector waves (slower, kept selectable).
+// The notes below were written for the RT = 2 variant; what carried over to RT = 1 is the pipeline, not the 64-row slice.
 //
 // sdf_fused_ws_kernel (kernels_bf16.hpp) gives a wave 32 output rows, so every 1 KiB B fragment it reads from LDS
 // feeds ONE MFMA, all eight waves re-read the same activation tile, and the 128 KiB weight matrix of the next layer

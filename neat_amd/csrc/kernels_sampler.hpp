@@ -1,7 +1,11 @@
-// Per-ray kernels for the ErrorBoundSampler (VolSDF Algorithm 1; reference: code/model/ray_sampler.py:130-293).
-// One wavefront per ray, the ray's samples (<= SMAX) live in LDS; prefix sums are wave scans with a cross-chunk
-// carry.  The batch-global convergence test of the reference (`beta.max() > beta0`, :200) is a device flag that
-// the host reads once per round -- the same single sync the reference has.
+// Per-ray kernels of the depth samplers (reference: code/model/ray_sampler.py).
+//  * ErrorBoundSampler (VolSDF Algorithm 1, :130-293): sampler_bound_kernel (one 4-wave workgroup per ray: d*, beta bisection),
+//    sampler_resample_kernel / sampler_finish_kernel / sampler_pick_kernel (one wavefront per ray); the ray's samples (<= SMAX) live
+//    in LDS, prefix sums are fp64 wave scans on the DPP network with a cross-chunk carry.  The batch-global convergence test of the
+//    reference (`beta.max() > beta0`, :200) is a device flag: read by the host once per round (the reference's single sync), or --
+//    device-decided mode -- consumed by the next round's launches themselves (gates, see SamplerResampleArgs).
+//  * sample_pdf + the sort of get_z_vals_fine (:16-59, :97-106): sample_pdf_kernel.
+//  * UniformSampler.get_z_vals (:61-95): uniform_depths_kernel.
 #pragma once
 #include "kernels.hpp"
 
