@@ -887,6 +887,28 @@ def test_sample_pdf_kernel_vs_torch_formulation(dev, det):
     assert (m_dev[:, 1:] >= m_dev[:, :-1]).all() and m_dev.shape == (R, nb + 1 + N)
 
 
+@pytest.mark.parametrize("R,J", [(257, 0), (64, 37), (1, 1)])
+def test_eik_points_and_ray_origins_kernels(dev, R, J):
+    """neat_eik_points against cat / addcmul, and the per-ray origins written by neat_camera_rays against the repeated camera centre."""
+    from neat_amd import ops, rend_util
+    gen = torch.Generator().manual_seed(R + J)
+    uni = (torch.rand(R, 3, generator=gen) * 6 - 3).to(dev)
+    o = torch.randn(R, 3, generator=gen).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).to(dev)
+    z = (torch.rand(R, 1, generator=gen) * 5).to(dev)
+    extra = torch.randn(J, 3, generator=gen).to(dev) if J else None
+    got = ops.eik_points(uni, o, d, z, extra)
+    ref = torch.cat([uni, o + z * d] + ([extra] if J else []), 0)
+    assert got.shape == (2 * R + J, 3)
+    close(got, ref, tol=1e-6, what="eik points")
+    assert torch.equal(got[:R], uni) and (J == 0 or torch.equal(got[2 * R:], extra))
+    sc = synth.synth_scene(seed=3, n_rays=R)
+    uv, pose, K = (T(sc[k]).to(dev) for k in ("uv", "pose", "intrinsics"))
+    dirs, cam, origins = ops.camera_rays(uv, pose, K, with_origins=True)
+    dirs2, cam2 = rend_util.get_camera_params(uv, pose, K)
+    assert torch.equal(dirs, dirs2) and torch.equal(origins, cam2.expand(R, 3))
+
+
 def test_hierarchical_sampler_on_device(dev, golden):
     """a2 + a13 (BASELINE config 5: 64 coarse + 64 fine): UniformSampler / sample_pdf / get_z_vals_fine on the device
     against the reference's golden vectors (det = linspace u, and recorded random u)."""
