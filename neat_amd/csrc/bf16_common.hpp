@@ -67,4 +67,14 @@ struct FusedArgs {
   const int* gate; int gate_value;      // device-side gate (sync-free sampler): the launch does nothing unless *gate == gate_value (null: run)
 };
 
+// argument block of the fused adjoint chain (kernels_fused.hpp: sdf_adjoint_w64_kernel)
+struct AdjArgs {
+  int P, ldp;
+  const uint4* Wp[8];            // transposed packs of layers 0 .. 7 (A fragments [tile][16][64])
+  const u16* h[9];               // h[1..8]: saved post-activations (octet-major)
+  u16* u[8];                     // u[0..7] (octet-major; written in SAVE mode)
+  const float* w8; const float* rs8;      // the sdf row of lin8 (weight_v row 0) and its weight-norm scale: the seed
+  float* es; float* e0;          // fp32 feature-major [39][ldp] each
+};
+
 }  // namespace neat

@@ -15,4 +15,7 @@ namespace neat {
 // SIMD) / eight waves (two per SIMD).
 hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, int nwg, bool full, bool interleave, int rows_per_wave);
 
+// fused adjoint chain (normals): seed + 8 transposed layers in one launch; save: write u_0 .. u_7 (training)
+hipError_t launch_sdf_adjoint_w64(hipStream_t st, const AdjArgs& a, int ntiles, int nwg, bool save);
+
 }  // namespace neat

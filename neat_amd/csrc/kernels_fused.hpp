@@ -62,6 +62,8 @@ struct F6Lane {
   const unsigned char* pe0;       // PE octet 0 of this lane's point: PE + (lane & 31) * 16        (+ t * 512)
   unsigned gquad;                 // HBM quad store:   ((8 wave) * ldp + p0 + (lane & 31)) * 16 + 8 hi      (per batch)
   unsigned ldp16;                 // ldp * 16
+  float* frows;                   // adjoint chain: fp32 feature-major rows [.][ldp] for the rows >= SPLIT of the current layer
+  unsigned fcol;                  // p0 + (lane & 31)                                                             (per batch)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -76,10 +78,18 @@ struct F6EpiState { float m0, m1, w0, w1; unsigned lo; };       // what travels 
 
 // epilogue of one layer (compile-time description): activation, destination, row count, bias rows
 template <bool ACT_, bool SAVE_, int N_, int DST_, int BIASOFF_> struct F6EpiCfg {
-  static constexpr bool ACT = ACT_, SAVE = SAVE_, NONE = false;
-  static constexpr int N = N_, DST = DST_, BIASOFF = BIASOFF_;
+  static constexpr bool ACT = ACT_, SAVE = SAVE_, NONE = false, REV = false;
+  static constexpr int N = N_, DST = DST_, BIASOFF = BIASOFF_, SPLIT = 1 << 30;
 };
-struct F6NoEpi { static constexpr bool ACT = false, SAVE = false, NONE = true; static constexpr int N = 256, DST = 0, BIASOFF = 0; };
+struct F6NoEpi { static constexpr bool ACT = false, SAVE = false, NONE = true, REV = false; static constexpr int N = 256, DST = 0, BIASOFF = 0, SPLIT = 1 << 30; };
+// adjoint chain (fused EPI_REV): value = acc * phi'(h), phi'(a) = 1 - exp(-100 h), h = the saved post-activation of the layer below,
+// which travels in the `bq` argument as raw bf16 quads (bq[g].x / .y = the two pairs of quad g).  Rows >= SPLIT leave as fp32 rows
+// (row - SPLIT) of F6Lane::frows without the phi' factor and are zero on chip and in the bf16 array: the PE cotangent of the skip
+// layer (SPLIT = 217) and the whole output of the last layer (SPLIT = 0, N = 39).
+template <bool SAVE_, int N_, int DST_, int SPLIT_> struct F6RevCfg {
+  static constexpr bool ACT = false, SAVE = SAVE_, NONE = false, REV = true;
+  static constexpr int N = N_, DST = DST_, BIASOFF = 0, SPLIT = SPLIT_;
+};
 
 // the bias rows of this lane for a layer: 8 quads x float4 (pre-scaled by SOFTPLUS_C for the activated layers)
 template <class E, int RT> __device__ __forceinline__ void f6_load_bias(const F6Lane& L, float4 (&bq)[4 * RT]) {
@@ -98,6 +108,36 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
   const int g = e >> 1, i = g >> 2, q = g & 3, pr = e & 1;
   const float x0 = ae[i][4 * q + 2 * pr], x1 = ae[i][4 * q + 2 * pr + 1];
   const float b0 = pr ? bq[g].z : bq[g].x, b1 = pr ? bq[g].w : bq[g].y;
+  if (E::REV) {
+    const int nb = 32 * (RT * wave + i) + 8 * q + 4 * hi + 2 * pr;          // rows nb, nb + 1 of the layer's output
+    if (h == 0) {
+      if (E::SPLIT > 0) {
+        const unsigned hw = __float_as_uint(pr ? bq[g].y : bq[g].x);
+        st.m0 = x0 * dphi_fast(bf_lo(hw));      // (the streaming EPI_REV epilogue's expression: bit-identical results)
+        st.m1 = x1 * dphi_fast(bf_hi(hw));
+      }
+      return;
+    }
+    float r0 = st.m0, r1 = st.m1;
+    if (E::SPLIT < 256 && 32 * (RT * wave + i) + 8 * q + 7 >= E::SPLIT) {      // (wave-uniform: only the row tiles that reach the split)
+      // row indices from an opaque copy of the lane's half: the per-(quad, pair) rows, masks and offsets are loop invariants that
+      // would otherwise be hoisted out of the batch loop -- 64 values -- and spilled
+      int hio = hi;
+      asm volatile("" : "+v"(hio));
+      const int n0 = 32 * (RT * wave + i) + 8 * q + 4 * hio + 2 * pr;
+      const bool st_ok = FULL || t < nt;
+      const unsigned col = L.fcol + t * 32, ld = L.ldp16 >> 4;
+      if (n0 >= E::SPLIT) { r0 = 0.0f; if (st_ok && n0 < E::N) L.frows[(unsigned)(n0 - E::SPLIT) * ld + col] = x0; }
+      if (n0 + 1 >= E::SPLIT) { r1 = 0.0f; if (st_ok && n0 + 1 < E::N) L.frows[(unsigned)(n0 + 1 - E::SPLIT) * ld + col] = x1; }
+    }
+    const unsigned pk = pack2(r0, r1);
+    if (pr == 0) { st.lo = pk; return; }
+    const uint2 v = make_uint2(st.lo, pk);
+    if (E::SPLIT > 0) *reinterpret_cast<uint2*>(L.quad[E::DST] + ((i * 4 + q) * BP + t * 32) * 16) = v;
+    if (E::SAVE && (FULL || t < nt))
+      *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((unsigned)(i * 4 + q) * L.ldp16 + L.gquad) + t * 512) = v;
+    return;
+  }
   if (h == 0) {
     if (E::ACT && NEAT_F6_ABLATE != 1) {
       const float u0 = NEAT_F6_ABLATE == 6 ? x0 : fmaf(x0, SOFTPLUS_C, b0), u1 = NEAT_F6_ABLATE == 6 ? x1 : fmaf(x1, SOFTPLUS_C, b1);
@@ -500,6 +540,150 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
     }
     __syncthreads();
    }
+  }
+}
+
+// ===============================================================================================================
+// Fused ADJOINT chain (normals: d sdf / d x through the SDF MLP, reference: autograd.grad at neat_wfr_rend_a.py:121-127).
+//   u_7 = w8 (.) phi'(h_8);   u_{l-1} = (W_l^T u_l) (.) phi'(h_l)  for l = 7 .. 1  (l = 4: rows 217.. are the PE cotangent of the skip,
+//   fp32, no phi');   e0 = W_0^T u_0 (39 fp32 rows).
+// Same stage pipeline, LDS ping-pong and register-resident double-buffered weight slices as sdf_fused_w64_kernel (RT = 1), with
+// the transposed packs; the chain variable u never leaves the chip between layers.  Per layer and point the kernel reads the
+// saved h_l once (8-byte quads in accumulator layout, requested one stage before the epilogue that uses them) and, in SAVE mode
+// (training: the tangent chain and the weight gradient read u_l), writes u_{l-1} once: 2 streams per layer where the streaming
+// EPI_REV launches move 3 (in, aux, out) -- and 8 launches + the seed kernel become one.
+// ===============================================================================================================
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int ntiles, int nwg) {
+  constexpr int NT = 4, RT = 1;
+  typedef F6Cfg<NT, RT> C;
+  constexpr int BP = C::BP, F6T = C::THREADS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char f6lds[];
+  float* seedw = reinterpret_cast<float*>(f6lds + C::BIAS);      // [256]: w8[k] * rs8
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int k = tid; k < 256; k += F6T) seedw[k] = a.w8[k] * a.rs8[0];
+
+  uint4 wA[RT][16], wB[RT][16];
+  auto load_w = [&](uint4 (&dst)[RT][16], const uint4* Wl, int N) {
+    const char* base = reinterpret_cast<const char*>(Wl);
+    const int tile = (RT * wave) * 32 < N ? RT * wave : 0;          // dead row tiles re-read a live one
+    unsigned voff = (unsigned)((tile * 16) * 64 + lane) * 16u;
+    asm volatile("" : "+v"(voff));
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) dst[0][ks] = *reinterpret_cast<const uint4*>(base + voff + ks * 1024);
+  };
+
+  F6Lane L;
+  {
+    const unsigned fo = (unsigned)(hi * BP + (lane & 31)) * 16u, qo = (unsigned)((4 * RT * wave) * BP + (lane & 31)) * 16u + 8u * hi;
+    unsigned b0 = fo, b1 = fo + C::XB, q0 = qo, q1 = qo + C::XB, bb = C::BIAS + (unsigned)(32 * RT * wave + 4 * hi) * 4u;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(q0), "+v"(q1), "+v"(bb));
+    L.frag[0] = f6lds + b0; L.frag[1] = f6lds + b1; L.frag[2] = f6lds + b0;
+    L.quad[0] = f6lds + q0; L.quad[1] = f6lds + q1; L.bias = f6lds + bb; L.pe0 = f6lds;
+  }
+  L.ldp16 = (unsigned)a.ldp * 16u;
+  __syncthreads();
+
+  const int t_begin = (int)(((long long)blockIdx.x * ntiles) / nwg), t_end = (int)(((long long)(blockIdx.x + 1) * ntiles) / nwg);
+  for (int tile0 = t_begin; tile0 < t_end; tile0 += NT) {
+    const int p0 = tile0 * 32;
+    const int nt = min(NT, t_end - tile0);
+    L.gquad = ((unsigned)(4 * RT * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
+    L.fcol = (unsigned)(p0 + (lane & 31));
+    // the row stride as an opaque per-batch VGPR: with a loop-invariant stride the 64 (array, quad) row bases of the sixteen h / u
+    // arrays are hoisted out of the batch loop as scalar pairs and spilled
+    L.ldp16 = (unsigned)a.ldp * 16u;
+    asm volatile("" : "+v"(L.ldp16));
+
+    auto chain = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      load_w(wA, a.Wp[7], 256);
+      load_w(wB, a.Wp[6], 256);
+      // the saved activation quads of this lane for point tile t: rows 32 wave + 8 q + 4 hi .. + 3, raw bf16 (see F6RevCfg)
+      auto load_h = [&](float4 (&dst)[4 * RT], const u16* hsrc, int t) {
+        if (!(FULL || t < nt)) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {      // kernarg base + one 32-bit per-lane offset (the arrays are < 4 GB) + immediate
+          const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512);
+          dst[q].x = __uint_as_float(v.x); dst[q].y = __uint_as_float(v.y);
+        }
+      };
+      float4 hq[2][4 * RT];
+      // ---- seed: u_7 = w8 (.) phi'(h_8) -> XA (+ HBM)
+      {
+        float4 wq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(L.bias + (8 * q) * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (!(FULL || t < nt)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(L.quad[0] + (q * BP + t * 32) * 16) = make_uint2(0u, 0u);
+            continue;
+          }
+          load_h(hq[0], a.h[8], t);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned h0 = __float_as_uint(hq[0][q].x), h1 = __float_as_uint(hq[0][q].y);
+            const uint2 v = make_uint2(pack2(wq[q].x * dphi_fast(bf_lo(h0)), wq[q].y * dphi_fast(bf_hi(h0))),
+                                       pack2(wq[q].z * dphi_fast(bf_lo(h1)), wq[q].w * dphi_fast(bf_hi(h1))));
+            *reinterpret_cast<uint2*>(L.quad[0] + (q * BP + t * 32) * 16) = v;
+            if (SAVE) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.u[7]) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = v;
+          }
+        }
+      }
+      __syncthreads();
+
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R7;      // l = 7: XA -> XB, * phi'(h_7), -> u_6
+      typedef F6RevCfg<SAVE, 256, 0, 1 << 30> R6;
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R5;
+      typedef F6RevCfg<SAVE, 256, 0, 217> R4;          // l = 4: rows 217 .. 255 -> es (PE cotangent of the skip)
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R3;
+      typedef F6RevCfg<SAVE, 256, 0, 1 << 30> R2;
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R1;
+      typedef F6RevCfg<false, 39, 0, 0> R0;            // l = 0: e0 = W_0^T u_0, 39 fp32 rows
+      f32x16 acc[2][RT];
+      uint4 ring[NEAT_F6_RING];
+      constexpr int RD = NEAT_F6_RING;
+#define ADJ_STAGE(S_, T_, SRC_, WC_, E_, H_, TE_, NFR_)                                                                              \
+      f6_stage<NT, RT, FULL, true, 16, SRC_, E_, (16 * (S_)) % RD, ((S_) % 2 == 1)>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], hq[((S_) + 1) & 1], TE_, nt, H_, wave, hi, ring, NFR_);
+      // HSRC_: the h array whose phi' multiplies this layer's output (null: none); FPREV_ / FCUR_: fp32 row destinations of the previous / this layer
+#define ADJ_LAYER(S0_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, HAS_H_, HSRC_, NSRC_, FPREV_, FCUR_)                                          \
+      { L.frows = FPREV_;                                                                                                         \
+        if (HAS_H_) load_h(hq[((S0_) + 0) & 1], HSRC_, 0);                                                                         \
+        ADJ_STAGE((S0_) + 0, 0, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512)                                         \
+        L.frows = FCUR_;                                                                                                          \
+        if (HAS_H_) load_h(hq[((S0_) + 1) & 1], HSRC_, 1);                                                                         \
+        ADJ_STAGE((S0_) + 1, 1, SRC_, WC_, ECUR_, HCUR_, 0, L.frag[SRC_] + 2 * 512)                                                \
+        if (HAS_H_) load_h(hq[((S0_) + 2) & 1], HSRC_, 2);                                                                         \
+        ADJ_STAGE((S0_) + 2, 2, SRC_, WC_, ECUR_, HCUR_, 1, L.frag[SRC_] + 3 * 512)                                                \
+        if (HAS_H_) load_h(hq[((S0_) + 3) & 1], HSRC_, 3);                                                                         \
+        ADJ_STAGE((S0_) + 3, 3, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 2 ? L.frag[(NSRC_) < 2 ? (NSRC_) : 0] : nullptr)) }
+#pragma unroll
+      for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[0] + j * 2 * BP * 16);
+      ADJ_LAYER(0, 0, wA, F6NoEpi, R7, nullptr, a.u[6], 1, a.h[7], 1, nullptr, nullptr)
+      load_w(wA, a.Wp[5], 256);
+      ADJ_LAYER(4, 1, wB, R7, R6, a.u[6], a.u[5], 1, a.h[6], 0, nullptr, nullptr)
+      load_w(wB, a.Wp[4], 256);
+      ADJ_LAYER(8, 0, wA, R6, R5, a.u[5], a.u[4], 1, a.h[5], 1, nullptr, nullptr)
+      load_w(wA, a.Wp[3], 256);
+      ADJ_LAYER(12, 1, wB, R5, R4, a.u[4], a.u[3], 1, a.h[4], 0, nullptr, a.es)
+      load_w(wB, a.Wp[2], 256);
+      ADJ_LAYER(16, 0, wA, R4, R3, a.u[3], a.u[2], 1, a.h[3], 1, a.es, nullptr)
+      load_w(wA, a.Wp[1], 256);
+      ADJ_LAYER(20, 1, wB, R3, R2, a.u[2], a.u[1], 1, a.h[2], 0, nullptr, nullptr)
+      load_w(wB, a.Wp[0], 39);
+      ADJ_LAYER(24, 0, wA, R2, R1, a.u[1], a.u[0], 1, a.h[1], 1, nullptr, nullptr)
+      ADJ_LAYER(28, 1, wB, R1, R0, a.u[0], nullptr, 0, a.h[1], 2, nullptr, a.e0)
+      // drain: the last tile of the last layer
+      f6_stage<NT, RT, FULL, false, 16, 0, R0, 0, true>(L, wB, 0, acc[0], acc[1], hq[1], NT - 1, nt, nullptr, wave, hi, ring, nullptr);
+#undef ADJ_LAYER
+#undef ADJ_STAGE
+    };
+    if (nt == NT) chain(std::true_type{});
+    else chain(std::false_type{});
+    __syncthreads();
   }
 }
 

@@ -175,6 +175,7 @@ inline int wgrad_batch_size(int ldp) {
 int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
 int g_wreduce_direct = 2;   // bf16 weight-gradient reduction: 2 = one launch per layer / batch with 16-byte loads (wreduce_direct_kernel), 0 = group
                             // sums + finish (two launches, stage buffer), 1 = one 16-wave pass with 4-byte loads (slowest)
+int g_fused_adj = 1;        // bf16 build: adjoint chain (normals) as one fused launch (sdf_adjoint_w64_kernel); 0 = seed + eight streaming EPI_REV launches (tuning key 13)
 int g_fused_ws = 3;         // fused primal chain: 4 = phase-staggered kernel (sdf_fused_ph_kernel; measured slower: a matrix wave and a
                             // vector wave on one SIMD do not overlap on this machine, scripts/probes/probe_roles.hip), 3 / 2 = stage-pipelined kernel of kernels_fused.hpp with 8 waves x 32 rows / 4 waves x 64 rows,
                             // 1 = first weight-stationary kernel (8 waves x 32 rows), 0 = sdf_fused_kernel_h
@@ -569,8 +570,30 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
 }
 
 // adjoint chain: u_l = d sdf_raw / d a_l, then e0/es = cotangent of the PE rows (autograd.grad at rend_a :121-127)
-hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w) {
+hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w, bool save = true) {
   const PackLayout& L = c.L();
+  if (c.prec && g_fused_adj) {
+    // bf16 build: the seed and the eight transposed layers as ONE launch (sdf_adjoint_w64_kernel): u stays on chip between the
+    // layers; `save` = the training pass, where the tangent chain and the weight gradients read u_0 .. u_7 later
+    AdjArgs a{};
+    a.P = c.P; a.ldp = c.ldp;
+    for (int l = 0; l < 8; ++l) {
+      const PackDesc2& d = L.d[L.tr[l]];
+      if (d.Kpad != 256) return hipErrorInvalidValue;
+      a.Wp[l] = reinterpret_cast<const uint4*>(c.packed + d.offset);
+      a.u[l] = reinterpret_cast<u16*>(w.u[l].p);
+    }
+    for (int l = 1; l <= 8; ++l) a.h[l] = reinterpret_cast<const u16*>(w.h[l].p);
+    a.w8 = c.net->v[8]; a.rs8 = c.rowscale(8); a.es = w.es; a.e0 = w.e0;
+    const int ntiles = c.ldp / 32;
+    const int nwg = ntiles < g_ws_grid ? ntiles : g_ws_grid;
+    double fl = 0.0;
+    for (int l = 0; l < 8; ++l) fl += 2.0 * kO[l] * kI[l] * (double)c.P;
+    ProfSlot* ps = prof_begin(c.st, 2, fl, (double)c.P * (8 * 512.0 + (save ? 8 * 512.0 : 0.0) + 2 * 39 * 4.0) + 2.0 * 589000.0);
+    hipError_t e = launch_sdf_adjoint_w64(c.st, a, ntiles, nwg, save);
+    prof_end(c.st, ps);
+    return e;
+  }
   if (c.prec)
     hipLaunchKernelGGL(adjoint_seed_kernel_h, dim3((c.ldp + 255) / 256, 32), dim3(256), 0, c.st, c.net->v[8], c.rowscale(8),
                        reinterpret_cast<const u16*>(w.h[8].p), c.ldp, reinterpret_cast<u16*>(w.u[7].p));
@@ -1088,6 +1111,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 10 && (value == 0 || value == 1)) { g_fused_interleave = value; return 0; }
   if (key == 11 && value >= 0 && value <= 63) { g_ws_aux_nt = value; return 0; }
   if (key == 12 && (value == 0 || value == 1)) { g_ws_wide_store = value; return 0; }
+  if (key == 13 && (value == 0 || value == 1)) { g_fused_adj = value; return 0; }
   return -1;
 }
 
@@ -1265,7 +1289,7 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
   HeadWs h = head_ws(ws + w.total, c.ldp, precision, fwd_only);
   hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points, eik_points, E);
   NEAT_CHECK(sdf_primal(c, w, true));
-  NEAT_CHECK(sdf_adjoint(c, w));
+  NEAT_CHECK(sdf_adjoint(c, w, !fwd_only));
   FINALIZE_LAUNCH(c, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
                      w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
   // the heads run over every column of the tile grid; only the first R*S columns are consumed

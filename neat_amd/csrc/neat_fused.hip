@@ -35,4 +35,18 @@ hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, 
   return rows_per_wave == 64 ? launch_rt<2>(st, a, ntiles, nwg, full, interleave) : launch_rt<1>(st, a, ntiles, nwg, full, interleave);
 }
 
+hipError_t launch_sdf_adjoint_w64(hipStream_t st, const AdjArgs& a, int ntiles, int nwg, bool save) {
+  typedef F6Cfg<4, 1> C;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_adjoint_w64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sdf_adjoint_w64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  if (save) hipLaunchKernelGGL((sdf_adjoint_w64_kernel<true>), dim3(nwg), dim3(C::THREADS), C::LDS, st, a, ntiles, nwg);
+  else hipLaunchKernelGGL((sdf_adjoint_w64_kernel<false>), dim3(nwg), dim3(C::THREADS), C::LDS, st, a, ntiles, nwg);
+  return hipGetLastError();
+}
+
 }  // namespace neat

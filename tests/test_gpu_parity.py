@@ -662,6 +662,43 @@ def test_bf16_layer_kernels_agree(dev, R, S):
         assert err <= 1e-3 * float(g0[k].abs().max()) + 1e-12, (k, err, float(g0[k].abs().max()))
 
 
+@pytest.mark.parametrize("P", [133120, 4160, 97])
+def test_fused_adjoint_chain_equals_streamed_layers(dev, P):
+    """sdf_adjoint_w64_kernel (seed + eight transposed layers in one launch, u on chip) against the seed kernel + eight streaming
+    EPI_REV launches it replaces: same bf16 products, k order and epilogue arithmetic -> normals, features and (second part) every
+    gradient of a train step bit-identical.  Full batches, ragged batches and a single partial tile."""
+    from neat_amd import _lib
+    from neat_amd.train import Trainer, synthetic_batch
+    lib = _lib.lib()
+    m = build_model(dev, "rough", precision="bf16")
+    x = (torch.rand(P, 3, generator=torch.Generator().manual_seed(P)) * 4 - 2).to(dev)
+    res = {}
+    try:
+        for k in (0, 1):
+            _lib.check(lib.neat_set_tuning(13, k), "neat_set_tuning")
+            with torch.no_grad():
+                res[k] = [t.clone() for t in m.implicit_network.get_outputs(x)]
+        for a, b in zip(res[0], res[1]):
+            assert torch.isfinite(b).all() and torch.equal(a, b)
+        if P > 4160:
+            return
+        grads = {}
+        for k in (0, 1):
+            _lib.check(lib.neat_set_tuning(13, k), "neat_set_tuning")
+            torch.manual_seed(1)
+            tr = Trainer(device=dev, state_dict={kk: T(v) for kk, v in synth.synth_state_dict(42, "rough").items()})
+            tr.model.set_precision("bf16")
+            _, inp, gt = synthetic_batch(42, 96, dev)
+            tr.model.z_vals_override = T(synth.synth_z_vals(42, 96, 40)).to(dev)
+            lo = tr.loss(tr.model(inp), gt)
+            lo["loss"].backward()
+            grads[k] = {n: p.grad.clone() for n, p in tr.model.named_parameters()}
+        for n in grads[0]:
+            assert torch.equal(grads[0][n], grads[1][n]), n
+    finally:
+        lib.neat_set_tuning(13, 1)
+
+
 @pytest.mark.parametrize("R,S", [(1024, 128), (37, 50), (3, 7)])
 def test_bf16_wgrad_kernels_agree(dev, R, S):
     """wgrad_kernel_h3 (LDS-DMA ring + ds_read_b64_tr_b16) against wgrad_kernel_h2 (register transposes) on identical
