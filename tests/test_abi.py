@@ -49,3 +49,16 @@ def test_ops_refuse_cpu_tensors():
     m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
     with pytest.raises(RuntimeError):
         m.implicit_network.get_sdf_vals(torch.zeros(4, 3))      # no CPU fallback: must fail loudly
+
+
+def test_torch_ops_are_registered_for_the_gpu_only():
+    """torch.ops.neat_hip.* (neat_amd/torch_ops.py) exist with tensor/scalar schemas and have no CPU kernel: the dispatcher refuses."""
+    import torch
+    from neat_amd import torch_ops
+    for name in torch_ops.OPS:
+        schema = str(getattr(torch.ops.neat_hip, name).default._schema)
+        assert schema.startswith(f"neat_hip::{name}("), schema
+    with pytest.raises(NotImplementedError):
+        torch.ops.neat_hip.volume_weights(torch.zeros(2, 4), torch.zeros(2, 4), torch.ones(1))
+    with pytest.raises(NotImplementedError):
+        torch.ops.neat_hip.sdf_values(torch.zeros(4, 3), [torch.zeros(1)] * 27, 3.0, 20.0, 0)

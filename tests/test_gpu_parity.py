@@ -1353,3 +1353,69 @@ def test_junction_block_kernels_vs_torch(dev):
             sel = okp
             assert torch.equal(j3.cpu()[sel], cand3d[cols[sel]]) and torch.equal(j2.cpu()[sel], cand2d[cols[sel]])
             assert torch.equal(j2c.cpu()[sel], cand2dc[cols[sel]]) and float(j3.cpu()[~sel].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_torch_ops_equal_the_autograd_functions(dev, precision):
+    """torch.ops.neat_hip.* (dispatcher binding of the C ABI, neat_amd/torch_ops.py) run the same launches as neat_amd.ops: the main
+    pass with its backward, the SDF network with its double backward, and the forward-only ops give identical bits."""
+    from neat_amd import ops, torch_ops
+    m = build_model(dev, "rough", train=True, precision=precision)
+    h, prm = m.handle(), torch_ops.net_params(m)
+    pcode = h.precision
+    R, S, E = 96, 50, 70
+    sc = synth.synth_scene(seed=5, n_rays=R, view=1)
+    cam = [T(sc[k]).to(dev) for k in ("uv", "pose", "intrinsics")]
+    dirs, origins = torch.ops.neat_hip.camera_rays(*cam)
+    d0, _, o0 = ops.camera_rays(*cam, with_origins=True)
+    assert torch.equal(dirs, d0) and torch.equal(origins, o0)
+    dirs = dirs[0]
+    z = T(synth.synth_z_vals(5, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    eik = torch.empty(E, 3).uniform_(-1, 1, generator=gen).to(dev)
+    beta = m.density.get_beta()
+    rad = float(m.scene_bounding_sphere)
+    cot = [torch.randn(R, 3, generator=gen).to(dev), torch.randn(R, 2, 3, generator=gen).to(dev), torch.randn(R, generator=gen).to(dev),
+           torch.randn(R, 3, generator=gen).to(dev), torch.randn(E, 3, generator=gen).to(dev)]
+
+    def grads(outs):
+        for p in m.parameters():
+            p.grad = None
+        sum((o * c).sum() for o, c in zip(outs[:5], cot)).backward()
+        return [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
+
+    a = ops.render_rays(h, origins, dirs, z, beta, rad, 20.0, False, eik)
+    ga = grads(a)
+    b = torch.ops.neat_hip.render_rays(origins, dirs, z, m.density.get_beta(), prm, eik, rad, 20.0, pcode, False)
+    gb = grads(b)
+    for x, y in zip(a[:8], b[:8]):
+        assert torch.equal(x, y)
+    assert sum(g is not None for g in ga) >= 58
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
+    e = torch.ops.neat_hip.render_rays_eval(origins, dirs, z, beta.detach(), prm, rad, 20.0, pcode)
+    e0 = ops.render_rays_eval(h, origins, dirs, z, beta, rad, 20.0)
+    for x, y in zip(e, (e0[0], e0[1], e0[2], e0[3], e0[5], e0[6], e0[7])):
+        assert torch.equal(x, y)
+    # SDF network alone: outputs and the double backward through d sdf / dx
+    x = eik * 0.7
+    sa = ops.sdf_outputs(h, x, rad, 20.0)
+    sb = torch.ops.neat_hip.sdf_outputs(x, prm[:27], rad, 20.0, pcode)
+    wcot = [torch.randn_like(t) for t in sa]
+
+    def sgrads(outs):
+        for p in m.parameters():
+            p.grad = None
+        sum((o * c).sum() for o, c in zip(outs[:4], wcot)).backward()
+        return [p.grad.clone() for p in prm[:27]]
+    for x1, y1 in zip(sa, sb[:4]):
+        assert torch.equal(x1, y1)
+    for x1, y1 in zip(sgrads(sa), sgrads(sb)):
+        assert torch.equal(x1, y1)
+    assert torch.equal(torch.ops.neat_hip.sdf_values(x, prm[:27], rad, 20.0, pcode), ops.sdf_values(h, x, rad, 20.0))
+    assert torch.equal(torch.ops.neat_hip.volume_weights(z, a[6], beta.detach()), ops.volume_weights(z, a[6], beta))
+    cost = torch.rand(17, 23, generator=gen).to(dev)
+    r1, c1, n1 = torch.ops.neat_hip.linear_sum_assignment(cost)
+    r0, c0, n0 = ops.linear_sum_assignment(cost)
+    assert torch.equal(r1, r0) and torch.equal(c1, c0) and int(n1) == int(n0) == 17
