@@ -1419,3 +1419,44 @@ def test_torch_ops_equal_the_autograd_functions(dev, precision):
     r1, c1, n1 = torch.ops.neat_hip.linear_sum_assignment(cost)
     r0, c0, n0 = ops.linear_sum_assignment(cost)
     assert torch.equal(r1, r0) and torch.equal(c1, c0) and int(n1) == int(n0) == 17
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_degenerate_sizes_give_empty_results(dev, precision):
+    """Zero rays / points / candidates and a single depth sample per ray: empty (or one-sample) results, no launch error, no fault;
+    the two ops the reference's own callees refuse on empty input (DBSCAN, the line loss's min over no segments) raise."""
+    from neat_amd import ops
+    m = build_model(dev, "rough", train=True, precision=precision)
+    h = m.handle()
+    z0 = lambda *s: torch.zeros(*s, device=dev)
+    shapes = lambda r: [tuple(x.shape) for x in r if isinstance(x, torch.Tensor)]
+    assert tuple(ops.sdf_values(h, z0(0, 3), 3.0, 20.0).shape) == (0, 1)
+    assert shapes(ops.sdf_outputs(h, z0(0, 3), 3.0, 20.0)) == [(0, 257), (0, 1), (0, 256), (0, 3)]
+    assert shapes(ops.heads_forward(h, z0(0, 3), z0(0, 3), z0(0, 3), z0(0, 256))) == [(0, 3), (0, 2, 3)]
+    beta = m.density.get_beta()
+    for grad in (True, False):
+        with torch.set_grad_enabled(grad):
+            r = ops.render_rays(h, z0(0, 3), z0(0, 3), z0(0, 16), beta, 3.0, 20.0)
+        assert shapes(r)[:8] == [(0, 3), (0, 2, 3), (0,), (0, 3), (0, 3), (0, 16), (0, 16), (0, 16, 3)]
+    one = ops.render_rays(h, z0(4, 3), torch.ones(4, 3, device=dev) / 3 ** 0.5, torch.ones(4, 1, device=dev), beta, 3.0, 20.0)
+    assert shapes(one)[:4] == [(4, 3), (4, 2, 3), (4,), (4, 3)] and all(torch.isfinite(t).all() for t in one[:4])
+    (one[0].sum() + one[1].sum()).backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+    assert tuple(ops.volume_weights(z0(0, 8), z0(0, 8), torch.ones(1, device=dev)).shape) == (0, 8)
+    assert shapes(ops.camera_rays(z0(1, 0, 2), torch.eye(4, device=dev)[None], torch.eye(4, device=dev)[None])) == [(1, 0, 3), (1, 3)]
+    assert tuple(ops.sample_pdf(z0(0, 9), z0(0, 8), torch.rand(4, device=dev))[0].shape) == (0, 4)
+    assert tuple(ops.uniform_depths(0, 8, 0.0, 1.0, None, dev).shape) == (0, 8)
+    assert tuple(ops.eik_points(z0(0, 3), z0(0, 3), z0(0, 3), z0(0)).shape) == (0, 3)
+    for shape in ((0, 5), (5, 0)):
+        rows, cols, n = ops.linear_sum_assignment(z0(*shape))
+        assert rows.numel() == 0 and cols.numel() == 0 and int(n) == 0
+    assert tuple(ops.project2d(torch.eye(3, device=dev), torch.eye(4, device=dev), z0(0, 3)).shape) == (0, 2)
+    assert tuple(ops.junction_cost(z0(0, 2), z0(5, 2)).shape) == (5, 0)
+    assert tuple(ops.l3d_points(z0(0, 3), z0(0, 3), z0(0, 3), z0(0, 3)).shape) == (0, 3)
+    for n in (0, 1):
+        with pytest.raises(RuntimeError):
+            ops.dbscan_means(z0(n, 3), 0.01)
+    with pytest.raises(RuntimeError):
+        ops.line_loss(z0(0, 4), z0(0, 4), z0(0))
+    torch.cuda.synchronize()
