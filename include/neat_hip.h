@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 6 */
+int neat_abi_version(void);      /* 7 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -186,6 +186,16 @@ int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, i
  * label [H,W] int32 = index of the nearest segment (the reference's labels_onehot.max(dim=0)[1]).
  * PARITY UNPINNED: hawp is an empty submodule here; semantics are those the call sites rely on. */
 int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream);
+
+/* ---- 8f-1, batch assembly on the device: the ray sampling of Dataset.__getitem__ (datasets/blender_hawp_dataset.py:186-198,
+ * scene_hawp_dataset.py:179-190) with the view's maps resident in HBM.  pool [npool] int32 = pixels of the line support
+ * (mask.nonzero()); draw [n] int64 = the step's draws into the pool (made on the host: np.random.choice's stream for the ABC class);
+ * att [HW,2] foot points, rgb [HW,3], labels [HW] int32 (nearest segment), lines [nlines,5].  Per ray i, pixel p = pool[draw[i]]:
+ * uv [n,2] = (p mod W, p div W), uv_proj [n,2] = att[p], rgb_out [n,3], lines_out [n,5] = lines[labels[p]], labels_out [n],
+ * pixel_out [n] = p. */
+int neat_gather_batch(const int* pool, int npool, const long long* draw, int n, int W, const float* att, const float* rgb, const int* labels,
+                      const float* lines, int nlines, float* uv, float* uv_proj, float* rgb_out, float* lines_out, long long* labels_out,
+                      long long* pixel_out, void* stream);
 
 /* ---- a11 / a14 glue as single launches.  neat_project2d = VolSDFNetwork.project2D (model/networks/neat_wfr_rend_a.py:317-326):
  * K [3,3] and w2c [3,4] = [R|T] row-major on the device, X [N,3] -> uv [N,2]; its backward gives d_X from d_uv.

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 6
+ABI_VERSION = 7
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/abl_build.sh)
@@ -65,6 +65,8 @@ _SIGNATURES = {
     "neat_sampler_finish_dev": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
+    "neat_gather_batch": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int,
+                                         c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_ffn_forward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 10),
     "neat_ffn_backward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 15),
     "neat_l3d": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),

@@ -438,6 +438,32 @@ __global__ __launch_bounds__(64) void sampler_finish_kernel(SamplerFinishArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dataset-side batch assembly ("a GPU path for the __getitem__ sampling", datasets/blender_hawp_dataset.py:186-198,
+// scene_hawp_dataset.py:179-190).  The view's images stay on the device; per step the host sends only n draws r_i into the view's
+// support pool.  One thread per ray: pixel p = pool[r_i]; uv = (p mod W, p div W); uv_proj = foot point of p; rgb = colour of p;
+// label = nearest segment of p; lines2d = that segment (5 floats: x1, y1, x2, y2, score).
+// ---------------------------------------------------------------------------------------------
+struct GatherBatchArgs {
+  const int* pool; const long long* draw; int n, W, npool;
+  const float* att; const float* rgb; const int* labels; const float* lines; int nlines;
+  float* uv; float* uv_proj; float* rgb_out; float* lines_out; long long* labels_out; long long* pixel_out;
+};
+__global__ void gather_batch_kernel(GatherBatchArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  long long r = a.draw[i];
+  r = r < 0 ? 0 : (r >= a.npool ? a.npool - 1 : r);
+  const int p = a.pool[r];
+  a.uv[2 * i] = (float)(p % a.W); a.uv[2 * i + 1] = (float)(p / a.W);
+  a.uv_proj[2 * i] = a.att[2 * (size_t)p]; a.uv_proj[2 * i + 1] = a.att[2 * (size_t)p + 1];
+  for (int c = 0; c < 3; ++c) a.rgb_out[3 * i + c] = a.rgb[3 * (size_t)p + c];
+  int lab = a.labels[p];
+  lab = lab < 0 ? 0 : (lab >= a.nlines ? a.nlines - 1 : lab);
+  for (int c = 0; c < 5; ++c) a.lines_out[5 * i + c] = a.lines[5 * lab + c];
+  a.labels_out[i] = lab; a.pixel_out[i] = p;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dataset-side attraction field: replacement for the un-vendored `hawp.base._C.encodels`
 // (call sites: datasets/blender_hawp_dataset.py:96, scene_hawp_dataset.py:95).  Per pixel: the nearest of the N
 // 2-D segments (distance to the segment, projection clamped to its ends); outputs, as the call sites consume them,

@@ -1095,7 +1095,7 @@ bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3; }
 // ================================================================================================
 extern "C" {
 
-int neat_abi_version(void) { return 6; }
+int neat_abi_version(void) { return 7; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
   if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
@@ -1446,6 +1446,17 @@ int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, i
 int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || !lines || !lmap || !label) return -1;
   hipLaunchKernelGGL(encode_lines_kernel, grid1(H * W), dim3(256), 0, (hipStream_t)stream, lines, N, H, W, lmap, label);
+  return (int)hipGetLastError();
+}
+
+int neat_gather_batch(const int* pool, int npool, const long long* draw, int n, int W, const float* att, const float* rgb, const int* labels,
+                      const float* lines, int nlines, float* uv, float* uv_proj, float* rgb_out, float* lines_out, long long* labels_out,
+                      long long* pixel_out, void* stream) {
+  if (n < 0 || npool <= 0 || W <= 0 || nlines <= 0 || !pool || !att || !rgb || !labels || !lines) return -1;
+  if (n == 0) return 0;
+  if (!draw || !uv || !uv_proj || !rgb_out || !lines_out || !labels_out || !pixel_out) return -1;
+  GatherBatchArgs a{pool, draw, n, W, npool, att, rgb, labels, lines, nlines, uv, uv_proj, rgb_out, lines_out, labels_out, pixel_out};
+  hipLaunchKernelGGL(gather_batch_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

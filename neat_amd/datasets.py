@@ -175,8 +175,70 @@ class BlenderDataset(torch.utils.data.Dataset):
     def change_sampling_idx(self, sampling_size):
         self.sampling_idx = None if sampling_size == -1 else torch.randperm(self.total_pixels)[:sampling_size]
 
+    def draw_rays(self, npool, n):
+        """The step's n draws into a view's support pool, as int64 on the host.  `np.random.choice(pool, n)` of __getitem__ IS
+        `pool[np.random.randint(0, len(pool), n)]` on numpy's global stream: the device path picks the same pixels."""
+        return torch.from_numpy(np.random.randint(0, npool, n).astype(np.int64))
+
+    def device_batches(self, device):
+        return DeviceBatches(self, device)
+
     def get_scale_mat(self):
         return np.eye(4)
+
+
+class DeviceBatches:
+    """Training batches assembled on the device ("a GPU path for the __getitem__ sampling").
+
+    `Dataset.__getitem__` (datasets/blender_hawp_dataset.py:159-198) rebuilds an [HW,2] pixel grid, runs `mask.nonzero()`, gathers
+    `lines[labels]` for EVERY pixel and then the n sampled rows, all on the host, every step: 1 ms at 512 x 512, 6+ ms at DTU's
+    1200 x 1600 -- longer than the whole train step takes on the GPU (3.4 ms).  Here a view's maps (support pool, foot points,
+    colours, labels, segments, camera) are uploaded once and stay in HBM (23 MB per DTU image); per step the host makes the n draws
+    (`Dataset.draw_rays`: the same RNG stream and therefore the same pixels as __getitem__), sends 8 KB, and ONE launch
+    (`neat_gather_batch`) writes uv, uv_proj, rgb, lines2d and labels.  `batch()` returns what the DataLoader's collate returns for
+    batch size 1 -- same keys, shapes and values (tests/test_gpu_parity.py::test_device_batches_equal_getitem), tensors on the device."""
+
+    def __init__(self, dataset, device):
+        self.ds, self.device = dataset, torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceBatches needs a CUDA device (no CPU path; use the Dataset's __getitem__)")
+        self._views = {}
+
+    def _view(self, idx):
+        v = self._views.get(idx)
+        if v is None:
+            ds, dev = self.ds, self.device
+            pool = ds.masks[idx].nonzero().flatten()
+            if pool.numel() == 0:
+                raise RuntimeError(f"view {idx}: empty line support")
+            lines = ds.lines[idx].float()
+            v = self._views[idx] = {
+                "npool": int(pool.numel()), "pool": pool.to(torch.int32).to(dev), "att": ds.att_points[idx].to(dev).float().contiguous(),
+                "rgb": ds.rgb_images[idx].to(dev).float().contiguous(), "labels": ds.labels[idx].to(torch.int32).to(dev),
+                "lines": lines.to(dev).contiguous(), "intrinsics": ds.intrinsics_all[idx].to(dev)[None], "pose": ds.pose_all[idx].to(dev)[None],
+                "juncs2d": ds.wireframes[idx].vertices[None], "mask": ds.masks[idx][None], "lines_uniq": ds.lines[idx][None]}
+        return v
+
+    def batch(self, idx, n):
+        """-> (indices [1], model_input, ground_truth) for view `idx` with n rays drawn from its line support."""
+        from .networks import _to_device_async
+        v = self._view(idx)
+        dev = self.device
+        draw = self.ds.draw_rays(v["npool"], n)
+        n = draw.numel()                                   # (drawing without replacement cannot exceed the pool)
+        draw = _to_device_async(draw, dev, site="dataset.draw")
+        uv, uv_proj = torch.empty(1, n, 2, device=dev), torch.empty(1, n, 2, device=dev)
+        rgb, lines = torch.empty(1, n, 3, device=dev), torch.empty(1, n, 5, device=dev)
+        labels, pixels = torch.empty(1, n, device=dev, dtype=torch.int64), torch.empty(1, n, device=dev, dtype=torch.int64)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().neat_gather_batch(P(v["pool"]), v["npool"], P(draw), n, self.ds.img_res[1], P(v["att"]), P(v["rgb"]),
+                                                P(v["labels"]), P(v["lines"]), v["lines"].shape[0], P(uv), P(uv_proj), P(rgb), P(lines),
+                                                P(labels), P(pixels), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "neat_gather_batch")
+        sample = {"uv": uv, "uv_proj": uv_proj, "juncs2d": v["juncs2d"], "intrinsics": v["intrinsics"], "pose": v["pose"],
+                  "wireframe": [self.ds.wireframes[idx]], "mask": v["mask"], "labels": labels, "lines": lines, "lines_uniq": v["lines_uniq"],
+                  "pixels": pixels}
+        return torch.LongTensor([idx]), sample, {"rgb": rgb, "lines2d": lines}
 
 
 class SceneDataset(BlenderDataset):
@@ -238,6 +300,19 @@ class SceneDataset(BlenderDataset):
             gt["lines2d"] = lines[labels[pick]]
             sample.update(lines=lines[labels[pick]], labels=labels[pick], uv=uv[pick, :], uv_proj=self.att_points[idx][pick.to(self.att_points[idx].device)])
         return idx, sample, gt
+
+    def draw_rays(self, npool, n):
+        """n DISTINCT draws into the pool, uniformly (the reference takes the first n of `torch.randperm(len(pool))`, :182: O(pool) host
+        work per step).  Drawing with replacement and keeping first occurrences until n distinct ones are in hand is the same
+        distribution -- a uniformly random n-subset in uniformly random order -- in O(n); it reads torch's CPU stream differently
+        from randperm, so the device path picks other pixels than __getitem__ would from the same seed."""
+        n = min(n, npool)
+        got = np.empty(0, dtype=np.int64)
+        while got.size < n:
+            cand = np.concatenate([got, torch.randint(npool, (n - got.size + 16,)).numpy()])
+            _, first = np.unique(cand, return_index=True)
+            got = cand[np.sort(first)]
+        return torch.from_numpy(got[:n].copy())
 
     def get_scale_mat(self):
         return np.load(self.cam_file)["scale_mat_0"]

@@ -93,6 +93,16 @@ class TrainRunner:
         self.trainer = Trainer(device=self.device, parts=(self.model, self.loss, self.optimizer, self.scheduler, self.bucket))
         if self.device.type == "cuda" and self.conf.get_bool("train.hip_graphs", default=True):
             self.trainer.auto_capture = 1
+        # batches assembled on the device from resident per-view maps (datasets.DeviceBatches) instead of Dataset.__getitem__ on the
+        # host; new optional conf key train.hip_dataset (default: on for CUDA and a dataset that offers it).  Views come up in the
+        # DataLoader's shuffle order either way.
+        self.batches = None
+        if (self.device.type == "cuda" and hasattr(self.train_dataset, "device_batches")
+                and self.conf.get_bool("train.hip_dataset", default=True)):
+            self.batches = self.train_dataset.device_batches(self.device)
+            gen2 = torch.Generator()
+            gen2.manual_seed(dp.rank_seed(42, self.rank))
+            self.view_order = torch.utils.data.DataLoader(range(len(self.train_dataset)), batch_size=1, shuffle=True, generator=gen2)
         self.checkpoint_freq = self.conf.get_int("train.checkpoint_freq", default=100)
         self.start_epoch = 0
         self.log_freq = log_freq
@@ -118,14 +128,20 @@ class TrainRunner:
         for epoch in range(self.start_epoch, self.nepochs + 1):
             if epoch % self.checkpoint_freq == 0:
                 self.save_checkpoints(epoch)
-            self.train_dataset.change_sampling_idx(self.num_pixels)
+            if self.batches is None:
+                self.train_dataset.change_sampling_idx(self.num_pixels)
             self.model.train()
-            for it, (indices, model_input, ground_truth) in enumerate(self.train_dataloader):
-                for k in ("intrinsics", "uv", "pose", "uv_proj"):
-                    model_input[k] = model_input[k].to(self.device)
+            for it, item in enumerate(self.train_dataloader if self.batches is None else self.view_order):
+                if self.batches is None:
+                    indices, model_input, ground_truth = item
+                    for k in ("intrinsics", "uv", "pose", "uv_proj"):
+                        model_input[k] = model_input[k].to(self.device)
+                else:
+                    indices, model_input, ground_truth = self.batches.batch(int(item), self.num_pixels)
                 # forward, loss, backward, [ONE flat all-reduce of all gradients when world > 1], Adam, scheduler
                 outputs, losses = self.trainer.step(model_input, ground_truth)
-                self.train_dataset.change_sampling_idx(self.num_pixels)
+                if self.batches is None:
+                    self.train_dataset.change_sampling_idx(self.num_pixels)      # (a full randperm of the image per step: only its length is used)
                 if (it + 1) % self.log_freq == 0 or it + 1 == len(self.train_dataloader):
                     with torch.no_grad():
                         psnr = rend_util.get_psnr(outputs["rgb_values"], ground_truth["rgb"].to(self.device).reshape(-1, 3))

@@ -45,19 +45,22 @@ def _toy_scene(root, res=64, n_views=3):
 
 
 @pytest.mark.gpu
-def test_runner_trains_and_checkpoints(tmp_path):
+@pytest.mark.parametrize("hip_dataset", [True, False])
+def test_runner_trains_and_checkpoints(tmp_path, hip_dataset):
+    """hip_dataset: batches assembled on the device from resident maps (the default) / by Dataset.__getitem__ through a DataLoader."""
     from neat_amd import networks, synth
     from neat_amd.runner import TrainRunner
     _toy_scene(tmp_path / "data" / "abc" / "toy")
     conf = {"train": {"expname": "toy_neat", "dataset_class": "datasets.blender_hawp_dataset.BlenderDataset",
                       "model_class": "model.networks.neat_wfr_rend_a.VolSDFNetwork", "loss_class": "model.networks.loss_wfr.VolSDFLoss",
-                      "learning_rate": 5.0e-4, "num_pixels": 128, "checkpoint_freq": 1},
+                      "learning_rate": 5.0e-4, "num_pixels": 128, "checkpoint_freq": 1, "hip_dataset": hip_dataset},
             "loss": dict(synth.ABC_NEAT_A_LOSS_CONF),
             "dataset": {"data_dir": "abc/toy", "img_res": [64, 64], "reverse_coordinate": True},
             "model": synth.ABC_NEAT_A_MODEL_CONF}
     path = tmp_path / "toy.conf"
     path.write_text(_hocon(conf))
     runner = TrainRunner(str(path), nepochs=1, exps_folder=str(tmp_path / "exps"), data_root=str(tmp_path / "data"), log_freq=1)
+    assert (runner.batches is not None) == hip_dataset
     assert type(runner.model).__module__ == "neat_amd.networks" and type(runner.train_dataset).__module__ == "neat_amd.datasets"
     hist = runner.run()
     assert len(hist) == 2 * 3 and all(np.isfinite(h[2]) for h in hist)
@@ -108,3 +111,31 @@ def test_runner_data_parallel_two_ranks(tmp_path):
     ck = tmp_path / "exps" / "toy_dp" / "dp" / "checkpoints"
     for sub in ("ModelParameters", "OptimizerParameters", "SchedulerParameters"):
         assert (ck / sub / "latest.pth").exists()
+
+
+@pytest.mark.gpu
+def test_device_batches_equal_getitem(tmp_path):
+    """datasets.DeviceBatches (one gather launch over maps resident in HBM) returns what Dataset.__getitem__ + collate return for the
+    same numpy RNG state: same pixels (np.random.choice's stream), same uv / uv_proj / rgb / lines2d / labels / camera, bit for bit."""
+    from neat_amd.datasets import BlenderDataset
+    _toy_scene(tmp_path / "data" / "abc" / "toy", res=96, n_views=2)
+    ds = BlenderDataset("abc/toy", [96, 96], reverse_coordinate=True, data_root=str(tmp_path / "data"))
+    dev = torch.device("cuda:0")
+    db = ds.device_batches(dev)
+    for idx in (0, 1, 0):
+        for n in (128, 1, 777):
+            np.random.seed(100 + idx + n)
+            ds.change_sampling_idx(n)
+            ref_idx, ref_in, ref_gt = ds.collate_fn([ds[idx]])
+            np.random.seed(100 + idx + n)
+            got_idx, got_in, got_gt = db.batch(idx, n)
+            assert torch.equal(got_idx, ref_idx)
+            for k in ("uv", "uv_proj", "intrinsics", "pose", "labels", "lines", "juncs2d", "lines_uniq", "mask"):
+                assert got_in[k].shape == ref_in[k].shape and torch.equal(got_in[k].cpu(), ref_in[k].cpu()), k
+            assert got_in["wireframe"][0] is ref_in["wireframe"][0]
+            for k in ("rgb", "lines2d"):
+                assert got_gt[k].shape == ref_gt[k].shape and torch.equal(got_gt[k].cpu(), ref_gt[k].cpu()), k
+            pix = got_in["pixels"][0].cpu()
+            assert bool(ds.masks[idx][pix].all())
+    with pytest.raises(RuntimeError):
+        ds.device_batches(torch.device("cpu"))

@@ -89,6 +89,16 @@ def test_scene_dataset_and_runner(tmp_path):
     pix = (s2["uv"][:, 1] * 64 + s2["uv"][:, 0]).long()
     assert pix.unique().numel() == 96 and bool(ds.masks[1][pix].all())          # without replacement, inside the line support
     assert np.allclose(ds.get_scale_mat(), cams["scale_mat_0"])
+    # the device path: n distinct pixels of the support, every field gathered from the same pixel
+    db = ds.device_batches(torch.device("cuda:0"))
+    _, s3, g3 = db.batch(1, 96)
+    pix = s3["pixels"][0].cpu()
+    assert pix.unique().numel() == 96 and bool(ds.masks[1][pix].all())
+    assert torch.equal(s3["uv"][0].cpu(), torch.stack([pix % 64, pix // 64], -1).float())
+    assert torch.equal(g3["rgb"][0].cpu(), ds.rgb_images[1][pix]) and torch.equal(s3["uv_proj"][0].cpu(), ds.att_points[1].cpu()[pix])
+    assert torch.equal(g3["lines2d"][0].cpu(), ds.lines[1][ds.labels[1][pix]]) and torch.equal(s3["labels"][0].cpu(), ds.labels[1][pix])
+    assert torch.equal(s3["intrinsics"][0].cpu(), ds.intrinsics_all[1]) and torch.equal(s3["pose"][0].cpu(), ds.pose_all[1])
+    assert db.batch(1, 10 ** 6)[1]["uv"].shape[1] == int(ds.masks[1].sum())      # more rays than support pixels: all of them, once
     # the reference's dtu.conf names this dataset class; the runner maps it and trains on the scan
     model_conf = dict(synth.ABC_NEAT_A_MODEL_CONF)
     model_conf.update(dbscan_enabled=True, use_median=False)
