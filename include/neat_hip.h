@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 7 */
+int neat_abi_version(void);      /* 8 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -45,10 +45,16 @@ int neat_abi_version(void);      /* 7 */
  *   NEAT_BF16X3 (2): the NEAT_F32 build (same layouts, workspaces, packed weights, kernels) whose two GEMM kernels evaluate every
  *                    product as three bf16 MFMAs on hi/lo splits of both operands, fp32 accumulate (~2^-17 relative per product):
  *                    fp32-grade parity at a multiple of the f32-MFMA rate
+ *   NEAT_F16 (3): the NEAT_BF16 build with IEEE half instead of bf16 as the 16-bit type: v_mfma_f32_32x32x16_f16, fp32 accumulate,
+ *                 f16 hidden activations (BASELINE config 5, "fp16 MFMA with fp32 accumulate").  Same kernels, layouts, workspaces
+ *                 and speed; 3 more mantissa bits (errors ~8x below NEAT_BF16's), 5 exponent bits: the backward pass runs on
+ *                 cotangents scaled by 4096 internally (scaled where the caller's cotangents are read, scaled back on the finished
+ *                 gradients; nothing visible at this interface).
  * Packed weights, workspaces and forward/backward calls of one pass must use the same value. */
 #define NEAT_F32 0
 #define NEAT_BF16 1
 #define NEAT_BF16X3 2
+#define NEAT_F16 3
 
 /* ---- a15: weight norm + packing (replaces the per-call `_weight_norm` pre-hook) -------------------
  * Computes W = g * v/|v| for all 19 layers once per step and stores W and W^T in MFMA-fragment order. */

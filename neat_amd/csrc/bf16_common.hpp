@@ -4,16 +4,40 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// NEAT_HALF = 1: the same kernels with IEEE half (f16) as the 16-bit storage / MFMA operand type instead of bf16 (precision NEAT_F16,
+// BASELINE config 5 "fp16 MFMA with fp32 accumulate").  Only this block knows the format: the conversions and the MFMA opcode; every
+// kernel moves the 16-bit values as opaque u16 / packed words.  The names keep their "bf" (bf16x8, f2bf, bf_lo ...): "the 16-bit type
+// of this build".  The f16 twin of each translation unit is compiled into its own namespace (see neat_api.hip).
+#ifndef NEAT_HALF
+#define NEAT_HALF 0
+#endif
+
 namespace neat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 constexpr int BMH = 128;         // point-stride granule of the bf16 build (ldp is a multiple of this)
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#if NEAT_HALF
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x2_t __attribute__((ext_vector_type(2)));
+#define NEAT_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+// float -> f16 round-to-nearest-even (v_cvt_f16_f32 x 2 + v_pack_b32_f16); f16 -> float is v_cvt_f32_f16 (op_sel picks the half)
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (_Float16)f); }
+__device__ __forceinline__ float bf2f(u16 h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return (float)__builtin_bit_cast(bf16x2_t, w).x; }
+__device__ __forceinline__ float bf_hi(unsigned w) { return (float)__builtin_bit_cast(bf16x2_t, w).y; }
+#else
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#define NEAT_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 // float -> bf16 round-to-nearest-even through the compiler's native conversion (v_cvt_pk_bf16_f32 on gfx950: one
 // instruction per PAIR; the hand-rolled add/shift form cost ~5 VALU per value and made the epilogues issue-bound)
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
@@ -25,6 +49,7 @@ __device__ __forceinline__ u16 f2bf(float f) { return (u16)(pack2(f, 0.0f) & 0xF
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+#endif
 
 // branch-free activation math for the bf16 build (hardware exp/log; absolute error ~1e-7, far below bf16 resolution)
 __device__ __forceinline__ float softplus100_fast(float a) {

@@ -97,9 +97,9 @@ __device__ __forceinline__ X3Frag x3_split(const float (&f)[8]) {
   return r;
 }
 __device__ __forceinline__ void x3_mfma(f32x16& acc, const X3Frag& A, const X3Frag& B) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, B.hi, acc, 0, 0, 0);      // small terms first
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc, 0, 0, 0);
+  acc = NEAT_MFMA16(A.lo, B.hi, acc, 0, 0, 0);      // small terms first
+  acc = NEAT_MFMA16(A.hi, B.lo, acc, 0, 0, 0);
+  acc = NEAT_MFMA16(A.hi, B.hi, acc, 0, 0, 0);
 }
 
 // wbase: this wave's first tile of the fp32 pack [tile][Kpad/2][64] (element (s, lane) = W[lane & 31][2 s + (lane >> 5)]);
@@ -778,11 +778,42 @@ __global__ void head_inputs_kernel(const float* __restrict__ x_fm, const float* 
   }
 }
 
+// f16 build: the backward pass runs on cotangents normalised by a power of two so that the largest incoming one lies in [1, 2)
+// (every backward kernel is linear in them).  Per-point cotangents of a train step are ~1e-7 ... 1e-3, below f16's normal range
+// (6e-5); a caller may just as well pass O(1) cotangents -- a fixed scale would underflow one or overflow the other.
+// slot[0] holds max |cotangent| as float bits (cot_max_kernel, atomicMax on the bit pattern: non-negative floats order like
+// unsigned ints).  slot == nullptr (bf16 / fp32 builds): scale 1.
+__device__ __forceinline__ float cot_scale_of(const float* slot) {
+  if (!slot) return 1.0f;
+  const float m = *slot;
+  if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1)
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.0f, 1 - e);
+}
+struct CotMaxArgs { const float* p[5]; long long n[5]; int narr; float* slot; };
+__global__ __launch_bounds__(256) void cot_max_kernel(CotMaxArgs a) {
+  float m = 0.0f;
+  for (int q = 0; q < a.narr; ++q) {
+    const float* p = a.p[q];
+    if (!p) continue;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[q]; i += (long long)gridDim.x * blockDim.x) {
+      const float v = fabsf(p[i]);
+      if (v < 3.0e38f) m = fmaxf(m, v);      // (inf / nan stay out of the scale; they propagate through the pass as they are)
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.slot), __float_as_uint(m));
+}
+
 // cotangent of the normals: g^ = (1-mask) (sc_r[30..32] + sc_a[6..8] + extra) ; also masks the sdf cotangent row
 __global__ void normal_cotangent_kernel(const float* __restrict__ sc_r, const float* __restrict__ sc_a,
                                         const float* __restrict__ extra_rm, const float* __restrict__ mask,
                                         int P, int ldp, float* __restrict__ gh_fm,
-                                        int P_main, const float* __restrict__ d_tail_rm) {
+                                        int P_main, const float* __restrict__ d_tail_rm, const float* __restrict__ cot_slot) {
+  // the scale multiplies the caller's cotangents (extra_rm, d_tail_rm); sc_r / sc_a come out of the backward pass and carry it already
+  const float ext_scale = cot_scale_of(cot_slot);
   // points [0, P_main): heads' normal cotangents (+ optional row-major extra), masked where the sphere clamp won;
   // points [P_main, P): appended eikonal points, cotangent d_tail_rm[p - P_main]
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -794,9 +825,9 @@ __global__ void normal_cotangent_kernel(const float* __restrict__ sc_r, const fl
     if (p < P_main) {
       if (sc_r) v += sc_r[(size_t)(30 + c) * ldp + p];
       if (sc_a) v += sc_a[(size_t)(6 + c) * ldp + p];
-      if (extra_rm) v += extra_rm[p * 3 + c];
+      if (extra_rm) v += extra_rm[p * 3 + c] * ext_scale;
     } else if (p < P && d_tail_rm) {
-      v = d_tail_rm[(p - P_main) * 3 + c];
+      v = d_tail_rm[(p - P_main) * 3 + c] * ext_scale;
     }
     gh_fm[(size_t)c * ldp + p] = v * keep;
   }
@@ -912,6 +943,7 @@ struct CompositeBwdArgs {
   float* dlin_fm;      // [6][ldp]  cotangent of the attraction offsets
   float* dsdf_row;     // [ldp]     cotangent of raw sdf (0 where the sphere clamp is active)
   float* dbeta_ray;    // [R]       per-ray partial of d loss / d beta
+  const float* cot_slot = nullptr;   // f16 build: the incoming cotangents are scaled on load, d beta is scaled back (cot_scale_of)
 };
 
 __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
@@ -921,14 +953,15 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
   const float dn = sqrtf(a.dirs[r * 3] * a.dirs[r * 3] + a.dirs[r * 3 + 1] * a.dirs[r * 3 + 1] + a.dirs[r * 3 + 2] * a.dirs[r * 3 + 2]);
   const float beta = *a.beta_ptr;
   float drgb[3] = {0.f, 0.f, 0.f}, dxyz[3] = {0.f, 0.f, 0.f}, dl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float cs = cot_scale_of(a.cot_slot);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    if (a.d_rgb) drgb[c] = a.d_rgb[r * 3 + c];
-    if (a.d_xyz) dxyz[c] = a.d_xyz[r * 3 + c];
+    if (a.d_rgb) drgb[c] = a.d_rgb[r * 3 + c] * cs;
+    if (a.d_xyz) dxyz[c] = a.d_xyz[r * 3 + c] * cs;
   }
 #pragma unroll
-  for (int c = 0; c < 6; ++c) if (a.d_lines3d) dl[c] = a.d_lines3d[r * 6 + c];
-  const float ddepth = a.d_depth ? a.d_depth[r] : 0.0f;
+  for (int c = 0; c < 6; ++c) if (a.d_lines3d) dl[c] = a.d_lines3d[r * 6 + c] * cs;
+  const float ddepth = a.d_depth ? a.d_depth[r] * cs : 0.0f;
   // pass 1 (forward over the ray): transmittance needs the exclusive prefix of E.  Park T_i and w^_i w_i in the
   // output rows (same thread reads them back in pass 2, so no hazard).
   const int nchunk = (a.S + 63) / 64;
@@ -1000,7 +1033,7 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
     }
   }
   dbeta = wave_sum(dbeta);
-  if (lane == 0 && a.dbeta_ray) a.dbeta_ray[r] = dbeta;
+  if (lane == 0 && a.dbeta_ray) a.dbeta_ray[r] = dbeta / cs;
 }
 
 // pixel -> ray (rend_util.py:55-81,95-108)

@@ -176,7 +176,7 @@ __device__ __forceinline__ void mma_rows_h(f32x16 (&acc)[2][PT], const uint4* __
       for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int q = 0; q < PT; ++q)
-          acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&ring[u][i]), *reinterpret_cast<bf16x8*>(&bv[q]),
+          acc[i][q] = NEAT_MFMA16(*reinterpret_cast<bf16x8*>(&ring[u][i]), *reinterpret_cast<bf16x8*>(&bv[q]),
                                                               acc[i][q], 0, 0, 0);
     }
   }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint4 bv = *reinterpret_cast<const uint4*>(slot + bfrag + ks * (2 * WSP * 16));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
+      acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
     }
     if (!live) continue;
     const int p = (t_begin + tau * a.tile_stride) * WSP + (lane & 31);
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
           if (mma_on && ks < KS) {
             const uint4 cur = bv;
             if (ks + 1 < KS) bv = *reinterpret_cast<const uint4*>(bp + (size_t)(ks + 1) * 2 * BP * 16 + t * 32 * 16);
-            am = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&cur), am, 0, 0, 0);
+            am = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&cur), am, 0, 0, 0);
           }
           if (epi_on && (ks & 3) == 3) epi_quad(ae, t - 1, ks >> 2);
           __builtin_amdgcn_sched_barrier(0);
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
         for (int t = 0; t < NT; ++t) {
           if (t >= nt) break;
           const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)(2 * wave + j) * 2 * BP * 16 + t * 32 * 16);
-          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&ws8[j]), *reinterpret_cast<const bf16x8*>(&bv), accs[t], 0, 0, 0);
+          accs[t] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&ws8[j]), *reinterpret_cast<const bf16x8*>(&bv), accs[t], 0, 0, 0);
         }
       if (hi == 0) {
 #pragma unroll
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(FWT, 2) void sdf_fused_ws_kernel(FusedArgs a, int n
           for (int t = 0; t < NT; ++t) {
             if (t >= nt) break;
             const uint4 bv = *reinterpret_cast<const uint4*>(bp + (size_t)ks * 2 * BP * 16 + t * 32 * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc[t], 0, 0, 0);
+            acc[t] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc[t], 0, 0, 0);
           }
           if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(W2T, 2) void wgrad_kernel_h2(WgradArgsH a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (liveC[j])
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
+              acc[i][j] = NEAT_MFMA16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
         }
       }
       __syncthreads();
@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
         for (int j = 0; j < 4; ++j)
           if (liveC[j]) {
             if (NEAT_W3_ABLATE == 1) { asm volatile("" :: "v"(av[i].x), "v"(av[i].w), "v"(bv[j].x), "v"(bv[j].w)); continue; }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = NEAT_MFMA16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
           }
       }
     }

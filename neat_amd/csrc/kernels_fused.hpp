@@ -217,7 +217,7 @@ __device__ __forceinline__ void f6_stage(const F6Lane& L, const uint4 (&wc)[RT][
       // between runs at ~75 cycles per MFMA instead of 32); they are summed after the last k-step
       f32x16& dst = (NEAT_F6_SPLITK && RT == 1 && (ks & 1)) ? odd : am[i];
       if (NEAT_F6_ABLATE != 2)
-        dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wc[i][ks]), *reinterpret_cast<const bf16x8*>(&cur), ks >= (NEAT_F6_SPLITK && RT == 1 ? 2 : 1) ? dst : zero, 0, 0, 0);
+        dst = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wc[i][ks]), *reinterpret_cast<const bf16x8*>(&cur), ks >= (NEAT_F6_SPLITK && RT == 1 ? 2 : 1) ? dst : zero, 0, 0, 0);
       else if (ks == 0) { am[i] = zero; am[i][0] = __uint_as_float(cur.x ^ wc[i][ks].x); }
       if (NEAT_F6_GROUP == 1) {
 #pragma unroll
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
 #pragma unroll
           for (int j = 0; j < KW; ++j) {
             const uint4 bv = *reinterpret_cast<const uint4*>(fr + j * 2 * BP * 16);
-            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wA[0][j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
+            accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wA[0][j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
           }
           if (hi == 0) red[wave * BP + lane] = accs[0];
         }
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
 #pragma unroll
           for (int j = 0; j < KW; ++j) {
             const uint4 bv = *reinterpret_cast<const uint4*>(fr + (j * 2 * BP * 16 + t * 512));
-            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wA[0][j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
+            accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wA[0][j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
           }
           if (hi == 0) red[wave * BP + t * 32 + lane] = accs[0];
         }
@@ -719,7 +719,7 @@ __device__ __forceinline__ void ph_mma(const F6Lane& L, const uint4 (&wc)[16], i
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + AH < KS) ring[(ks + AH) % RD] = *reinterpret_cast<const uint4*>(fr + (ks + AH) * STEP);
     const uint4 cur = ring[ks % RD];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wc[ks]), *reinterpret_cast<const bf16x8*>(&cur), ks ? acc : zero, 0, 0, 0);
+    acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wc[ks]), *reinterpret_cast<const bf16x8*>(&cur), ks ? acc : zero, 0, 0, 0);
   }
 }
 // request the first fragments of the next matrix phase (tile t of region SRC; KS >= 3)
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(PHT, 2) void sdf_fused_ph_kernel(FusedArgs a, int n
 #pragma unroll
           for (int j = 0; j < KW; ++j) {
             const uint4 bv = *reinterpret_cast<const uint4*>(fr + (j * 2 * BP * 16 + t * 512));
-            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&wA[j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
+            accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wA[j]), *reinterpret_cast<const bf16x8*>(&bv), accs, 0, 0, 0);
           }
           if (hi == 0) red[wave * BP + t * 32 + lane] = accs[0];
         }

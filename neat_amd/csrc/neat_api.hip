@@ -3,11 +3,21 @@
 // Two builds of the GEMM-class kernels share the orchestration: precision 0 = exact-f32 MFMA with fp32
 // feature-major activations (parity build), precision 1 = bf16 MFMA (fp32 accumulate) with bf16 octet-major
 // hidden activations (throughput build).  Small arrays are fp32 feature-major in both.
+// NEAT_F16 (precision 3) is this same file compiled a second time with -DNEAT_HALF=1 (build.sh): namespace neat becomes neat_f16, every
+// C entry point gets the prefix f16_ (f16_symbols.h, generated from include/neat_hip.h), bf16_common.hpp switches the 16-bit format
+// to IEEE half.  The primary build's entry points forward precision 3 to that twin as ITS precision 1 (NEAT_F16_FWD below).
+#if defined(NEAT_HALF) && NEAT_HALF
+#define neat neat_f16
+#include "f16_symbols.h"
+#endif
 #include "kernels_bf16.hpp"
 #include "fused_launch.hpp"
 #include "kernels_sampler.hpp"
 #include "kernels_junction.hpp"
 #include "../../include/neat_hip.h"
+#include <algorithm>
+#include <initializer_list>
+#include <utility>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1058,7 +1068,8 @@ __global__ void lines_from_offsets_kernel(const float* __restrict__ lin_fm, cons
 // abar8 (source row order) row 0 <- (1-mask) d_sdf ; rows 1.. <- d_feat ; (+ d_out257)
 __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const float* __restrict__ d_sdf,
                                    const float* __restrict__ d_feat, const float* __restrict__ mask, int P, int ldp,
-                                   float* __restrict__ abar8) {
+                                   float* __restrict__ abar8, const float* __restrict__ cot_slot) {
+  const float scale = cot_scale_of(cot_slot);
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y;
   if (p >= ldp) return;
@@ -1068,7 +1079,42 @@ __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const flo
     if (n == 0) { if (d_sdf) v += d_sdf[p] * (1.0f - mask[p]); }
     else if (d_feat) v += d_feat[(size_t)p * 256 + (n - 1)];
   }
-  abar8[(size_t)n * ldp + p] = v;
+  abar8[(size_t)n * ldp + p] = v * scale;
+}
+
+// f16 build: cotangent normalisation (kernels.hpp: cot_scale_of).  cot_scale_begin reduces max |cotangent| over the caller's arrays
+// into `slot` (a float of the workspace: the `ones` row, which only the fp32 build uses); the kernels that read the caller's
+// cotangents scale by 2^k; grad_unscale takes the factor out of the finished parameter gradients.  Other builds: slot = nullptr.
+const float* cot_scale_begin(const Ctx& c, float* slot, std::initializer_list<std::pair<const float*, long long>> arrays) {
+  if (!NEAT_HALF) return nullptr;
+  (void)hipMemsetAsync(slot, 0, sizeof(float), c.st);
+  CotMaxArgs a{};
+  long long total = 0;
+  for (const auto& it : arrays) { a.p[a.narr] = it.first; a.n[a.narr] = it.first ? it.second : 0; total += a.n[a.narr]; ++a.narr; }
+  a.slot = slot;
+  const int blocks = (int)std::min<long long>(1024, (total + 2047) / 2048);
+  if (blocks > 0) hipLaunchKernelGGL(cot_max_kernel, dim3(blocks), dim3(256), 0, c.st, a);
+  return slot;
+}
+struct GradUnscaleArgs { float* p[3 * NLAYERS]; int n[3 * NLAYERS]; const float* slot; };
+__global__ void grad_unscale_kernel(GradUnscaleArgs a) {
+  float* p = a.p[blockIdx.y];
+  const int n = a.n[blockIdx.y];
+  if (!p) return;
+  const float inv = 1.0f / cot_scale_of(a.slot);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] *= inv;
+}
+void grad_unscale(const Ctx& c, const neat_net_grads* gr, int first, int count, const float* slot) {
+  if (!slot) return;
+  GradUnscaleArgs a{};
+  for (int l = 0; l < NLAYERS; ++l) {
+    const bool on = l >= first && l < first + count && gr->dv[l];
+    a.p[3 * l] = on ? gr->dv[l] : nullptr; a.n[3 * l] = kO[l] * kI[l];
+    a.p[3 * l + 1] = on ? gr->dg[l] : nullptr; a.n[3 * l + 1] = kO[l];
+    a.p[3 * l + 2] = on ? gr->db[l] : nullptr; a.n[3 * l + 2] = kO[l];
+  }
+  a.slot = slot;
+  hipLaunchKernelGGL(grad_unscale_kernel, dim3(64, 3 * NLAYERS), dim3(256), 0, c.st, a);
 }
 
 // row-major copies of the lin8 output for the stand-alone module API
@@ -1093,11 +1139,26 @@ bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3; }
 // ================================================================================================
 // C ABI
 // ================================================================================================
+#if !NEAT_HALF
+#define NEAT_TWIN(fn) extern "C" decltype(fn) f16_##fn;
+NEAT_TWIN(neat_set_tuning) NEAT_TWIN(neat_prof_enable) NEAT_TWIN(neat_prof_collect)
+NEAT_TWIN(neat_packed_floats) NEAT_TWIN(neat_pack_weights) NEAT_TWIN(neat_sdf_ws_floats) NEAT_TWIN(neat_sdf_forward)
+NEAT_TWIN(neat_sdf_backward) NEAT_TWIN(neat_heads_ws_floats) NEAT_TWIN(neat_heads_forward) NEAT_TWIN(neat_render_ws_floats)
+NEAT_TWIN(neat_render_forward) NEAT_TWIN(neat_render_backward) NEAT_TWIN(neat_render_eval_ws_floats)
+NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated)
+#define NEAT_F16_FWD(call) if (precision == 3) { precision = BF16; return f16_##call; }
+#else
+#define NEAT_F16_FWD(call)
+#endif
+
 extern "C" {
 
-int neat_abi_version(void) { return 7; }
+int neat_abi_version(void) { return 8; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
+#if !NEAT_HALF
+  f16_neat_set_tuning(key, value);                 /* the f16 twin keeps its own copies of the switches */
+#endif
   if (key == 0 && (value == 2 || value == 4)) { g_pt_bf16 = value; return 0; }
   if (key == 1 && (value == 0 || value == 1)) { g_wgrad_h3 = value; return 0; }
   if (key == 2 && (value == 0 || value == 1)) { g_layer_ws = value; return 0; }
@@ -1116,6 +1177,9 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
 }
 
 int neat_prof_enable(int on) {
+#if !NEAT_HALF
+  f16_neat_prof_enable(on);
+#endif
   g_prof.on = on != 0;
   g_prof.used = 0;
   return 0;
@@ -1133,6 +1197,15 @@ int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launc
     if ((e = hipEventElapsedTime(&t, s.e0, s.e1)) != hipSuccess) return (int)e;
     ms += t; fl += s.flops; by += s.bytes; ++n;
   }
+#if !NEAT_HALF
+  {                                                  /* launches made through the f16 twin are counted there */
+    double ms2 = 0.0, fl2 = 0.0, by2 = 0.0;
+    int n2 = 0;
+    const int rc = f16_neat_prof_collect(cls, &ms2, &fl2, &n2, &by2);
+    if (rc != 0) return rc;
+    ms += ms2; fl += fl2; by += by2; n += n2;
+  }
+#endif
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = n;
@@ -1141,9 +1214,11 @@ int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launc
 }
 
 size_t neat_packed_floats(int precision) {
+  NEAT_F16_FWD(neat_packed_floats(precision))
   const int x3 = take_x3(precision); (void)x3; return bad_prec(precision) ? 0 : pack_layout(precision).total; }
 
 int neat_pack_weights(const neat_net_params* net, float* packed, int precision, void* stream) {
+  NEAT_F16_FWD(neat_pack_weights(net, packed, precision, stream))
   const int x3 = take_x3(precision); (void)x3;
   if (!net || !packed || bad_prec(precision)) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -1177,6 +1252,7 @@ int neat_eik_points(const float* uniform, const float* origins, const float* dir
 }
 
 size_t neat_sdf_ws_floats(int P, int mode, int precision) {
+  NEAT_F16_FWD(neat_sdf_ws_floats(P, mode, precision))
   const int x3 = take_x3(precision); (void)x3;
   return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision).total;
 }
@@ -1184,6 +1260,7 @@ size_t neat_sdf_ws_floats(int P, int mode, int precision) {
 int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
                      float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad,
                      void* stream) {
+  NEAT_F16_FWD(neat_sdf_forward(packed, net, x, P, mode, precision, radius, scale, ws, out257, sdf, feat, grad, stream))
   const int x3 = take_x3(precision); (void)x3;
   if (P <= 0) return 0;
   if (!packed || !net || !x || !ws || bad_prec(precision)) return -1;
@@ -1212,6 +1289,7 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
 
 int neat_sdf_values_gated(const float* packed, const neat_net_params* net, const float* x, int P, int precision, float radius,
                           float scale, float* ws, float* sdf, const int* gate, int gate_value, void* stream) {
+  NEAT_F16_FWD(neat_sdf_values_gated(packed, net, x, P, precision, radius, scale, ws, sdf, gate, gate_value, stream))
   if (P <= 0) return 0;
   if (!packed || !net || !x || !ws || !sdf || bad_prec(precision)) return -1;
   g_gate = gate; g_gate_value = gate_value;
@@ -1223,21 +1301,25 @@ int neat_sdf_values_gated(const float* packed, const neat_net_params* net, const
 int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws, int P, int precision,
                       const float* d_out257, const float* d_sdf, const float* d_feat, const float* d_grad,
                       const neat_net_grads* grads, void* stream) {
+  NEAT_F16_FWD(neat_sdf_backward(packed, net, ws, P, precision, d_out257, d_sdf, d_feat, d_grad, grads, stream))
   const int x3 = take_x3(precision); (void)x3;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   c.x3 = x3;
   SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
-  hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8);
+  const float* slot = cot_scale_begin(c, w.ones, {{d_out257, 257LL * P}, {d_sdf, (long long)P}, {d_feat, 256LL * P}, {d_grad, 3LL * P}});
+  hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8, slot);
   if (precision) oct_pack(c, {{w.abar8 + c.ldp, 256, w.featc}});
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, (const float*)nullptr, (const float*)nullptr,
-                     d_grad, w.mask, P, c.ldp, w.gh, P, (const float*)nullptr);
+                     d_grad, w.mask, P, c.ldp, w.gh, P, (const float*)nullptr, slot);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));
+  grad_unscale(c, grads, 0, 9, slot);
   return (int)hipGetLastError();
 }
 
 size_t neat_heads_ws_floats(int P, int precision) {
+  NEAT_F16_FWD(neat_heads_ws_floats(P, precision))
   const int x3 = take_x3(precision); (void)x3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(P, precision);
@@ -1247,6 +1329,7 @@ size_t neat_heads_ws_floats(int P, int precision) {
 int neat_heads_forward(const float* packed, const neat_net_params* net, const float* points, const float* normals,
                        const float* view_dirs, const float* feats, int P, int precision, float* ws, float* rgb, float* lines,
                        void* stream) {
+  NEAT_F16_FWD(neat_heads_forward(packed, net, points, normals, view_dirs, feats, P, precision, ws, rgb, lines, stream))
   const int x3 = take_x3(precision); (void)x3;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || bad_prec(precision)) return -1;
@@ -1268,6 +1351,7 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
 }
 
 size_t neat_render_ws_floats(int R, int S, int E, int precision) {
+  NEAT_F16_FWD(neat_render_ws_floats(R, S, E, precision))
   const int x3 = take_x3(precision); (void)x3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S + E, precision);
@@ -1307,11 +1391,13 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
                         const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
                         float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                         float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream) {
+  NEAT_F16_FWD(neat_render_forward(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d, depth, xyz, normal_map, eik_points, E, eik_grad, stream))
   return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d,
                              depth, xyz, normal_map, eik_points, E, eik_grad, stream, false);
 }
 
 size_t neat_render_eval_ws_floats(int R, int S, int precision) {
+  NEAT_F16_FWD(neat_render_eval_ws_floats(R, S, precision))
   const int x3 = take_x3(precision); (void)x3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S, precision);
@@ -1322,6 +1408,7 @@ int neat_render_forward_eval(const float* packed, const neat_net_params* net, co
                              const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
                              float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                              float* xyz, float* normal_map, void* stream) {
+  NEAT_F16_FWD(neat_render_forward_eval(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d, depth, xyz, normal_map, stream))
   return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d,
                              depth, xyz, normal_map, nullptr, 0, nullptr, stream, true);
 }
@@ -1330,6 +1417,7 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
                          int R, int S, int E, int precision, const float* beta, const float* d_rgb, const float* d_lines3d,
                          const float* d_depth, const float* d_xyz, const float* d_eik_grad, const neat_net_grads* grads,
                          float* dbeta_ray, void* stream) {
+  NEAT_F16_FWD(neat_render_backward(packed, net, ws, dirs, z, R, S, E, precision, beta, d_rgb, d_lines3d, d_depth, d_xyz, d_eik_grad, grads, dbeta_ray, stream))
   const int x3 = take_x3(precision); (void)x3;
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision) || E < 0) return -1;
@@ -1343,6 +1431,9 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   cb.R = R; cb.S = S; cb.ldp = c.ldp; cb.beta_ptr = beta;
   cb.d_rgb = d_rgb; cb.d_lines3d = d_lines3d; cb.d_depth = d_depth; cb.d_xyz = d_xyz;
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
+  const float* slot = cot_scale_begin(c, w.ones, {{d_rgb, 3LL * R}, {d_lines3d, 6LL * R}, {d_depth, (long long)R}, {d_xyz, 3LL * R},
+                                                  {d_eik_grad, 3LL * E}});
+  cb.cot_slot = slot;
   if (!c.prec)      // the ones row is the bias column of the fp32 weight-gradient kernel; the bf16 kernels sum the rows of A themselves
     hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, cb);
@@ -1351,8 +1442,9 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   }
   NEAT_CHECK(heads_backward(c, h, w, grads));
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
-                     w.gh, Pm, d_eik_grad);
+                     w.gh, Pm, d_eik_grad, slot);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));
+  grad_unscale(c, grads, 0, NLAYERS, slot);
   return (int)hipGetLastError();
 }
 

@@ -1,4 +1,7 @@
 // Translation unit of the fused chain kernels (see fused_launch.hpp for why it is separate).
+#if defined(NEAT_HALF) && NEAT_HALF      // the f16 twin of this translation unit (see neat_api.hip)
+#define neat neat_f16
+#endif
 #include "kernels_fused.hpp"
 
 namespace neat {

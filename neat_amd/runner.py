@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--exps_folder", default="exps")
     ap.add_argument("--scan_id", type=int, default=-1)
     ap.add_argument("--data_root", default="../data")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default=None)
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "fp16"], default=None)
     ap.add_argument("--is_continue", default=None, help="checkpoints directory of the run to continue")
     ap.add_argument("--checkpoint", default="latest")
     ap.add_argument("--gpus", type=int, default=1, help="data-parallel ranks (one per GPU); > 1 re-executes under torch.distributed.run")

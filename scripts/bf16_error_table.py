@@ -13,7 +13,7 @@ for (R,S,seed) in [(96,128,1),(33,50,2),(256,128,3)]:
     eik_idx = torch.randint(S, (R,), generator=gen)
     eik_uniform = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
     p, ref, ref_lo = oracle_train_step(sd, sc, z, eik_idx, eik_uniform)
-    for prec in ("bf16","fp32"):
+    for prec in (sys.argv[1:] or ["bf16","fp16","fp32"]):
         m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
         m.load_state_dict({k: T(v) for k, v in sd.items()})
         m.to(dev).train().set_precision(prec)
