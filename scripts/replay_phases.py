@@ -7,7 +7,7 @@ from neat_amd.train import Trainer, synthetic_batch
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
 tr = Trainer(device=dev, state_dict={k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()})
-tr.model.set_precision("bf16")
+tr.model.set_precision("fp16" if "fp16" in sys.argv[1:] else "bf16")
 _, inp, gt = synthetic_batch(42, 1024, dev)
 if "sampler" not in sys.argv[1:]:
     tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(42, 1024, 128)).to(dev)

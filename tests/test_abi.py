@@ -41,6 +41,11 @@ def test_workspace_queries_are_consistent():
         assert lib.neat_sdf_ws_floats(1, 0, prec) == lib.neat_sdf_ws_floats(tile, 0, prec)
         assert lib.neat_sdf_ws_floats(tile + 1, 0, prec) == lib.neat_sdf_ws_floats(2 * tile, 0, prec)
     assert lib.neat_packed_floats(7) == 0          # unknown precision is rejected
+    # NEAT_F16 (3) = the bf16 build's layouts with IEEE half as the 16-bit type; NEAT_BF16X3 (2) = the fp32 build's
+    assert lib.neat_packed_floats(3) == lib.neat_packed_floats(1) and lib.neat_packed_floats(2) == lib.neat_packed_floats(0)
+    assert lib.neat_render_ws_floats(64, 32, 8, 3) == lib.neat_render_ws_floats(64, 32, 8, 1)
+    assert lib.neat_render_eval_ws_floats(64, 32, 3) == lib.neat_render_eval_ws_floats(64, 32, 1)
+    assert lib.neat_sdf_ws_floats(100, 1, 3) == lib.neat_sdf_ws_floats(100, 1, 1) and lib.neat_heads_ws_floats(100, 3) == lib.neat_heads_ws_floats(100, 1)
 
 
 def test_ops_refuse_cpu_tensors():
