@@ -177,10 +177,13 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
 // first two fragments of the NEXT stage (base address nfr, or null) are requested during the last two k-steps, i.e. before the
 // barrier that ends the stage: they were written at least two barriers ago.  ROFF = ring slot of this stage's k-step 0
 // (every KS is 1 mod 3, so it advances by one per stage).  BAR: end the stage with the workgroup barrier.
-template <int NT, int RT, bool FULL, bool MMA, int KS, int SRC, class E, int ROFF, bool BAR>
-__device__ __forceinline__ void f6_stage(const F6Lane& L, const uint4 (&wc)[RT][16], int t, f32x16 (&am)[RT], const f32x16 (&ae)[RT],
-                                         const float4 (&bq)[4 * RT], int te, int nt, u16* hout, int wave, int hi, uint4 (&ring)[NEAT_F6_RING],
-                                         const unsigned char* nfr) {
+// WROLL (adjoint chain): this is the layer's last tile -- slot ks of the weight registers is dead after its MFMA and is refilled right
+// there with the NEXT layer's slot ks (wnx = that layer's per-lane fragment address), so one set of 16 fragment registers serves
+// the whole chain instead of two (the request is a full stage, >= 1000 cycles, ahead of its first use; the weights sit in L2).
+template <int NT, int RT, bool FULL, bool MMA, int KS, int SRC, class E, int ROFF, bool BAR, bool WROLL = false>
+__device__ __forceinline__ void f6_stage(const F6Lane& L, std::conditional_t<WROLL, uint4, const uint4> (&wc)[RT][16], int t, f32x16 (&am)[RT],
+                                         const f32x16 (&ae)[RT], const float4 (&bq)[4 * RT], int te, int nt, u16* hout, int wave, int hi,
+                                         uint4 (&ring)[NEAT_F6_RING], const unsigned char* nfr, const unsigned char* wnx = nullptr) {
   typedef F6Cfg<NT, RT> C;
   constexpr int STEP = 2 * C::BP * 16;                 // bytes between k-steps of a fragment column
   constexpr int HU = 16 * RT;                          // epilogue half units of a tile: 8 RT value pairs x {A, B}
@@ -219,6 +222,7 @@ __device__ __forceinline__ void f6_stage(const F6Lane& L, const uint4 (&wc)[RT][
       if (NEAT_F6_ABLATE != 2)
         dst = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wc[i][ks]), *reinterpret_cast<const bf16x8*>(&cur), ks >= (NEAT_F6_SPLITK && RT == 1 ? 2 : 1) ? dst : zero, 0, 0, 0);
       else if (ks == 0) { am[i] = zero; am[i][0] = __uint_as_float(cur.x ^ wc[i][ks].x); }
+      if constexpr (WROLL) wc[i][ks] = *reinterpret_cast<const uint4*>(wnx + ks * 1024);
       if (NEAT_F6_GROUP == 1) {
 #pragma unroll
         for (int u = 0; u < UPS; ++u) {
@@ -564,15 +568,21 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int k = tid; k < 256; k += F6T) seedw[k] = a.w8[k] * a.rs8[0];
 
-  uint4 wA[RT][16], wB[RT][16];
-  auto load_w = [&](uint4 (&dst)[RT][16], const uint4* Wl, int N) {
-    const char* base = reinterpret_cast<const char*>(Wl);
+  // ONE set of weight fragment registers (64 VGPRs): a layer's last tile refills each slot with the next layer's fragment right after
+  // the slot's last MFMA (f6_stage WROLL) -- the double-buffered form of the primal kernel (128 VGPRs) left this kernel, which also
+  // carries the h quads, 19 scratch reloads, each an s_waitcnt vmcnt(0) that drains the stores in flight
+  uint4 wA[RT][16];
+  auto w_addr = [&](const uint4* Wl, int N) -> const unsigned char* {
     const int tile = (RT * wave) * 32 < N ? RT * wave : 0;          // dead row tiles re-read a live one
     unsigned voff = (unsigned)((tile * 16) * 64 + lane) * 16u;
     asm volatile("" : "+v"(voff));
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) dst[0][ks] = *reinterpret_cast<const uint4*>(base + voff + ks * 1024);
+    return reinterpret_cast<const unsigned char*>(Wl) + voff;
   };
+  {
+    const unsigned char* w7 = w_addr(a.Wp[7], 256);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) wA[0][ks] = *reinterpret_cast<const uint4*>(w7 + ks * 1024);
+  }
 
   F6Lane L;
   {
@@ -598,8 +608,6 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
 
     auto chain = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
-      load_w(wA, a.Wp[7], 256);
-      load_w(wB, a.Wp[6], 256);
       // the saved activation quads of this lane for point tile t: rows 32 wave + 8 q + 4 hi .. + 3, raw bf16 (see F6RevCfg)
       auto load_h = [&](float4 (&dst)[4 * RT], const u16* hsrc, int t) {
         if (!(FULL || t < nt)) return;
@@ -648,8 +656,10 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
       constexpr int RD = NEAT_F6_RING;
 #define ADJ_STAGE(S_, T_, SRC_, WC_, E_, H_, TE_, NFR_)                                                                              \
       f6_stage<NT, RT, FULL, true, 16, SRC_, E_, (16 * (S_)) % RD, ((S_) % 2 == 1)>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], hq[((S_) + 1) & 1], TE_, nt, H_, wave, hi, ring, NFR_);
+#define ADJ_STAGE_ROLL(S_, T_, SRC_, WC_, E_, H_, TE_, NFR_, WNX_)                                                                   \
+      f6_stage<NT, RT, FULL, true, 16, SRC_, E_, (16 * (S_)) % RD, ((S_) % 2 == 1), true>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], hq[((S_) + 1) & 1], TE_, nt, H_, wave, hi, ring, NFR_, WNX_);
       // HSRC_: the h array whose phi' multiplies this layer's output (null: none); FPREV_ / FCUR_: fp32 row destinations of the previous / this layer
-#define ADJ_LAYER(S0_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, HAS_H_, HSRC_, NSRC_, FPREV_, FCUR_)                                          \
+#define ADJ_LAYER(S0_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, HAS_H_, HSRC_, NSRC_, FPREV_, FCUR_, WNEXT_, NNEXT_)                           \
       { L.frows = FPREV_;                                                                                                         \
         if (HAS_H_) load_h(hq[((S0_) + 0) & 1], HSRC_, 0);                                                                         \
         ADJ_STAGE((S0_) + 0, 0, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512)                                         \
@@ -659,29 +669,30 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
         if (HAS_H_) load_h(hq[((S0_) + 2) & 1], HSRC_, 2);                                                                         \
         ADJ_STAGE((S0_) + 2, 2, SRC_, WC_, ECUR_, HCUR_, 1, L.frag[SRC_] + 3 * 512)                                                \
         if (HAS_H_) load_h(hq[((S0_) + 3) & 1], HSRC_, 3);                                                                         \
-        ADJ_STAGE((S0_) + 3, 3, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 2 ? L.frag[(NSRC_) < 2 ? (NSRC_) : 0] : nullptr)) }
+        ADJ_STAGE_ROLL((S0_) + 3, 3, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 2 ? L.frag[(NSRC_) < 2 ? (NSRC_) : 0] : nullptr), w_addr(WNEXT_, NNEXT_)) }
 #pragma unroll
       for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[0] + j * 2 * BP * 16);
-      ADJ_LAYER(0, 0, wA, F6NoEpi, R7, nullptr, a.u[6], 1, a.h[7], 1, nullptr, nullptr)
-      load_w(wA, a.Wp[5], 256);
-      ADJ_LAYER(4, 1, wB, R7, R6, a.u[6], a.u[5], 1, a.h[6], 0, nullptr, nullptr)
-      load_w(wB, a.Wp[4], 256);
-      ADJ_LAYER(8, 0, wA, R6, R5, a.u[5], a.u[4], 1, a.h[5], 1, nullptr, nullptr)
-      load_w(wA, a.Wp[3], 256);
-      ADJ_LAYER(12, 1, wB, R5, R4, a.u[4], a.u[3], 1, a.h[4], 0, nullptr, a.es)
-      load_w(wB, a.Wp[2], 256);
-      ADJ_LAYER(16, 0, wA, R4, R3, a.u[3], a.u[2], 1, a.h[3], 1, a.es, nullptr)
-      load_w(wA, a.Wp[1], 256);
-      ADJ_LAYER(20, 1, wB, R3, R2, a.u[2], a.u[1], 1, a.h[2], 0, nullptr, nullptr)
-      load_w(wB, a.Wp[0], 39);
-      ADJ_LAYER(24, 0, wA, R2, R1, a.u[1], a.u[0], 1, a.h[1], 1, nullptr, nullptr)
-      ADJ_LAYER(28, 1, wB, R1, R0, a.u[0], nullptr, 0, a.h[1], 2, nullptr, a.e0)
+      ADJ_LAYER(0, 0, wA, F6NoEpi, R7, nullptr, a.u[6], 1, a.h[7], 1, nullptr, nullptr, a.Wp[6], 256)
+      ADJ_LAYER(4, 1, wA, R7, R6, a.u[6], a.u[5], 1, a.h[6], 0, nullptr, nullptr, a.Wp[5], 256)
+      ADJ_LAYER(8, 0, wA, R6, R5, a.u[5], a.u[4], 1, a.h[5], 1, nullptr, nullptr, a.Wp[4], 256)
+      ADJ_LAYER(12, 1, wA, R5, R4, a.u[4], a.u[3], 1, a.h[4], 0, nullptr, a.es, a.Wp[3], 256)
+      ADJ_LAYER(16, 0, wA, R4, R3, a.u[3], a.u[2], 1, a.h[3], 1, a.es, nullptr, a.Wp[2], 256)
+      ADJ_LAYER(20, 1, wA, R3, R2, a.u[2], a.u[1], 1, a.h[2], 0, nullptr, nullptr, a.Wp[1], 256)
+      ADJ_LAYER(24, 0, wA, R2, R1, a.u[1], a.u[0], 1, a.h[1], 1, nullptr, nullptr, a.Wp[0], 39)
+      ADJ_LAYER(28, 1, wA, R1, R0, a.u[0], nullptr, 0, a.h[1], 2, nullptr, a.e0, a.Wp[7], 256)      // (the next batch starts with W_7 again)
       // drain: the last tile of the last layer
-      f6_stage<NT, RT, FULL, false, 16, 0, R0, 0, true>(L, wB, 0, acc[0], acc[1], hq[1], NT - 1, nt, nullptr, wave, hi, ring, nullptr);
+      f6_stage<NT, RT, FULL, false, 16, 0, R0, 0, true>(L, wA, 0, acc[0], acc[1], hq[1], NT - 1, nt, nullptr, wave, hi, ring, nullptr);
 #undef ADJ_LAYER
+#undef ADJ_STAGE_ROLL
 #undef ADJ_STAGE
     };
-    if (nt == NT) chain(std::true_type{});
+#ifndef NEAT_ADJ_ONE_VARIANT
+#define NEAT_ADJ_ONE_VARIANT 1
+#endif
+    // one variant of the chain for full and partial batches (per-tile `t < nt` predicates on the loads / stores): with a second,
+    // predicate-free copy for full batches the rolling weight registers are carried into both copies and the allocator spills them
+    if (NEAT_ADJ_ONE_VARIANT) chain(std::false_type{});
+    else if (nt == NT) chain(std::true_type{});
     else chain(std::false_type{});
     __syncthreads();
   }
