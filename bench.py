@@ -222,6 +222,28 @@ def main():
     if not args.no_graph:
         graphed = tr.capture(inp, gt)          # untimed: 2 more warm-up steps, the capture, one replayed step
         note("HIP graph captured" if graphed else f"graph capture failed, staying eager: {tr.capture_error!r}")
+    graph_note = ""
+    if graphed and world > 1:
+        # insurance for multi-process runs (untimed, 6 steps): if replaying the graph measures slower than stepping eagerly on this
+        # node, every rank steps eagerly.  One GPU per rank: the graph wins (3.4 vs 5.5 ms) and stays.  (Not a cure for the
+        # functional gloo check with several ranks on ONE device: there, once both processes hold an instantiated graph, replayed AND
+        # eager steps take 0.3-1.9 s -- the device's queue scheduler thrashes between the processes; without graphs 9.6 ms.)
+        def timed(fn, n=3):
+            barrier()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        t_graph = timed(lambda: tr.step(inp, gt))
+        t_eager = timed(lambda: tr.step_eager(inp, gt))
+        slow = torch.tensor([1.0 if t_graph > 1.5 * t_eager else 0.0], device=dev)
+        dist.all_reduce(slow, op=dist.ReduceOp.MAX)
+        if float(slow.item()) > 0.0:
+            tr._graphs.clear()
+            graphed = False
+            graph_note = f" (graph replay measured slower than eager here: {1e3 * t_graph:.1f} vs {1e3 * t_eager:.1f} ms per step on rank 0's clock)"
+            note("graph replay slower than eager steps on this box: staying eager" + graph_note)
     barrier()
     if not args.no_prof and not graphed:
         lib.neat_prof_enable(1)
@@ -302,7 +324,7 @@ def main():
                                    ((" + RCCL grad all-reduce" if dist.get_backend() == "nccl" else " + gloo grad all-reduce (functional check)") if world > 1 else ""),
                        "rays_per_gpu": R_RAYS, "samples_per_ray": S_SAMPLES, "global_rays": world * R_RAYS,
                        "parallelism": f"dp{world}", "weights": "synthetic 'rough' (seed 42)",
-                       "launch": "hip graph replay (forward+loss+backward) + eager all-reduce/Adam" if graphed else "eager",
+                       "launch": "hip graph replay (forward+loss+backward) + eager all-reduce/Adam" if graphed else "eager" + graph_note,
                        "dist_backend": (dist.get_backend() if world > 1 else None)},
             "rays_per_s": world * R_RAYS * args.steps / elapsed,
             "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,
