@@ -1,6 +1,6 @@
 """Do the 16-bit builds TRAIN like the fp32 build?  The same synthetic scene directory, the same initial weights and the same random
 streams, `neat_amd.runner` for N iterations per precision; prints the mean loss / rgb PSNR over windows of the run.
-    python scripts/train_curves.py [iterations] [rays]"""
+    python scripts/train_curves.py [iterations] [rays] [precisions, comma separated]"""
 import sys, tempfile, pathlib, random
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -13,7 +13,8 @@ views, res = 4, 128
 tmp = pathlib.Path(tempfile.mkdtemp())
 _toy_scene(tmp / "data" / "abc" / "toy", res=res, n_views=views)
 rows = {}
-for prec in ("fp32", "bf16x3", "bf16", "fp16"):
+precs = sys.argv[3].split(",") if len(sys.argv) > 3 else ["fp32", "bf16x3", "bf16", "fp16"]
+for prec in precs:
     torch.manual_seed(42); np.random.seed(42); random.seed(42)
     model = dict(synth.ABC_NEAT_A_MODEL_CONF)
     model["hip_precision"] = prec
@@ -34,8 +35,8 @@ for prec in ("fp32", "bf16x3", "bf16", "fp16"):
     print(f"{prec:7s} loss per sixth of the run: " + " ".join(f"{loss[i * w:(i + 1) * w].mean():.4f}" for i in range(6)) +
           "   psnr: " + " ".join(f"{psnr[i * w:(i + 1) * w].mean():.2f}" for i in range(6)) +
           f"   (replays {r.trainer.replays}, eager {r.trainer.eager_steps})", flush=True)
-ref = rows["fp32"]
-for prec in ("bf16x3", "bf16", "fp16"):
+ref = rows[precs[0]]
+for prec in precs[1:]:
     w = len(ref[0]) // 6
     d = abs(rows[prec][0][-w:].mean() - ref[0][-w:].mean()) / ref[0][-w:].mean()
-    print(f"{prec}: final-window loss differs from fp32's by {100 * d:.2f} %; psnr {rows[prec][1][-w:].mean() - ref[1][-w:].mean():+.2f} dB")
+    print(f"{prec}: final-window loss differs from {precs[0]}'s by {100 * d:.2f} %; psnr {rows[prec][1][-w:].mean() - ref[1][-w:].mean():+.2f} dB")
