@@ -1,18 +1,26 @@
 #!/bin/bash
 # Probe builds of libneat_hip.so with extra -D flags:  scripts/abl_build.sh NAME -DNEAT_F6_ABLATE=9 ...   -> abl_libs/libneat_NAME.so
-# (flags that only touch the fused chains: NAME starting with "f" reuses the cached neat_api.o)
+# The flags go to the PRIMARY translation units only (NAME starting with "f": only the fused chains' unit; otherwise only neat_api.hip);
+# the f16 twin and the other primary unit are compiled once without flags and cached in abl_libs/.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); name=$1; shift
 mkdir -p $R/abl_libs; cd $R/neat_amd/csrc
+[ -f f16_symbols.h ] || bash build.sh > /dev/null 2>&1
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I."
-api=$R/abl_libs/neat_api_$name.o
+C=$R/abl_libs
+[ -f $C/neat_api.o ] || /opt/rocm/bin/hipcc $F -c neat_api.hip -o $C/neat_api.o 2>/dev/null &
+[ -f $C/neat_api_f16.o ] || /opt/rocm/bin/hipcc $F -DNEAT_HALF=1 -c neat_api.hip -o $C/neat_api_f16.o 2>/dev/null &
+[ -f $C/neat_fused.o ] || /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -c neat_fused.hip -o $C/neat_fused.o 2>/dev/null &
+[ -f $C/neat_fused_f16.o ] || /opt/rocm/bin/hipcc $F -DNEAT_HALF=1 -mllvm -amdgpu-mfma-vgpr-form=1 -c neat_fused.hip -o $C/neat_fused_f16.o 2>/dev/null &
+wait
+api=$C/neat_api.o; fused=$C/neat_fused.o
 if [[ $name == f* ]]; then
-  api=$R/abl_libs/neat_api.o
-  [ -f $api ] || /opt/rocm/bin/hipcc $F -c neat_api.hip -o $api 2>/dev/null
+  fused=$C/neat_fused_$name.o
+  /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c neat_fused.hip -o $fused 2>/dev/null
 else
+  api=$C/neat_api_$name.o
   /opt/rocm/bin/hipcc $F "$@" -c neat_api.hip -o $api 2>/dev/null
 fi
-/opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c neat_fused.hip -o $R/abl_libs/neat_fused_$name.o 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $api $R/abl_libs/neat_fused_$name.o -o $R/abl_libs/libneat_$name.so
-rm -f $R/abl_libs/neat_fused_$name.o $R/abl_libs/neat_api_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $api $C/neat_api_f16.o $fused $C/neat_fused_f16.o -o $C/libneat_$name.so
+[[ $name == f* ]] && rm -f $fused || rm -f $api
 echo built abl_libs/libneat_$name.so
