@@ -114,3 +114,25 @@ def test_scene_dataset_and_runner(tmp_path):
     assert type(runner.train_dataset).__name__ == "SceneDataset"
     hist = runner.run()
     assert len(hist) >= 3 and all(np.isfinite(h[2]) for h in hist)
+
+
+def test_draw_rules_of_the_device_batches():
+    """The host side of datasets.DeviceBatches (no GPU needed): the ABC class draws the pixels np.random.choice would draw from the same
+    numpy state; the DTU class draws n DISTINCT pool entries, every n-subset order equally likely, and never more than the pool holds."""
+    from collections import Counter
+    from neat_amd.datasets import BlenderDataset, SceneDataset
+    b, s = BlenderDataset.__new__(BlenderDataset), SceneDataset.__new__(SceneDataset)
+    pool = torch.arange(100, 1000, 3)
+    for seed, n in ((0, 1), (1, 64), (2, 777)):
+        np.random.seed(seed)
+        ref = np.random.choice(pool, n)
+        np.random.seed(seed)
+        got = pool[b.draw_rays(pool.numel(), n)]
+        assert got.dtype == torch.int64 and np.array_equal(got.numpy(), ref)
+    torch.manual_seed(0)
+    for npool, n in ((50, 50), (50, 40), (100000, 2048), (5, 9), (1, 1)):
+        r = s.draw_rays(npool, n)
+        assert r.dtype == torch.int64 and r.numel() == min(n, npool) and r.unique().numel() == r.numel()
+        assert int(r.min()) >= 0 and int(r.max()) < npool
+    counts = Counter(tuple(s.draw_rays(4, 2).tolist()) for _ in range(12000))
+    assert len(counts) == 12 and min(counts.values()) > 800 and max(counts.values()) < 1200      # 12 ordered pairs, 1000 expected each
