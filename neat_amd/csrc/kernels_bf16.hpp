@@ -439,6 +439,9 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     ws_wait_barrier(ahead * C::G);
     if (tau + C::NS - 1 < T) issue(tau + C::NS - 1);
     const unsigned char* slot = wslds + (tau % C::NS) * C::STAGE;
+    // a wave without live output rows (narrow layers: N = 3, 6, 39 ... leave waves 1..7 idle) only moves its share of the DMA and
+    // keeps the barriers: its fragment reads and MFMAs would compete with the stream for the LDS port and the issue slots
+    if (!live) continue;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -447,7 +450,6 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
       const uint4 bv = *reinterpret_cast<const uint4*>(slot + bfrag + ks * (2 * WSP * 16));
       acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wreg[ks]), *reinterpret_cast<const bf16x8*>(&bv), acc, 0, 0, 0);
     }
-    if (!live) continue;
     const int p = (t_begin + tau * a.tile_stride) * WSP + (lane & 31);
     float sp = 0.0f;
     if (C::HAS_S) sp = *reinterpret_cast<const float*>(slot + EXTRA + wave * 256 + (lane & 31) * 4);
