@@ -223,6 +223,16 @@ def main():
         graphed = tr.capture(inp, gt)          # untimed: 2 more warm-up steps, the capture, one replayed step
         note("HIP graph captured" if graphed else f"graph capture failed, staying eager: {tr.capture_error!r}")
     graph_note = ""
+    if world > 1 and not args.no_graph:
+        # every rank must take the same path from here on (the eager steps of the roofline pass below issue collectives):
+        # a capture that failed on one rank sends all ranks to eager steps
+        ok_all = torch.tensor([1.0 if graphed else 0.0], device=dev)
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+        if graphed and float(ok_all.item()) == 0.0:
+            tr._graphs.clear()
+            graphed = False
+            graph_note = " (graph capture failed on another rank)"
+            note("graph capture failed on another rank: staying eager")
     if graphed and world > 1:
         # insurance for multi-process runs (untimed, 6 steps): if replaying the graph measures slower than stepping eagerly on this
         # node, every rank steps eagerly.  One GPU per rank: the graph wins (3.4 vs 5.5 ms) and stays.  (Not a cure for the
