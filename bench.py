@@ -28,7 +28,7 @@ FLOP_PER_RAY_SAMPLE = 9.1254e6        # 4 562 688 MAC per ray-sampl
 CPU_BASELINE_THREADS = 16
 DEFAULT_PRECISION = "bf16"      # BASELINE.json configs[1]: "8x256 SDF MLP, bf16, 1x MI355X"; --precision fp32 = parity build
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "fp16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32-input MFMA / bf16 MFMA)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "fp16": 2500.0, "fp16x3": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks (f32-input MFMA / bf16 MFMA)
 CPU_BASELINE_RAYS = 256         # bounded sample of the C2 workload for the CPU leg (x 128 samples per ray)
 
 
@@ -161,7 +161,7 @@ def main():
                     help="run the timed steps eagerly (default: forward+loss+backward of the step replayed from a HIP graph)")
     ap.add_argument("--pt", type=int, default=0, help="(tuning) bf16 layer-kernel point tile: 2 = 64 points, 4 = 128 points")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launcher + gloo rendezvous + gradient all-reduce only (CPU test)")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "fp16"], default=DEFAULT_PRECISION,
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "fp16", "fp16x3"], default=DEFAULT_PRECISION,
                     help="GEMM build: fp32 = exact-f32 MFMA (parity build); bf16 = bf16 MFMA, fp32 accumulate (BASELINE config 2)")
     args = ap.parse_args()
 
@@ -225,7 +225,8 @@ def main():
     graph_note = ""
     if world > 1 and not args.no_graph:
         # every rank must take the same path from here on (the eager steps of the roofline pass below issue collectives):
-        # a capture that failed on one rank sends all ranks to eager steps
+        # a capture that failed on one rank sends all ranks to eager steps.  (Trainer.capture takes warmup + 1 optimizer steps --
+        # gradient all-reduces -- whether it succeeds or fails, so the ranks arrive here after the same number of collectives.)
         ok_all = torch.tensor([1.0 if graphed else 0.0], device=dev)
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
         if graphed and float(ok_all.item()) == 0.0:
@@ -328,7 +329,7 @@ def main():
             "metric": "ray-samples/s (train step) on ABC-neat-a", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "fp16": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
+            "dtype": {"fp32": "f32", "fp16": "f16", "fp16x3": "f16x3 forward / f16 backward"}.get(args.precision, "bf16"), "data": "synthetic",
             "config": {"workload": "C2: abc-neat-a networks, 1024 rays x 128 samples per GPU, depth samples given, "
                                    "train step = forward + loss + backward + Adam" +
                                    ((" + RCCL grad all-reduce" if dist.get_backend() == "nccl" else " + gloo grad all-reduce (functional check)") if world > 1 else ""),

@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 8 */
+int neat_abi_version(void);      /* 9 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -50,11 +50,17 @@ int neat_abi_version(void);      /* 8 */
  *                 and speed; 3 more mantissa bits (errors ~8x below NEAT_BF16's), 5 exponent bits: the backward pass runs on
  *                 cotangents scaled by 4096 internally (scaled where the caller's cotangents are read, scaled back on the finished
  *                 gradients; nothing visible at this interface).
+ *   NEAT_F16X3 (4): the NEAT_F16 build (layouts, workspaces + lo planes, the whole backward pass) whose three FORWARD chains -- SDF
+ *                   primal (rend_a :78-96), SDF adjoint = normals (:121-127), both heads (:139-255) -- are fused launches that
+ *                   evaluate every product as three f16 MFMAs on hi/lo splits of both operands (~22 mantissa bits): forward outputs
+ *                   within 1e-4 of the reference like NEAT_F32, gradients at the fp32 build's bar (the backward pass reads the hi
+ *                   planes = exactly what NEAT_F16 saves), at about the speed of NEAT_F16.
  * Packed weights, workspaces and forward/backward calls of one pass must use the same value. */
 #define NEAT_F32 0
 #define NEAT_BF16 1
 #define NEAT_BF16X3 2
 #define NEAT_F16 3
+#define NEAT_F16X3 4
 
 /* ---- a15: weight norm + packing (replaces the per-call `_weight_norm` pre-hook) -------------------
  * Computes W = g * v/|v| for all 19 layers once per step and stores W and W^T in MFMA-fragment order. */

@@ -17,19 +17,27 @@ def cpu_quota():
     return avail
 
 
-def _cap_host_threads():
+_capped = False
+
+
+def cap_host_threads():
     """torch sizes its intra-op pool by the machine's core count (128 on the MI355X hosts), not by the container's CPU quota (16).
     The host side of the hot path only draws a few hundred KB of CPU randoms per step; with a 128-thread pool every such draw leaves
     OpenMP workers spinning, the cgroup runs out of quota and the kernel parks the whole process -- including the thread that feeds
     the GPU -- for the rest of the 100 ms period (measured: every other train step with the sampler on took 90 ms instead of 6).
-    Unless OMP_NUM_THREADS says otherwise, keep the pool at a quarter of this rank's share of the quota (at most 8 threads)."""
-    if "OMP_NUM_THREADS" in os.environ:
+    Called by the GPU step drivers (train.Trainer on a CUDA device, neat_amd.runner), NOT at import: a host application that only
+    imports the package keeps its thread pool.  Unless OMP_NUM_THREADS is set or NEAT_NO_THREAD_CAP=1, the pool is lowered (never
+    raised) to a quarter of this rank's share of the quota, at most 8 threads; said once on stderr."""
+    global _capped
+    if _capped or "OMP_NUM_THREADS" in os.environ or os.environ.get("NEAT_NO_THREAD_CAP") == "1":
         return
+    _capped = True
     import torch
     ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))      # torchrun: the ranks of this node share the quota
     want = max(1, min(8, cpu_quota() // (4 * ranks)))
-    if torch.get_num_threads() > want:
+    have = torch.get_num_threads()
+    if have > want:
         torch.set_num_threads(want)
-
-
-_cap_host_threads()
+        import sys
+        print(f"[neat_amd] torch intra-op threads {have} -> {want} (CPU quota {cpu_quota()}; OMP_NUM_THREADS or NEAT_NO_THREAD_CAP=1 to keep)",
+              file=sys.stderr, flush=True)

@@ -6,8 +6,8 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 8
-PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3}
+ABI_VERSION = 9
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "fp16x3": 4}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/abl_build.sh)
 

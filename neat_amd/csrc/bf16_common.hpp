@@ -84,8 +84,9 @@ struct FusedArgs {
   const uint4* Wp[9]; int KS[9]; const float* bias[9];
   int save, values_only;
   u16* h[9];                  // h[1..8], octet-major (save mode)
-  float* E;                   // [39][ldp] fp32 (save mode)
+  float* E;                   // [39][ldp] fp32 (save mode; the split-precision chain READS it: kernels_x3.hpp)
   u16* feat; float* sdfraw;   // lin8 outputs (save mode): 256 feature rows (octet-major) + raw sdf row
+  const uint4* Wlo[9]; u16* hlo[9]; u16* featlo;      // split-precision chain only: lo packs, lo planes of h[1..8] and of the feature rows
   float* sdf_out;             // values mode: clamped sdf, row-major [P]
   float radius, scale;
   int bias8_rot, bias8_n;     // lin8 rows are packed [feature | sdf]
@@ -100,6 +101,18 @@ struct AdjArgs {
   u16* u[8];                     // u[0..7] (octet-major; written in SAVE mode)
   const float* w8; const float* rs8;      // the sdf row of lin8 (weight_v row 0) and its weight-norm scale: the seed
   float* es; float* e0;          // fp32 feature-major [39][ldp] each
+  const uint4* Wlo[8]; const u16* hlo[9];  // split-precision chain only: lo packs, lo planes of h[1..8]
+};
+
+// one head of the split-precision forward (kernels_x3.hpp: head_chain_x3_kernel)
+struct HeadX3Args {
+  int P, ldp;
+  const u16* feat; const u16* featlo;         // octet-major, 256 rows
+  const float* small; int srows;              // fp32 feature-major [srows][ldp]
+  const uint4* Wp[5]; const uint4* Wlo[5];    // packs: lin0 has 20 k-steps ([256 feature | small rows, padded to 64])
+  const float* bias[5];
+  u16* hid[5];                                // hid[1..4]: hi planes of the hidden activations (save mode)
+  float* out;                                 // [3 | 6][ldp] fp32
 };
 
 }  // namespace neat

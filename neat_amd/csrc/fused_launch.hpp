@@ -18,4 +18,10 @@ hipError_t launch_sdf_fused_w64(hipStream_t st, const FusedArgs& a, int ntiles, 
 // fused adjoint chain (normals): seed + 8 transposed layers in one launch; save: write u_0 .. u_7 (training)
 hipError_t launch_sdf_adjoint_w64(hipStream_t st, const AdjArgs& a, int ntiles, int nwg, bool save);
 
+// split-precision forward chains (kernels_x3.hpp; precision NEAT_F16X3): batches of X3_BATCH points over nwg persistent workgroups
+constexpr int X3_BATCH = 64;
+hipError_t launch_sdf_chain_x3(hipStream_t st, const FusedArgs& a, int nbatches, int nwg, bool full);
+hipError_t launch_sdf_adjoint_x3(hipStream_t st, const AdjArgs& a, int nbatches, int nwg, bool save);
+hipError_t launch_head_chain_x3(hipStream_t st, const HeadX3Args& a, int head, int nbatches, int nwg, bool save);
+
 }  // namespace neat

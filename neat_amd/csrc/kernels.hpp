@@ -811,9 +811,12 @@ __global__ __launch_bounds__(256) void cot_max_kernel(CotMaxArgs a) {
 __global__ void normal_cotangent_kernel(const float* __restrict__ sc_r, const float* __restrict__ sc_a,
                                         const float* __restrict__ extra_rm, const float* __restrict__ mask,
                                         int P, int ldp, float* __restrict__ gh_fm,
-                                        int P_main, const float* __restrict__ d_tail_rm, const float* __restrict__ cot_slot) {
+                                        int P_main, const float* __restrict__ d_tail_rm, const float* __restrict__ cot_slot,
+                                        const float* __restrict__ cot_slot_a = nullptr) {
   // the scale multiplies the caller's cotangents (extra_rm, d_tail_rm); sc_r / sc_a come out of the backward pass and carry it already
+  // (sc_a in the attraction head's own scale, cot_slot_a: brought to the common one here)
   const float ext_scale = cot_scale_of(cot_slot);
+  const float rho_a = cot_slot_a ? ext_scale / cot_scale_of(cot_slot_a) : 1.0f;
   // points [0, P_main): heads' normal cotangents (+ optional row-major extra), masked where the sphere clamp won;
   // points [P_main, P): appended eikonal points, cotangent d_tail_rm[p - P_main]
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -824,7 +827,7 @@ __global__ void normal_cotangent_kernel(const float* __restrict__ sc_r, const fl
     float v = 0.0f;
     if (p < P_main) {
       if (sc_r) v += sc_r[(size_t)(30 + c) * ldp + p];
-      if (sc_a) v += sc_a[(size_t)(6 + c) * ldp + p];
+      if (sc_a) v += sc_a[(size_t)(6 + c) * ldp + p] * rho_a;
       if (extra_rm) v += extra_rm[p * 3 + c] * ext_scale;
     } else if (p < P && d_tail_rm) {
       v = d_tail_rm[(p - P_main) * 3 + c] * ext_scale;
@@ -944,6 +947,9 @@ struct CompositeBwdArgs {
   float* dsdf_row;     // [ldp]     cotangent of raw sdf (0 where the sphere clamp is active)
   float* dbeta_ray;    // [R]       per-ray partial of d loss / d beta
   const float* cot_slot = nullptr;   // f16 build: the incoming cotangents are scaled on load, d beta is scaled back (cot_scale_of)
+  const float* cot_slot_a = nullptr; // f16 build: the attraction head's backward chain runs in its own power-of-two scale (its cotangents,
+                                     // line-loss weight 0.01 and detached weights, are orders of magnitude below the colour ones: in the
+                                     // common scale they sit in f16's subnormal range); null = the common one
 };
 
 __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
@@ -959,8 +965,9 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
     if (a.d_rgb) drgb[c] = a.d_rgb[r * 3 + c] * cs;
     if (a.d_xyz) dxyz[c] = a.d_xyz[r * 3 + c] * cs;
   }
+  const float cs_a = a.cot_slot_a ? cot_scale_of(a.cot_slot_a) : cs;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) if (a.d_lines3d) dl[c] = a.d_lines3d[r * 6 + c] * cs;
+  for (int c = 0; c < 6; ++c) if (a.d_lines3d) dl[c] = a.d_lines3d[r * 6 + c] * cs_a;
   const float ddepth = a.d_depth ? a.d_depth[r] * cs : 0.0f;
   // pass 1 (forward over the ray): transmittance needs the exclusive prefix of E.  Park T_i and w^_i w_i in the
   // output rows (same thread reads them back in pass 2, so no hazard).

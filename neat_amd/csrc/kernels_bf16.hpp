@@ -311,6 +311,8 @@ struct LayerArgsWS {
   int wide_store;                                        // 1: bf16 outputs leave as 16-byte stores (v_permlane32_swap), 0: 8-byte
   int aux_nt;                                            // non-temporal: bit 0 / 1 fetch of aux0 / aux1, bit 2 fetch of `in`, bit 3 store of out1
   int tile_stride;                                       // 1: workgroup w owns tiles [w per_wg, (w+1) per_wg); gridDim.x: tiles w, w + grid, ...
+  const float* rho_num; const float* rho_den;            // EPI_LINACC: acc is scaled by cot_scale_of(rho_num) / cot_scale_of(rho_den) before aux0 is added
+                                                         // (the two heads' backward chains run in different cotangent scales; null = 1)
 };
 // epilogues that exist only in the weight-stationary kernel
 constexpr int EPI_LINACC = 8;      // out0 = acc + aux0                      (feature cotangent: second head adds to the first)
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
     if (EPI == EPI_BWD8 && n < a.N) b = a.wrow[n] * a.wrow_scale[0];
     bias[r] = b;
   }
+  const float rho = (EPI == EPI_LINACC && a.rho_num && a.rho_den) ? cot_scale_of(a.rho_num) / cot_scale_of(a.rho_den) : 1.0f;
   const unsigned bfrag = (unsigned)((lane >> 5) * WSP + (lane & 31)) * 16;        // + ks * 2 * WSP * 16
   const unsigned efrag = dma_off + (unsigned)(lane & 31) * 16 + (unsigned)(lane >> 5) * 8;   // + q * WSP * 16
   const int Npad = (a.N + 7) & ~7;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_ws(LayerArgsWS a) {
         if (EPI == EPI_RELU) r0 = fmaxf(v + bias[4 * q + e], 0.0f);
         else if (EPI == EPI_LINEAR) r0 = v + bias[4 * q + e];
         else if (EPI == EPI_SIGMOID) r0 = 1.0f / (1.0f + __expf(-(v + bias[4 * q + e])));
-        else if (EPI == EPI_LINACC) r0 = v + x0[e];
+        else if (EPI == EPI_LINACC) r0 = v * rho + x0[e];
         else if (EPI == EPI_REV) { r0 = (n0 + e < a.n_split) ? v * dphi_fast(x0[e]) : 0.0f; r1 = v; }
         else if (EPI == EPI_TAN || EPI == EPI_TAN_PF) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
         else if (EPI == EPI_BWD) r0 = v * dphi_fast(x0[e]) + x1[e];
@@ -1492,6 +1495,7 @@ struct PackDesc2 {
   int s0, s0p, off0, off1;      // packed input index j -> source column: j<s0p ? (j<s0 ? off0+j : none) : off1 + (j-s0p)
   int rot;                      // packed output index n -> source row (n + rot) mod O
   float scale; int offset; int blk0; int bf16;
+  int lo;                       // 1: the pack holds the LOW plane of the hi/lo split, 16-bit(w - 16-bit(w)) (split-precision forward, kernels_x3.hpp)
 };
 constexpr int MAXPACKS2 = 48;
 struct PackArgs2 { NetPtrs net; const float* rowscale; int row_off[NLAYERS + 1]; PackDesc2 d[MAXPACKS2]; int npacks; float* out; };
@@ -1526,6 +1530,10 @@ __global__ __launch_bounds__(WG) void pack_kernel2(PackArgs2 a) {
       float w[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) w[t] = packed_weight(d, v, rs, O, I, n, kb + t);
+      if (d.lo) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w[t] -= bf2f(f2bf(w[t]));
+      }
       out[e] = make_uint4(pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]), pack2(w[6], w[7]));
     }
   } else {
@@ -1557,24 +1565,34 @@ __global__ void adjoint_seed_kernel_h(const float* __restrict__ v8, const float*
 }
 
 // bf16 octet-major [C rows] -> row-major fp32 [P, C] at column offset col0 of a [P, ldc] matrix
-__global__ void oct_to_rm_kernel(const u16* __restrict__ src, int P, int C, int ldp, float* __restrict__ dst, int ldc, int col0) {
+// (srclo: the low plane of a hi/lo split, added in; null = none)
+__global__ void oct_to_rm_kernel(const u16* __restrict__ src, int P, int C, int ldp, float* __restrict__ dst, int ldc, int col0,
+                                 const u16* __restrict__ srclo = nullptr) {
   // one thread per (point, octet): 16-byte read, 8 consecutive floats of the row out (grid.y = octets)
   const int p = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
   if (p >= P) return;
   const uint4 v = reinterpret_cast<const uint4*>(src)[(size_t)o * ldp + p];
-  const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+  uint4 vl = make_uint4(0u, 0u, 0u, 0u);
+  if (srclo) vl = reinterpret_cast<const uint4*>(srclo)[(size_t)o * ldp + p];
+  const unsigned w4[4] = {v.x, v.y, v.z, v.w}, l4[4] = {vl.x, vl.y, vl.z, vl.w};
   float* d = dst + (size_t)p * ldc + col0 + o * 8;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (o * 8 + 2 * j < C) d[2 * j] = bf_lo(w4[j]);
-    if (o * 8 + 2 * j + 1 < C) d[2 * j + 1] = bf_hi(w4[j]);
+    if (o * 8 + 2 * j < C) d[2 * j] = bf_lo(w4[j]) + bf_lo(l4[j]);
+    if (o * 8 + 2 * j + 1 < C) d[2 * j + 1] = bf_hi(w4[j]) + bf_hi(l4[j]);
   }
 }
-__global__ void rm_to_oct_kernel(const float* __restrict__ src, int P, int C, int ldp, u16* __restrict__ dst) {
+// (dstlo: also write the low plane of the hi/lo split)
+__global__ void rm_to_oct_kernel(const float* __restrict__ src, int P, int C, int ldp, u16* __restrict__ dst, u16* __restrict__ dstlo = nullptr) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= ldp) return;
   const int Cp = (C + 7) & ~7;
-  for (int c = 0; c < Cp; ++c) dst[oct_index(c, p, ldp)] = (p < P && c < C) ? f2bf(src[(size_t)p * C + c]) : (u16)0;
+  for (int c = 0; c < Cp; ++c) {
+    const float v = (p < P && c < C) ? src[(size_t)p * C + c] : 0.0f;
+    const u16 h = f2bf(v);
+    dst[oct_index(c, p, ldp)] = h;
+    if (dstlo) dstlo[oct_index(c, p, ldp)] = f2bf(v - bf2f(h));
+  }
 }
 __global__ void fm_col_to_rm_kernel(const float* __restrict__ src, int P, float* __restrict__ dst, int ldc, int col) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,649 @@
+// Split-precision FORWARD chains (precision NEAT_F16X3): every product of the three forward chains -- SDF primal (rend_a :78-96),
+// SDF adjoint = the normals (:121-127), the two heads (:139-255) -- is evaluated as  hi*hi + lo*hi + hi*lo  on 16-bit hi/lo splits
+// of BOTH operands (three v_mfma_f32_32x32x16 per 16 k, fp32 accumulate): ~22 mantissa bits, which is what north_star's 1e-4 needs.
+// The backward pass of that precision is the plain 16-bit build's and reads the HI planes only: a hi plane is exactly the array the
+// 16-bit build saves (f16(h)), the lo plane f16(h - hi) exists on chip and -- only where a later forward kernel needs it -- in HBM
+// (h_1..h_8 for the adjoint chain's phi', the 256 feature rows for the heads).  scripts/precision_emul.py: on the oracle, 3-product
+// forward + 16-bit backward gives the same gradient error as 3-product everything.
+//
+// One design for the three kernels (why fused: with 3 MFMAs per product the matrix time of a fused chain covers its epilogue's
+// vector work, while a streamed layer would move twice the bytes):
+//   * persistent 8-wave workgroup per CU, batches of 64 points = 2 tiles of 32; wave w owns output rows 32w .. 32w+31;
+//   * activations ping-pong between two LDS buffers, each a hi plane and a lo plane in the octet-major layout of kernels_bf16.hpp
+//     (2 x 2 x 32 KiB), small inputs (PE rows / the heads' few non-feature rows) in a third region;
+//   * the weight slice of a layer lives in registers as 16 hi + 16 lo A fragments (128 VGPRs, ONE set): the layer's last tile
+//     refills each slot with the next layer's fragment right after the slot's last MFMA (as sdf_adjoint_w64_kernel does);
+//   * stage pipeline as in kernels_fused.hpp: a stage = the 16 k-steps x 3 MFMAs of one (layer, tile), the epilogue of the PREVIOUS
+//     stage's accumulators is issued element by element behind the k-steps; one workgroup barrier per stage.
+#pragma once
+#include "bf16_common.hpp"
+#include "fused_launch.hpp"
+
+namespace neat {
+
+struct X3 {
+  static constexpr int BP = X3_BATCH, THREADS = 512;
+  static constexpr int XPL = 32 * BP * 16;              // one plane of an activation buffer [32 octets][BP][16 B]
+  static constexpr int SPL = 8 * BP * 16;               // one plane of the small-input region (K padded to 64)
+  static constexpr int XA = 0, XB = 2 * XPL, S = 4 * XPL;       // hi plane at the offset, lo plane XPL (SPL) behind it
+  static constexpr int BIAS = S + 2 * SPL;
+  static constexpr int BIAS_FLOATS = 9 * 256 + 8;
+  static constexpr int RED = BIAS + BIAS_FLOATS * 4;    // [8 waves][BP] partial sums of the sdf row
+  static constexpr int LDS = RED + 8 * BP * 4;          // 158 752 B of the CU's 160 KiB
+  static constexpr int KSTEP = 2 * BP * 16;             // bytes between the k-steps of a fragment column
+};
+
+// hi / lo split of a pair of fp32 values: hi = 16-bit(v) round-to-nearest, lo = 16-bit(v - hi)
+__device__ __forceinline__ void x3_split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+  hi = pack2(v0, v1);
+  lo = pack2(v0 - bf_lo(hi), v1 - bf_hi(hi));
+}
+
+// Per-lane LDS bases (opaque to the compiler; every access is base + compile-time immediate, see F6Lane)
+struct X3Lane {
+  const unsigned char* frag[3];      // fragment reads of XA / XB / S:  region + (hi * BP + (lane & 31)) * 16
+  unsigned char* quad[2];            // accumulator-quad writes to XA / XB: region + (4 wave * BP + (lane & 31)) * 16 + 8 hi
+  const unsigned char* bias;         // BIAS + (32 wave + 4 hi) * 4
+  unsigned gquad;                    // HBM quad offset of this lane for the batch: ((4 wave) ldp + p0 + (lane & 31)) * 16 + 8 hi
+  unsigned ldp16;                    // ldp * 16 (opaque per batch)
+};
+
+__device__ __forceinline__ uint4 x3_ldg(const void* base, unsigned off) {
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(base) + off);
+}
+
+// One stage: KS k-steps (3 MFMAs each) of `acc` over the fragment column `fr` (hi plane; lo plane LO bytes behind), with epi(e)
+// called 16 / KS times per k-step for e = 0 .. 15.  ZERO: the accumulator starts at zero.  ROLL: slot ks of the weight registers is
+// refilled with the next layer's fragment (wnh / wnl = its hi / lo packs + this lane's offset, NKS slots) right after its MFMAs;
+// slots KS .. NKS-1 (free in this layer) are requested up front.
+template <int KS, int LO, bool ZERO, bool ROLL, int NKS, class Epi>
+__device__ __forceinline__ void x3_stage(const unsigned char* fr, uint4 (&wh)[16], uint4 (&wl)[16], f32x16& acc,
+                                         const void* wnh, const void* wnl, unsigned woff, Epi&& epi) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint4 bh = *reinterpret_cast<const uint4*>(fr), bl = *reinterpret_cast<const uint4*>(fr + LO);
+  if (ROLL) {
+#pragma unroll
+    for (int ks = KS; ks < NKS; ++ks) { wh[ks] = x3_ldg(wnh, woff + ks * 1024); wl[ks] = x3_ldg(wnl, woff + ks * 1024); }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4 nh = bh, nl = bl;
+    if (ks + 1 < KS) {
+      nh = *reinterpret_cast<const uint4*>(fr + (ks + 1) * X3::KSTEP);
+      nl = *reinterpret_cast<const uint4*>(fr + LO + (ks + 1) * X3::KSTEP);
+    }
+    acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wh[ks]), *reinterpret_cast<const bf16x8*>(&bh), (ZERO && ks == 0) ? zero : acc, 0, 0, 0);
+    acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wl[ks]), *reinterpret_cast<const bf16x8*>(&bh), acc, 0, 0, 0);
+    acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wh[ks]), *reinterpret_cast<const bf16x8*>(&bl), acc, 0, 0, 0);
+    if (ROLL && ks < NKS) { wh[ks] = x3_ldg(wnh, woff + ks * 1024); wl[ks] = x3_ldg(wnl, woff + ks * 1024); }
+#pragma unroll
+    for (int e = ks * (16 / KS); e < (ks + 1) * (16 / KS); ++e) epi(e);
+    __builtin_amdgcn_sched_barrier(0);
+    bh = nh; bl = nl;
+  }
+}
+// drain: the epilogue alone
+template <class Epi> __device__ __forceinline__ void x3_drain(Epi&& epi) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { epi(e); if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SDF primal chain: E (PE rows, fp32, written by posenc6_kernel with libm's sin / cos) -> lin0 .. lin8.
+//   VALUES: only the clamped sdf leaves the chip (sampler queries);  otherwise: h_1..h_8 (hi to a.h[l] -- the arrays the 16-bit
+//   backward reads -- and lo to a.hlo[l]), the 256 feature rows (a.feat / a.featlo) and the raw sdf row.
+// FusedArgs: Wp = hi packs, Wlo = lo packs, KS as in the 16-bit build; E is an INPUT here.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool VALUES>
+__global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int nbatches) {
+  typedef X3 C;
+  constexpr int BP = C::BP, LO = C::XPL, SLO = C::SPL;
+  if (a.gate && *a.gate != a.gate_value) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3lds[];
+  float* biasl = reinterpret_cast<float*>(x3lds + C::BIAS);
+  float* red = reinterpret_cast<float*>(x3lds + C::RED);
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr bool SAVE = !VALUES;
+
+  for (int idx = tid; idx < 8 * 256; idx += C::THREADS) {
+    const int l = idx >> 8, n = idx & 255;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (l == k && n < (k == 3 ? 217 : 256)) v = a.bias[k][n];
+    biasl[idx] = v * SOFTPLUS_C;             // hidden layers: pre-scaled for the softplus epilogue
+  }
+  for (int n = tid; n < 257; n += C::THREADS) {
+    int bi = n + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
+    biasl[8 * 256 + n] = VALUES ? (n == 0 ? a.bias[8][0] : 0.0f) : a.bias[8][bi];
+  }
+  // small-input region: rows 39..63 of both planes stay zero for the whole launch
+  for (int idx = tid; idx < 2 * C::SPL / 16; idx += C::THREADS) reinterpret_cast<uint4*>(x3lds + C::S)[idx] = make_uint4(0u, 0u, 0u, 0u);
+
+  uint4 wh[16], wl[16];
+  // per-lane offset of this wave's fragments inside a pack [tile][KS][64 lanes] x 16 B (dead row tiles re-read tile 0)
+  auto w_off = [&](int KS, int N) -> unsigned {
+    const int tile = wave * 32 < N ? wave : 0;
+    unsigned v = (unsigned)((tile * KS) * 64 + lane) * 16u;
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  X3Lane L;
+  {
+    const unsigned fo = (unsigned)(hi * BP + (lane & 31)) * 16u, qo = (unsigned)((4 * wave) * BP + (lane & 31)) * 16u + 8u * hi;
+    unsigned b0 = C::XA + fo, b1 = C::XB + fo, b2 = C::S + fo, q0 = C::XA + qo, q1 = C::XB + qo, bb = C::BIAS + (unsigned)(32 * wave + 4 * hi) * 4u;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(q0), "+v"(q1), "+v"(bb));
+    L.frag[0] = x3lds + b0; L.frag[1] = x3lds + b1; L.frag[2] = x3lds + b2;
+    L.quad[0] = x3lds + q0; L.quad[1] = x3lds + q1; L.bias = x3lds + bb;
+  }
+  __syncthreads();
+
+  for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+    const int p0 = batch * BP;
+    L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
+    L.ldp16 = (unsigned)a.ldp * 16u;
+    asm volatile("" : "+v"(L.ldp16));
+    // an opaque copy of the thread index per batch: whatever the staging / copy phases derive from it is recomputed where it is used
+    // instead of being hoisted out of the batch loop (dozens of loop-invariant addresses) and spilled
+    int tb = tid;
+    asm volatile("" : "+v"(tb));
+    // lin0's four k-steps of weights travel while the PE rows are staged
+    {
+      const unsigned o0 = w_off(4, 256);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { wh[ks] = x3_ldg(a.Wp[0], o0 + ks * 1024); wl[ks] = x3_ldg(a.Wlo[0], o0 + ks * 1024); }
+    }
+    // ---- PE rows -> small-input region, hi / lo planes: thread = (point, row group): rows g, g + 8, ...
+    {
+      const int p = tb & (BP - 1), g = tb >> 6;
+      unsigned pvo = (unsigned)(p0 + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
+      asm volatile("" : "+v"(pvo), "+v"(ldp4));
+      u16* shi = reinterpret_cast<u16*>(x3lds + C::S);
+      u16* slo = reinterpret_cast<u16*>(x3lds + C::S + SLO);
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj) {
+        const int j = g + 8 * jj;
+        if (j < 39) {
+          const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.E) + ((unsigned)j * ldp4 + pvo));
+          const u16 h = f2bf(v);
+          shi[((j >> 3) * BP + p) * 8 + (j & 7)] = h;
+          slo[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v - bf2f(h));
+        }
+      }
+    }
+    __syncthreads();
+
+    f32x16 acc[2];
+    float4 bq[4];
+    auto load_bias = [&](int l) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(L.bias + (l * 256 + 8 * q) * 4);
+    };
+    // epilogue element e of accumulator tile `ap` (point tile t) of a layer with N rows: activation, hi / lo split, the quad
+    // (4 consecutive rows of one point) goes to LDS buffer DST (both planes) and, SAVE, to the HBM arrays hout / lout
+    unsigned ph[2], pl[2];
+    float keep = 0.0f;
+    auto epi_elem = [&](const f32x16& ap, int e, int t, bool act, int N, int DST, bool to_lds, bool save, u16* hout, u16* lout) {
+      const int q = e >> 2, j = e & 3;
+      const float b = j == 0 ? bq[q].x : (j == 1 ? bq[q].y : (j == 2 ? bq[q].z : bq[q].w));
+      float r;
+      if (act) {
+        const float u = fmaf(ap[e], SOFTPLUS_C, b);
+        r = (fmaxf(u, 0.0f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(u)))) * 0.0069314718055994531f;
+      } else {
+        r = ap[e] + b;
+      }
+      if ((j & 1) == 0) { keep = r; return; }
+      x3_split2(keep, r, ph[j >> 1], pl[j >> 1]);
+      if (j != 3) return;
+      uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
+      if (N == 217 && q == 3 && wave == 6) {
+        // lin3, rows 216..223: [h216 | PE rows 0..6] -- what lin4 (skip connection, rend_a :87-88) and the saved h4 expect in the
+        // last octet of the 217-row array
+        const uint4 sh = *reinterpret_cast<const uint4*>(x3lds + C::S + ((lane & 31) + t * 32) * 16);
+        const uint4 sl = *reinterpret_cast<const uint4*>(x3lds + C::S + SLO + ((lane & 31) + t * 32) * 16);
+        if (hi == 0) { vh = make_uint2((vh.x & 0xFFFFu) | (sh.x << 16), (sh.x >> 16) | (sh.y << 16)); vl = make_uint2((vl.x & 0xFFFFu) | (sl.x << 16), (sl.x >> 16) | (sl.y << 16)); }
+        else { vh = make_uint2((sh.y >> 16) | (sh.z << 16), (sh.z >> 16) | (sh.w << 16)); vl = make_uint2((sl.y >> 16) | (sl.z << 16), (sl.z >> 16) | (sl.w << 16)); }
+      }
+      if (to_lds) {
+        *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
+        *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
+      }
+      if (save) {
+        const unsigned off = (unsigned)q * L.ldp16 + L.gquad + t * 512;
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + off) = vh;
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(lout) + off) = vl;
+      }
+    };
+    auto none = [](int) {};
+    // skip connection (rend_a :87-88): rows 224..255 of lin4's input (octets 28..31 of XB) = PE rows 7..38 (the 1/sqrt2 is folded
+    // into W4).  One thread per (point, octet, plane): PE rows 7+8k .. 14+8k straddle PE octets k and k+1.
+    auto skip_copy = [&]() {
+      int ts = tid;
+      asm volatile("" : "+v"(ts));
+      const int pp = ts & (BP - 1), k = (ts >> 6) & 3, pln = ts >> 8;
+      const uint4* pe = reinterpret_cast<const uint4*>(x3lds + C::S + pln * SLO);
+      const uint4 lo4 = pe[k * BP + pp], hi4 = pe[(k + 1) * BP + pp];
+      reinterpret_cast<uint4*>(x3lds + C::XB + pln * LO)[(28 + k) * BP + pp] =
+          make_uint4((lo4.w >> 16) | (hi4.x << 16), (hi4.x >> 16) | (hi4.y << 16), (hi4.y >> 16) | (hi4.z << 16), (hi4.z >> 16) | (hi4.w << 16));
+    };
+
+    // One layer = 2 stages.  SRC / DST: input / output LDS buffer (0 = XA, 1 = XB, 2 = S); the epilogue of the previous stage
+    // belongs to layer LP (activated, NP rows, written to buffer SRC -- this layer's input buffer is the previous layer's output).
+#define X3_LAYER(LCUR, KS_, SRC_, SRCLO_, LIVE_, FIRST_, NKS_, WNH_, WNL_, NOFF_, PREV_EPI0_, CUR_EPI_)                                   \
+    {                                                                                                                               \
+      if (LIVE_) x3_stage<KS_, SRCLO_, true, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI0_);             \
+      else x3_drain(PREV_EPI0_);                                                                                                   \
+      __syncthreads();                                                                                                              \
+      load_bias(LCUR);                                                                                                              \
+      if (LIVE_) x3_stage<KS_, SRCLO_, true, true, NKS_>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, NOFF_, CUR_EPI_);           \
+      else { const unsigned o_ = NOFF_; _Pragma("unroll") for (int ks = 0; ks < NKS_; ++ks) { wh[ks] = x3_ldg(WNH_, o_ + ks * 1024); wl[ks] = x3_ldg(WNL_, o_ + ks * 1024); } x3_drain(CUR_EPI_); } \
+      __syncthreads();                                                                                                              \
+    }
+    // epilogues: E_<l>(tile) = epilogue of layer l's tile
+#define X3_EPI(ACC_, T_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_) [&](int e) { epi_elem(ACC_, e, T_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_); }
+    // lin0: S -> XA
+    X3_LAYER(0, 4, 2, SLO, true, true, 16, a.Wp[1], a.Wlo[1], w_off(16, 256), none, X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]))
+    // lin1: XA -> XB
+    X3_LAYER(1, 16, 0, LO, true, false, 16, a.Wp[2], a.Wlo[2], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]), X3_EPI(acc[0], 0, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]))
+    // lin2: XB -> XA
+    X3_LAYER(2, 16, 1, LO, true, false, 16, a.Wp[3], a.Wlo[3], w_off(16, 217), X3_EPI(acc[1], 1, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]), X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]))
+    // lin3 (217 rows; wave 7 has no rows): XA -> XB rows 0..216 (+ PE rows 0..6), then PE rows 7..38 into rows 224..255
+    skip_copy();
+    X3_LAYER(3, 16, 0, LO, (wave != 7), false, 16, a.Wp[4], a.Wlo[4], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]), X3_EPI(acc[0], 0, true, 217, 1, (wave != 7), SAVE && wave != 7, a.h[4], a.hlo[4]))
+    // lin4: XB -> XA
+    X3_LAYER(4, 16, 1, LO, true, false, 16, a.Wp[5], a.Wlo[5], w_off(16, 256), X3_EPI(acc[1], 1, true, 217, 1, (wave != 7), SAVE && wave != 7, a.h[4], a.hlo[4]), X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]))
+    // lin5: XA -> XB
+    X3_LAYER(5, 16, 0, LO, true, false, 16, a.Wp[6], a.Wlo[6], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]), X3_EPI(acc[0], 0, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]))
+    // lin6: XB -> XA
+    X3_LAYER(6, 16, 1, LO, true, false, 16, a.Wp[7], a.Wlo[7], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]), X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]))
+    // lin7: XA -> XB (h8); its last tile fetches the 256 feature rows of lin8 (save mode; values mode: nothing to prefetch but the
+    // macro refills anyway -- from lin8's pack, which exists in both modes)
+    X3_LAYER(7, 16, 0, LO, true, false, 16, a.Wp[8], a.Wlo[8], w_off(16, VALUES ? 1 : 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]), X3_EPI(acc[0], 0, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]))
+    // drain: h8's second tile
+    x3_drain(X3_EPI(acc[1], 1, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]));
+    __syncthreads();
+    // ---- lin8: the sdf row, split over the waves' k-steps (2 each) and reduced through LDS
+    {
+      unsigned so = (unsigned)((((VALUES ? 0 : 8) * 16 + 2 * wave) * 64 + lane) * 16);
+      asm volatile("" : "+v"(so));
+      uint4 sh[2], sl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { sh[j] = x3_ldg(a.Wp[8], so + j * 1024); sl[j] = x3_ldg(a.Wlo[8], so + j * 1024); }
+      const unsigned char* fr = L.frag[1] + (unsigned)(2 * wave) * C::KSTEP;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 accs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint4 bh = *reinterpret_cast<const uint4*>(fr + j * C::KSTEP + t * 512);
+          const uint4 bl = *reinterpret_cast<const uint4*>(fr + LO + j * C::KSTEP + t * 512);
+          accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&sh[j]), *reinterpret_cast<const bf16x8*>(&bh), accs, 0, 0, 0);
+          accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&sl[j]), *reinterpret_cast<const bf16x8*>(&bh), accs, 0, 0, 0);
+          accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&sh[j]), *reinterpret_cast<const bf16x8*>(&bl), accs, 0, 0, 0);
+        }
+        if (hi == 0) red[wave * BP + t * 32 + lane] = accs[0];
+      }
+    }
+    if (SAVE) {
+      // ---- the 256 feature rows of lin8 (linear): XB -> HBM only
+      x3_stage<16, LO, true, false, 16>(L.frag[1], wh, wl, acc[0], nullptr, nullptr, 0u, none);
+      load_bias(8);
+      x3_stage<16, LO, true, false, 16>(L.frag[1] + 512, wh, wl, acc[1], nullptr, nullptr, 0u, X3_EPI(acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));
+      x3_drain(X3_EPI(acc[1], 1, false, 256, 0, false, true, a.feat, a.featlo));
+    }
+    __syncthreads();
+#undef X3_EPI
+#undef X3_LAYER
+    int tf = tid;
+    asm volatile("" : "+v"(tf));
+    if (tf < BP) {
+      float sv = biasl[8 * 256 + (VALUES ? 0 : 256)];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sv += red[w * BP + tf];
+      const int p = p0 + tf;
+      if (VALUES) {
+        if (a.radius > 0.0f) {
+          const float x0 = a.x_fm[p], x1 = a.x_fm[(size_t)a.ldp + p], x2 = a.x_fm[(size_t)2 * a.ldp + p];
+          sv = fminf(sv, a.scale * (a.radius - sqrtf(x0 * x0 + x1 * x1 + x2 * x2)));
+        }
+        if (p < a.P) a.sdf_out[p] = sv;
+      } else {
+        a.sdfraw[p] = sv;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SDF adjoint chain (the normals, autograd.grad at rend_a :121-127) with 3-product arithmetic:
+//   u_7 = w8 (.) phi'(h_8);  u_{l-1} = (W_l^T u_l) (.) phi'(h_l), l = 7 .. 1 (l = 4: rows 217.. = PE cotangent of the skip, fp32, no phi');
+//   e0 = W_0^T u_0 (39 fp32 rows).   phi'(h) = 1 - exp(-100 h) from h = hi + lo (both planes are read: 2^-11 on h would be 1e-3 on the normals).
+// u stays on chip with both planes; SAVE writes the hi planes u_0 .. u_7 the 16-bit backward reads.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int nbatches) {
+  typedef X3 C;
+  constexpr int BP = C::BP, LO = C::XPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3lds[];
+  float* seedw = reinterpret_cast<float*>(x3lds + C::BIAS);      // [256]: w8[k] * rs8
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int k = tid; k < 256; k += C::THREADS) seedw[k] = a.w8[k] * a.rs8[0];
+
+  uint4 wh[16], wl[16];
+  auto w_off = [&](int N) -> unsigned {
+    const int tile = wave * 32 < N ? wave : 0;
+    unsigned v = (unsigned)((tile * 16) * 64 + lane) * 16u;
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  {
+    const unsigned o7 = w_off(256);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) { wh[ks] = x3_ldg(a.Wp[7], o7 + ks * 1024); wl[ks] = x3_ldg(a.Wlo[7], o7 + ks * 1024); }
+  }
+  X3Lane L;
+  {
+    const unsigned fo = (unsigned)(hi * BP + (lane & 31)) * 16u, qo = (unsigned)((4 * wave) * BP + (lane & 31)) * 16u + 8u * hi;
+    unsigned b0 = C::XA + fo, b1 = C::XB + fo, q0 = C::XA + qo, q1 = C::XB + qo, bb = C::BIAS + (unsigned)(32 * wave + 4 * hi) * 4u;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(q0), "+v"(q1), "+v"(bb));
+    L.frag[0] = x3lds + b0; L.frag[1] = x3lds + b1; L.frag[2] = x3lds + b0;
+    L.quad[0] = x3lds + q0; L.quad[1] = x3lds + q1; L.bias = x3lds + bb;
+  }
+  __syncthreads();
+
+  for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+    const int p0 = batch * BP;
+    L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
+    L.ldp16 = (unsigned)a.ldp * 16u;
+    asm volatile("" : "+v"(L.ldp16));
+    unsigned fcol = (unsigned)(p0 + (lane & 31)) * 4u, ldp4 = (unsigned)a.ldp * 4u;      // fp32 rows: byte offset of this lane's point / row stride
+    asm volatile("" : "+v"(fcol), "+v"(ldp4));
+
+    // saved activation quads of this lane (rows 32 wave + 8 q + 4 hi .. + 3 of point tile t), both planes, raw 16-bit
+    uint2 hqh[2][4], hql[2][4];
+    auto load_h = [&](int set, const u16* hs, const u16* ls, int t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned off = (unsigned)q * L.ldp16 + L.gquad + t * 512;
+        hqh[set][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hs) + off);
+        hql[set][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ls) + off);
+      }
+    };
+    auto dphi2 = [](unsigned hw, unsigned lw, float& d0, float& d1) {      // phi' of the two values of a packed pair
+      const float h0 = bf_lo(hw) + bf_lo(lw), h1 = bf_hi(hw) + bf_hi(lw);
+      d0 = 1.0f - __builtin_amdgcn_exp2f(-SOFTPLUS_C * h0);
+      d1 = 1.0f - __builtin_amdgcn_exp2f(-SOFTPLUS_C * h1);
+    };
+    // ---- seed: u_7 = w8 (.) phi'(h_8) -> XA (+ HBM hi plane)
+    {
+      float4 wq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(L.bias + (8 * q) * 4);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        load_h(0, a.h[8], a.hlo[8], t);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float d0, d1, d2, d3;
+          dphi2(hqh[0][q].x, hql[0][q].x, d0, d1);
+          dphi2(hqh[0][q].y, hql[0][q].y, d2, d3);
+          uint2 vh, vl;
+          x3_split2(wq[q].x * d0, wq[q].y * d1, vh.x, vl.x);
+          x3_split2(wq[q].z * d2, wq[q].w * d3, vh.y, vl.y);
+          *reinterpret_cast<uint2*>(L.quad[0] + (q * BP + t * 32) * 16) = vh;
+          *reinterpret_cast<uint2*>(L.quad[0] + LO + (q * BP + t * 32) * 16) = vl;
+          if (SAVE) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.u[7]) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+        }
+      }
+    }
+    __syncthreads();
+
+    f32x16 acc[2];
+    unsigned ph[2], pl[2];
+    float keep = 0.0f;
+    // epilogue element e of `ap` (tile t): MODE 0: * phi'(h) -> buffer DST (+ hi plane to uout); MODE 1 (l = 4): rows < 217 as MODE 0,
+    // rows >= 217 -> fp32 rows (n - 217) of frows and zero on chip; MODE 2 (l = 0): rows < 39 -> fp32 rows of frows, nothing on chip
+    auto epi_elem = [&](const f32x16& ap, int e, int t, int set, int MODE, int DST, u16* uout, float* frows) {
+      const int q = e >> 2, j = e & 3;
+      const int n = 32 * wave + 8 * q + 4 * hi + j;               // output row (hi: per lane half)
+      if (MODE == 2) {
+        if (wave < 2 && n < 39) *reinterpret_cast<float*>(reinterpret_cast<char*>(frows) + ((unsigned)n * ldp4 + fcol + t * 128)) = ap[e];
+        return;
+      }
+      float r;
+      {
+        const unsigned hw = (j < 2) ? hqh[set][q].x : hqh[set][q].y, lw = (j < 2) ? hql[set][q].x : hql[set][q].y;
+        const float h = (j & 1) ? (bf_hi(hw) + bf_hi(lw)) : (bf_lo(hw) + bf_lo(lw));
+        r = ap[e] * (1.0f - __builtin_amdgcn_exp2f(-SOFTPLUS_C * h));
+      }
+      if (MODE == 1 && wave >= 6 && n >= 217) {
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(frows) + ((unsigned)(n - 217) * ldp4 + fcol + t * 128)) = ap[e];
+        r = 0.0f;
+      }
+      if ((j & 1) == 0) { keep = r; return; }
+      x3_split2(keep, r, ph[j >> 1], pl[j >> 1]);
+      if (j != 3) return;
+      const uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
+      *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
+      *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
+      if (SAVE && (MODE == 0 || wave < 7)) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(uout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+    };
+    auto none = [](int) {};
+#define ADJ_EPI(ACC_, T_, SET_, MODE_, DST_, U_, F_) [&](int e) { epi_elem(ACC_, e, T_, SET_, MODE_, DST_, U_, F_); }
+    // one layer: stage (tile 0) with the previous layer's tile-1 epilogue, stage (tile 1, rolling in the next layer's weights) with
+    // this layer's tile-0 epilogue.  HS / HL: the h planes whose phi' multiplies THIS layer's output (requested a stage ahead).
+#define ADJ_LAYER(SRC_, HS_, HL_, HAS_H_, LIVE_, WNH_, WNL_, NNEXT_, PREV_EPI_, CUR_EPI_)                                              \
+    {                                                                                                                             \
+      if (HAS_H_) load_h(0, HS_, HL_, 0);                                                                                         \
+      if (LIVE_) x3_stage<16, LO, true, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI_);                \
+      else x3_drain(PREV_EPI_);                                                                                                   \
+      __syncthreads();                                                                                                            \
+      if (HAS_H_) load_h(1, HS_, HL_, 1);                                                                                         \
+      if (LIVE_) x3_stage<16, LO, true, true, 16>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, w_off(NNEXT_), CUR_EPI_);       \
+      else { const unsigned o_ = w_off(NNEXT_); _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) { wh[ks] = x3_ldg(WNH_, o_ + ks * 1024); wl[ks] = x3_ldg(WNL_, o_ + ks * 1024); } x3_drain(CUR_EPI_); } \
+      __syncthreads();                                                                                                            \
+    }
+    // (set index = tile: the quads of tile t live in set t until that tile's epilogue has run, one stage after its MFMAs)
+    ADJ_LAYER(0, a.h[7], a.hlo[7], true, true, a.Wp[6], a.Wlo[6], 256, none, ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[6], nullptr))                                                        // l = 7: XA -> XB
+    ADJ_LAYER(1, a.h[6], a.hlo[6], true, true, a.Wp[5], a.Wlo[5], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[6], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 0, a.u[5], nullptr))               // l = 6: XB -> XA
+    ADJ_LAYER(0, a.h[5], a.hlo[5], true, true, a.Wp[4], a.Wlo[4], 256, ADJ_EPI(acc[1], 1, 1, 0, 0, a.u[5], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[4], nullptr))               // l = 5
+    ADJ_LAYER(1, a.h[4], a.hlo[4], true, true, a.Wp[3], a.Wlo[3], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[4], nullptr), ADJ_EPI(acc[0], 0, 0, 1, 0, a.u[3], a.es))                  // l = 4: rows 217.. -> es
+    ADJ_LAYER(0, a.h[3], a.hlo[3], true, true, a.Wp[2], a.Wlo[2], 256, ADJ_EPI(acc[1], 1, 1, 1, 0, a.u[3], a.es), ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[2], nullptr))                  // l = 3
+    ADJ_LAYER(1, a.h[2], a.hlo[2], true, true, a.Wp[1], a.Wlo[1], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[2], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 0, a.u[1], nullptr))               // l = 2
+    ADJ_LAYER(0, a.h[1], a.hlo[1], true, true, a.Wp[0], a.Wlo[0], 39, ADJ_EPI(acc[1], 1, 1, 0, 0, a.u[1], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[0], nullptr))                // l = 1
+    ADJ_LAYER(1, a.h[1], a.hlo[1], false, (wave < 2), a.Wp[7], a.Wlo[7], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[0], nullptr), ADJ_EPI(acc[0], 0, 0, 2, 0, nullptr, a.e0))                // l = 0: e0 (fp32)
+    x3_drain(ADJ_EPI(acc[1], 1, 1, 2, 0, nullptr, a.e0));
+    __syncthreads();
+#undef ADJ_LAYER
+#undef ADJ_EPI
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One head (HEAD 0: rendering network rend_a :199-255, sigmoid, 3 rows; HEAD 1: attraction field :139-197, linear, 6 rows) with
+// 3-product arithmetic: [feature rows (hi / lo from the primal chain) | small inputs (fp32 rows, split here)] -> 4 x (256, ReLU) -> out.
+// SAVE: the hi planes of the four hidden activations go to a.hid[1..4] (what the 16-bit backward reads).
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int HEAD, bool SAVE>
+__global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int nbatches) {
+  typedef X3 C;
+  constexpr int BP = C::BP, LO = C::XPL, SLO = C::SPL, NOUT = HEAD ? 6 : 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3lds[];
+  float* biasl = reinterpret_cast<float*>(x3lds + C::BIAS);      // [4][256] + [8]
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int idx = tid; idx < 4 * 256; idx += C::THREADS) {
+    const int l = idx >> 8, n = idx & 255;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (l == k) v = a.bias[k][n];
+    biasl[idx] = v;
+  }
+  if (tid < 8) biasl[4 * 256 + tid] = tid < NOUT ? a.bias[4][tid] : 0.0f;
+  for (int idx = tid; idx < 2 * C::SPL / 16; idx += C::THREADS) reinterpret_cast<uint4*>(x3lds + C::S)[idx] = make_uint4(0u, 0u, 0u, 0u);
+
+  uint4 wh[16], wl[16];
+  auto w_off = [&](int KS, int N) -> unsigned {
+    const int tile = wave * 32 < N ? wave : 0;
+    unsigned v = (unsigned)((tile * KS) * 64 + lane) * 16u;
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  X3Lane L;
+  {
+    const unsigned fo = (unsigned)(hi * BP + (lane & 31)) * 16u, qo = (unsigned)((4 * wave) * BP + (lane & 31)) * 16u + 8u * hi;
+    unsigned b0 = C::XA + fo, b1 = C::XB + fo, b2 = C::S + fo, q0 = C::XA + qo, q1 = C::XB + qo, bb = C::BIAS + (unsigned)(32 * wave + 4 * hi) * 4u;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(q0), "+v"(q1), "+v"(bb));
+    L.frag[0] = x3lds + b0; L.frag[1] = x3lds + b1; L.frag[2] = x3lds + b2;
+    L.quad[0] = x3lds + q0; L.quad[1] = x3lds + q1; L.bias = x3lds + bb;
+  }
+  __syncthreads();
+
+  for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+    const int p0 = batch * BP;
+    L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
+    L.ldp16 = (unsigned)a.ldp * 16u;
+    asm volatile("" : "+v"(L.ldp16));
+    int tb = tid;
+    asm volatile("" : "+v"(tb));
+    // lin0's weights: the 16 feature k-steps into the stationary set, the 4 small-input k-steps into a short-lived one
+    uint4 sh[4], sl[4];
+    {
+      const unsigned o0 = w_off(20, 256);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) { wh[ks] = x3_ldg(a.Wp[0], o0 + ks * 1024); wl[ks] = x3_ldg(a.Wlo[0], o0 + ks * 1024); }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { sh[ks] = x3_ldg(a.Wp[0], o0 + (16 + ks) * 1024); sl[ks] = x3_ldg(a.Wlo[0], o0 + (16 + ks) * 1024); }
+    }
+    // ---- the feature tile (both planes) -> XA: a straight copy of 32 octet rows x 64 points x 16 B per plane
+    {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tb + i * C::THREADS, oct = idx >> 6, pp = idx & 63;
+        const unsigned go = ((unsigned)oct * (unsigned)a.ldp + (unsigned)(p0 + pp)) * 16u;
+        const uint4 vh = x3_ldg(a.feat, go), vl = x3_ldg(a.featlo, go);
+        reinterpret_cast<uint4*>(x3lds + C::XA)[oct * BP + pp] = vh;
+        reinterpret_cast<uint4*>(x3lds + C::XA + LO)[oct * BP + pp] = vl;
+      }
+    }
+    // ---- the small inputs -> S region, split
+    {
+      const int p = tb & (BP - 1), g = tb >> 6;
+      unsigned pvo = (unsigned)(p0 + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
+      asm volatile("" : "+v"(pvo), "+v"(ldp4));
+      u16* shi = reinterpret_cast<u16*>(x3lds + C::S);
+      u16* slo = reinterpret_cast<u16*>(x3lds + C::S + SLO);
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj) {
+        const int j = g + 8 * jj;
+        if (j < a.srows) {
+          const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.small) + ((unsigned)j * ldp4 + pvo));
+          const u16 h = f2bf(v);
+          shi[((j >> 3) * BP + p) * 8 + (j & 7)] = h;
+          slo[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v - bf2f(h));
+        }
+      }
+    }
+    __syncthreads();
+
+    f32x16 acc[2];
+    float4 bq[4];
+    auto load_bias = [&](int l) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(L.bias + (l * 256 + 8 * q) * 4);
+    };
+    // the small-input part of lin0 seeds both accumulator tiles
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc[t] = zero;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 bh = *reinterpret_cast<const uint4*>(L.frag[2] + t * 512 + ks * C::KSTEP);
+        const uint4 bl = *reinterpret_cast<const uint4*>(L.frag[2] + SLO + t * 512 + ks * C::KSTEP);
+        acc[t] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&sh[ks]), *reinterpret_cast<const bf16x8*>(&bh), acc[t], 0, 0, 0);
+        acc[t] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&sl[ks]), *reinterpret_cast<const bf16x8*>(&bh), acc[t], 0, 0, 0);
+        acc[t] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&sh[ks]), *reinterpret_cast<const bf16x8*>(&bl), acc[t], 0, 0, 0);
+      }
+    }
+    unsigned ph[2], pl[2];
+    float keep = 0.0f;
+    auto epi_elem = [&](const f32x16& ap, int e, int t, int DST, u16* hout) {      // ReLU, split, quad -> buffer DST (+ hi plane to HBM)
+      const int q = e >> 2, j = e & 3;
+      const float b = j == 0 ? bq[q].x : (j == 1 ? bq[q].y : (j == 2 ? bq[q].z : bq[q].w));
+      const float r = fmaxf(ap[e] + b, 0.0f);
+      if ((j & 1) == 0) { keep = r; return; }
+      x3_split2(keep, r, ph[j >> 1], pl[j >> 1]);
+      if (j != 3) return;
+      const uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
+      *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
+      *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
+      if (SAVE) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+    };
+    auto none = [](int) {};
+#define HD_EPI(ACC_, T_, DST_, H_) [&](int e) { epi_elem(ACC_, e, T_, DST_, H_); }
+#define HD_LAYER(LCUR, SRC_, ZERO_, ROLL_, WNH_, WNL_, PREV_EPI_, CUR_EPI_)                                                         \
+    {                                                                                                                             \
+      x3_stage<16, LO, ZERO_, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI_);                          \
+      __syncthreads();                                                                                                            \
+      load_bias(LCUR);                                                                                                            \
+      x3_stage<16, LO, ZERO_, ROLL_, 16>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, w_off(16, 256), CUR_EPI_);               \
+      __syncthreads();                                                                                                            \
+    }
+    HD_LAYER(0, 0, false, true, a.Wp[1], a.Wlo[1], none, HD_EPI(acc[0], 0, 1, a.hid[1]))                                   // lin0: XA (+ seeded small part) -> XB
+    HD_LAYER(1, 1, true, true, a.Wp[2], a.Wlo[2], HD_EPI(acc[1], 1, 1, a.hid[1]), HD_EPI(acc[0], 0, 0, a.hid[2]))          // lin1: XB -> XA
+    HD_LAYER(2, 0, true, true, a.Wp[3], a.Wlo[3], HD_EPI(acc[1], 1, 0, a.hid[2]), HD_EPI(acc[0], 0, 1, a.hid[3]))          // lin2: XA -> XB
+    HD_LAYER(3, 1, true, false, nullptr, nullptr, HD_EPI(acc[1], 1, 1, a.hid[3]), HD_EPI(acc[0], 0, 0, a.hid[4]))          // lin3: XB -> XA
+    x3_drain(HD_EPI(acc[1], 1, 0, a.hid[4]));
+    __syncthreads();
+#undef HD_LAYER
+#undef HD_EPI
+    // ---- lin4 (3 / 6 rows): K split over the waves (2 k-steps each), partial sums through XB (free now), then bias (+ sigmoid)
+    {
+      float* red = reinterpret_cast<float*>(x3lds + C::XB);       // [8 waves][8 rows][BP]
+      unsigned so = (unsigned)(((2 * wave) * 64 + lane) * 16);
+      asm volatile("" : "+v"(so));
+      uint4 oh[2], ol[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { oh[j] = x3_ldg(a.Wp[4], so + j * 1024); ol[j] = x3_ldg(a.Wlo[4], so + j * 1024); }
+      const unsigned char* fr = L.frag[0] + (unsigned)(2 * wave) * C::KSTEP;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 accs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint4 bh = *reinterpret_cast<const uint4*>(fr + j * C::KSTEP + t * 512);
+          const uint4 bl = *reinterpret_cast<const uint4*>(fr + LO + j * C::KSTEP + t * 512);
+          accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&oh[j]), *reinterpret_cast<const bf16x8*>(&bh), accs, 0, 0, 0);
+          accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&ol[j]), *reinterpret_cast<const bf16x8*>(&bh), accs, 0, 0, 0);
+          accs = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&oh[j]), *reinterpret_cast<const bf16x8*>(&bl), accs, 0, 0, 0);
+        }
+        // rows 0..3 in lanes 0-31 (registers 0..3), rows 4..7 in lanes 32-63
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 8 + 4 * hi + r) * BP + t * 32 + (lane & 31)] = accs[r];
+      }
+      __syncthreads();
+      int tf = tid;
+      asm volatile("" : "+v"(tf));
+      for (int idx = tf; idx < NOUT * BP; idx += C::THREADS) {
+        const int n = idx / BP, pp = idx % BP;
+        float v = biasl[4 * 256 + n];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[(w * 8 + n) * BP + pp];
+        if (HEAD == 0) v = 1.0f / (1.0f + __expf(-v));
+        a.out[(size_t)n * a.ldp + p0 + pp] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace neat

@@ -34,7 +34,11 @@ constexpr int L_REND = 9, L_ATTR = 14;
 const int kO[NLAYERS] = {256, 256, 256, 217, 256, 256, 256, 256, 257, 256, 256, 256, 256, 3, 256, 256, 256, 256, 6};
 const int kI[NLAYERS] = {39, 256, 256, 256, 256, 256, 256, 256, 256, 289, 256, 256, 256, 256, 265, 256, 256, 256, 256};
 constexpr int PE_ROWS = 39, SMALL_R = 33, SMALL_A = 9;
-enum { F32 = 0, BF16 = 1, BF16X3 = 2 };
+enum { F32 = 0, BF16 = 1, BF16X3 = 2, HX3 = 4 };
+// HX3 (NEAT_F16X3, served by the f16 twin only) = the 16-bit build (layouts, backward pass) whose three FORWARD chains run with
+// 3-product hi/lo arithmetic (kernels_x3.hpp) and save lo planes where a later forward kernel needs them: every entry point maps it
+// to BF16 + Ctx::hx3 (take_hx3)
+inline int take_hx3(int& precision) { if (NEAT_HALF && precision == HX3) { precision = BF16; return 1; } return 0; }
 // BF16X3 = the F32 build (layouts, kernels, workspaces) with split-bf16 products in its two GEMM kernels: every entry point maps it
 // to F32 + Ctx::x3 (take_x3)
 inline int take_x3(int& precision) { if (precision == BF16X3) { precision = F32; return 1; } return 0; }
@@ -44,21 +48,24 @@ inline int pad8(int k) { return (k + 7) & ~7; }
 inline int tiles32(int n) { return (n + 31) / 32; }
 
 struct PackLayout {
-  PackDesc2 d[MAXPACKS2];
-  int npacks, nblocks;
+  PackDesc2 d[2 * MAXPACKS2];
+  int npacks, nblocks;                         // the packs of the plain builds: d[0 .. npacks)
+  int npacks_lo, nblocks_lo;                   // HX3: lo-plane packs d[npacks .. npacks + npacks_lo), blk0 counted from 0 again (second launch)
   int fwd[NLAYERS], tr[NLAYERS], sdf_row;      // pack ids (sdf_row: lin8 restricted to the sdf output row)
+  int fwd_lo[NLAYERS], tr_lo[NLAYERS], sdf_row_lo;
   int row_off[NLAYERS + 1];
   size_t rowscale_off, total;
 };
 
-void build_layout(PackLayout& L, int prec) {
+void build_layout(PackLayout& L, int prec, int hx3) {
   size_t off = 0;
   int np = 0, blk = 0;
   L.row_off[0] = 0;
   for (int l = 0; l < NLAYERS; ++l) L.row_off[l + 1] = L.row_off[l] + kO[l];
+  int lo_plane = 0;
   auto add = [&](int l, int t, int nrows_limit, int rot) {
     PackDesc2& d = L.d[np];
-    d.layer = l; d.transpose = t; d.bf16 = prec;
+    d.layer = l; d.transpose = t; d.bf16 = prec; d.lo = lo_plane;
     d.s0 = kI[l]; d.s0p = kI[l]; d.off0 = 0; d.off1 = 0;
     if (l == L_REND) { d.s0 = 256; d.s0p = 256; d.off0 = SMALL_R; d.off1 = 0; }          // [feature | p, PE4(view), normal]
     if (l == L_ATTR) { d.s0 = 256; d.s0p = 256; d.off0 = SMALL_A; d.off1 = 0; }          // [feature | p, view, normal]
@@ -81,16 +88,27 @@ void build_layout(PackLayout& L, int prec) {
   }
   L.sdf_row = add(8, 0, 1, 0);
   L.npacks = np; L.nblocks = blk;
+  L.npacks_lo = 0; L.nblocks_lo = 0;
+  if (hx3) {           // lo planes: every forward pack, the transposed packs of the SDF layers the adjoint chain walks, the sdf row
+    lo_plane = 1; blk = 0;
+    for (int l = 0; l < NLAYERS; ++l) {
+      L.fwd_lo[l] = add(l, 0, 0, (l == 8) ? 1 : 0);
+      if (l < 8) L.tr_lo[l] = add(l, 1, 0, 0);
+    }
+    L.sdf_row_lo = add(8, 0, 1, 0);
+    L.npacks_lo = np - L.npacks; L.nblocks_lo = blk;
+  }
   L.rowscale_off = off;
   off += (size_t)((L.row_off[NLAYERS] + 63) & ~63);
   L.total = off;
 }
 
-const PackLayout& pack_layout(int prec) {
-  static PackLayout L[2];
-  static bool init[2] = {false, false};
-  if (!init[prec]) { build_layout(L[prec], prec); init[prec] = true; }
-  return L[prec];
+const PackLayout& pack_layout(int prec, int hx3 = 0) {
+  static PackLayout L[3];
+  static bool init[3] = {false, false, false};
+  const int i = hx3 ? 2 : prec;
+  if (!init[i]) { build_layout(L[i], prec, hx3); init[i] = true; }
+  return L[i];
 }
 
 NetPtrs to_ptrs(const neat_net_params* net) {
@@ -308,7 +326,7 @@ hipError_t dispatch_h(hipStream_t st, int epi, const LayerArgsH& a, int nt) { EP
 // sdf_finalize_kernel<FAST>: hardware sin/cos in the bf16 build
 #define FINALIZE_LAUNCH(c, ...)                                                                                         \
   do {                                                                                                                   \
-    if ((c).prec) hipLaunchKernelGGL(sdf_finalize_kernel<true>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__);     \
+    if ((c).prec && !(c).hx3) hipLaunchKernelGGL(sdf_finalize_kernel<true>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__);     \
     else hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__);             \
   } while (0)
 
@@ -318,7 +336,8 @@ struct Ctx {
   const neat_net_params* net;
   int P, ldp, prec;
   int x3 = 0;                // NEAT_BF16X3: fp32 layouts, split-bf16 products (kernels.hpp, x3_mfma)
-  const PackLayout& L() const { return pack_layout(prec); }
+  int hx3 = 0;               // NEAT_F16X3: 16-bit layouts and backward, 3-product forward chains (kernels_x3.hpp)
+  const PackLayout& L() const { return pack_layout(prec, hx3); }
   const float* rowscale(int l) const { return packed + L().rowscale_off + L().row_off[l]; }
 };
 
@@ -387,14 +406,15 @@ hipError_t layer(const Ctx& c, int pid, int epi, In in0, In in1, const float* bi
 
 // a hidden-size layer straight on the weight-stationary kernel (bf16 build; rows [0, N) of pack `pid`, K = 256 columns)
 hipError_t layer_ws(const Ctx& c, int pid, int epi, Arr in0, int N, Arr out0, Arr aux0 = Arr{}, Arr aux1 = Arr{},
-                    const float* srow = nullptr, const float* wrow = nullptr, const float* wrow_scale = nullptr) {
+                    const float* srow = nullptr, const float* wrow = nullptr, const float* wrow_scale = nullptr,
+                    const float* rho_num = nullptr, const float* rho_den = nullptr) {
   const PackDesc2& d = c.L().d[pid];
   if (!c.prec || !in0.bf16 || !out0.bf16 || N > 256 || N > d.N || d.Kpad < 256) return hipErrorInvalidValue;
   LayerArgsWS a{};
   a.in = reinterpret_cast<const u16*>(in0.p); a.Wp = reinterpret_cast<const uint4*>(c.packed + d.offset);
   a.aux0 = reinterpret_cast<const u16*>(aux0.p); a.aux1 = reinterpret_cast<const u16*>(aux1.p);
   a.out0 = reinterpret_cast<u16*>(out0.p);
-  a.srow = srow; a.wrow = wrow; a.wrow_scale = wrow_scale;
+  a.srow = srow; a.wrow = wrow; a.wrow_scale = wrow_scale; a.rho_num = rho_num; a.rho_den = rho_den;
   a.N = N; a.in_octs = 32; a.ldp = c.ldp; a.kstride = d.Kpad / 16;
   a.split_oct = 32; a.n_split = 1 << 30;
   const double P = (double)c.P;
@@ -416,6 +436,7 @@ struct SdfWs {
   Arr featc;                      // bf16 build: cotangent of the 256 feature rows of lin8 (octet-major); abar8 row 0 keeps the sdf row
   Arr Ebf, Ebf4, Ehbf, Ehbf4;     // bf16 build: octet-major copies of the PE rows 0..38 / 7..38 and of their tangents
   Arr h[9], feat, u[8], vh[9], m[8];                                                   // big (bf16 in the bf16 build)
+  Arr hlo[9], featlo;             // HX3: lo planes of h_1..h_8 (read by the adjoint chain) and of the feature rows (read by the heads)
   size_t total;
 };
 constexpr int WSPLIT = 128;                 // fp32 build: point-splits of the weight-gradient reduction
@@ -427,7 +448,7 @@ constexpr int WGROUPS = 8;                  // stage-1 groups of the split reduc
 constexpr size_t WSTAGE_FLOATS = (size_t)WGROUPS * WREDUCE_BATCH * 256 * 264;   // >= WGROUPS*WLDN*WLDK; the group sums of up to 6 batched 256x(256+1) layers
 constexpr size_t WPARTIAL_FLOATS = (size_t)W2SPLIT * W2LDN * W2LDK + WSTAGE_FLOATS;   // >= WSPLIT*WLDN*WLDK + stage
 
-SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
+SdfWs sdf_ws(float* base, int ldp, int mode, int prec, int hx3 = 0) {
   SdfWs w{};
   size_t off = 0;
   auto take = [&](int rows) { float* p = base ? base + off : nullptr; off += (size_t)rows * ldp; return p; };
@@ -458,6 +479,10 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec) {
     if (prec) { w.Ebf = big(20); w.Ebf4 = big(16); w.Ehbf = big(20); w.Ehbf4 = big(16); w.featc = big(256); }
     w.partial = base ? base + off : nullptr;
     off += WPARTIAL_FLOATS;
+  }
+  if (hx3 && mode != 0) {
+    for (int l = 1; l <= 8; ++l) w.hlo[l] = big(128);      // (a 16-bit plane of 256 rows = 128 float rows)
+    w.featlo = big(128);
   }
   w.total = off;
   return w;
@@ -517,6 +542,24 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
     a.E = w.E; a.feat = reinterpret_cast<u16*>(w.feat.p); a.sdfraw = w.sdfraw; a.sdf_out = sdf_out;
     a.radius = radius; a.scale = scale; a.bias8_rot = 1; a.bias8_n = 257;
     a.gate = g_gate; a.gate_value = g_gate_value;
+    if (c.hx3) {
+      // split-precision forward: PE rows by posenc6_kernel (libm sin / cos: the hardware forms are ~1e-6 off at |arg| ~ 100), then
+      // ONE launch of the 3-product chain, which also writes the lo planes the adjoint chain and the heads read
+      for (int l = 0; l < 9; ++l) {
+        const PackDesc2& d = L.d[(l == 8 && !full) ? L.sdf_row_lo : L.fwd_lo[l]];
+        a.Wlo[l] = reinterpret_cast<const uint4*>(c.packed + d.offset);
+        a.hlo[l] = (l && full) ? reinterpret_cast<u16*>(w.hlo[l].p) : nullptr;
+      }
+      a.featlo = full ? reinterpret_cast<u16*>(w.featlo.p) : nullptr;
+      hipLaunchKernelGGL(posenc6_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, c.ldp, w.E);
+      double fl3 = 0.0;
+      for (int l = 0; l < 8; ++l) fl3 += 2.0 * kO[l] * kI[l] * (double)c.P;
+      fl3 += 2.0 * (full ? 257 : 1) * 256 * (double)c.P;
+      ProfSlot* ps3 = prof_begin(c.st, 2, fl3, (double)c.P * (12.0 + 39 * 4.0 + (full ? 2.0 * (7 * 256 + 224 + 256) * 2.0 + 4.0 : 4.0)) + 4.0 * 589000.0);
+      hipError_t e3 = launch_sdf_chain_x3(c.st, a, c.ldp / X3_BATCH, g_ws_grid, full);
+      prof_end(c.st, ps3);
+      return e3;
+    }
     constexpr int PT = 2;
     const size_t lds = (size_t)(32 + 8) * (32 * PT) * 16;
     double fl = 0.0;
@@ -582,7 +625,7 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
 // adjoint chain: u_l = d sdf_raw / d a_l, then e0/es = cotangent of the PE rows (autograd.grad at rend_a :121-127)
 hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w, bool save = true) {
   const PackLayout& L = c.L();
-  if (c.prec && g_fused_adj) {
+  if (c.prec && (g_fused_adj || c.hx3)) {
     // bf16 build: the seed and the eight transposed layers as ONE launch (sdf_adjoint_w64_kernel): u stays on chip between the
     // layers; `save` = the training pass, where the tangent chain and the weight gradients read u_0 .. u_7 later
     AdjArgs a{};
@@ -599,6 +642,14 @@ hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w, bool save = true) {
     const int nwg = ntiles < g_ws_grid ? ntiles : g_ws_grid;
     double fl = 0.0;
     for (int l = 0; l < 8; ++l) fl += 2.0 * kO[l] * kI[l] * (double)c.P;
+    if (c.hx3) {
+      for (int l = 0; l < 8; ++l) a.Wlo[l] = reinterpret_cast<const uint4*>(c.packed + L.d[L.tr_lo[l]].offset);
+      for (int l = 1; l <= 8; ++l) a.hlo[l] = reinterpret_cast<const u16*>(w.hlo[l].p);
+      ProfSlot* ps3 = prof_begin(c.st, 2, fl, (double)c.P * (2 * 8 * 512.0 + (save ? 8 * 512.0 : 0.0) + 2 * 39 * 4.0) + 4.0 * 589000.0);
+      hipError_t e3 = launch_sdf_adjoint_x3(c.st, a, c.ldp / X3_BATCH, g_ws_grid, save);
+      prof_end(c.st, ps3);
+      return e3;
+    }
     ProfSlot* ps = prof_begin(c.st, 2, fl, (double)c.P * (8 * 512.0 + (save ? 8 * 512.0 : 0.0) + 2 * 39 * 4.0) + 2.0 * 589000.0);
     hipError_t e = launch_sdf_adjoint_w64(c.st, a, ntiles, nwg, save);
     prof_end(c.st, ps);
@@ -954,11 +1005,39 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
 // ------------------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------------------
-hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat) {
+hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = Arr{}, bool save = true) {
   const PackLayout& L = c.L();
   hipError_t e;
   // bf16 build: octet-major copies of the small head inputs (the input layers then stream like every other layer)
   if (c.prec) oct_pack(c, {{h.small_r, SMALL_R, h.smallbf_r}, {h.small_a, SMALL_A, h.smallbf_a}});
+  if (c.hx3) {
+    // split-precision forward: one fused launch per head (kernels_x3.hpp); the hidden activations stay on chip, their hi planes
+    // go to hr / ha for the 16-bit backward (save)
+    if (!featlo.p) return hipErrorInvalidValue;
+    for (int head = 0; head < 2; ++head) {
+      const int base = head ? L_ATTR : L_REND;
+      const Arr* hh = head ? h.ha : h.hr;
+      HeadX3Args a{};
+      a.P = c.P; a.ldp = c.ldp;
+      a.feat = reinterpret_cast<const u16*>(feat.p); a.featlo = reinterpret_cast<const u16*>(featlo.p);
+      a.small = head ? h.small_a : h.small_r; a.srows = head ? SMALL_A : SMALL_R;
+      for (int l = 0; l < 5; ++l) {
+        a.Wp[l] = reinterpret_cast<const uint4*>(c.packed + L.d[L.fwd[base + l]].offset);
+        a.Wlo[l] = reinterpret_cast<const uint4*>(c.packed + L.d[L.fwd_lo[base + l]].offset);
+        a.bias[l] = c.net->b[base + l];
+        a.hid[l] = (l && save) ? reinterpret_cast<u16*>(hh[l].p) : nullptr;
+      }
+      if (L.d[L.fwd[base]].Kpad != 320) return hipErrorInvalidValue;
+      a.out = head ? h.lin : h.rgb;
+      double fl3 = 0.0;
+      for (int l = 0; l < 5; ++l) fl3 += 2.0 * kO[base + l] * kI[base + l] * (double)c.P;
+      ProfSlot* ps3 = prof_begin(c.st, 2, fl3, (double)c.P * (2 * 512.0 + a.srows * 4.0 + (save ? 4 * 512.0 : 0.0) + (head ? 24.0 : 12.0)) + 4.0 * 540000.0);
+      e = launch_head_chain_x3(c.st, a, head, c.ldp / X3_BATCH, g_ws_grid, save);
+      prof_end(c.st, ps3);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
     const Arr* hh = head ? h.ha : h.hr;
@@ -977,7 +1056,9 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat) {
 
 // zrgb / dlin hold the cotangents of the heads' last linear outputs; accumulates the feature cotangent into
 // abar8 rows 1..256 (render overwrites, attraction adds) and the small-input cotangents into sc_r / sc_a.
-hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const neat_net_grads* gr) {
+// slot / slot_a (f16 build): the common cotangent scale and the attraction head's own (null: one scale)
+hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const neat_net_grads* gr, const float* slot = nullptr,
+                          const float* slot_a = nullptr) {
   const PackLayout& L = c.L();
   hipError_t e;
   const bool oct = oct_operands(c);
@@ -996,7 +1077,8 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     if (c.prec) {
       // feature cotangent (256 rows, octet-major bf16: render writes, attraction adds) on the streaming kernel; the few
       // small-input rows (packed rows 256..) with the narrow-output path
-      if ((e = layer_ws(c, L.tr[base], head ? EPI_LINACC : EPI_LINEAR, ab[0], 256, w.featc, head ? w.featc : Arr{})) != hipSuccess) return e;
+      if ((e = layer_ws(c, L.tr[base], head ? EPI_LINACC : EPI_LINEAR, ab[0], 256, w.featc, head ? w.featc : Arr{}, Arr{}, nullptr, nullptr, nullptr,
+                        (head && slot_a) ? slot : nullptr, (head && slot_a) ? slot_a : nullptr)) != hipSuccess) return e;
       if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, srows, F(head ? h.sc_a : h.sc_r), Arr{}, 1 << 30,
                      Arr{}, Arr{}, 0, 0, 1 << 30, nullptr, 0, 8)) != hipSuccess) return e;
     } else if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, 256 + srows, F(w.abar8 + c.ldp),
@@ -1123,16 +1205,18 @@ void export_out8(const Ctx& c, const SdfWs& w, float* out257, float* feat) {
   if (c.prec) {
     if (out257) {
       hipLaunchKernelGGL(fm_col_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, out257, 257, 0);
-      hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, out257, 257, 1);
+      hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, out257, 257, 1,
+                         reinterpret_cast<const u16*>(w.featlo.p));
     }
-    if (feat) hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, feat, 256, 0);
+    if (feat) hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, feat, 256, 0,
+                                 reinterpret_cast<const u16*>(w.featlo.p));
   } else {
     if (out257) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, 257, c.ldp, out257, 0);
     if (feat) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.feat.f(), P, 256, c.ldp, feat, 0);
   }
 }
 
-bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3; }
+bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3 && !(NEAT_HALF && p == HX3); }
 
 }  // namespace
 
@@ -1146,14 +1230,14 @@ NEAT_TWIN(neat_packed_floats) NEAT_TWIN(neat_pack_weights) NEAT_TWIN(neat_sdf_ws
 NEAT_TWIN(neat_sdf_backward) NEAT_TWIN(neat_heads_ws_floats) NEAT_TWIN(neat_heads_forward) NEAT_TWIN(neat_render_ws_floats)
 NEAT_TWIN(neat_render_forward) NEAT_TWIN(neat_render_backward) NEAT_TWIN(neat_render_eval_ws_floats)
 NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated)
-#define NEAT_F16_FWD(call) if (precision == 3) { precision = BF16; return f16_##call; }
+#define NEAT_F16_FWD(call) if (precision == 3) { precision = BF16; return f16_##call; } if (precision == HX3) return f16_##call;
 #else
 #define NEAT_F16_FWD(call)
 #endif
 
 extern "C" {
 
-int neat_abi_version(void) { return 8; }
+int neat_abi_version(void) { return 9; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
 #if !NEAT_HALF
@@ -1215,14 +1299,17 @@ int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launc
 
 size_t neat_packed_floats(int precision) {
   NEAT_F16_FWD(neat_packed_floats(precision))
-  const int x3 = take_x3(precision); (void)x3; return bad_prec(precision) ? 0 : pack_layout(precision).total; }
+  const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision);
+  return bad_prec(precision) ? 0 : pack_layout(precision, hx3).total; }
 
 int neat_pack_weights(const neat_net_params* net, float* packed, int precision, void* stream) {
   NEAT_F16_FWD(neat_pack_weights(net, packed, precision, stream))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (!net || !packed || bad_prec(precision)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  const PackLayout& L = pack_layout(precision);
+  const PackLayout& L = pack_layout(precision, hx3);
   RowScaleArgs ra;
   ra.net = to_ptrs(net);
   ra.rowscale = packed + L.rowscale_off;
@@ -1234,6 +1321,12 @@ int neat_pack_weights(const neat_net_params* net, float* packed, int precision, 
   for (int i = 0; i < L.npacks; ++i) pa.d[i] = L.d[i];
   pa.npacks = L.npacks; pa.out = packed;
   hipLaunchKernelGGL(pack_kernel2, dim3(L.nblocks, 4), dim3(WG), 0, st, pa);      // 4 slices per 32-row tile: the pack is latency-bound
+  if (L.npacks_lo > 0) {          // HX3: the lo planes, a second launch (the descriptor table is a kernel argument of bounded size)
+    if (L.npacks_lo > MAXPACKS2) return -1;
+    for (int i = 0; i < L.npacks_lo; ++i) pa.d[i] = L.d[L.npacks + i];
+    pa.npacks = L.npacks_lo;
+    hipLaunchKernelGGL(pack_kernel2, dim3(L.nblocks_lo, 4), dim3(WG), 0, st, pa);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1254,7 +1347,8 @@ int neat_eik_points(const float* uniform, const float* origins, const float* dir
 size_t neat_sdf_ws_floats(int P, int mode, int precision) {
   NEAT_F16_FWD(neat_sdf_ws_floats(P, mode, precision))
   const int x3 = take_x3(precision); (void)x3;
-  return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision).total;
+  const int hx3 = take_hx3(precision); (void)hx3;
+  return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision, hx3).total;
 }
 
 int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
@@ -1262,11 +1356,12 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
                      void* stream) {
   NEAT_F16_FWD(neat_sdf_forward(packed, net, x, P, mode, precision, radius, scale, ws, out257, sdf, feat, grad, stream))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (P <= 0) return 0;
   if (!packed || !net || !x || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
-  c.x3 = x3;
-  SdfWs w = sdf_ws(ws, c.ldp, mode, precision);
+  c.x3 = x3; c.hx3 = hx3;
+  SdfWs w = sdf_ws(ws, c.ldp, mode, precision, hx3);
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
   if (mode == 0 && precision) {
     NEAT_CHECK(sdf_primal(c, w, false, radius, scale, sdf));      // fused: PE -> 9 layers -> clamp, one launch
@@ -1303,11 +1398,12 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
                       const neat_net_grads* grads, void* stream) {
   NEAT_F16_FWD(neat_sdf_backward(packed, net, ws, P, precision, d_out257, d_sdf, d_feat, d_grad, grads, stream))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
-  c.x3 = x3;
-  SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
+  c.x3 = x3; c.hx3 = hx3;
+  SdfWs w = sdf_ws(ws, c.ldp, 1, precision, hx3);
   const float* slot = cot_scale_begin(c, w.ones, {{d_out257, 257LL * P}, {d_sdf, (long long)P}, {d_feat, 256LL * P}, {d_grad, 3LL * P}});
   hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8, slot);
   if (precision) oct_pack(c, {{w.abar8 + c.ldp, 256, w.featc}});
@@ -1321,6 +1417,7 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
 size_t neat_heads_ws_floats(int P, int precision) {
   NEAT_F16_FWD(neat_heads_ws_floats(P, precision))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(P, precision);
   return head_ws(nullptr, ldp, precision).total + (size_t)(3 + 3 + 256) * ldp;
@@ -1331,20 +1428,24 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
                        void* stream) {
   NEAT_F16_FWD(neat_heads_forward(packed, net, points, normals, view_dirs, feats, P, precision, ws, rgb, lines, stream))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
-  c.x3 = x3;
+  c.x3 = x3; c.hx3 = hx3;
   HeadWs h = head_ws(ws, c.ldp, precision);
   float* x_fm = ws + h.total; float* g_fm = x_fm + 3 * (size_t)c.ldp; float* f_fm = g_fm + 3 * (size_t)c.ldp;
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, points, P, 3, c.ldp, x_fm);
   hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, normals, P, 3, c.ldp, g_fm);
   Arr feat;
   feat.p = f_fm; feat.bf16 = precision;
-  if (precision) hipLaunchKernelGGL(rm_to_oct_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, reinterpret_cast<u16*>(f_fm));
+  Arr featlo;      // HX3: the lo plane of the feature rows in the second half of the same 256 float rows
+  featlo.p = hx3 ? reinterpret_cast<u16*>(f_fm) + (size_t)256 * c.ldp : nullptr; featlo.bf16 = 1;
+  if (precision) hipLaunchKernelGGL(rm_to_oct_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, reinterpret_cast<u16*>(f_fm),
+                                    reinterpret_cast<u16*>(featlo.p));
   else hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, f_fm);
   hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, x_fm, g_fm, view_dirs, P, 1, c.ldp, h.small_r, h.small_a);
-  NEAT_CHECK(heads_forward(c, h, feat));
+  NEAT_CHECK(heads_forward(c, h, feat, featlo));
   if (rgb) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, h.rgb, P, 3, c.ldp, rgb, 0);
   if (lines) hipLaunchKernelGGL(lines_from_offsets_kernel, grid1(P), dim3(256), 0, c.st, h.lin, x_fm, P, c.ldp, lines);   // y = p + offsets (rend_a :195)
   return (int)hipGetLastError();
@@ -1353,9 +1454,10 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
 size_t neat_render_ws_floats(int R, int S, int E, int precision) {
   NEAT_F16_FWD(neat_render_ws_floats(R, S, E, precision))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S + E, precision);
-  return sdf_ws(nullptr, ldp, 1, precision).total + head_ws(nullptr, ldp, precision).total;
+  return sdf_ws(nullptr, ldp, 1, precision, hx3).total + head_ws(nullptr, ldp, precision).total;
 }
 
 static int render_forward_impl(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
@@ -1363,13 +1465,14 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
                                float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                                float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream, bool fwd_only) {
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !origins || !dirs || !z || !rgb || !lines3d || !depth || !xyz || bad_prec(precision)) return -1;
   if (E < 0 || (E > 0 && (!eik_points || !eik_grad))) return -1;
   const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
-  c.x3 = x3;
-  SdfWs w = sdf_ws(ws, c.ldp, fwd_only ? 2 : 1, precision);
+  c.x3 = x3; c.hx3 = hx3;
+  SdfWs w = sdf_ws(ws, c.ldp, fwd_only ? 2 : 1, precision, hx3);
   HeadWs h = head_ws(ws + w.total, c.ldp, precision, fwd_only);
   hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points, eik_points, E);
   NEAT_CHECK(sdf_primal(c, w, true));
@@ -1378,7 +1481,7 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
                      w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
   // the heads run over every column of the tile grid; only the first R*S columns are consumed
   hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, Pm, S, c.ldp, h.small_r, h.small_a);
-  NEAT_CHECK(heads_forward(c, h, w.feat));
+  NEAT_CHECK(heads_forward(c, h, w.feat, w.featlo, !fwd_only));
   CompositeArgs ca;
   ca.z = z; ca.sdf = w.sdf; ca.dirs = dirs; ca.x_fm = w.x; ca.rgb_fm = h.rgb; ca.lin_fm = h.lin; ca.g_fm = w.g;
   ca.R = R; ca.S = S; ca.ldp = c.ldp; ca.beta_ptr = beta;
@@ -1399,9 +1502,10 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
 size_t neat_render_eval_ws_floats(int R, int S, int precision) {
   NEAT_F16_FWD(neat_render_eval_ws_floats(R, S, precision))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S, precision);
-  return sdf_ws(nullptr, ldp, 2, precision).total + head_ws(nullptr, ldp, precision, true).total;
+  return sdf_ws(nullptr, ldp, 2, precision, hx3).total + head_ws(nullptr, ldp, precision, true).total;
 }
 
 int neat_render_forward_eval(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
@@ -1419,12 +1523,13 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
                          float* dbeta_ray, void* stream) {
   NEAT_F16_FWD(neat_render_backward(packed, net, ws, dirs, z, R, S, E, precision, beta, d_rgb, d_lines3d, d_depth, d_xyz, d_eik_grad, grads, dbeta_ray, stream))
   const int x3 = take_x3(precision); (void)x3;
+  const int hx3 = take_hx3(precision); (void)hx3;
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision) || E < 0) return -1;
   const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
-  c.x3 = x3;
-  SdfWs w = sdf_ws(ws, c.ldp, 1, precision);
+  c.x3 = x3; c.hx3 = hx3;
+  SdfWs w = sdf_ws(ws, c.ldp, 1, precision, hx3);
   HeadWs h = head_ws(ws + w.total, c.ldp, precision);
   CompositeBwdArgs cb;
   cb.z = z; cb.sdf = w.sdf; cb.dirs = dirs; cb.mask = w.mask; cb.x_fm = w.x; cb.rgb_fm = h.rgb;
@@ -1433,18 +1538,21 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
   const float* slot = cot_scale_begin(c, w.ones, {{d_rgb, 3LL * R}, {d_lines3d, 6LL * R}, {d_depth, (long long)R}, {d_xyz, 3LL * R},
                                                   {d_eik_grad, 3LL * E}});
-  cb.cot_slot = slot;
+  // the attraction head's chain in its own scale (only its top cotangent d_lines3d feeds it)
+  const float* slot_a = (slot && d_lines3d) ? cot_scale_begin(c, w.ones + 1, {{d_lines3d, 6LL * R}}) : nullptr;
+  cb.cot_slot = slot; cb.cot_slot_a = slot_a;
   if (!c.prec)      // the ones row is the bias column of the fp32 weight-gradient kernel; the bf16 kernels sum the rows of A themselves
     hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, cb);
   if (c.ldp > Pm) {      // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents
     hipLaunchKernelGGL(zero_tail3_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, h.dlin, 6, w.abar8, 1, Pm, c.ldp);
   }
-  NEAT_CHECK(heads_backward(c, h, w, grads));
+  NEAT_CHECK(heads_backward(c, h, w, grads, slot, slot_a));
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
-                     w.gh, Pm, d_eik_grad, slot);
+                     w.gh, Pm, d_eik_grad, slot, slot_a);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));
-  grad_unscale(c, grads, 0, NLAYERS, slot);
+  if (slot_a) { grad_unscale(c, grads, 0, L_ATTR, slot); grad_unscale(c, grads, L_ATTR, NLAYERS - L_ATTR, slot_a); }
+  else grad_unscale(c, grads, 0, NLAYERS, slot);
   return (int)hipGetLastError();
 }
 

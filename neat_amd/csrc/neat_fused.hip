@@ -3,6 +3,7 @@
 #define neat neat_f16
 #endif
 #include "kernels_fused.hpp"
+#include "kernels_x3.hpp"
 
 namespace neat {
 
@@ -50,6 +51,34 @@ hipError_t launch_sdf_adjoint_w64(hipStream_t st, const AdjArgs& a, int ntiles, 
   if (save) hipLaunchKernelGGL((sdf_adjoint_w64_kernel<true>), dim3(nwg), dim3(C::THREADS), C::LDS, st, a, ntiles, nwg);
   else hipLaunchKernelGGL((sdf_adjoint_w64_kernel<false>), dim3(nwg), dim3(C::THREADS), C::LDS, st, a, ntiles, nwg);
   return hipGetLastError();
+}
+
+template <class K, class A> static hipError_t x3_launch(K kern, bool& attr_done, hipStream_t st, int nbatches, int nwg, const A& args) {
+  if (!attr_done) {      // not a stream operation: keep it out of graph capture
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, X3::LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int grid = nbatches < nwg ? nbatches : nwg;
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(X3::THREADS), X3::LDS, st, args, nbatches);
+  return hipGetLastError();
+}
+
+hipError_t launch_sdf_chain_x3(hipStream_t st, const FusedArgs& a, int nbatches, int nwg, bool full) {
+  static bool d0 = false, d1 = false;
+  return full ? x3_launch(&sdf_chain_x3_kernel<false>, d0, st, nbatches, nwg, a) : x3_launch(&sdf_chain_x3_kernel<true>, d1, st, nbatches, nwg, a);
+}
+
+hipError_t launch_sdf_adjoint_x3(hipStream_t st, const AdjArgs& a, int nbatches, int nwg, bool save) {
+  static bool d0 = false, d1 = false;
+  return save ? x3_launch(&sdf_adjoint_x3_kernel<true>, d0, st, nbatches, nwg, a) : x3_launch(&sdf_adjoint_x3_kernel<false>, d1, st, nbatches, nwg, a);
+}
+
+hipError_t launch_head_chain_x3(hipStream_t st, const HeadX3Args& a, int head, int nbatches, int nwg, bool save) {
+  static bool d[4] = {false, false, false, false};
+  if (head == 0) return save ? x3_launch(&head_chain_x3_kernel<0, true>, d[0], st, nbatches, nwg, a) : x3_launch(&head_chain_x3_kernel<0, false>, d[1], st, nbatches, nwg, a);
+  return save ? x3_launch(&head_chain_x3_kernel<1, true>, d[2], st, nbatches, nwg, a) : x3_launch(&head_chain_x3_kernel<1, false>, d[3], st, nbatches, nwg, a);
 }
 
 }  // namespace neat

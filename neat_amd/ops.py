@@ -46,7 +46,7 @@ class NetHandle:
 
     def __init__(self):
         self.layers = [None] * _lib.NUM_LAYERS      # (weight_v, weight_g, bias) Parameters
-        self.precision = 0                          # _lib.PRECISIONS: 0 = fp32 (parity build), 1 = bf16 MFMA (throughput build), 2 = bf16x3, 3 = f16 MFMA
+        self.precision = 0                          # _lib.PRECISIONS: 0 = fp32 (parity build), 1 = bf16 MFMA (throughput build), 2 = bf16x3, 3 = f16 MFMA, 4 = f16x3 forward + f16 backward
         self._key = None
         self._packed = None
         self._netp = None

@@ -234,7 +234,7 @@ class ErrorBoundSampler(RaySampler):
             return False
         net = getattr(model, "implicit_network", None)
         handle = getattr(net, "handle", None)
-        return handle is not None and handle().precision in (1, 3)      # bf16 / f16 builds
+        return handle is not None and handle().precision in (1, 3, 4)      # bf16 / f16 / f16x3 builds
 
     def rounds_taken(self):
         """Rounds of Algorithm 1 the last call ran (one device read when the last call was sync-free)."""

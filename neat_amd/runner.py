@@ -114,6 +114,10 @@ class TrainRunner:
         self.start_epoch = state["epoch"]
 
     def save_checkpoints(self, epoch):
+        # a replayed step keeps the line-loss NaN flag on the device (train.Trainer.check_nan): never write a checkpoint past it
+        # (the reference stops at the NaN, loss_wfr.py:66-67)
+        if self.device.type == "cuda":
+            self.trainer.check_nan()
         if self.rank != 0:
             return
         payload = (("model_state_dict", self.model.state_dict()), ("optimizer_state_dict", self.optimizer.state_dict()),
@@ -143,6 +147,8 @@ class TrainRunner:
                 if self.batches is None:
                     self.train_dataset.change_sampling_idx(self.num_pixels)      # (a full randperm of the image per step: only its length is used)
                 if (it + 1) % self.log_freq == 0 or it + 1 == len(self.train_dataloader):
+                    if self.device.type == "cuda":
+                        self.trainer.check_nan()            # (one sync per log interval; eager steps raise on their own)
                     with torch.no_grad():
                         psnr = rend_util.get_psnr(outputs["rgb_values"], ground_truth["rgb"].to(self.device).reshape(-1, 3))
                     history.append((epoch, it, float(losses["loss"].detach()), float(psnr)))
@@ -161,7 +167,7 @@ def main():
     ap.add_argument("--exps_folder", default="exps")
     ap.add_argument("--scan_id", type=int, default=-1)
     ap.add_argument("--data_root", default="../data")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "fp16"], default=None)
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "fp16", "fp16x3"], default=None)
     ap.add_argument("--is_continue", default=None, help="checkpoints directory of the run to continue")
     ap.add_argument("--checkpoint", default="latest")
     ap.add_argument("--gpus", type=int, default=1, help="data-parallel ranks (one per GPU); > 1 re-executes under torch.distributed.run")
@@ -187,6 +193,8 @@ def main():
     random.seed(seed)
     np.random.seed(seed)
     local = local % max(torch.cuda.device_count(), 1)      # (more ranks than GPUs only under NEAT_DIST_BACKEND=gloo: functional checks)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)      # the ctypes launches take torch.cuda.current_stream(): it must be this rank's device, whatever the backend
     runner = TrainRunner(args.conf, args.nepoch, args.exps_folder, args.expname, args.scan_id, args.data_root, device=f"cuda:{local}",
                          timestamp=args.timestamp, precision=args.precision, rank=rank, world=world)
     if args.is_continue:

@@ -14,6 +14,9 @@ GT_KEYS = ("rgb", "lines2d")      # what VolSDFLoss reads from the ground truth 
 class Trainer:
     def __init__(self, model_conf=None, loss_conf=None, lr=5.0e-4, decay_steps=200000, device="cuda:0", state_dict=None, parts=None):
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            from . import cap_host_threads
+            cap_host_threads()             # the host thread pool follows the container's CPU quota (neat_amd/__init__.py)
         if parts is not None:              # an already built model / loss / optimizer / scheduler / bucket (neat_amd.runner)
             self.model, self.loss, self.optimizer, self.scheduler, self.bucket = parts
         else:
@@ -32,6 +35,7 @@ class Trainer:
         self._graphs, self._pool, self._ring_pos, self.capture_error = {}, None, 0, None
         self.auto_capture = 0             # > 0: a batch layout seen this many times eagerly is captured on its next visit
         self._visits, self._uncapturable, self._last = {}, set(), None
+        self._capture_fault = None
         self.replays = self.eager_steps = 0
 
     def step(self, model_input, ground_truth):
@@ -89,7 +93,10 @@ class Trainer:
     def capture(self, model_input, ground_truth, warmup=2):
         """Capture the step for this batch layout.  Returns True if it is now replayed from a HIP graph, False if capture was not
         possible (the layout stays eager; `capture_error` holds the reason).  `warmup` eager optimizer steps on this batch run first
-        (lazy initialisations; 0 when the layout has already been stepped eagerly)."""
+        (lazy initialisations; 0 when the layout has already been stepped eagerly).
+        With warmup > 0 the call takes EXACTLY warmup + 1 optimizer steps (= gradient all-reduces) whether the capture succeeds
+        (warm-ups + the first replayed step) or fails anywhere on the way (the missing steps are run eagerly): ranks of a data-parallel
+        run whose captures end differently stay in lock step, same number of collectives and the same Adam step count."""
         if self.device.type != "cuda":
             return False
         key = self._layout_key(model_input, ground_truth)
@@ -120,6 +127,7 @@ class Trainer:
         if entry.static_z is not None:
             self.model.z_vals_override = entry.static_z
         ok = False
+        finished = 0                                        # optimizer steps taken so far by this call
         torch.cuda.synchronize()                            # (captures are rare: start from an idle device)
         try:
             if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
@@ -131,6 +139,7 @@ class Trainer:
                     self._refill_randoms(entry)
                     self._fwd_bwd(entry)
                     self._finish_step(None)
+                    finished += 1
                 if not entry.randoms:                       # no warm-up step ran (auto-capture of a layout that already ran eagerly):
                     rng = torch.get_rng_state()             # one forward registers the draw sites, without consuming the CPU stream
                     with torch.no_grad():
@@ -143,6 +152,8 @@ class Trainer:
             # whatever the model caches per parameter version (the packed weights, ops.NetHandle.packed) must be rebuilt INSIDE the
             # graph: a cache filled by the forward just above would be read, never refreshed, by every replay
             torch._C._increment_version(list(self.model.parameters()))
+            if self._capture_fault is not None:              # (tests: a capture that fails on this rank only)
+                self._capture_fault()
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             graph = torch.cuda.CUDAGraph()
@@ -172,6 +183,11 @@ class Trainer:
             self._finish_step(entry)                        # the capture pass itself does not execute: replay it once
             self.replays += 1
             self._last = entry
+        elif warmup > 0:
+            self.optimizer.zero_grad(set_to_none=True)      # (whatever a half-finished attempt left in .grad)
+            for _ in range(warmup + 1 - finished):          # the steps the successful path would have taken
+                self.step_eager(model_input, ground_truth)
+                self.eager_steps += 1
         return ok
 
     def _fwd_bwd(self, entry, zero=True):

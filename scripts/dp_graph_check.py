@@ -22,7 +22,18 @@ tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(dp.rank_seed(42, rank
 tr.model.set_precision("bf16")
 for _ in range(2):
     tr.step(inp, gt)
+fault_rank = int(os.environ.get("NEAT_TEST_CAPTURE_FAULT_RANK", "-1"))      # tests: the capture fails on this rank only
+if rank == fault_rank:
+    def _fault():
+        raise RuntimeError("injected capture fault")
+    tr._capture_fault = _fault
 ok = tr.capture(inp, gt)
+# the agreement bench.py makes: a rank whose capture failed sends everybody to eager steps.  Trainer.capture took the same
+# number of optimizer steps (= all-reduces) on every rank whatever its outcome, so this small collective pairs with itself.
+ok_all = torch.tensor([1.0 if ok else 0.0], device=dev)
+dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+if ok and float(ok_all.item()) == 0.0:
+    tr._graphs.clear()
 for _ in range(4):
     _, lo = tr.step(inp, gt)
 flat = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).cpu()
@@ -32,5 +43,7 @@ diff = max(float((g - gathered[0]).abs().max()) for g in gathered)
 if rank == 0:
     print(f"backend {backend}; graph captured: {ok} ({tr.capture_error!r}); replays {tr.replays}; loss {float(lo['loss'].detach()):.5f}; "
           f"max parameter difference across ranks: {diff:.3e}", flush=True)
-    assert ok and tr.replays >= 4 and diff == 0.0 and torch.isfinite(lo["loss"]).all()
+    if fault_rank < 0:
+        assert ok and tr.replays >= 4
+    assert diff == 0.0 and torch.isfinite(lo["loss"]).all()
 dist.destroy_process_group()

@@ -5,7 +5,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 python - <<'PY'
 import re
 s = open('/tmp/fused.s').read()
-for k in re.split(r'\n(?=_ZN4neat\w+:)', s):
+for k in re.split(r'\n(?=_ZN\d+neat\w+:)', s):
     name = k.split(':')[0]
     if 'kernel' not in name or name.startswith('\t'):
         continue
@@ -15,5 +15,5 @@ for k in re.split(r'\n(?=_ZN4neat\w+:)', s):
     w0 = sum(l.startswith('s_waitcnt vmcnt(0)') for l in lines)
     sp = re.search(r'; ScratchSize: (\d+)', k)
     vg = re.search(r'; NumVgprs: (\d+)', k)
-    print(name[9:62], 'scratch ld/st', sl, ss, 'bytes', sp and sp.group(1), 'vgpr', vg and vg.group(1), 'vmcnt(0)', w0, 'lines', len(lines))
+    print(name[4:70], 'scratch ld/st', sl, ss, 'bytes', sp and sp.group(1), 'vgpr', vg and vg.group(1), 'vmcnt(0)', w0, 'lines', len(lines))
 PY

@@ -30,10 +30,10 @@ def build_model(dev, variant, seed=42, train=False, precision="fp32"):
     return m.train() if train else m.eval()
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
+@pytest.fixture(params=["fp32", "bf16x3", "fp16x3"])
 def prec(request):
-    """The two builds that claim the fp32 parity bars (1e-4 outputs, 2e-3 gradients vs the reference's goldens): exact-f32 MFMA and
-    the split-bf16 products of NEAT_BF16X3."""
+    """The builds that claim the fp32 parity bars (1e-4 outputs, 2e-3 gradients vs the reference's goldens): exact-f32 MFMA, the
+    split-bf16 products of NEAT_BF16X3, and NEAT_F16X3 = fused 3-product f16 forward chains + the f16 build's backward pass."""
     return request.param
 
 
