@@ -195,9 +195,13 @@ int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, i
 /* ---- 8f-1 (next row): dataset attraction field, replacement for the un-vendored hawp.base._C.encodels ------------
  * (datasets/blender_hawp_dataset.py:96, scene_hawp_dataset.py:95).  lines [N,4] = (x1,y1,x2,y2) in pixels;
  * lmap [6,H,W] = closest point - pixel (0:2), endpoint 1 - pixel (2:4), endpoint 2 - pixel (4:6), all (x,y);
- * label [H,W] int32 = index of the nearest segment (the reference's labels_onehot.max(dim=0)[1]).
+ * label [H,W] int32 = index of the nearest segment (the reference's labels_onehot.max(dim=0)[1]);
+ * valid [H,W] uint8 (may be null) = the reference's labels_onehot.max(dim=0)[0], which the dataset multiplies into its support mask
+ *   (blender_hawp_dataset.py:98,130): 1 where the pixel HAS a nearest segment -- i.e. at least one segment with finite coordinates
+ *   exists; 0 everywhere for N = 0 (then lmap = 0, label = 0) and for segments that are all non-finite.  A zero-length segment is a
+ *   segment (a point).
  * PARITY UNPINNED: hawp is an empty submodule here; semantics are those the call sites rely on. */
-int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream);
+int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, unsigned char* valid, void* stream);
 
 /* ---- 8f-1, batch assembly on the device: the ray sampling of Dataset.__getitem__ (datasets/blender_hawp_dataset.py:186-198,
  * scene_hawp_dataset.py:179-190) with the view's maps resident in HBM.  pool [npool] int32 = pixels of the line support

@@ -64,7 +64,7 @@ _SIGNATURES = {
                                                  c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "neat_sampler_finish_dev": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
-    "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
+    "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_gather_batch": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int,
                                          c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_ffn_forward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 10),

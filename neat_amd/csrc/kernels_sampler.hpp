@@ -472,7 +472,7 @@ __global__ void gather_batch_kernel(GatherBatchArgs a) {
 // Ties go to the lower index.  Segments are cached in LDS in chunks; one thread per pixel.
 // ---------------------------------------------------------------------------------------------
 __global__ void encode_lines_kernel(const float* __restrict__ lines, int N, int H, int W, float* __restrict__ lmap,
-                                    int* __restrict__ label) {
+                                    int* __restrict__ label, unsigned char* __restrict__ valid) {
   __shared__ float sl[256 * 4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = idx < H * W;
@@ -502,6 +502,7 @@ __global__ void encode_lines_kernel(const float* __restrict__ lines, int N, int 
   lmap[2 * hw + idx] = e1x; lmap[3 * hw + idx] = e1y;
   lmap[4 * hw + idx] = e2x; lmap[5 * hw + idx] = e2y;
   label[idx] = bi;
+  if (valid) valid[idx] = best < INFINITY ? 1 : 0;      // a nearest segment exists (N > 0 and not all segments non-finite)
 }
 
 }  // namespace neat

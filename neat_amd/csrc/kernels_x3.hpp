@@ -56,10 +56,22 @@ __device__ __forceinline__ uint4 x3_ldg(const void* base, unsigned off) {
 // called 16 / KS times per k-step for e = 0 .. 15.  ZERO: the accumulator starts at zero.  ROLL: slot ks of the weight registers is
 // refilled with the next layer's fragment (wnh / wnl = its hi / lo packs + this lane's offset, NKS slots) right after its MFMAs;
 // slots KS .. NKS-1 (free in this layer) are requested up front.
+#ifndef NEAT_X3_CHAINS
+#define NEAT_X3_CHAINS 1      // independent accumulator chains the 3 MFMAs of a k-step rotate through (summed after the last k-step)
+#endif
+#ifndef NEAT_X3_ABLATE
+#define NEAT_X3_ABLATE 0      // probe builds only (results are WRONG): 1 = no epilogue, 2 = no MFMAs
+#endif
 template <int KS, int LO, bool ZERO, bool ROLL, int NKS, class Epi>
 __device__ __forceinline__ void x3_stage(const unsigned char* fr, uint4 (&wh)[16], uint4 (&wl)[16], f32x16& acc,
                                          const void* wnh, const void* wnl, unsigned woff, Epi&& epi) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int NC = NEAT_X3_CHAINS;
+  f32x16 ch[NC];                 // chain 0 continues `acc` (ZERO: starts at zero), the others start at zero
+  bool started[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) started[c] = false;
+  if (!ZERO) { ch[0] = acc; started[0] = true; }
   uint4 bh = *reinterpret_cast<const uint4*>(fr), bl = *reinterpret_cast<const uint4*>(fr + LO);
   if (ROLL) {
 #pragma unroll
@@ -72,15 +84,31 @@ __device__ __forceinline__ void x3_stage(const unsigned char* fr, uint4 (&wh)[16
       nh = *reinterpret_cast<const uint4*>(fr + (ks + 1) * X3::KSTEP);
       nl = *reinterpret_cast<const uint4*>(fr + LO + (ks + 1) * X3::KSTEP);
     }
-    acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wh[ks]), *reinterpret_cast<const bf16x8*>(&bh), (ZERO && ks == 0) ? zero : acc, 0, 0, 0);
-    acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wl[ks]), *reinterpret_cast<const bf16x8*>(&bh), acc, 0, 0, 0);
-    acc = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wh[ks]), *reinterpret_cast<const bf16x8*>(&bl), acc, 0, 0, 0);
-    if (ROLL && ks < NKS) { wh[ks] = x3_ldg(wnh, woff + ks * 1024); wl[ks] = x3_ldg(wnl, woff + ks * 1024); }
 #pragma unroll
-    for (int e = ks * (16 / KS); e < (ks + 1) * (16 / KS); ++e) epi(e);
+    for (int i = 0; i < 3; ++i) {
+      const int c = (3 * ks + i) % NC;
+      const uint4& wa = (i == 1) ? wl[ks] : wh[ks];
+      const uint4& bb = (i == 2) ? bl : bh;
+      if (NEAT_X3_ABLATE != 2)
+        ch[c] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wa), *reinterpret_cast<const bf16x8*>(&bb), started[c] ? ch[c] : zero, 0, 0, 0);
+      else if (!started[c]) { ch[c] = zero; ch[c][0] = __uint_as_float(wa.x ^ bb.x); }
+      started[c] = true;
+    }
+    if (ROLL && ks < NKS) { wh[ks] = x3_ldg(wnh, woff + ks * 1024); wl[ks] = x3_ldg(wnl, woff + ks * 1024); }
+    if (NEAT_X3_ABLATE != 1) {
+#pragma unroll
+      for (int e = ks * (16 / KS); e < (ks + 1) * (16 / KS); ++e) epi(e);
+    }
     __builtin_amdgcn_sched_barrier(0);
     bh = nh; bl = nl;
   }
+  acc = ch[0];
+#pragma unroll
+  for (int c = 1; c < NC; ++c)
+    if (started[c]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += ch[c][r];
+    }
 }
 // drain: the epilogue alone
 template <class Epi> __device__ __forceinline__ void x3_drain(Epi&& epi) {
@@ -174,18 +202,16 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     __syncthreads();
 
     f32x16 acc[2];
-    float4 bq[4];
-    auto load_bias = [&](int l) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(L.bias + (l * 256 + 8 * q) * 4);
-    };
+    // the bias rows of a quad are read from LDS when its first element comes up (4 registers instead of 16 held over the stage)
+    float4 bqv = make_float4(0.f, 0.f, 0.f, 0.f);
     // epilogue element e of accumulator tile `ap` (point tile t) of a layer with N rows: activation, hi / lo split, the quad
     // (4 consecutive rows of one point) goes to LDS buffer DST (both planes) and, SAVE, to the HBM arrays hout / lout
     unsigned ph[2], pl[2];
     float keep = 0.0f;
-    auto epi_elem = [&](const f32x16& ap, int e, int t, bool act, int N, int DST, bool to_lds, bool save, u16* hout, u16* lout) {
+    auto epi_elem = [&](const f32x16& ap, int e, int t, int lb, bool act, int N, int DST, bool to_lds, bool save, u16* hout, u16* lout) {
       const int q = e >> 2, j = e & 3;
-      const float b = j == 0 ? bq[q].x : (j == 1 ? bq[q].y : (j == 2 ? bq[q].z : bq[q].w));
+      if (j == 0) bqv = *reinterpret_cast<const float4*>(L.bias + (lb * 256 + 8 * q) * 4);
+      const float b = j == 0 ? bqv.x : (j == 1 ? bqv.y : (j == 2 ? bqv.z : bqv.w));
       float r;
       if (act) {
         const float u = fmaf(ap[e], SOFTPLUS_C, b);
@@ -197,28 +223,23 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
       x3_split2(keep, r, ph[j >> 1], pl[j >> 1]);
       if (j != 3) return;
       uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
-      if (N == 217 && q == 3 && wave == 6) {
-        // lin3, rows 216..223: [h216 | PE rows 0..6] -- what lin4 (skip connection, rend_a :87-88) and the saved h4 expect in the
-        // last octet of the 217-row array
-        const uint4 sh = *reinterpret_cast<const uint4*>(x3lds + C::S + ((lane & 31) + t * 32) * 16);
-        const uint4 sl = *reinterpret_cast<const uint4*>(x3lds + C::S + SLO + ((lane & 31) + t * 32) * 16);
-        if (hi == 0) { vh = make_uint2((vh.x & 0xFFFFu) | (sh.x << 16), (sh.x >> 16) | (sh.y << 16)); vl = make_uint2((vl.x & 0xFFFFu) | (sl.x << 16), (sl.x >> 16) | (sl.y << 16)); }
-        else { vh = make_uint2((sh.y >> 16) | (sh.z << 16), (sh.z >> 16) | (sh.w << 16)); vl = make_uint2((sl.y >> 16) | (sl.z << 16), (sl.z >> 16) | (sl.w << 16)); }
-      }
       if (to_lds) {
         *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
         *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
       }
-      if (save) {
+      // (lin3, N = 217: the octet of rows 216..223 = [h216 | PE rows 0..6] is completed and stored by skip_fix below)
+      if (save && !(N == 217 && q == 3 && wave == 6)) {
         const unsigned off = (unsigned)q * L.ldp16 + L.gquad + t * 512;
         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + off) = vh;
         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(lout) + off) = vl;
       }
     };
     auto none = [](int) {};
-    // skip connection (rend_a :87-88): rows 224..255 of lin4's input (octets 28..31 of XB) = PE rows 7..38 (the 1/sqrt2 is folded
-    // into W4).  One thread per (point, octet, plane): PE rows 7+8k .. 14+8k straddle PE octets k and k+1.
-    auto skip_copy = [&]() {
+    // skip connection (rend_a :87-88): lin4's input is [h4 (217 rows) | PE (39 rows)] (the 1/sqrt2 is folded into W4).  After lin3's
+    // epilogues: rows 224..255 (octets 28..31 of XB) = PE rows 7..38 -- one thread per (point, octet, plane); PE rows 7+8k .. 14+8k
+    // straddle PE octets k and k+1 --, and octet 27 = [h216 | PE rows 0..6] (read-modify-write, threads 0..127), which also goes to
+    // the saved h4 planes in that form (what lin4's consumers in the backward pass expect in the last octet of the 217-row array).
+    auto skip_fix = [&]() {
       int ts = tid;
       asm volatile("" : "+v"(ts));
       const int pp = ts & (BP - 1), k = (ts >> 6) & 3, pln = ts >> 8;
@@ -226,6 +247,18 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
       const uint4 lo4 = pe[k * BP + pp], hi4 = pe[(k + 1) * BP + pp];
       reinterpret_cast<uint4*>(x3lds + C::XB + pln * LO)[(28 + k) * BP + pp] =
           make_uint4((lo4.w >> 16) | (hi4.x << 16), (hi4.x >> 16) | (hi4.y << 16), (hi4.y >> 16) | (hi4.z << 16), (hi4.z >> 16) | (hi4.w << 16));
+      if (ts < 2 * BP) {
+        const int p2 = ts & (BP - 1), pl2 = ts >> 6;
+        const uint4 e = reinterpret_cast<const uint4*>(x3lds + C::S + pl2 * SLO)[p2];
+        uint4* dst = reinterpret_cast<uint4*>(x3lds + C::XB + pl2 * LO) + 27 * BP + p2;
+        const unsigned h216 = dst->x & 0xFFFFu;
+        const uint4 v = make_uint4(h216 | (e.x << 16), (e.x >> 16) | (e.y << 16), (e.y >> 16) | (e.z << 16), (e.z >> 16) | (e.w << 16));
+        *dst = v;
+        if (SAVE) {
+          u16* arr = pl2 ? a.hlo[4] : a.h[4];
+          *reinterpret_cast<uint4*>(reinterpret_cast<char*>(arr) + ((unsigned)27 * (unsigned)a.ldp + (unsigned)(p0 + p2)) * 16u) = v;
+        }
+      }
     };
 
     // One layer = 2 stages.  SRC / DST: input / output LDS buffer (0 = XA, 1 = XB, 2 = S); the epilogue of the previous stage
@@ -235,33 +268,37 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
       if (LIVE_) x3_stage<KS_, SRCLO_, true, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI0_);             \
       else x3_drain(PREV_EPI0_);                                                                                                   \
       __syncthreads();                                                                                                              \
-      load_bias(LCUR);                                                                                                              \
       if (LIVE_) x3_stage<KS_, SRCLO_, true, true, NKS_>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, NOFF_, CUR_EPI_);           \
       else { const unsigned o_ = NOFF_; _Pragma("unroll") for (int ks = 0; ks < NKS_; ++ks) { wh[ks] = x3_ldg(WNH_, o_ + ks * 1024); wl[ks] = x3_ldg(WNL_, o_ + ks * 1024); } x3_drain(CUR_EPI_); } \
       __syncthreads();                                                                                                              \
     }
     // epilogues: E_<l>(tile) = epilogue of layer l's tile
-#define X3_EPI(ACC_, T_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_) [&](int e) { epi_elem(ACC_, e, T_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_); }
+#define X3_EPI(LB_, ACC_, T_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_) [&](int e) { epi_elem(ACC_, e, T_, LB_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_); }
     // lin0: S -> XA
-    X3_LAYER(0, 4, 2, SLO, true, true, 16, a.Wp[1], a.Wlo[1], w_off(16, 256), none, X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]))
+    X3_LAYER(0, 4, 2, SLO, true, true, 16, a.Wp[1], a.Wlo[1], w_off(16, 256), none, X3_EPI(0, acc[0], 0, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]))
     // lin1: XA -> XB
-    X3_LAYER(1, 16, 0, LO, true, false, 16, a.Wp[2], a.Wlo[2], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]), X3_EPI(acc[0], 0, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]))
+    X3_LAYER(1, 16, 0, LO, true, false, 16, a.Wp[2], a.Wlo[2], w_off(16, 256), X3_EPI(0, acc[1], 1, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]), X3_EPI(1, acc[0], 0, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]))
     // lin2: XB -> XA
-    X3_LAYER(2, 16, 1, LO, true, false, 16, a.Wp[3], a.Wlo[3], w_off(16, 217), X3_EPI(acc[1], 1, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]), X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]))
-    // lin3 (217 rows; wave 7 has no rows): XA -> XB rows 0..216 (+ PE rows 0..6), then PE rows 7..38 into rows 224..255
-    skip_copy();
-    X3_LAYER(3, 16, 0, LO, (wave != 7), false, 16, a.Wp[4], a.Wlo[4], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]), X3_EPI(acc[0], 0, true, 217, 1, (wave != 7), SAVE && wave != 7, a.h[4], a.hlo[4]))
+    X3_LAYER(2, 16, 1, LO, true, false, 16, a.Wp[3], a.Wlo[3], w_off(16, 217), X3_EPI(1, acc[1], 1, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]), X3_EPI(2, acc[0], 0, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]))
+    // lin3 (217 rows): XA -> XB like every other layer (wave 7 multiplies a duplicate of tile 0: its rows 224.. do not exist and are
+    // overwritten below; nothing of it is stored), drained, then the PE rows complete lin4's input (skip_fix)
+    const bool w7 = wave != 7;
+    X3_LAYER(3, 16, 0, LO, true, false, 16, a.Wp[4], a.Wlo[4], w_off(16, 256), X3_EPI(2, acc[1], 1, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]), X3_EPI(3, acc[0], 0, true, 217, 1, true, SAVE && w7, a.h[4], a.hlo[4]))
+    x3_drain(X3_EPI(3, acc[1], 1, true, 217, 1, true, SAVE && w7, a.h[4], a.hlo[4]));
+    __syncthreads();
+    skip_fix();
+    __syncthreads();
     // lin4: XB -> XA
-    X3_LAYER(4, 16, 1, LO, true, false, 16, a.Wp[5], a.Wlo[5], w_off(16, 256), X3_EPI(acc[1], 1, true, 217, 1, (wave != 7), SAVE && wave != 7, a.h[4], a.hlo[4]), X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]))
+    X3_LAYER(4, 16, 1, LO, true, false, 16, a.Wp[5], a.Wlo[5], w_off(16, 256), none, X3_EPI(4, acc[0], 0, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]))
     // lin5: XA -> XB
-    X3_LAYER(5, 16, 0, LO, true, false, 16, a.Wp[6], a.Wlo[6], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]), X3_EPI(acc[0], 0, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]))
+    X3_LAYER(5, 16, 0, LO, true, false, 16, a.Wp[6], a.Wlo[6], w_off(16, 256), X3_EPI(4, acc[1], 1, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]), X3_EPI(5, acc[0], 0, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]))
     // lin6: XB -> XA
-    X3_LAYER(6, 16, 1, LO, true, false, 16, a.Wp[7], a.Wlo[7], w_off(16, 256), X3_EPI(acc[1], 1, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]), X3_EPI(acc[0], 0, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]))
+    X3_LAYER(6, 16, 1, LO, true, false, 16, a.Wp[7], a.Wlo[7], w_off(16, 256), X3_EPI(5, acc[1], 1, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]), X3_EPI(6, acc[0], 0, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]))
     // lin7: XA -> XB (h8); its last tile fetches the 256 feature rows of lin8 (save mode; values mode: nothing to prefetch but the
     // macro refills anyway -- from lin8's pack, which exists in both modes)
-    X3_LAYER(7, 16, 0, LO, true, false, 16, a.Wp[8], a.Wlo[8], w_off(16, VALUES ? 1 : 256), X3_EPI(acc[1], 1, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]), X3_EPI(acc[0], 0, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]))
+    X3_LAYER(7, 16, 0, LO, true, false, 16, a.Wp[8], a.Wlo[8], w_off(16, VALUES ? 1 : 256), X3_EPI(6, acc[1], 1, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]), X3_EPI(7, acc[0], 0, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]))
     // drain: h8's second tile
-    x3_drain(X3_EPI(acc[1], 1, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]));
+    x3_drain(X3_EPI(7, acc[1], 1, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]));
     __syncthreads();
     // ---- lin8: the sdf row, split over the waves' k-steps (2 each) and reduced through LDS
     {
@@ -290,9 +327,8 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     if (SAVE) {
       // ---- the 256 feature rows of lin8 (linear): XB -> HBM only
       x3_stage<16, LO, true, false, 16>(L.frag[1], wh, wl, acc[0], nullptr, nullptr, 0u, none);
-      load_bias(8);
-      x3_stage<16, LO, true, false, 16>(L.frag[1] + 512, wh, wl, acc[1], nullptr, nullptr, 0u, X3_EPI(acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));
-      x3_drain(X3_EPI(acc[1], 1, false, 256, 0, false, true, a.feat, a.featlo));
+      x3_stage<16, LO, true, false, 16>(L.frag[1] + 512, wh, wl, acc[1], nullptr, nullptr, 0u, X3_EPI(8, acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));
+      x3_drain(X3_EPI(8, acc[1], 1, false, 256, 0, false, true, a.feat, a.featlo));
     }
     __syncthreads();
 #undef X3_EPI

@@ -1643,9 +1643,9 @@ int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, i
   return (int)hipGetLastError();
 }
 
-int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, void* stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || !lines || !lmap || !label) return -1;
-  hipLaunchKernelGGL(encode_lines_kernel, grid1(H * W), dim3(256), 0, (hipStream_t)stream, lines, N, H, W, lmap, label);
+int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int* label, unsigned char* valid, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || (N > 0 && !lines) || !lmap || !label) return -1;
+  hipLaunchKernelGGL(encode_lines_kernel, grid1(H * W), dim3(256), 0, (hipStream_t)stream, lines, N, H, W, lmap, label, valid);
   return (int)hipGetLastError();
 }
 

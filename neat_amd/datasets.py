@@ -5,9 +5,9 @@ that the reference delegates to the un-vendored CUDA op `hawp.base._C.encodels` 
 
 PARITY UNPINNED at the encodels boundary: the hawp submodule is empty in the reference tree, so its exact tie-breaking
 cannot be checked; the semantics implemented are the ones the call sites depend on (see include/neat_hip.h) and are
-tested against a brute-force numpy oracle (oracle/attraction_oracle.py).  One known difference: the reference multiplies
-the validity map `labels_onehot.max(dim=0)` that encodels returns into the support mask (blender_hawp_dataset.py:98,130);
-with at least one segment every pixel has a nearest segment, so that map is taken to be all ones here.
+tested against a brute-force numpy oracle (oracle/attraction_oracle.py).  The validity map `labels_onehot.max(dim=0)[0]` that
+encodels returns and the reference multiplies into the support mask (blender_hawp_dataset.py:98,130) is the kernel's `valid`
+output: 1 where a pixel has a nearest segment (all ones as soon as one finite segment exists, all zeros for an empty set).
 
 `SceneDataset` is the DTU / BlendedMVS counterpart (code/datasets/scene_hawp_dataset.py): cameras come as projection
 matrices `world_mat_i @ scale_mat_i` and are decomposed into K and pose; the reference uses
@@ -25,18 +25,20 @@ from . import _lib
 from .wireframe import WireframeGraph
 
 
-def encode_lines(lines, height, width):
-    """lines [N,4] (x1,y1,x2,y2) on the GPU -> lmap [6,H,W] float32, labels [H,W] int64."""
+def encode_lines(lines, height, width, return_valid=False):
+    """lines [N,4] (x1,y1,x2,y2) on the GPU -> lmap [6,H,W] float32, labels [H,W] int64 (, valid [H,W] bool: the pixel has a
+    nearest segment = the reference's labels_onehot.max(dim=0)[0])."""
     lib = _lib.lib()
     if not lines.is_cuda:
         raise RuntimeError("encode_lines needs CUDA tensors (no CPU path)")
     lines = lines.detach().float().contiguous()
     lmap = torch.empty(6, height, width, device=lines.device)
     label = torch.empty(height, width, device=lines.device, dtype=torch.int32)
-    _lib.check(lib.neat_encode_lines(ctypes.c_void_p(lines.data_ptr()), lines.shape[0], height, width,
-                                     ctypes.c_void_p(lmap.data_ptr()), ctypes.c_void_p(label.data_ptr()),
+    valid = torch.empty(height, width, device=lines.device, dtype=torch.uint8)
+    _lib.check(lib.neat_encode_lines(ctypes.c_void_p(lines.data_ptr()) if lines.shape[0] else None, lines.shape[0], height, width,
+                                     ctypes.c_void_p(lmap.data_ptr()), ctypes.c_void_p(label.data_ptr()), ctypes.c_void_p(valid.data_ptr()),
                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "neat_encode_lines")
-    return lmap, label.long()
+    return (lmap, label.long(), valid.bool()) if return_valid else (lmap, label.long())
 
 
 def _unit(v):
@@ -48,7 +50,7 @@ def compute_point_line_attraction(lines, img_res, distance=10.0):
     A pixel supports its nearest segment when it is within `distance` px; the reference's two angle tests on the
     endpoints rotated into the foot-point frame are kept for fidelity, but its clamps (:125-128) make them always pass."""
     H, W = img_res
-    lmap, labels = encode_lines(lines[:, :4].cuda(), H, W)
+    lmap, labels, valid = encode_lines(lines[:, :4].cuda(), H, W, return_valid=True)
     dist = torch.sqrt(lmap[0] ** 2 + lmap[1] ** 2)
     md = _unit(lmap[:2]).reshape(2, -1)
     st, ed = lmap[2:4].reshape(2, -1), lmap[4:6].reshape(2, -1)
@@ -60,7 +62,7 @@ def compute_point_line_attraction(lines, img_res, distance=10.0):
     neg = torch.where(swap, st_r, ed_r)
     pos = torch.stack([pos[0].clamp(min=1e-9), pos[1].clamp(min=1e-9)])
     neg = torch.stack([neg[0].clamp(min=1e-9), neg[1].clamp(max=-1e-9)])
-    mask = (dist <= distance).reshape(-1)
+    mask = (dist <= distance).reshape(-1) & valid.reshape(-1)      # `mask, labels = labels_onehot.max(dim=0)`; `mask = (dismap <= d) * mask` (:98,130)
     mask &= torch.atan2(pos[1], pos[0]) > 0
     mask &= torch.atan2(neg[1], neg[0]) < 0
     ys, xs = torch.meshgrid(torch.arange(H, device=lmap.device), torch.arange(W, device=lmap.device), indexing="ij")

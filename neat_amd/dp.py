@@ -16,8 +16,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("NEAT_FORCE_DIST") == "1"      # world size 1 with a real process group: exercises RCCL on a single GPU
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29577")      # (forced single-rank group: nothing else needs to find it)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or os.environ.get("NEAT_DIST_BACKEND") or None      # gloo on GPUs: functional checks with ranks sharing a device
         if backend is None:
@@ -53,6 +56,9 @@ class FlatGradBucket:
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        # world size 1 normally skips the exchange; NEAT_FORCE_DIST=1 (or this attribute) sends the flat buffer through the
+        # initialised backend anyway: the one-GPU test of the RCCL path (library load, stream ordering against the step's graph)
+        self.force_collective = os.environ.get("NEAT_FORCE_DIST") == "1"
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         self._views = None
@@ -69,7 +75,7 @@ class FlatGradBucket:
     def all_reduce_mean(self, flat_grad=None):
         """grad_i <- mean over ranks of grad_i (a parameter with no gradient on this rank contributes zeros).
         `flat_grad`: the gradients already live in this flat buffer -> reduced in place."""
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.force_collective):
             return
         world = dist.get_world_size(self.group)
         if flat_grad is not None:

@@ -27,8 +27,13 @@ def encode_lines(lines, H, W):
     return lmap, label, best
 
 
-def support(lmap, distance):
-    """mask of pixels that support their nearest segment (:104-140), and their foot points."""
+def valid_map(best):
+    """The validity map the call sites take from `labels_onehot.max(dim=0)[0]` (:98): the pixel has a nearest segment."""
+    return np.isfinite(best)
+
+
+def support(lmap, distance, valid=None):
+    """mask of pixels that support their nearest segment (:104-140; `valid` multiplied in as at :130), and their foot points."""
     H, W = lmap.shape[1:]
     mag = np.sqrt(lmap[0] ** 2 + lmap[1] ** 2)
     md = lmap[:2] / (mag + 1e-6)
@@ -40,6 +45,8 @@ def support(lmap, distance):
     pos = np.stack([np.maximum(pos[0], 1e-9), np.maximum(pos[1], 1e-9)])
     neg = np.stack([np.maximum(neg[0], 1e-9), np.minimum(neg[1], -1e-9)])
     mask = (mag <= distance) & (np.arctan2(pos[1], pos[0]) > 0) & (np.arctan2(neg[1], neg[0]) < 0)
+    if valid is not None:
+        mask &= valid
     ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
     foot = np.stack([lmap[0] + xs, lmap[1] + ys], -1) * mask[..., None]
     return mask, foot

@@ -258,6 +258,66 @@ def extra_goldens():
     save("g12_train_step_hierarchical", **arrs)
 
 
+def real_scene_golden():
+    """G13 (round 3): view 0 of the scene BASELINE configs 1 / 2 name, ABC 00075213, as bundled with the reference:
+    K / pose from data/abc/00075213/cameras.npz, the HAWP wireframe from hawp/image_0000.json through the reference's own
+    WireframeGraph.load_json (datasets/utils/wireframe.py:51-68), colours from images/image_0000.png.  The rays are 64 supporting
+    pixels of the wireframe's attraction field (blender_hawp_dataset.py:93-198; hawp's `encodels` is absent, the field comes from
+    oracle/attraction_oracle.py -- it only SELECTS inputs here: uv, uv_proj and the per-ray ground-truth segment are stored in the
+    fixture as data).  One eval forward and one train step of the reference, rough weights."""
+    install_shims()
+    torch.set_default_dtype(torch.float32)
+    from PIL import Image
+    from oracle import attraction_oracle as AO
+    WG = load_wireframe_cls()
+    root = "/root/reference/data/abc/00075213"
+    cams = np.load(os.path.join(root, "cameras.npz"))
+    K = cams["intrinsics"][0].astype(np.float32)
+    pose = cams["extrinsics"][0].astype(np.float32)
+    wf = WG.load_json(os.path.join(root, "hawp", "image_0000.json"))
+    lines = wf.line_segments(0.05)                       # [N, 5] (x1, y1, x2, y2, score), dataset ctor :69
+    H, W = wf.frame_height, wf.frame_width
+    lmap, label, _ = AO.encode_lines(np_(lines)[:, :4], H, W)
+    mask, foot = AO.support(lmap, 10.0)
+    img = np.asarray(Image.open(os.path.join(root, "images", "image_0000.png")).convert("RGB"), dtype=np.float32) / 255.0
+    rng = np.random.RandomState(13)
+    R = 64
+    pix = rng.choice(np.flatnonzero(mask.reshape(-1)), R)          # with replacement, like __getitem__ (:190)
+    ys, xs = pix // W, pix % W
+    sc = {"uv": np.stack([xs, ys], -1).astype(np.float32)[None], "uv_proj": foot.reshape(-1, 2)[pix].astype(np.float32)[None],
+          "pose": pose[None], "intrinsics": K[None],
+          "wf_vertices": np_(wf.vertices), "wf_vconf": np_(wf.v_confidences), "wf_edges": np_(wf.edges), "wf_weights": np_(wf.weights),
+          "gt_rgb": img.reshape(-1, 3)[pix][None], "gt_lines2d": np_(lines)[label.reshape(-1)[pix]][None]}
+    inp = {"intrinsics": torch.tensor(sc["intrinsics"]), "pose": torch.tensor(sc["pose"]), "uv": torch.tensor(sc["uv"]),
+           "uv_proj": torch.tensor(sc["uv_proj"]), "wireframe": [wf]}
+    gt = {"rgb": torch.tensor(sc["gt_rgb"]), "lines2d": torch.tensor(sc["gt_lines2d"])}
+    # eval forward (all keys) with the sampler's depths recorded
+    net = build_model("rough")
+    net.eval()
+    rec = {}
+    inner = net.ray_sampler.get_z_vals
+
+    def recording(*a, _inner=inner, _rec=rec, **k):
+        _rec["z"], _rec["z_eik"] = _inner(*a, **k)
+        return _rec["z"], _rec["z_eik"]
+    net.ray_sampler.get_z_vals = recording
+    with RngTape() as tp:
+        out = net(inp)
+    eik_idx = [t for n, t in tp.tape if n == "randint"][-1]
+    keys = ["points", "rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "lines2d", "sdf", "normal_map"]
+    arrs = {"eval_" + k: np_(out[k]) for k in keys}
+    arrs.update(eval_z_vals=np_(rec["z"]), eval_eik_idx=np_(eik_idx), frame=np.array([H, W]))
+    # train step on the same rays
+    net = build_model("rough")
+    net.train()
+    net.ray_sampler.get_z_vals = (lambda *a, _inner=net.ray_sampler.get_z_vals, _rec=rec, **k: _rec.__setitem__("zt", _inner(*a, **k)) or _rec["zt"])
+    tarrs, tape = train_step_arrays(net, sc, inp, gt, ["rand", "randint", "rand", "randperm", "randint", "uniform_"])
+    arrs.update(tarrs)
+    arrs.update(z_vals=np_(rec["zt"][0]), z_eik=np_(rec["zt"][1]))
+    arrs.update(t_rand=np_(tape[0][1]), u_final=np_(tape[2][1]), perm=np_(tape[3][1]), eik_idx=np_(tape[4][1]), eik_uniform=np_(tape[5][1]))
+    save("g13_real_scene_abc_00075213", **arrs)
+
+
 def main():
     install_shims()
     torch.set_default_dtype(torch.float32)
@@ -408,6 +468,9 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":      # only the round-2 fixtures (G11, G12); the others are left untouched
         extra_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "real":     # only the round-3 fixture (G13)
+        real_scene_golden()
     else:
         main()
         extra_goldens()
+        real_scene_golden()

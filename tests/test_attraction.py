@@ -46,6 +46,47 @@ def test_encode_lines_vs_oracle(H, W, N, seed):
     assert np.abs(foot.cpu().numpy().reshape(H, W, 2) - ref_foot)[both].max() <= 1e-3
 
 
+def test_oracle_validity_map():
+    """zero segments: no pixel has a nearest segment; a zero-length segment is a segment; a non-finite segment is none."""
+    lmap, label, best = A.encode_lines(np.zeros((0, 4), np.float32), 8, 8)
+    assert not A.valid_map(best).any() and (lmap == 0).all() and (label == 0).all()
+    assert not A.support(lmap, 10.0, A.valid_map(best))[0].any()
+    lmap, label, best = A.encode_lines(np.array([[3.0, 3.0, 3.0, 3.0]], np.float32), 8, 8)
+    assert A.valid_map(best).all() and np.allclose(lmap[:2, 3, 3], 0.0) and np.allclose(lmap[:2, 0, 0], [3.0, 3.0])
+    with np.errstate(invalid="ignore"):
+        lmap, label, best = A.encode_lines(np.array([[np.nan, 1.0, 2.0, 2.0]], np.float32), 8, 8)
+    assert not A.valid_map(best).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["empty", "point", "nan", "mixed"])
+def test_encode_lines_validity_vs_oracle(case):
+    """The `labels_onehot.max(dim=0)[0]` output of the encodels replacement on the degenerate inputs, against the
+    oracle, and multiplied into the support mask as blender_hawp_dataset.py:98,130 do."""
+    from neat_amd import datasets
+    H, W = 24, 40
+    lines = {"empty": np.zeros((0, 4), np.float32), "point": np.array([[7.0, 5.0, 7.0, 5.0]], np.float32),
+             "nan": np.array([[np.nan, 1.0, 2.0, 2.0]], np.float32),
+             "mixed": np.array([[np.nan, 1.0, 2.0, 2.0], [3.0, 4.0, 30.0, 20.0], [9.0, 9.0, 9.0, 9.0]], np.float32)}[case]
+    lmap, label, valid = datasets.encode_lines(torch.tensor(lines).reshape(-1, 4).cuda(), H, W, return_valid=True)
+    with np.errstate(invalid="ignore"):
+        ref_lmap, ref_label, ref_best = A.encode_lines(lines, H, W)
+    ref_valid = A.valid_map(ref_best)
+    assert (valid.cpu().numpy() == ref_valid).all()
+    assert valid.any().item() == (case in ("point", "mixed"))
+    ok = ref_valid & (label.cpu().numpy() == ref_label)
+    assert ok.sum() == ref_valid.sum()
+    if ok.any():
+        assert np.abs(lmap.cpu().numpy() - ref_lmap)[:, ok].max() <= 1e-4
+    else:
+        assert (lmap == 0).all() and (label == 0).all()
+    lines5 = np.concatenate([lines.reshape(-1, 4), np.ones((lines.reshape(-1, 4).shape[0], 1), np.float32)], 1)
+    mask, lab, foot = datasets.compute_point_line_attraction(torch.tensor(lines5), (H, W), distance=10.0)
+    with np.errstate(invalid="ignore"):
+        ref_mask, _ = A.support(ref_lmap, 10.0, ref_valid)
+    assert (mask.numpy().reshape(H, W) == ref_mask).mean() > 0.995 and (mask.numpy().reshape(H, W) & ~ref_valid).sum() == 0
+
+
 @pytest.mark.gpu
 def test_blender_dataset_end_to_end(tmp_path):
     """Synthetic scene directory in the reference's layout -> dataset -> one model/loss step."""

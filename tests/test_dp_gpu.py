@@ -27,3 +27,19 @@ def test_two_ranks_stay_in_lock_step(fault_rank):
                          env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "max parameter difference across ranks: 0.000e+00" in out.stdout
+
+
+@pytest.mark.gpu
+def test_rccl_all_reduce_on_one_gpu():
+    """SURVEY 8e's collective on the hardware a one-GPU box has: world-size-1 `nccl` (= RCCL) group, the flat gradient bucket through
+    a real dist.all_reduce eagerly and between HIP-graph replays and Adam; same trajectory as without a group; librccl in the maps."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), NEAT_FORCE_DIST="1", WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_world1_check.py")], env=env, capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "RCCL world-1 check OK" in out.stdout

@@ -226,3 +226,24 @@ def test_sampler_is_ill_conditioned(golden):
         assert float(err[err <= 2e-4].max()) < 2e-4 and float(err.max()) <= 2 * 6.0 / 127 + 1e-3
     assert flips >= 1                                               # at least one whole-bin move from one ulp of input noise
     assert flips / total <= 0.003
+
+
+def test_real_scene_abc_00075213(golden):
+    """G13: view 0 of the scene BASELINE configs 1 / 2 name (K / pose from the reference's cameras.npz, its HAWP wireframe through
+    the reference's own WireframeGraph.load_json): eval forward with all keys, then a train step with all gradients."""
+    g = golden("g13_real_scene_abc_00075213")
+    lines, verts = _wf(g)
+    # (HAWP scores this view's 13 edges 0.77 .. 1e-4: none passes the 0.97 default of line_segments() that the model's forward uses,
+    #  rend_a :428 -- the junction block runs on an EMPTY ground-truth segment set here, the dataset's 0.05 threshold keeps 9)
+    assert [int(v) for v in g["frame"]] == [512, 512] and tuple(verts.shape) == (8, 2) and lines.shape[0] == 0
+    p = params("rough")
+    out = O.full_forward(p, _inp(g), lines, verts, training=False, rand={"eik_idx": T(g["eval_eik_idx"])})
+    for k in ("points", "rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "normal_map"):
+        close(out[k], g["eval_" + k], 5e-5, k)
+    close(out["lines2d"], g["eval_lines2d"], 2e-2, "lines2d (pixels)")
+    p = params("rough", grad=True)
+    rand = {k: T(g[k]) for k in ("t_rand", "u_final", "perm", "eik_idx", "eik_uniform")}
+    out = O.full_forward(p, _inp(g), lines, verts, training=True, rand=rand)
+    lo = O.neat_loss(out, T(g["gt_rgb"]), T(g["gt_lines2d"]))
+    _check_train_step(g, p, out, lo, ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+                                      "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median"))
