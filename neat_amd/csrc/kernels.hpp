@@ -694,13 +694,14 @@ __global__ void adjoint_seed_kernel(const float* __restrict__ v8, const float* _
 }
 
 // normals + sphere clamp:  g = J^T (e0 + eskip) ; sdf = min(raw, scale (radius - |x|))  (rend_a :111-129)
-// FAST (bf16 build): hardware sin/cos (|arg| <= 96, abs error ~1e-6); the fp32 build keeps libm's for the 1e-4 parity bar
+// FAST (bf16 build): hardware sin/cos (|arg| <= 96, abs error ~1e-6); the fp32 build keeps libm's for the 1e-4 parity bar.
+// E (optional): the PE rows [39][ldp] of the same points (posenc6_kernel: sin / cos by libm) -- read instead of recomputed
 template <bool FAST>
 __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float* __restrict__ out8,
                                     const float* __restrict__ e0, const float* __restrict__ es, int P, int ldp,
                                     float radius, float scale, float* __restrict__ sdf, float* __restrict__ g_fm,
                                     float* __restrict__ mask, float* __restrict__ sdf_rm, float* __restrict__ g_rm,
-                                    int n_clamp, float* __restrict__ g_extra_rm) {
+                                    int n_clamp, float* __restrict__ g_extra_rm, const float* __restrict__ E = nullptr) {
   // points [0, n_clamp) get the bounding-sphere clamp (get_outputs); points [n_clamp, P) are eikonal points:
   // raw network gradient (ImplicitNetwork.gradient), written to g_extra_rm
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -719,7 +720,8 @@ __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float*
         const float es_ = e0[(size_t)(3 + 6 * k + c) * ldp + p] + es[(size_t)(3 + 6 * k + c) * ldp + p];
         const float ec_ = e0[(size_t)(6 + 6 * k + c) * ldp + p] + es[(size_t)(6 + 6 * k + c) * ldp + p];
         const float ang = xv[c] * f;
-        acc += f * (FAST ? __cosf(ang) : cosf(ang)) * es_ - f * (FAST ? __sinf(ang) : sinf(ang)) * ec_;
+        if (E) acc += f * E[(size_t)(6 + 6 * k + c) * ldp + p] * es_ - f * E[(size_t)(3 + 6 * k + c) * ldp + p] * ec_;
+        else acc += f * (FAST ? __cosf(ang) : cosf(ang)) * es_ - f * (FAST ? __sinf(ang) : sinf(ang)) * ec_;
         f *= 2.0f;
       }
       gv[c] = acc;

@@ -397,18 +397,25 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.ldp16 = (unsigned)a.ldp * 16u;
     asm volatile("" : "+v"(L.ldp16));
-    unsigned fcol = (unsigned)(p0 + (lane & 31)) * 4u, ldp4 = (unsigned)a.ldp * 4u;      // fp32 rows: byte offset of this lane's point / row stride
-    asm volatile("" : "+v"(fcol), "+v"(ldp4));
+    // fp32 rows (es / e0): row n = nu + 4 hi with nu wave-uniform -> address = array + (nu - split) ldp4 [scalar] + fcol, where fcol
+    // carries this lane's point and its half's four rows
+    unsigned ldp4 = (unsigned)a.ldp * 4u;
+    asm volatile("" : "+s"(ldp4));
+    unsigned fcol = (unsigned)(p0 + (lane & 31)) * 4u + (unsigned)hi * 4u * ldp4;
+    asm volatile("" : "+v"(fcol));
 
     // saved activation quads of this lane (rows 32 wave + 8 q + 4 hi .. + 3 of point tile t), both planes, raw 16-bit
-    uint2 hqh[2][4], hql[2][4];
-    auto load_h = [&](int set, const u16* hs, const u16* ls, int t) {
+    // ONE set (16 registers): an epilogue refills each quad right after its last use with the quad its successor (the epilogue of the
+    // tile being multiplied in the same stage) needs a full stage later -- two sets did not fit beside 128 weight registers
+    uint2 hqh[4], hql[4];
+    auto load_hq = [&](int q, const u16* hs, const u16* ls, int t) {
+      const unsigned off = (unsigned)q * L.ldp16 + L.gquad + t * 512;
+      hqh[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hs) + off);
+      hql[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ls) + off);
+    };
+    auto load_h = [&](const u16* hs, const u16* ls, int t) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned off = (unsigned)q * L.ldp16 + L.gquad + t * 512;
-        hqh[set][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hs) + off);
-        hql[set][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ls) + off);
-      }
+      for (int q = 0; q < 4; ++q) load_hq(q, hs, ls, t);
     };
     auto dphi2 = [](unsigned hw, unsigned lw, float& d0, float& d1) {      // phi' of the two values of a packed pair
       const float h0 = bf_lo(hw) + bf_lo(lw), h1 = bf_hi(hw) + bf_hi(lw);
@@ -422,12 +429,12 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
       for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(L.bias + (8 * q) * 4);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        load_h(0, a.h[8], a.hlo[8], t);
+        load_h(a.h[8], a.hlo[8], t);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float d0, d1, d2, d3;
-          dphi2(hqh[0][q].x, hql[0][q].x, d0, d1);
-          dphi2(hqh[0][q].y, hql[0][q].y, d2, d3);
+          dphi2(hqh[q].x, hql[q].x, d0, d1);
+          dphi2(hqh[q].y, hql[q].y, d2, d3);
           uint2 vh, vl;
           x3_split2(wq[q].x * d0, wq[q].y * d1, vh.x, vl.x);
           x3_split2(wq[q].z * d2, wq[q].w * d3, vh.y, vl.y);
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
         }
       }
     }
+    load_h(a.h[7], a.hlo[7], 0);            // what the first epilogue (layer 7, tile 0) needs; every later quad set is requested by an epilogue
     __syncthreads();
 
     f32x16 acc[2];
@@ -444,56 +452,68 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
     float keep = 0.0f;
     // epilogue element e of `ap` (tile t): MODE 0: * phi'(h) -> buffer DST (+ hi plane to uout); MODE 1 (l = 4): rows < 217 as MODE 0,
     // rows >= 217 -> fp32 rows (n - 217) of frows and zero on chip; MODE 2 (l = 0): rows < 39 -> fp32 rows of frows, nothing on chip
-    auto epi_elem = [&](const f32x16& ap, int e, int t, int set, int MODE, int DST, u16* uout, float* frows) {
+    // nhs / nls / nt: the h planes and tile whose quads replace this epilogue's (null: none)
+    auto epi_elem = [&](const f32x16& ap, int e, int t, int MODE, int DST, u16* uout, float* frows, const u16* nhs, const u16* nls, int nt) {
       const int q = e >> 2, j = e & 3;
-      const int n = 32 * wave + 8 * q + 4 * hi + j;               // output row (hi: per lane half)
-      if (MODE == 2) {
-        if (wave < 2 && n < 39) *reinterpret_cast<float*>(reinterpret_cast<char*>(frows) + ((unsigned)n * ldp4 + fcol + t * 128)) = ap[e];
+      const int nu = 32 * wave + 8 * q + j;                       // output row of the lower half (hi = 0); the upper half's is nu + 4
+      if (MODE == 2) {                                            // rows < 39 -> e0 (waves 0, 1)
+        if (nu + 4 < 39 || (nu < 39 && hi == 0))
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(frows) + ((unsigned)nu * ldp4 + fcol + t * 128)) = ap[e];
         return;
       }
       float r;
       {
-        const unsigned hw = (j < 2) ? hqh[set][q].x : hqh[set][q].y, lw = (j < 2) ? hql[set][q].x : hql[set][q].y;
+        const unsigned hw = (j < 2) ? hqh[q].x : hqh[q].y, lw = (j < 2) ? hql[q].x : hql[q].y;
         const float h = (j & 1) ? (bf_hi(hw) + bf_hi(lw)) : (bf_lo(hw) + bf_lo(lw));
         r = ap[e] * (1.0f - __builtin_amdgcn_exp2f(-SOFTPLUS_C * h));
       }
-      if (MODE == 1 && wave >= 6 && n >= 217) {
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(frows) + ((unsigned)(n - 217) * ldp4 + fcol + t * 128)) = ap[e];
-        r = 0.0f;
+      if (MODE == 1 && nu + 4 >= 217) {                           // (wave-uniform: waves 6 and 7 only)
+        if (nu >= 217 || hi == 1) {
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(frows) + ((unsigned)(nu - 217) * ldp4 + fcol + t * 128)) = ap[e];
+          r = 0.0f;
+        }
       }
       if ((j & 1) == 0) { keep = r; return; }
       x3_split2(keep, r, ph[j >> 1], pl[j >> 1]);
       if (j != 3) return;
+      if (nhs) load_hq(q, nhs, nls, nt);                          // (this quad's h values are dead now)
       const uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
       *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
       *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
       if (SAVE && (MODE == 0 || wave < 7)) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(uout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
     };
     auto none = [](int) {};
-#define ADJ_EPI(ACC_, T_, SET_, MODE_, DST_, U_, F_) [&](int e) { epi_elem(ACC_, e, T_, SET_, MODE_, DST_, U_, F_); }
+    // ADJ_EPI(accumulators, tile, mode, destination buffer, u array, fp32 rows, [h planes, tile] of the NEXT epilogue's quads)
+#define ADJ_EPI(ACC_, T_, MODE_, DST_, U_, F_, NH_, NL_, NT_) [&](int e) { epi_elem(ACC_, e, T_, MODE_, DST_, U_, F_, NH_, NL_, NT_); }
     // one layer: stage (tile 0) with the previous layer's tile-1 epilogue, stage (tile 1, rolling in the next layer's weights) with
     // this layer's tile-0 epilogue.  HS / HL: the h planes whose phi' multiplies THIS layer's output (requested a stage ahead).
-#define ADJ_LAYER(SRC_, HS_, HL_, HAS_H_, LIVE_, WNH_, WNL_, NNEXT_, PREV_EPI_, CUR_EPI_)                                              \
+#define ADJ_LAYER(SRC_, WNH_, WNL_, NNEXT_, PREV_EPI_, CUR_EPI_)                                                                     \
     {                                                                                                                             \
-      if (HAS_H_) load_h(0, HS_, HL_, 0);                                                                                         \
-      if (LIVE_) x3_stage<16, LO, true, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI_);                \
-      else x3_drain(PREV_EPI_);                                                                                                   \
+      x3_stage<16, LO, true, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI_);                           \
       __syncthreads();                                                                                                            \
-      if (HAS_H_) load_h(1, HS_, HL_, 1);                                                                                         \
-      if (LIVE_) x3_stage<16, LO, true, true, 16>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, w_off(NNEXT_), CUR_EPI_);       \
-      else { const unsigned o_ = w_off(NNEXT_); _Pragma("unroll") for (int ks = 0; ks < 16; ++ks) { wh[ks] = x3_ldg(WNH_, o_ + ks * 1024); wl[ks] = x3_ldg(WNL_, o_ + ks * 1024); } x3_drain(CUR_EPI_); } \
+      x3_stage<16, LO, true, true, 16>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, w_off(NNEXT_), CUR_EPI_);                  \
       __syncthreads();                                                                                                            \
     }
-    // (set index = tile: the quads of tile t live in set t until that tile's epilogue has run, one stage after its MFMAs)
-    ADJ_LAYER(0, a.h[7], a.hlo[7], true, true, a.Wp[6], a.Wlo[6], 256, none, ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[6], nullptr))                                                        // l = 7: XA -> XB
-    ADJ_LAYER(1, a.h[6], a.hlo[6], true, true, a.Wp[5], a.Wlo[5], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[6], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 0, a.u[5], nullptr))               // l = 6: XB -> XA
-    ADJ_LAYER(0, a.h[5], a.hlo[5], true, true, a.Wp[4], a.Wlo[4], 256, ADJ_EPI(acc[1], 1, 1, 0, 0, a.u[5], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[4], nullptr))               // l = 5
-    ADJ_LAYER(1, a.h[4], a.hlo[4], true, true, a.Wp[3], a.Wlo[3], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[4], nullptr), ADJ_EPI(acc[0], 0, 0, 1, 0, a.u[3], a.es))                  // l = 4: rows 217.. -> es
-    ADJ_LAYER(0, a.h[3], a.hlo[3], true, true, a.Wp[2], a.Wlo[2], 256, ADJ_EPI(acc[1], 1, 1, 1, 0, a.u[3], a.es), ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[2], nullptr))                  // l = 3
-    ADJ_LAYER(1, a.h[2], a.hlo[2], true, true, a.Wp[1], a.Wlo[1], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[2], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 0, a.u[1], nullptr))               // l = 2
-    ADJ_LAYER(0, a.h[1], a.hlo[1], true, true, a.Wp[0], a.Wlo[0], 39, ADJ_EPI(acc[1], 1, 1, 0, 0, a.u[1], nullptr), ADJ_EPI(acc[0], 0, 0, 0, 1, a.u[0], nullptr))                // l = 1
-    ADJ_LAYER(1, a.h[1], a.hlo[1], false, (wave < 2), a.Wp[7], a.Wlo[7], 256, ADJ_EPI(acc[1], 1, 1, 0, 1, a.u[0], nullptr), ADJ_EPI(acc[0], 0, 0, 2, 0, nullptr, a.e0))                // l = 0: e0 (fp32)
-    x3_drain(ADJ_EPI(acc[1], 1, 1, 2, 0, nullptr, a.e0));
+    // stage (l, tile 0) runs the epilogue of (l + 1, tile 1), whose quads make room for (l, tile 0)'s; stage (l, tile 1) runs the
+    // epilogue of (l, tile 0), whose quads make room for (l, tile 1)'s.  (The first stage has no epilogue: its successor's quads
+    // were requested before the loop; layer 0's epilogues read no h.)
+    ADJ_LAYER(0, a.Wp[6], a.Wlo[6], 256, none,
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[6], nullptr, a.h[7], a.hlo[7], 1))                                                     // l = 7: XA -> XB
+    ADJ_LAYER(1, a.Wp[5], a.Wlo[5], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[6], nullptr, a.h[6], a.hlo[6], 0),
+              ADJ_EPI(acc[0], 0, 0, 0, a.u[5], nullptr, a.h[6], a.hlo[6], 1))                                                     // l = 6: XB -> XA
+    ADJ_LAYER(0, a.Wp[4], a.Wlo[4], 256, ADJ_EPI(acc[1], 1, 0, 0, a.u[5], nullptr, a.h[5], a.hlo[5], 0),
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[4], nullptr, a.h[5], a.hlo[5], 1))                                                     // l = 5
+    ADJ_LAYER(1, a.Wp[3], a.Wlo[3], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[4], nullptr, a.h[4], a.hlo[4], 0),
+              ADJ_EPI(acc[0], 0, 1, 0, a.u[3], a.es, a.h[4], a.hlo[4], 1))                                                        // l = 4: rows 217.. -> es
+    ADJ_LAYER(0, a.Wp[2], a.Wlo[2], 256, ADJ_EPI(acc[1], 1, 1, 0, a.u[3], a.es, a.h[3], a.hlo[3], 0),
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[2], nullptr, a.h[3], a.hlo[3], 1))                                                     // l = 3
+    ADJ_LAYER(1, a.Wp[1], a.Wlo[1], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[2], nullptr, a.h[2], a.hlo[2], 0),
+              ADJ_EPI(acc[0], 0, 0, 0, a.u[1], nullptr, a.h[2], a.hlo[2], 1))                                                     // l = 2
+    ADJ_LAYER(0, a.Wp[0], a.Wlo[0], 39, ADJ_EPI(acc[1], 1, 0, 0, a.u[1], nullptr, a.h[1], a.hlo[1], 0),
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[0], nullptr, a.h[1], a.hlo[1], 1))                                                     // l = 1
+    ADJ_LAYER(1, a.Wp[7], a.Wlo[7], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[0], nullptr, nullptr, nullptr, 0),
+              ADJ_EPI(acc[0], 0, 2, 0, nullptr, a.e0, nullptr, nullptr, 0))                                                       // l = 0: e0 (fp32)
+    x3_drain(ADJ_EPI(acc[1], 1, 2, 0, nullptr, a.e0, nullptr, nullptr, 0));
     __syncthreads();
 #undef ADJ_LAYER
 #undef ADJ_EPI

@@ -324,10 +324,12 @@ hipError_t dispatch_f(hipStream_t st, int epi, const LayerArgs& a, int nt) { EPI
 hipError_t dispatch_h(hipStream_t st, int epi, const LayerArgsH& a, int nt) { EPI_SWITCH(launch_layer_h, st, epi, a, nt) }
 
 // sdf_finalize_kernel<FAST>: hardware sin/cos in the bf16 build
+// (the split-precision forward has the PE rows of the points in w.E -- libm's sin / cos, posenc6_kernel -- and reads them back)
 #define FINALIZE_LAUNCH(c, ...)                                                                                         \
   do {                                                                                                                   \
-    if ((c).prec && !(c).hx3) hipLaunchKernelGGL(sdf_finalize_kernel<true>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__);     \
-    else hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__);             \
+    if ((c).hx3) hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)w.E); \
+    else if ((c).prec) hipLaunchKernelGGL(sdf_finalize_kernel<true>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)nullptr); \
+    else hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)nullptr); \
   } while (0)
 
 struct Ctx {
