@@ -411,7 +411,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():          # (world > 1, or the forced single-rank RCCL group of NEAT_FORCE_DIST=1)
         dist.destroy_process_group()
 
 

@@ -107,6 +107,7 @@ struct AdjArgs {
 // one head of the split-precision forward (kernels_x3.hpp: head_chain_x3_kernel)
 struct HeadX3Args {
   int P, ldp;
+  int nvalid;                                 // batches of 64 points that hold ray samples; later ones (eikonal points, padding) are zero-filled
   const u16* feat; const u16* featlo;         // octet-major, 256 rows
   const float* small; int srows;              // fp32 feature-major [srows][ldp]
   const uint4* Wp[5]; const uint4* Wlo[5];    // packs: lin0 has 20 k-steps ([256 feature | small rows, padded to 64])

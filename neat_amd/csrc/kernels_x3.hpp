@@ -561,6 +561,10 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
   }
   __syncthreads();
 
+  const int nwork = nbatches < a.nvalid ? nbatches : a.nvalid;      // batches >= nvalid hold no ray sample (eikonal points, padding)
+  // (Tried: requesting the next batch's lin0 weights and feature tile during lin4 -- registers idle there -- with the two activation
+  //  buffers swapping roles per batch: 280 -> 380 us per launch.  The requests sit in front of lin4's own weight loads in the in-order
+  //  vector-memory queue and the extra live registers spill; kept simple.)
   for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
     const int p0 = batch * BP;
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
@@ -568,6 +572,21 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
     asm volatile("" : "+v"(L.ldp16));
     int tb = tid;
     asm volatile("" : "+v"(tb));
+    if (batch >= nwork) {
+      // columns no ray sample lives in: nothing is computed; the saved hidden activations are zeroed (the backward pass contracts
+      // them with zero cotangents: they must be finite) and so are the outputs
+      if (SAVE) {
+#pragma unroll
+        for (int l = 1; l <= 4; ++l)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = tb + i * C::THREADS, oct = idx >> 6, pp = idx & 63;
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.hid[l]) + ((unsigned)oct * (unsigned)a.ldp + (unsigned)(p0 + pp)) * 16u) = make_uint4(0u, 0u, 0u, 0u);
+          }
+      }
+      for (int idx = tb; idx < NOUT * BP; idx += C::THREADS) a.out[(size_t)(idx / BP) * a.ldp + p0 + idx % BP] = 0.0f;
+      continue;
+    }
     // lin0's weights: the 16 feature k-steps into the stationary set, the 4 small-input k-steps into a short-lived one
     uint4 sh[4], sl[4];
     {
@@ -584,8 +603,8 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
         const int idx = tb + i * C::THREADS, oct = idx >> 6, pp = idx & 63;
         const unsigned go = ((unsigned)oct * (unsigned)a.ldp + (unsigned)(p0 + pp)) * 16u;
         const uint4 vh = x3_ldg(a.feat, go), vl = x3_ldg(a.featlo, go);
-        reinterpret_cast<uint4*>(x3lds + C::XA)[oct * BP + pp] = vh;
-        reinterpret_cast<uint4*>(x3lds + C::XA + LO)[oct * BP + pp] = vl;
+        reinterpret_cast<uint4*>(x3lds + C::XA)[idx] = vh;
+        reinterpret_cast<uint4*>(x3lds + C::XA + LO)[idx] = vl;
       }
     }
     // ---- the small inputs -> S region, split
@@ -660,9 +679,10 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
     __syncthreads();
 #undef HD_LAYER
 #undef HD_EPI
-    // ---- lin4 (3 / 6 rows): K split over the waves (2 k-steps each), partial sums through XB (free now), then bias (+ sigmoid)
+    // ---- lin4 (3 / 6 rows): K split over the waves (2 k-steps each), partial sums through the B-role buffer (idle since lin3's
+    // last read), then bias (+ sigmoid).  (Not through the small-input region: its rows beyond the inputs must stay zero.)
     {
-      float* red = reinterpret_cast<float*>(x3lds + C::XB);       // [8 waves][8 rows][BP]
+      float* red = reinterpret_cast<float*>(x3lds + C::XB);       // [8 waves][8 rows][BP] = 16 KiB
       unsigned so = (unsigned)(((2 * wave) * 64 + lane) * 16);
       asm volatile("" : "+v"(so));
       uint4 oh[2], ol[2];

@@ -1007,7 +1007,8 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
 // ------------------------------------------------------------------------------------------------
 // heads
 // ------------------------------------------------------------------------------------------------
-hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = Arr{}, bool save = true) {
+// n_main: points that hold ray samples (the heads' outputs beyond them are never read)
+hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = Arr{}, bool save = true, int n_main = -1) {
   const PackLayout& L = c.L();
   hipError_t e;
   // bf16 build: octet-major copies of the small head inputs (the input layers then stream like every other layer)
@@ -1021,6 +1022,7 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = A
       const Arr* hh = head ? h.ha : h.hr;
       HeadX3Args a{};
       a.P = c.P; a.ldp = c.ldp;
+      a.nvalid = ((n_main < 0 ? c.P : n_main) + X3_BATCH - 1) / X3_BATCH;
       a.feat = reinterpret_cast<const u16*>(feat.p); a.featlo = reinterpret_cast<const u16*>(featlo.p);
       a.small = head ? h.small_a : h.small_r; a.srows = head ? SMALL_A : SMALL_R;
       for (int l = 0; l < 5; ++l) {
@@ -1483,7 +1485,7 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
                      w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
   // the heads run over every column of the tile grid; only the first R*S columns are consumed
   hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, Pm, S, c.ldp, h.small_r, h.small_a);
-  NEAT_CHECK(heads_forward(c, h, w.feat, w.featlo, !fwd_only));
+  NEAT_CHECK(heads_forward(c, h, w.feat, w.featlo, !fwd_only, Pm));
   CompositeArgs ca;
   ca.z = z; ca.sdf = w.sdf; ca.dirs = dirs; ca.x_fm = w.x; ca.rgb_fm = h.rgb; ca.lin_fm = h.lin; ca.g_fm = w.g;
   ca.R = R; ca.S = S; ca.ldp = c.ldp; ca.beta_ptr = beta;

@@ -1,19 +1,23 @@
-# Regenerates everything under profiles/ in ONE gpurun call:  rm -rf gpurun_out/refresh; gpurun --timeout 1500 -- 'bash scripts/refresh_profiles.sh'
+# Regenerates the round's files under profiles/ in ONE gpurun call:  rm -rf gpurun_out/refresh; gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh'
 # (delete the local gpurun_out/refresh first: gpurun merges into it and stale rocprofv3 files of another PID would be picked up)
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $O/tests.log
-python bench.py > $O/bench_bf16.log 2>&1; tail -1 $O/bench_bf16.log > $O/bench_bf16.json
-python bench.py --precision fp32 > $O/bench_fp32.log 2>&1; tail -1 $O/bench_fp32.log > $O/bench_fp32.json
-python bench.py --precision bf16x3 --no-cpu-baseline > $O/bench_bf16x3.log 2>&1; tail -1 $O/bench_bf16x3.log > $O/bench_bf16x3.json
-python bench.py --precision fp16 --no-cpu-baseline > $O/bench_fp16.log 2>&1; tail -1 $O/bench_fp16.log > $O/bench_fp16.json
+python bench.py > $O/bench_bf16.log 2>&1; grep \'^{"metric"\' $O/bench_bf16.log | tail -1 > $O/bench_bf16.json
+python bench.py --precision fp16x3 --no-secondary > $O/bench_fp16x3.log 2>&1; grep \'^{"metric"\' $O/bench_fp16x3.log | tail -1 > $O/bench_fp16x3.json
+python bench.py --precision fp32 --no-secondary --no-cpu-baseline > $O/bench_fp32.log 2>&1; grep \'^{"metric"\' $O/bench_fp32.log | tail -1 > $O/bench_fp32.json
+python bench.py --precision bf16x3 --no-secondary --no-cpu-baseline > $O/bench_bf16x3.log 2>&1; grep \'^{"metric"\' $O/bench_bf16x3.log | tail -1 > $O/bench_bf16x3.json
+python bench.py --precision fp16 --no-secondary --no-cpu-baseline > $O/bench_fp16.log 2>&1; grep \'^{"metric"\' $O/bench_fp16.log | tail -1 > $O/bench_fp16.json
+# the RCCL path on the one GPU: world size 1 with a real nccl group
+NEAT_FORCE_DIST=1 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 python bench.py --no-secondary --no-cpu-baseline > $O/bench_bf16_rccl_world1.log 2>&1; grep \'^{"metric"\' $O/bench_bf16_rccl_world1.log | tail -1 > $O/bench_bf16_rccl_world1.json
 python scripts/bench_workloads.py 2>&1 | grep workload > $O/workloads.jsonl
-python scripts/bench_workloads.py --precision fp16 2>&1 | grep workload > $O/workloads_fp16.jsonl
+python scripts/bench_workloads.py --precision fp16x3 2>&1 | grep workload > $O/workloads_fp16x3.jsonl
 python scripts/runner_rate.py 512 4 2>&1 | grep "ms per iteration" > $O/runner_rate.txt
-python scripts/runner_rate.py 1400 3 2>&1 | grep "ms per iteration" >> $O/runner_rate.txt
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > $O/prof_bf16.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32 -- python $R/bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-prof > $O/prof_fp32.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-prof > $O/prof_bf16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp16x3 -- python $R/bench.py --precision fp16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-prof > $O/prof_fp16x3.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-prof --no-graph > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-prof --no-graph > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_x3 -- python $R/bench.py --precision fp16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-prof --no-graph > $O/pmc_fetch_x3.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_x3 -- python $R/bench.py --precision fp16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-prof --no-graph > $O/pmc_write_x3.log 2>&1
 find $O -name "*kernel_trace*" -delete
-du -sh $O; find $O -type f | head -30
+du -sh $O; find $O -type f | head -40

@@ -546,7 +546,7 @@ def test_c3_dtu_switches_vs_oracle_small(dev):
         assert float((prm.grad.cpu() - r).abs().max()) <= 2e-3 * scale + 1e-7, k
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16", "fp16x3"])
 def test_c3_full_size_dtu_step(dev, precision):
     """BASELINE config 3 at full size: 2048 rays x 128 samples, DTU model switches (device DBSCAN + matching, 1024 junction latents),
     full losses (rgb + eikonal + line + junction), whole train step through Trainer (forward, loss, backward, Adam).  No oracle
@@ -1572,7 +1572,7 @@ def test_junction_block_kernels_vs_torch(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16", "fp16x3"])
 def test_torch_ops_equal_the_autograd_functions(dev, precision):
     """torch.ops.neat_hip.* (dispatcher binding of the C ABI, neat_amd/torch_ops.py) run the same launches as neat_amd.ops: the main
     pass with its backward, the SDF network with its double backward, and the forward-only ops give identical bits."""
@@ -1638,7 +1638,7 @@ def test_torch_ops_equal_the_autograd_functions(dev, precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16", "fp16x3"])
 def test_degenerate_sizes_give_empty_results(dev, precision):
     """Zero rays / points / candidates and a single depth sample per ray: empty (or one-sample) results, no launch error, no fault;
     the two ops the reference's own callees refuse on empty input (DBSCAN, the line loss's min over no segments) raise."""
