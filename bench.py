@@ -361,7 +361,12 @@ def main():
             traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(args.precision, {}).get(dom, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath)).get(args.precision, {})
+                traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+                if traffic is None and dom == "sdf_fused_kernel" and any(k.endswith("_x3_kernel") for k in tj):
+                    # fp16x3: the class holds three different fused chains; their full-size launches, per step: primal + adjoint + two heads
+                    traffic = (tj["sdf_chain_x3_kernel"]["hbm_bytes_per_launch"] + tj["sdf_adjoint_x3_kernel"]["hbm_bytes_per_launch"] +
+                               2.0 * tj["head_chain_x3_kernel"]["hbm_bytes_per_launch"]) / 4.0
                 if traffic is not None:
                     traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
             # the hot path is bounded by the MFMA roof (fused, it moves ~5 B per ray-sample against 9.1 MFLOP), so the
@@ -391,11 +396,11 @@ def main():
             "dtype": {"fp32": "f32", "fp16": "f16", "fp16x3": "f16x3 forward / f16 backward"}.get(args.precision, "bf16"), "data": "synthetic",
             "config": {"workload": "C2: abc-neat-a networks, 1024 rays x 128 samples per GPU, depth samples given, "
                                    "train step = forward + loss + backward + Adam" +
-                                   ((" + RCCL grad all-reduce" if dist.get_backend() == "nccl" else " + gloo grad all-reduce (functional check)") if world > 1 else ""),
+                                   ((" + RCCL grad all-reduce" if dist.get_backend() == "nccl" else " + gloo grad all-reduce (functional check)") if dist.is_initialized() else ""),
                        "rays_per_gpu": R_RAYS, "samples_per_ray": S_SAMPLES, "global_rays": world * R_RAYS,
                        "parallelism": f"dp{world}", "weights": "synthetic 'rough' (seed 42)",
                        "launch": "hip graph replay (forward+loss+backward) + eager all-reduce/Adam" if graphed else "eager" + graph_note,
-                       "dist_backend": (dist.get_backend() if world > 1 else None)},
+                       "dist_backend": (dist.get_backend() if dist.is_initialized() else None)},
             "rays_per_s": world * R_RAYS * args.steps / elapsed,
             "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,
             "step_frac_of_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (peak * world),

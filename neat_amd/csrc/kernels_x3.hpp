@@ -464,7 +464,12 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
       float r;
       {
         const unsigned hw = (j < 2) ? hqh[q].x : hqh[q].y, lw = (j < 2) ? hql[q].x : hql[q].y;
+#ifdef NEAT_X3_ADJ_HI_ONLY      // probe: phi' from the hi plane alone
+        const float h = (j & 1) ? bf_hi(hw) : bf_lo(hw);
+        (void)lw;
+#else
         const float h = (j & 1) ? (bf_hi(hw) + bf_hi(lw)) : (bf_lo(hw) + bf_lo(lw));
+#endif
         r = ap[e] * (1.0f - __builtin_amdgcn_exp2f(-SOFTPLUS_C * h));
       }
       if (MODE == 1 && nu + 4 >= 217) {                           // (wave-uniform: waves 6 and 7 only)

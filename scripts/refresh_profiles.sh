@@ -2,13 +2,13 @@
 # (delete the local gpurun_out/refresh first: gpurun merges into it and stale rocprofv3 files of another PID would be picked up)
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $O/tests.log
-python bench.py > $O/bench_bf16.log 2>&1; grep \'^{"metric"\' $O/bench_bf16.log | tail -1 > $O/bench_bf16.json
-python bench.py --precision fp16x3 --no-secondary > $O/bench_fp16x3.log 2>&1; grep \'^{"metric"\' $O/bench_fp16x3.log | tail -1 > $O/bench_fp16x3.json
-python bench.py --precision fp32 --no-secondary --no-cpu-baseline > $O/bench_fp32.log 2>&1; grep \'^{"metric"\' $O/bench_fp32.log | tail -1 > $O/bench_fp32.json
-python bench.py --precision bf16x3 --no-secondary --no-cpu-baseline > $O/bench_bf16x3.log 2>&1; grep \'^{"metric"\' $O/bench_bf16x3.log | tail -1 > $O/bench_bf16x3.json
-python bench.py --precision fp16 --no-secondary --no-cpu-baseline > $O/bench_fp16.log 2>&1; grep \'^{"metric"\' $O/bench_fp16.log | tail -1 > $O/bench_fp16.json
+python bench.py > $O/bench_bf16.log 2>&1; grep '^{"metric"' $O/bench_bf16.log | tail -1 > $O/bench_bf16.json
+python bench.py --precision fp16x3 --no-secondary > $O/bench_fp16x3.log 2>&1; grep '^{"metric"' $O/bench_fp16x3.log | tail -1 > $O/bench_fp16x3.json
+python bench.py --precision fp32 --no-secondary --no-cpu-baseline > $O/bench_fp32.log 2>&1; grep '^{"metric"' $O/bench_fp32.log | tail -1 > $O/bench_fp32.json
+python bench.py --precision bf16x3 --no-secondary --no-cpu-baseline > $O/bench_bf16x3.log 2>&1; grep '^{"metric"' $O/bench_bf16x3.log | tail -1 > $O/bench_bf16x3.json
+python bench.py --precision fp16 --no-secondary --no-cpu-baseline > $O/bench_fp16.log 2>&1; grep '^{"metric"' $O/bench_fp16.log | tail -1 > $O/bench_fp16.json
 # the RCCL path on the one GPU: world size 1 with a real nccl group
-NEAT_FORCE_DIST=1 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 python bench.py --no-secondary --no-cpu-baseline > $O/bench_bf16_rccl_world1.log 2>&1; grep \'^{"metric"\' $O/bench_bf16_rccl_world1.log | tail -1 > $O/bench_bf16_rccl_world1.json
+NEAT_FORCE_DIST=1 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 python bench.py --no-secondary --no-cpu-baseline > $O/bench_bf16_rccl_world1.log 2>&1; grep '^{"metric"' $O/bench_bf16_rccl_world1.log | tail -1 > $O/bench_bf16_rccl_world1.json
 python scripts/bench_workloads.py 2>&1 | grep workload > $O/workloads.jsonl
 python scripts/bench_workloads.py --precision fp16x3 2>&1 | grep workload > $O/workloads_fp16x3.jsonl
 python scripts/runner_rate.py 512 4 2>&1 | grep "ms per iteration" > $O/runner_rate.txt
