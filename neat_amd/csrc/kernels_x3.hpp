@@ -392,7 +392,14 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
   }
   __syncthreads();
 
-  for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
+  // NEAT_X3_ADJ_REVERSE = 1 (probe): batches in the REVERSE of the primal chain's order, so that what the primal launch wrote last
+  // (~1.7 rounds' worth of h planes fit the 256 MB Infinity Cache) is read first.  Measured neutral (631 / 642 us against 615 / 693 us
+  // in forward order, two runs each on one box): off.
+#ifndef NEAT_X3_ADJ_REVERSE
+#define NEAT_X3_ADJ_REVERSE 0
+#endif
+  for (int bi = blockIdx.x; bi < nbatches; bi += gridDim.x) {
+    const int batch = NEAT_X3_ADJ_REVERSE ? nbatches - 1 - bi : bi;
     const int p0 = batch * BP;
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.ldp16 = (unsigned)a.ldp * 16u;
