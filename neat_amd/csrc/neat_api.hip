@@ -1543,7 +1543,8 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   const float* slot = cot_scale_begin(c, w.ones, {{d_rgb, 3LL * R}, {d_lines3d, 6LL * R}, {d_depth, (long long)R}, {d_xyz, 3LL * R},
                                                   {d_eik_grad, 3LL * E}});
   // the attraction head's chain in its own scale (only its top cotangent d_lines3d feeds it)
-  const float* slot_a = (slot && d_lines3d) ? cot_scale_begin(c, w.ones + 1, {{d_lines3d, 6LL * R}}) : nullptr;
+  static const bool one_scale = getenv("NEAT_ONE_COT_SCALE") != nullptr;      // probe: the attraction head in the common scale
+  const float* slot_a = (slot && d_lines3d && !one_scale) ? cot_scale_begin(c, w.ones + 1, {{d_lines3d, 6LL * R}}) : nullptr;
   cb.cot_slot = slot; cb.cot_slot_a = slot_a;
   if (!c.prec)      // the ones row is the bias column of the fp32 weight-gradient kernel; the bf16 kernels sum the rows of A themselves
     hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
