@@ -59,6 +59,9 @@ __device__ __forceinline__ uint4 x3_ldg(const void* base, unsigned off) {
 #ifndef NEAT_X3_CHAINS
 #define NEAT_X3_CHAINS 1      // independent accumulator chains the 3 MFMAs of a k-step rotate through (summed after the last k-step)
 #endif
+#ifndef NEAT_X3_SGB
+#define NEAT_X3_SGB 0         // > 0: sched_group_barrier pattern per k-step with this many VALU instructions per MFMA (probe)
+#endif
 #ifndef NEAT_X3_ABLATE
 #define NEAT_X3_ABLATE 0      // probe builds only (results are WRONG): 1 = no epilogue, 2 = no MFMAs
 #endif
@@ -99,6 +102,18 @@ __device__ __forceinline__ void x3_stage(const unsigned char* fr, uint4 (&wh)[16
 #pragma unroll
       for (int e = ks * (16 / KS); e < (ks + 1) * (16 / KS); ++e) epi(e);
     }
+#if NEAT_X3_SGB
+    // ask the scheduler for an even spread of the k-step's other work behind its three MFMAs: (1 MFMA, up to NEAT_X3_SGB VALU, 1 LDS
+    // read, 1 global load, 1 LDS / global write) x 3
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NEAT_X3_SGB, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x240, 1, 0);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     bh = nh; bl = nl;
   }
@@ -164,42 +179,56 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     L.frag[0] = x3lds + b0; L.frag[1] = x3lds + b1; L.frag[2] = x3lds + b2;
     L.quad[0] = x3lds + q0; L.quad[1] = x3lds + q1; L.bias = x3lds + bb;
   }
+  // ---- PE rows of a batch -> small-input region, hi / lo planes: thread = (point, row group): rows g, g + 8, ...  Requested (e_load)
+  // for the NEXT batch once skip_fix has made the last use of the region, written (e_store) at the end of the batch: no batch but a
+  // workgroup's first waits for HBM before its first MFMA (PREFETCH; values mode only: the training variant has no five registers to
+  // spare -- they spill right behind the load, which waits for it there).  lin0's four k-steps of weights arrive through the last
+  // layer's rolling refill in both modes.
+  constexpr bool PREFETCH = VALUES;
+  float en[5];
+  auto e_load = [&](int b) {
+    int te = tid;
+    asm volatile("" : "+v"(te));
+    const int p = te & (BP - 1), g = te >> 6;
+    unsigned pvo = (unsigned)(b * BP + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
+    asm volatile("" : "+v"(pvo), "+v"(ldp4));
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj) {
+      const int j = g + 8 * jj;
+      en[jj] = j < 39 ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.E) + ((unsigned)j * ldp4 + pvo)) : 0.0f;
+    }
+  };
+  auto e_store = [&]() {
+    int te = tid;
+    asm volatile("" : "+v"(te));
+    const int p = te & (BP - 1), g = te >> 6;
+    u16* shi = reinterpret_cast<u16*>(x3lds + C::S);
+    u16* slo = reinterpret_cast<u16*>(x3lds + C::S + SLO);
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj) {
+      const int j = g + 8 * jj;
+      if (j < 39) {
+        const u16 h = f2bf(en[jj]);
+        shi[((j >> 3) * BP + p) * 8 + (j & 7)] = h;
+        slo[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(en[jj] - bf2f(h));
+      }
+    }
+  };
+  if ((int)blockIdx.x < nbatches) {
+    const unsigned o0 = w_off(4, 256);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { wh[ks] = x3_ldg(a.Wp[0], o0 + ks * 1024); wl[ks] = x3_ldg(a.Wlo[0], o0 + ks * 1024); }
+    if (PREFETCH) { e_load(blockIdx.x); e_store(); }
+  }
   __syncthreads();
 
   for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
     const int p0 = batch * BP;
+    const bool more = batch + (int)gridDim.x < nbatches;
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.ldp16 = (unsigned)a.ldp * 16u;
     asm volatile("" : "+v"(L.ldp16));
-    // an opaque copy of the thread index per batch: whatever the staging / copy phases derive from it is recomputed where it is used
-    // instead of being hoisted out of the batch loop (dozens of loop-invariant addresses) and spilled
-    int tb = tid;
-    asm volatile("" : "+v"(tb));
-    // lin0's four k-steps of weights travel while the PE rows are staged
-    {
-      const unsigned o0 = w_off(4, 256);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { wh[ks] = x3_ldg(a.Wp[0], o0 + ks * 1024); wl[ks] = x3_ldg(a.Wlo[0], o0 + ks * 1024); }
-    }
-    // ---- PE rows -> small-input region, hi / lo planes: thread = (point, row group): rows g, g + 8, ...
-    {
-      const int p = tb & (BP - 1), g = tb >> 6;
-      unsigned pvo = (unsigned)(p0 + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
-      asm volatile("" : "+v"(pvo), "+v"(ldp4));
-      u16* shi = reinterpret_cast<u16*>(x3lds + C::S);
-      u16* slo = reinterpret_cast<u16*>(x3lds + C::S + SLO);
-#pragma unroll
-      for (int jj = 0; jj < 5; ++jj) {
-        const int j = g + 8 * jj;
-        if (j < 39) {
-          const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.E) + ((unsigned)j * ldp4 + pvo));
-          const u16 h = f2bf(v);
-          shi[((j >> 3) * BP + p) * 8 + (j & 7)] = h;
-          slo[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v - bf2f(h));
-        }
-      }
-    }
-    __syncthreads();
+    if (!PREFETCH) { e_load(batch); e_store(); __syncthreads(); }
 
     f32x16 acc[2];
     // the bias rows of a quad are read from LDS when its first element comes up (4 registers instead of 16 held over the stage)
@@ -288,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     __syncthreads();
     skip_fix();
     __syncthreads();
+    if (PREFETCH && more) e_load(batch + gridDim.x);
     // lin4: XB -> XA
     X3_LAYER(4, 16, 1, LO, true, false, 16, a.Wp[5], a.Wlo[5], w_off(16, 256), none, X3_EPI(4, acc[0], 0, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]))
     // lin5: XA -> XB
@@ -296,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     X3_LAYER(6, 16, 1, LO, true, false, 16, a.Wp[7], a.Wlo[7], w_off(16, 256), X3_EPI(5, acc[1], 1, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]), X3_EPI(6, acc[0], 0, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]))
     // lin7: XA -> XB (h8); its last tile fetches the 256 feature rows of lin8 (save mode; values mode: nothing to prefetch but the
     // macro refills anyway -- from lin8's pack, which exists in both modes)
-    X3_LAYER(7, 16, 0, LO, true, false, 16, a.Wp[8], a.Wlo[8], w_off(16, VALUES ? 1 : 256), X3_EPI(6, acc[1], 1, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]), X3_EPI(7, acc[0], 0, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]))
+    X3_LAYER(7, 16, 0, LO, true, false, (VALUES ? 4 : 16), a.Wp[VALUES ? 0 : 8], a.Wlo[VALUES ? 0 : 8], w_off(VALUES ? 4 : 16, 256), X3_EPI(6, acc[1], 1, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]), X3_EPI(7, acc[0], 0, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]))
     // drain: h8's second tile
     x3_drain(X3_EPI(7, acc[1], 1, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]));
     __syncthreads();
@@ -327,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     if (SAVE) {
       // ---- the 256 feature rows of lin8 (linear): XB -> HBM only
       x3_stage<16, LO, true, false, 16>(L.frag[1], wh, wl, acc[0], nullptr, nullptr, 0u, none);
-      x3_stage<16, LO, true, false, 16>(L.frag[1] + 512, wh, wl, acc[1], nullptr, nullptr, 0u, X3_EPI(8, acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));
+      x3_stage<16, LO, true, true, 4>(L.frag[1] + 512, wh, wl, acc[1], a.Wp[0], a.Wlo[0], w_off(4, 256), X3_EPI(8, acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));      // (rolls in lin0 of the next batch)
       x3_drain(X3_EPI(8, acc[1], 1, false, 256, 0, false, true, a.feat, a.featlo));
     }
     __syncthreads();
@@ -350,6 +380,7 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
         a.sdfraw[p] = sv;
       }
     }
+    if (PREFETCH && more) e_store();
     __syncthreads();
   }
 }
