@@ -113,6 +113,10 @@ def secondary_legs(dev, sd, headline_precision, steps, note):
         for _ in range(3):
             tr.step(inp, gt)
         graphed = tr.capture(inp, gt)
+        # untimed: the first ~20 replays of the first sampler graph of a process run 0.6-1.2 ms slow (host-side enqueue of the refilled
+        # random draws next to a cold launch path; scripts/sampler_first_steps.py), a one-time 20 ms that is not the steady state
+        for _ in range(20):
+            tr.step(inp, gt)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -148,6 +152,18 @@ def secondary_legs(dev, sd, headline_precision, steps, note):
                    workload="train step with the conf-default ErrorBoundSampler (VolSDF Alg. 1, 98 samples per ray), rounds decided on the device")
         legs[f"sampler_step_{prec}"] = leg
         del tr
+    # the parity-grade precision with the sampler's SDF queries through the one-product f16 chain (conf key
+    # model.hip_sampler_fast_values): main pass and gradients unchanged, sampled depths statistically the reference's
+    torch.manual_seed(42)
+    tr = Trainer(device=dev, state_dict=sd)
+    tr.model.set_precision(parity)
+    tr.model.sampler_fast_values = True
+    tr.model.ray_sampler.sync_free = True
+    leg = timed(tr, inp, gt, f"sampler_step_{parity}_fast_values")
+    leg.update(precision=parity, rounds=tr.model.ray_sampler.rounds_taken(),
+               workload="train step with the conf-default ErrorBoundSampler, its SDF queries in one-product f16 (hip_sampler_fast_values)")
+    legs[f"sampler_step_{parity}_fast_values"] = leg
+    del tr
     return legs
 
 

@@ -55,12 +55,17 @@ int neat_abi_version(void);      /* 9 */
  *                   evaluate every product as three f16 MFMAs on hi/lo splits of both operands (~22 mantissa bits): forward outputs
  *                   within 1e-4 of the reference like NEAT_F32, gradients at the fp32 build's bar (the backward pass reads the hi
  *                   planes = exactly what NEAT_F16 saves), at about the speed of NEAT_F16.
+ *   NEAT_F16X3_FASTVALUES (5): accepted by the VALUES-mode calls only (neat_sdf_forward mode 0, neat_sdf_values_gated,
+ *                   neat_sdf_ws_floats) together with a NEAT_F16X3 pack: the query runs through NEAT_F16's one-product chain (3x
+ *                   faster).  For a depth sampler that may trade the reference's exact samples for speed (the sampled distribution
+ *                   stays the reference's to ~1e-4 of the depth range, tests/test_gpu_parity.py::test_sampler_vs_reference_golden).
  * Packed weights, workspaces and forward/backward calls of one pass must use the same value. */
 #define NEAT_F32 0
 #define NEAT_BF16 1
 #define NEAT_BF16X3 2
 #define NEAT_F16 3
 #define NEAT_F16X3 4
+#define NEAT_F16X3_FASTVALUES 5
 
 /* ---- a15: weight norm + packing (replaces the per-call `_weight_norm` pre-hook) -------------------
  * Computes W = g * v/|v| for all 19 layers once per step and stores W and W^T in MFMA-fragment order. */

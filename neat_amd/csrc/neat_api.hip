@@ -34,11 +34,17 @@ constexpr int L_REND = 9, L_ATTR = 14;
 const int kO[NLAYERS] = {256, 256, 256, 217, 256, 256, 256, 256, 257, 256, 256, 256, 256, 3, 256, 256, 256, 256, 6};
 const int kI[NLAYERS] = {39, 256, 256, 256, 256, 256, 256, 256, 256, 289, 256, 256, 256, 256, 265, 256, 256, 256, 256};
 constexpr int PE_ROWS = 39, SMALL_R = 33, SMALL_A = 9;
-enum { F32 = 0, BF16 = 1, BF16X3 = 2, HX3 = 4 };
+enum { F32 = 0, BF16 = 1, BF16X3 = 2, HX3 = 4, HX3_FASTVALUES = 5 };
 // HX3 (NEAT_F16X3, served by the f16 twin only) = the 16-bit build (layouts, backward pass) whose three FORWARD chains run with
 // 3-product hi/lo arithmetic (kernels_x3.hpp) and save lo planes where a later forward kernel needs them: every entry point maps it
 // to BF16 + Ctx::hx3 (take_hx3)
-inline int take_hx3(int& precision) { if (NEAT_HALF && precision == HX3) { precision = BF16; return 1; } return 0; }
+// HX3_FASTVALUES (5): values-mode calls only (neat_sdf_forward mode 0, neat_sdf_values_gated) on a NEAT_F16X3 pack: the ONE-product
+// f16 chain of the fp16 build evaluates the query (3x faster; for a sampler that may trade the reference's exact depths for speed)
+inline int take_hx3(int& precision) {
+  if (NEAT_HALF && precision == HX3) { precision = BF16; return 1; }
+  if (NEAT_HALF && precision == HX3_FASTVALUES) { precision = BF16; return 2; }
+  return 0;
+}
 // BF16X3 = the F32 build (layouts, kernels, workspaces) with split-bf16 products in its two GEMM kernels: every entry point maps it
 // to F32 + Ctx::x3 (take_x3)
 inline int take_x3(int& precision) { if (precision == BF16X3) { precision = F32; return 1; } return 0; }
@@ -339,7 +345,7 @@ struct Ctx {
   int P, ldp, prec;
   int x3 = 0;                // NEAT_BF16X3: fp32 layouts, split-bf16 products (kernels.hpp, x3_mfma)
   int hx3 = 0;               // NEAT_F16X3: 16-bit layouts and backward, 3-product forward chains (kernels_x3.hpp)
-  const PackLayout& L() const { return pack_layout(prec, hx3); }
+  const PackLayout& L() const { return pack_layout(prec, hx3 != 0); }
   const float* rowscale(int l) const { return packed + L().rowscale_off + L().row_off[l]; }
 };
 
@@ -544,7 +550,8 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
     a.E = w.E; a.feat = reinterpret_cast<u16*>(w.feat.p); a.sdfraw = w.sdfraw; a.sdf_out = sdf_out;
     a.radius = radius; a.scale = scale; a.bias8_rot = 1; a.bias8_n = 257;
     a.gate = g_gate; a.gate_value = g_gate_value;
-    if (c.hx3) {
+    if (c.hx3 == 2 && full) return hipErrorInvalidValue;
+    if (c.hx3 == 1) {
       // split-precision forward: PE rows by posenc6_kernel (libm sin / cos: the hardware forms are ~1e-6 off at |arg| ~ 100), then
       // ONE launch of the 3-product chain, which also writes the lo planes the adjoint chain and the heads read
       for (int l = 0; l < 9; ++l) {
@@ -1220,7 +1227,7 @@ void export_out8(const Ctx& c, const SdfWs& w, float* out257, float* feat) {
   }
 }
 
-bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3 && !(NEAT_HALF && p == HX3); }
+bool bad_prec(int p) { return p != F32 && p != BF16 && p != BF16X3 && !(NEAT_HALF && (p == HX3 || p == HX3_FASTVALUES)); }
 
 }  // namespace
 
@@ -1234,7 +1241,7 @@ NEAT_TWIN(neat_packed_floats) NEAT_TWIN(neat_pack_weights) NEAT_TWIN(neat_sdf_ws
 NEAT_TWIN(neat_sdf_backward) NEAT_TWIN(neat_heads_ws_floats) NEAT_TWIN(neat_heads_forward) NEAT_TWIN(neat_render_ws_floats)
 NEAT_TWIN(neat_render_forward) NEAT_TWIN(neat_render_backward) NEAT_TWIN(neat_render_eval_ws_floats)
 NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated)
-#define NEAT_F16_FWD(call) if (precision == 3) { precision = BF16; return f16_##call; } if (precision == HX3) return f16_##call;
+#define NEAT_F16_FWD(call) if (precision == 3) { precision = BF16; return f16_##call; } if (precision == HX3 || precision == HX3_FASTVALUES) return f16_##call;
 #else
 #define NEAT_F16_FWD(call)
 #endif
@@ -1305,15 +1312,16 @@ size_t neat_packed_floats(int precision) {
   NEAT_F16_FWD(neat_packed_floats(precision))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision);
-  return bad_prec(precision) ? 0 : pack_layout(precision, hx3).total; }
+  return (bad_prec(precision) || hx3 == 2) ? 0 : pack_layout(precision, hx3 != 0).total; }
 
 int neat_pack_weights(const neat_net_params* net, float* packed, int precision, void* stream) {
   NEAT_F16_FWD(neat_pack_weights(net, packed, precision, stream))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return -1;
   if (!net || !packed || bad_prec(precision)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  const PackLayout& L = pack_layout(precision, hx3);
+  const PackLayout& L = pack_layout(precision, hx3 != 0);
   RowScaleArgs ra;
   ra.net = to_ptrs(net);
   ra.rowscale = packed + L.rowscale_off;
@@ -1352,7 +1360,7 @@ size_t neat_sdf_ws_floats(int P, int mode, int precision) {
   NEAT_F16_FWD(neat_sdf_ws_floats(P, mode, precision))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
-  return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision, hx3).total;
+  return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision, hx3 == 1).total;
 }
 
 int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
@@ -1361,6 +1369,7 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
   NEAT_F16_FWD(neat_sdf_forward(packed, net, x, P, mode, precision, radius, scale, ws, out257, sdf, feat, grad, stream))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2 && mode != 0) return -1;      // NEAT_F16X3 fast values: values-mode calls only
   if (P <= 0) return 0;
   if (!packed || !net || !x || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
@@ -1403,6 +1412,7 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
   NEAT_F16_FWD(neat_sdf_backward(packed, net, ws, P, precision, d_out257, d_sdf, d_feat, d_grad, grads, stream))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return -1;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
@@ -1422,6 +1432,7 @@ size_t neat_heads_ws_floats(int P, int precision) {
   NEAT_F16_FWD(neat_heads_ws_floats(P, precision))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return 0;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(P, precision);
   return head_ws(nullptr, ldp, precision).total + (size_t)(3 + 3 + 256) * ldp;
@@ -1433,6 +1444,7 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
   NEAT_F16_FWD(neat_heads_forward(packed, net, points, normals, view_dirs, feats, P, precision, ws, rgb, lines, stream))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return -1;
   if (P <= 0) return 0;
   if (!packed || !net || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
@@ -1459,6 +1471,7 @@ size_t neat_render_ws_floats(int R, int S, int E, int precision) {
   NEAT_F16_FWD(neat_render_ws_floats(R, S, E, precision))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return 0;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S + E, precision);
   return sdf_ws(nullptr, ldp, 1, precision, hx3).total + head_ws(nullptr, ldp, precision).total;
@@ -1470,6 +1483,7 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
                                float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream, bool fwd_only) {
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return -1;
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !origins || !dirs || !z || !rgb || !lines3d || !depth || !xyz || bad_prec(precision)) return -1;
   if (E < 0 || (E > 0 && (!eik_points || !eik_grad))) return -1;
@@ -1507,6 +1521,7 @@ size_t neat_render_eval_ws_floats(int R, int S, int precision) {
   NEAT_F16_FWD(neat_render_eval_ws_floats(R, S, precision))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return 0;
   if (bad_prec(precision)) return 0;
   const int ldp = round_ldp(R * S, precision);
   return sdf_ws(nullptr, ldp, 2, precision, hx3).total + head_ws(nullptr, ldp, precision, true).total;
@@ -1528,6 +1543,7 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   NEAT_F16_FWD(neat_render_backward(packed, net, ws, dirs, z, R, S, E, precision, beta, d_rgb, d_lines3d, d_depth, d_xyz, d_eik_grad, grads, dbeta_ray, stream))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
+  if (hx3 == 2) return -1;
   if (R <= 0 || S <= 0) return 0;
   if (!packed || !net || !ws || !grads || bad_prec(precision) || E < 0) return -1;
   const int Pm = R * S, P = Pm + E;

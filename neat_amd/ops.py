@@ -157,9 +157,10 @@ def sdf_outputs(handle, x, radius, scale):
     return SdfOutputsFn.apply(handle, x, radius, scale, *handle.tensors(0, N_SDF))
 
 
-def sdf_values(handle, x, radius, scale, gate=None):
+def sdf_values(handle, x, radius, scale, gate=None, fast=False):
     """get_sdf_vals without autograd (sampler path): primal chain only, nothing saved.
-    gate = (int32 tensor, index, value): the launch does nothing unless tensor[index] == value on the device (sync-free sampler)."""
+    gate = (int32 tensor, index, value): the launch does nothing unless tensor[index] == value on the device (sync-free sampler).
+    fast (fp16x3 only): the one-product f16 chain on the fp16x3 pack (NEAT_F16X3_FASTVALUES)."""
     lib = _lib.lib()
     x = _f32c(x.detach())
     P = x.shape[0]
@@ -167,14 +168,15 @@ def sdf_values(handle, x, radius, scale, gate=None):
     if P == 0:
         return sdf
     packed, netp = handle.packed()
-    ws = torch.empty(lib.neat_sdf_ws_floats(P, 0, handle.precision), device=x.device, dtype=torch.float32)
+    prec = 5 if (fast and handle.precision == 4) else handle.precision
+    ws = torch.empty(lib.neat_sdf_ws_floats(P, 0, prec), device=x.device, dtype=torch.float32)
     if gate is not None:
         ctl, idx, val = gate
-        _lib.check(lib.neat_sdf_values_gated(_p(packed), ctypes.byref(netp), _p(x), P, handle.precision, float(radius), float(scale), _p(ws),
+        _lib.check(lib.neat_sdf_values_gated(_p(packed), ctypes.byref(netp), _p(x), P, prec, float(radius), float(scale), _p(ws),
                                              _p(sdf), ctypes.c_void_p(ctl.data_ptr() + 4 * idx), int(val), _stream()),
                    "neat_sdf_values_gated")
         return sdf
-    _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 0, handle.precision, float(radius), float(scale), _p(ws),
+    _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 0, prec, float(radius), float(scale), _p(ws),
                                     None, _p(sdf), None, None, _stream()), "neat_sdf_forward(values)")
     return sdf
 

@@ -67,6 +67,12 @@ def _draw(model, name, fn, dev):
     return hook(name, fn, dev) if hook is not None else fn().to(dev)
 
 
+def _fast(model):
+    """Keyword for get_sdf_vals: the model's opt-in to one-product f16 SDF queries in the sampler (conf key
+    model.hip_sampler_fast_values, fp16x3 only).  A reference-shaped model object without the attribute gets none."""
+    return {"fast": True} if getattr(model, "sampler_fast_values", False) else {}
+
+
 class RaySampler:
     def __init__(self, near, far):
         self.near, self.far = near, far
@@ -141,7 +147,7 @@ class HierarchicalSampler(RaySampler):
         zc = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
         pts = cam_loc.unsqueeze(1) + zc.unsqueeze(2) * ray_dirs.unsqueeze(1)
         with torch.no_grad():
-            sdf = model.implicit_network.get_sdf_vals(pts.reshape(-1, 3))
+            sdf = model.implicit_network.get_sdf_vals(pts.reshape(-1, 3), **_fast(model))
             w = model.volume_rendering(zc, sdf)
         z = self.uniform_sampler.get_z_vals_fine(zc, w, model)
         n, R = z.shape[-1], z.shape[0]
@@ -212,7 +218,7 @@ class ErrorBoundSampler(RaySampler):
         for k in range(K):
             pts = torch.addcmul(cam, fresh.unsqueeze(2), dirs).reshape(-1, 3)
             with torch.no_grad():
-                new_sdf = model.implicit_network.get_sdf_vals(pts, gate=(ctl, K + k - 1, 1) if k > 0 else None).reshape(R, -1)
+                new_sdf = model.implicit_network.get_sdf_vals(pts, gate=(ctl, K + k - 1, 1) if k > 0 else None, **_fast(model)).reshape(R, -1)
             sdf, beta, fresh, z_next, order_next = ops.sampler_round_dev(z, sdf, new_sdf, order, beta, beta0, self.eps, self.beta_iters,
                                                                          self.add_tiny, u_refine, u_final, samples, z_final, ctl, k, K)
             z, order = z_next, order_next
@@ -260,7 +266,7 @@ class ErrorBoundSampler(RaySampler):
         while open_ and rounds < self.max_total_iters:
             pts = (cam_loc.unsqueeze(1) + fresh.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
             with torch.no_grad():
-                new_sdf = model.implicit_network.get_sdf_vals(pts).reshape(R, -1)
+                new_sdf = model.implicit_network.get_sdf_vals(pts, **_fast(model)).reshape(R, -1)
             flag.zero_()
             sdf, beta = ops.sampler_bound(z, sdf, new_sdf, order, beta, beta0, self.eps, self.beta_iters, flag)
             rounds += 1
@@ -298,7 +304,7 @@ class ErrorBoundSampler(RaySampler):
         while open_ and rounds < self.max_total_iters:
             pts = (cam_loc.unsqueeze(1) + fresh.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
             with torch.no_grad():
-                new_sdf = model.implicit_network.get_sdf_vals(pts).reshape(R, -1)
+                new_sdf = model.implicit_network.get_sdf_vals(pts, **_fast(model)).reshape(R, -1)
             sdf = new_sdf if order is None else torch.cat([sdf, new_sdf], -1).gather(1, order)
             gap = z[:, 1:] - z[:, :-1]
             d_star = self._interval_bound(sdf, gap)
