@@ -51,6 +51,38 @@ __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 #endif
 
+// Packed 16-bit helpers of the fused head chains (kernels_heads.hpp, kernels_x3.hpp).  Both 16-bit formats are sign-magnitude, so on a
+// packed pair ReLU is a signed 16-bit max with 0 (v_pk_max_i16: negative values and -0 have the top bit set) and "is positive" is an
+// unsigned min with 1 (v_pk_min_u16), one instruction per PAIR each.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_relu16(unsigned p) {
+  const s16x2_t z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, p), z));
+}
+__device__ __forceinline__ unsigned pk_nonzero16(unsigned p) {          // halves -> 0 / 1  (the builtin min is expanded into compares and selects)
+  unsigned r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(p), "s"(0x00010001u));
+  return r;
+}
+typedef float pk2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2f_t pk_add_f32(pk2f_t a, pk2f_t b) {       // two fp32 adds per issue slot
+  pk2f_t r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// ReLU-mask word of one lane and stage (16 accumulator elements = 8 pairs): the forward chains shift the pairs' 0 / 1 halves in,
+// pair 0 first (relu_mask_push), and store relu_mask_word: pair i's even / odd element at bits 15 - i / 31 - i.  The backward chain
+// walks the pairs in the same order: the two sign bits select the current pair (relu_mask_apply), then the word moves up by one.
+__device__ __forceinline__ void relu_mask_push(unsigned& m, unsigned relu_pair) { m = (m << 1) | pk_nonzero16(relu_pair); }
+__device__ __forceinline__ unsigned relu_mask_word(unsigned m) { return m << 8; }
+__device__ __forceinline__ unsigned relu_mask_apply(unsigned& m, unsigned pair) {
+  const s16x2_t sh = {15, 15};
+  const unsigned keep = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2_t, m) >> sh);      // v_pk_ashrrev_i16: halves -> 0 / 0xFFFF
+  m <<= 1;
+  return pair & keep;
+}
+
 // branch-free activation math for the bf16 build (hardware exp/log; absolute error ~1e-7, far below bf16 resolution)
 __device__ __forceinline__ float softplus100_fast(float a) {
   // base-2 form on the raw v_exp_f32 / v_log_f32 (8 VALU ops; `__logf` expands to ~15 with its denormal and ln2 fix-ups):
@@ -114,6 +146,23 @@ struct HeadX3Args {
   const float* bias[5];
   u16* hid[5];                                // hid[1..4]: hi planes of the hidden activations (save mode)
   float* out;                                 // [3 | 6][ldp] fp32
+  const u16* smallbf;                         // one-product chain (kernels_heads.hpp): the small inputs octet-major, 16-bit (oct_pack)
+  u16* mask[5];                               // mask[1..4] (save mode): ReLU masks, one 32-bit word per (tile, wave, lane) in the accumulator layout (relu_mask_word)
+};
+
+// one head of the fused backward chain (kernels_heads.hpp: head_bwd_chain_kernel)
+struct HeadBwdArgs {
+  int P, ldp;
+  int nvalid;                        // pairs of 32-point tiles that hold ray samples
+  const u16* top;                    // cotangent of the head's output, octet-major (one octet: rows 0..2 / 0..5, the rest zero)
+  const uint4* Wt[5];                // transposed packs of lin0 .. lin4 (Wt[4]: 4 k-steps per row tile, only the first is non-zero;
+                                     // Wt[0]: 256 feature rows, then the small-input rows)
+  const u16* mask[5];                // mask[1..4]: ReLU masks written by the forward chain
+  u16* ab[4];                        // ab[l]: cotangent of the pre-activation of hid[l + 1] (octet-major; the weight gradients read them)
+  u16* featc;                        // feature cotangent, 256 rows octet-major
+  int accumulate;                    // 1: featc += (the second head), scaled by cot_scale_of(rho_num) / cot_scale_of(rho_den)
+  const float* rho_num; const float* rho_den;
+  float* sc; int srows;              // small-input cotangents, fp32 [srows][ldp]
 };
 
 }  // namespace neat

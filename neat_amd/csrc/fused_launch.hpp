@@ -24,4 +24,9 @@ hipError_t launch_sdf_chain_x3(hipStream_t st, const FusedArgs& a, int nbatches,
 hipError_t launch_sdf_adjoint_x3(hipStream_t st, const AdjArgs& a, int nbatches, int nwg, bool save);
 hipError_t launch_head_chain_x3(hipStream_t st, const HeadX3Args& a, int head, int nbatches, int nwg, bool save);
 
+// the heads of the 16-bit builds as fused chains (kernels_heads.hpp): npairs pairs of 32-point tiles over nwg persistent workgroups
+constexpr int HC_BATCH = 128;
+hipError_t launch_head_chain(hipStream_t st, const HeadX3Args& a, int head, int npairs, int nwg, bool save);
+hipError_t launch_head_bwd_chain(hipStream_t st, const HeadBwdArgs& a, int head, int npairs, int nwg);
+
 }  // namespace neat

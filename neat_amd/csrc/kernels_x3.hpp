@@ -626,6 +626,9 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
             const int idx = tb + i * C::THREADS, oct = idx >> 6, pp = idx & 63;
             *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.hid[l]) + ((unsigned)oct * (unsigned)a.ldp + (unsigned)(p0 + pp)) * 16u) = make_uint4(0u, 0u, 0u, 0u);
           }
+#pragma unroll
+        for (int l = 1; l <= 4; ++l)
+          if (a.mask[l] && tb < 256) reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.mask[l]) + (size_t)batch * 4096)[tb] = make_uint4(0u, 0u, 0u, 0u);
       }
       for (int idx = tb; idx < NOUT * BP; idx += C::THREADS) a.out[(size_t)(idx / BP) * a.ldp + p0 + idx % BP] = 0.0f;
       continue;
@@ -692,12 +695,20 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
     }
     unsigned ph[2], pl[2];
     float keep = 0.0f;
-    auto epi_elem = [&](const f32x16& ap, int e, int t, int DST, u16* hout) {      // ReLU, split, quad -> buffer DST (+ hi plane to HBM)
+    unsigned mbits = 0;
+    // this lane's ReLU-mask word of tile 0 of the batch (kernels_heads.hpp: the fused backward chain reads it); + 2048 for tile 1
+    const unsigned mlane = ((((unsigned)p0 >> 5) * 8u + (unsigned)wave) * 64u + (unsigned)lane) * 4u;
+    auto epi_elem = [&](const f32x16& ap, int e, int t, int DST, u16* hout, u16* mout) {      // ReLU, split, quad -> buffer DST (+ hi plane to HBM)
       const int q = e >> 2, j = e & 3;
       const float b = j == 0 ? bq[q].x : (j == 1 ? bq[q].y : (j == 2 ? bq[q].z : bq[q].w));
       const float r = fmaxf(ap[e] + b, 0.0f);
       if ((j & 1) == 0) { keep = r; return; }
       x3_split2(keep, r, ph[j >> 1], pl[j >> 1]);
+      if (SAVE) relu_mask_push(mbits, ph[j >> 1]);          // (r >= 0 here: the hi halves are zero or positive)
+      if (SAVE && e == 15) {
+        if (mout) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(mout) + (mlane + t * 2048)) = relu_mask_word(mbits);
+        mbits = 0;
+      }
       if (j != 3) return;
       const uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
       *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
       if (SAVE) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
     };
     auto none = [](int) {};
-#define HD_EPI(ACC_, T_, DST_, H_) [&](int e) { epi_elem(ACC_, e, T_, DST_, H_); }
+#define HD_EPI(ACC_, T_, DST_, L_) [&](int e) { epi_elem(ACC_, e, T_, DST_, a.hid[L_], a.mask[L_]); }
 #define HD_LAYER(LCUR, SRC_, ZERO_, ROLL_, WNH_, WNL_, PREV_EPI_, CUR_EPI_)                                                         \
     {                                                                                                                             \
       x3_stage<16, LO, ZERO_, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI_);                          \
@@ -714,11 +725,11 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
       x3_stage<16, LO, ZERO_, ROLL_, 16>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, w_off(16, 256), CUR_EPI_);               \
       __syncthreads();                                                                                                            \
     }
-    HD_LAYER(0, 0, false, true, a.Wp[1], a.Wlo[1], none, HD_EPI(acc[0], 0, 1, a.hid[1]))                                   // lin0: XA (+ seeded small part) -> XB
-    HD_LAYER(1, 1, true, true, a.Wp[2], a.Wlo[2], HD_EPI(acc[1], 1, 1, a.hid[1]), HD_EPI(acc[0], 0, 0, a.hid[2]))          // lin1: XB -> XA
-    HD_LAYER(2, 0, true, true, a.Wp[3], a.Wlo[3], HD_EPI(acc[1], 1, 0, a.hid[2]), HD_EPI(acc[0], 0, 1, a.hid[3]))          // lin2: XA -> XB
-    HD_LAYER(3, 1, true, false, nullptr, nullptr, HD_EPI(acc[1], 1, 1, a.hid[3]), HD_EPI(acc[0], 0, 0, a.hid[4]))          // lin3: XB -> XA
-    x3_drain(HD_EPI(acc[1], 1, 0, a.hid[4]));
+    HD_LAYER(0, 0, false, true, a.Wp[1], a.Wlo[1], none, HD_EPI(acc[0], 0, 1, 1))                                   // lin0: XA (+ seeded small part) -> XB
+    HD_LAYER(1, 1, true, true, a.Wp[2], a.Wlo[2], HD_EPI(acc[1], 1, 1, 1), HD_EPI(acc[0], 0, 0, 2))          // lin1: XB -> XA
+    HD_LAYER(2, 0, true, true, a.Wp[3], a.Wlo[3], HD_EPI(acc[1], 1, 0, 2), HD_EPI(acc[0], 0, 1, 3))          // lin2: XA -> XB
+    HD_LAYER(3, 1, true, false, nullptr, nullptr, HD_EPI(acc[1], 1, 1, 3), HD_EPI(acc[0], 0, 0, 4))          // lin3: XB -> XA
+    x3_drain(HD_EPI(acc[1], 1, 0, 4));
     __syncthreads();
 #undef HD_LAYER
 #undef HD_EPI

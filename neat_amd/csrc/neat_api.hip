@@ -209,6 +209,8 @@ inline int wgrad_batch_size(int ldp) {
 int g_wgrad_interleave = 0; // 1: launch each SDF layer's weight gradient right after the reverse step that produced its cotangent (Infinity-Cache reuse; measured neutral)
 int g_wreduce_direct = 2;   // bf16 weight-gradient reduction: 2 = one launch per layer / batch with 16-byte loads (wreduce_direct_kernel), 0 = group
                             // sums + finish (two launches, stage buffer), 1 = one 16-wave pass with 4-byte loads (slowest)
+int g_head_chain = 2;       // 16-bit builds: the heads as fused chains (kernels_heads.hpp): 2 = forward and backward, 1 = forward only, 0 = per-layer
+                            // launches of layer_kernel_ws (tuning key 14)
 int g_fused_adj = 1;        // bf16 build: adjoint chain (normals) as one fused launch (sdf_adjoint_w64_kernel); 0 = seed + eight streaming EPI_REV launches (tuning key 13)
 int g_fused_ws = 3;         // fused primal chain: 4 = phase-staggered kernel (sdf_fused_ph_kernel; measured slower: a matrix wave and a
                             // vector wave on one SIMD do not overlap on this machine, scripts/probes/probe_roles.hip), 3 / 2 = stage-pipelined kernel of kernels_fused.hpp with 8 waves x 32 rows / 4 waves x 64 rows,
@@ -500,6 +502,7 @@ struct HeadWs {
   float *small_r, *small_a, *rgb, *lin, *zrgb, *dlin, *sc_r, *sc_a;      // fp32
   Arr hr[5], ha[5], ar[4], aa[4];                                       // big
   Arr smallbf_r, smallbf_a, topbf_r, topbf_a;                           // bf16 build: octet-major copies of small_* / zrgb / dlin
+  float *mr[5], *ma[5];                                                 // 16-bit builds: ReLU masks of hr / ha [1..4] (fused head chains), one word per 16 elements
   size_t total;
 };
 HeadWs head_ws(float* base, int ldp, int prec, bool fwd_only = false) {
@@ -522,6 +525,7 @@ HeadWs head_ws(float* base, int ldp, int prec, bool fwd_only = false) {
   for (int l = 0; l < 4; ++l) { w.ar[l] = big(256); w.aa[l] = big(256); }
   w.sc_r = take(SMALL_R); w.sc_a = take(SMALL_A);
   if (prec) { w.smallbf_r = big(20); w.smallbf_a = big(8); w.topbf_r = big(4); w.topbf_a = big(4); }
+  if (prec) for (int l = 1; l <= 4; ++l) { w.mr[l] = take(16); w.ma[l] = take(16); }
   w.total = off;
   return w;
 }
@@ -1040,11 +1044,39 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = A
       }
       if (L.d[L.fwd[base]].Kpad != 320) return hipErrorInvalidValue;
       a.out = head ? h.lin : h.rgb;
+      if (save && g_head_chain == 2) for (int l = 1; l <= 4; ++l) a.mask[l] = reinterpret_cast<u16*>(head ? h.ma[l] : h.mr[l]);
       double fl3 = 0.0;
       for (int l = 0; l < 5; ++l) fl3 += 2.0 * kO[base + l] * kI[base + l] * (double)c.P;
       ProfSlot* ps3 = prof_begin(c.st, 2, fl3, (double)c.P * (2 * 512.0 + a.srows * 4.0 + (save ? 4 * 512.0 : 0.0) + (head ? 24.0 : 12.0)) + 4.0 * 540000.0);
       e = launch_head_chain_x3(c.st, a, head, c.ldp / X3_BATCH, g_ws_grid, save);
       prof_end(c.st, ps3);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  if (c.prec && g_head_chain) {
+    // 16-bit builds: one fused launch per head (kernels_heads.hpp)
+    for (int head = 0; head < 2; ++head) {
+      const int base = head ? L_ATTR : L_REND;
+      const Arr* hh = head ? h.ha : h.hr;
+      HeadX3Args a{};
+      a.P = c.P; a.ldp = c.ldp;
+      a.nvalid = ((n_main < 0 ? c.P : n_main) + 63) / 64;
+      a.feat = reinterpret_cast<const u16*>(feat.p);
+      a.smallbf = reinterpret_cast<const u16*>((head ? h.smallbf_a : h.smallbf_r).p); a.srows = head ? SMALL_A : SMALL_R;
+      for (int l = 0; l < 5; ++l) {
+        a.Wp[l] = reinterpret_cast<const uint4*>(c.packed + L.d[L.fwd[base + l]].offset);
+        a.bias[l] = c.net->b[base + l];
+        a.hid[l] = (l && save) ? reinterpret_cast<u16*>(hh[l].p) : nullptr;
+        a.mask[l] = (l && save) ? reinterpret_cast<u16*>(head ? h.ma[l] : h.mr[l]) : nullptr;
+      }
+      if (L.d[L.fwd[base]].Kpad != 320 || L.d[L.fwd[base + 4]].Kpad != 256) return hipErrorInvalidValue;
+      a.out = head ? h.lin : h.rgb;
+      double fl = 0.0;
+      for (int l = 0; l < 5; ++l) fl += 2.0 * kO[base + l] * kI[base + l] * (double)c.P;
+      ProfSlot* ps = prof_begin(c.st, 2, fl, (double)c.P * (512.0 + a.srows * 2.0 + (save ? 4 * (512.0 + 64.0) : 0.0) + (head ? 24.0 : 12.0)) + 2.0 * 540000.0);
+      e = launch_head_chain(c.st, a, head, c.ldp / 64, g_ws_grid, save);
+      prof_end(c.st, ps);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1069,7 +1101,7 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = A
 // abar8 rows 1..256 (render overwrites, attraction adds) and the small-input cotangents into sc_r / sc_a.
 // slot / slot_a (f16 build): the common cotangent scale and the attraction head's own (null: one scale)
 hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const neat_net_grads* gr, const float* slot = nullptr,
-                          const float* slot_a = nullptr) {
+                          const float* slot_a = nullptr, int n_main = -1) {
   const PackLayout& L = c.L();
   hipError_t e;
   const bool oct = oct_operands(c);
@@ -1082,6 +1114,30 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     const int top_rows = head ? 6 : 3;
     const float* small = head ? h.small_a : h.small_r;
     const int srows = head ? SMALL_A : SMALL_R;
+    if (oct && g_head_chain == 2) {
+      // fused backward chain (kernels_heads.hpp): the ReLU masks come from the forward chain of this step
+      HeadBwdArgs a{};
+      a.P = c.P; a.ldp = c.ldp;
+      a.nvalid = ((n_main < 0 ? c.P : n_main) + 63) / 64;
+      a.top = reinterpret_cast<const u16*>((head ? h.topbf_a : h.topbf_r).p);
+      for (int l = 0; l < 5; ++l) {
+        a.Wt[l] = reinterpret_cast<const uint4*>(c.packed + L.d[L.tr[base + l]].offset);
+        a.mask[l] = l ? reinterpret_cast<const u16*>(head ? h.ma[l] : h.mr[l]) : nullptr;
+      }
+      for (int l = 0; l < 4; ++l) a.ab[l] = reinterpret_cast<u16*>(ab[l].p);
+      if (L.d[L.tr[base + 4]].Kpad != 64 || L.d[L.tr[base]].Kpad != 256) return hipErrorInvalidValue;
+      a.featc = reinterpret_cast<u16*>(w.featc.p);
+      a.accumulate = head;
+      a.rho_num = (head && slot_a) ? slot : nullptr; a.rho_den = (head && slot_a) ? slot_a : nullptr;
+      a.sc = head ? h.sc_a : h.sc_r; a.srows = srows;
+      double fl = 0.0;
+      for (int l = 0; l < 5; ++l) fl += 2.0 * kO[base + l] * kI[base + l] * (double)c.P;
+      ProfSlot* ps = prof_begin(c.st, 2, fl, (double)c.P * (16.0 + 4 * (512.0 + 64.0) + (head ? 1024.0 : 512.0) + srows * 4.0) + 2.0 * 540000.0);
+      e = launch_head_bwd_chain(c.st, a, head, c.ldp / 64, g_ws_grid);
+      prof_end(c.st, ps);
+      if (e != hipSuccess) return e;
+      continue;
+    }
     if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, in(oct ? (head ? h.topbf_a : h.topbf_r) : F(top), top_rows), NOIN, nullptr, 256, ab[3], Arr{}, 1 << 30, hh[4])) != hipSuccess) return e;
     for (int l = 3; l >= 1; --l)
       if ((e = layer(c, L.tr[base + l], EPI_BWD_RELU, in(ab[l], 256), NOIN, nullptr, 256, ab[l - 1], Arr{}, 1 << 30, hh[l])) != hipSuccess) return e;
@@ -1268,6 +1324,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 11 && value >= 0 && value <= 63) { g_ws_aux_nt = value; return 0; }
   if (key == 12 && (value == 0 || value == 1)) { g_ws_wide_store = value; return 0; }
   if (key == 13 && (value == 0 || value == 1)) { g_fused_adj = value; return 0; }
+  if (key == 14 && value >= 0 && value <= 2) { g_head_chain = value; return 0; }
   return -1;
 }
 
@@ -1568,7 +1625,7 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   if (c.ldp > Pm) {      // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents
     hipLaunchKernelGGL(zero_tail3_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, h.dlin, 6, w.abar8, 1, Pm, c.ldp);
   }
-  NEAT_CHECK(heads_backward(c, h, w, grads, slot, slot_a));
+  NEAT_CHECK(heads_backward(c, h, w, grads, slot, slot_a, Pm));
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
                      w.gh, Pm, d_eik_grad, slot, slot_a);
   NEAT_CHECK(sdf_backward_chains(c, w, grads));

@@ -4,6 +4,7 @@
 #endif
 #include "kernels_fused.hpp"
 #include "kernels_x3.hpp"
+#include "kernels_heads.hpp"
 
 namespace neat {
 
@@ -79,6 +80,30 @@ hipError_t launch_head_chain_x3(hipStream_t st, const HeadX3Args& a, int head, i
   static bool d[4] = {false, false, false, false};
   if (head == 0) return save ? x3_launch(&head_chain_x3_kernel<0, true>, d[0], st, nbatches, nwg, a) : x3_launch(&head_chain_x3_kernel<0, false>, d[1], st, nbatches, nwg, a);
   return save ? x3_launch(&head_chain_x3_kernel<1, true>, d[2], st, nbatches, nwg, a) : x3_launch(&head_chain_x3_kernel<1, false>, d[3], st, nbatches, nwg, a);
+}
+
+template <class K, class A> static hipError_t hc_launch(K kern, bool& attr_done, hipStream_t st, int npairs, int nwg, const A& args) {
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HC::LDS);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int nb = (npairs + 1) / 2;
+  const int grid = nb < nwg ? nb : nwg;
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(HC::THREADS), HC::LDS, st, args, npairs);
+  return hipGetLastError();
+}
+
+hipError_t launch_head_chain(hipStream_t st, const HeadX3Args& a, int head, int npairs, int nwg, bool save) {
+  static bool d[4] = {false, false, false, false};
+  if (head == 0) return save ? hc_launch(&head_chain_kernel<0, true>, d[0], st, npairs, nwg, a) : hc_launch(&head_chain_kernel<0, false>, d[1], st, npairs, nwg, a);
+  return save ? hc_launch(&head_chain_kernel<1, true>, d[2], st, npairs, nwg, a) : hc_launch(&head_chain_kernel<1, false>, d[3], st, npairs, nwg, a);
+}
+
+hipError_t launch_head_bwd_chain(hipStream_t st, const HeadBwdArgs& a, int head, int npairs, int nwg) {
+  static bool d[2] = {false, false};
+  return head == 0 ? hc_launch(&head_bwd_chain_kernel<0>, d[0], st, npairs, nwg, a) : hc_launch(&head_bwd_chain_kernel<1>, d[1], st, npairs, nwg, a);
 }
 
 }  // namespace neat

@@ -1,7 +1,8 @@
 """bench.py with tuning keys: python scripts/bench_tune.py key=value ... [-- bench args]"""
-import sys, runpy
+import os, sys, runpy
 import torch  # first: libneat_hip.so must bind to the HIP runtime torch loads
-sys.path.insert(0, '.')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from neat_amd import _lib
 args = sys.argv[1:]
 rest = []
@@ -11,4 +12,4 @@ for kv in args:
     k, v = kv.split('=')
     _lib.check(_lib.lib().neat_set_tuning(int(k), int(v)), f"tuning {kv}")
 sys.argv = ['bench.py'] + rest
-runpy.run_path('bench.py', run_name='__main__')
+runpy.run_path(os.path.join(ROOT, 'bench.py'), run_name='__main__')

@@ -903,6 +903,55 @@ def test_bf16_layer_kernels_agree(dev, R, S, half):
         assert err <= 1e-3 * float(g0[k].abs().max()) + 1e-12, (k, err, float(g0[k].abs().max()))
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16", "fp16x3"])
+@pytest.mark.parametrize("R,S", [(1024, 128), (600, 98), (37, 50), (3, 7)])
+def test_fused_head_chains_agree_with_layer_launches(dev, R, S, half):
+    """head_chain_kernel / head_bwd_chain_kernel (kernels_heads.hpp: one launch per head and direction, activations in LDS, ReLU masks
+    instead of re-read activations) against the per-layer layer_kernel_ws launches they replace (tuning key 14 = 0): the same 16-bit
+    products with fp32 accumulation; only the order in which lin0 adds its small-input columns differs, so outputs agree to a rounding
+    of the first hidden layer and gradients to a few 16-bit roundings (relative L2 per tensor 3e-2 / 1e-2 for bf16 / fp16).  Key 1 (fused forward, per-layer backward) against key 2
+    isolates the backward chain: its masks must select exactly what `saved activation > 0` selects -- identical gradients but for the
+    last bit of the feature cotangent.  Sizes: full rounds of 2-pair batches; single-pair tail batches + zero-filled eikonal pairs;
+    fewer batches than workgroups; one partial tile."""
+    from neat_amd import _lib, rend_util
+    m = build_model(dev, "rough", seed=4, train=True).set_precision(half)
+    sc = synth.synth_scene(seed=4, n_rays=R)
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(4, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(2)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def run(key):
+        _lib.check(_lib.lib().neat_set_tuning(14, key), "neat_set_tuning")
+        m.zero_grad()
+        torch.manual_seed(7)                  # (the eikonal points of the train-mode main pass)
+        rgb, l3, *_ = m._render(c, d, z, False)
+        ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        return rgb.detach().clone(), l3.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        r0, l0, g0 = run(0)
+        r1, l1, g1 = run(1)
+        r2, l2, g2 = run(2)
+    finally:
+        _lib.lib().neat_set_tuning(14, 2)
+    out_tol = 1e-6 if half == "fp16x3" else (2e-2 if half == "bf16" else 3e-3)      # fp16x3: the forward is the 3-product chain in both
+    g_tol = {"bf16": 3e-2, "fp16": 1e-2, "fp16x3": 2e-3}[half]
+    close(r2, r0, tol=out_tol, what="fused heads rgb")
+    close(l2, l0, tol=out_tol * float(l0.abs().max()), what="fused heads lines3d")
+    assert torch.equal(r1, r2) and torch.equal(l1, l2)
+    for k in g0:
+        assert torch.isfinite(g2[k]).all(), k
+        # per tensor in relative L2: a hidden unit whose pre-activation sits at the ReLU kink for some point takes that point's whole
+        # cotangent in one variant and nothing in the other (single entries of a bias gradient move by 1-2 % of the largest one)
+        nrm = float(g0[k].norm())
+        assert float((g2[k] - g0[k]).norm()) <= g_tol * nrm + 1e-12, (k, float((g2[k] - g0[k]).norm()), nrm)
+        assert float((g2[k] - g1[k]).norm()) <= 2e-3 * nrm + 1e-12, (k, float((g2[k] - g1[k]).norm()), nrm)
+
+
 @pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("P", [133120, 4160, 97])
 def test_fused_adjoint_chain_equals_streamed_layers(dev, P, half):
