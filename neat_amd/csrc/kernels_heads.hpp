@@ -50,6 +50,23 @@ __device__ __forceinline__ void hc_store8(void* p, uint2 v) {
   if (NEAT_HC_NT) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v), reinterpret_cast<u64_t*>(p));
   else *reinterpret_cast<uint2*>(p) = v;
 }
+#ifndef NEAT_HC_WIDE
+#define NEAT_HC_WIDE 1        // the hidden arrays leave in 16-byte stores: v_permlane32_swap hands lanes 0-31 the whole octet of an even quad and
+                              // lanes 32-63 the whole octet of the odd quad next to it (the accumulator layout gives a lane half an octet)
+#endif
+// quads q - 1 (prev) and q (cur, odd) of this lane -> the octet this lane stores: rows 8 (q - 1) .. + 7 for lanes 0-31, 8 q .. + 7 for lanes 32-63
+__device__ __forceinline__ uint4 hc_octet(uint2 prev, uint2 cur) {
+  typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+  const v2u_t s0 = __builtin_amdgcn_permlane32_swap(prev.x, cur.x, false, false);
+  const v2u_t s1 = __builtin_amdgcn_permlane32_swap(prev.y, cur.y, false, false);
+  return make_uint4(s0.x, s1.x, s0.y, s1.y);
+}
+__device__ __forceinline__ void hc_store16(void* p, uint4 v) {
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  const v4u_t w = {v.x, v.y, v.z, v.w};
+  if (NEAT_HC_NT) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t*>(p));
+  else *reinterpret_cast<v4u_t*>(p) = w;
+}
 #ifndef NEAT_HC_TIMING
 #define NEAT_HC_TIMING 0      // probe builds only: workgroup 0 prints the cycle counts of its first batches' phases (forward kernel)
 #endif
@@ -195,9 +212,10 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
   __syncthreads();
 
   const HcWork work(nvp, gridDim.x);
-  // (Tried: requesting a batch's inputs into registers while the previous batch computes -- 40 registers -- so that the workgroups do
-  //  not all wait for HBM at the top of a batch (a quarter of the kernel by the cycle counter): 115 -> 138 us.  The vector-memory
-  //  counter is in order: the rolling weight refills of every layer then wait behind the prefetch, and the extra registers spill.)
+  // (Tried, twice: requesting a batch's inputs into 40 registers during the previous batch -- right after its lin0, or at the start of
+  //  its lin4 behind the last weight refill -- so that the workgroups do not all wait for HBM at the top of a batch (9 000 - 32 000 of
+  //  a batch's ~55 000 cycles by the cycle counter): 115 -> 138 / 135 us.  The vector-memory counter is in order -- the rolling weight
+  //  refills of the layers wait behind the prefetch --, and the loads then compete with the hidden arrays' stores they overlap.)
   for (int it = 0;; ++it) {
     int pair0;
     const int np = work.batch(it, blockIdx.x, pair0);
@@ -211,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
     unsigned ldp16 = (unsigned)a.ldp * 16u;      // (scalar: the row-quad part of a store address goes into the scalar base)
     asm volatile("" : "+s"(ldp16));
     const unsigned gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + p0 + (unsigned)(lane & 31)) * 16u + 8u * hi;
+    const unsigned goct = ((unsigned)(4 * wave + hi) * (unsigned)a.ldp + p0 + (unsigned)(lane & 31)) * 16u;
     const unsigned mlane = (((p0 >> 5) * 8u + (unsigned)wave) * 64u + (unsigned)lane) * 4u;       // + t * 2048: this lane's mask word of tile t
     int tb = tid;
     asm volatile("" : "+v"(tb));
@@ -236,6 +255,8 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
     u16* phout = nullptr; u16* pmout = nullptr; unsigned pmoff = 0;
     float4 bqv = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned ph[2]; float keep = 0.0f; unsigned mbits = 0;
+    uint2 vprev = make_uint2(0u, 0u);   // wide stores: the even quad waits for its odd neighbour
+    unsigned pgw = 0;                   // ... and the lane's octet offset: lanes 32-63 one octet row further, no half-octet offset
     // one call per accumulator element; the work is done per PAIR (odd e) on the packed ALU: bias (v_pk_add_f32), rounding
     // (v_cvt_pk), ReLU and mask bit on the packed 16-bit pair
     auto epi_elem = [&](const f32x16& ap, int e) {
@@ -257,7 +278,10 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
       const uint2 vh = make_uint2(ph[0], ph[1]);
       if (!(NEAT_HC_ABLATE & 16)) *reinterpret_cast<uint2*>(plq + q * (BP * 16)) = vh;
       if (SAVE) {
-        if (!(NEAT_HC_ABLATE & 4)) hc_store8(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
+        if (NEAT_HC_WIDE) {
+          if (q & 1) hc_store16(reinterpret_cast<char*>(phout) + (size_t)(q - 1) * ldp16 + pgw, hc_octet(vprev, vh));
+          else vprev = vh;
+        } else if (!(NEAT_HC_ABLATE & 4)) hc_store8(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
         if (q == 3 && !(NEAT_HC_ABLATE & 8)) { *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pmout) + pmoff) = relu_mask_word(mbits); mbits = 0; }
       }
     };
@@ -265,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
       pboff = (unsigned)l * 1024u;
       plq = quad[dst] + t * 512;
       pg = gquad + (unsigned)t * 512u;
+      pgw = goct + (unsigned)t * 512u;
       phout = a.hid[l + 1]; pmout = a.mask[l + 1]; pmoff = mlane + (unsigned)t * 2048u;
     };
     auto none = [](int) {};
@@ -428,9 +453,14 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
     unsigned ldp16 = (unsigned)a.ldp * 16u;      // (scalar: the row-quad part of a store address goes into the scalar base)
     asm volatile("" : "+s"(ldp16));
     const unsigned gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + p0 + (unsigned)(lane & 31)) * 16u + 8u * hi;
+    const unsigned goct = ((unsigned)(4 * wave + hi) * (unsigned)a.ldp + p0 + (unsigned)(lane & 31)) * 16u;
     const unsigned mlane = (((p0 >> 5) * 8u + (unsigned)wave) * 64u + (unsigned)lane) * 4u;
     int tb = tid;
     asm volatile("" : "+v"(tb));
+#if NEAT_HC_TIMING
+    unsigned long long stamp[8];
+#endif
+    HC_STAMP(0);
     // ---- the output cotangent (one octet per point) -> S
     if (tb < npts) reinterpret_cast<uint4*>(hclds + C::S)[tb] = hc_ldg(a.top, (p0 + (unsigned)tb) * 16u);
     __syncthreads();
@@ -442,6 +472,8 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
     unsigned pmask = 0, nmask = 0;        // mask words of the pending stage / of the stage being computed (requested a stage ahead)
     uint2 pf[4], nf[4];                   // accumulate: the feature cotangent already there, same schedule
     unsigned ph[2];
+    uint2 vprev = make_uint2(0u, 0u);   // wide stores (hc_octet): the even quad waits for its odd neighbour
+    unsigned pgw = 0;
     auto ldmask = [&](int l, int t) -> unsigned {
       return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.mask[l]) + (mlane + (unsigned)t * 2048u));
     };
@@ -454,7 +486,10 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
       if (j != 3) return;
       const uint2 vh = make_uint2(ph[0], ph[1]);
       *reinterpret_cast<uint2*>(plq + q * (BP * 16)) = vh;
-      hc_store8(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
+      if (NEAT_HC_WIDE) {
+        if (q & 1) hc_store16(reinterpret_cast<char*>(phout) + (size_t)(q - 1) * ldp16 + pgw, hc_octet(vprev, vh));
+        else vprev = vh;
+      } else hc_store8(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
     };
     // feature-cotangent epilogue: quad -> featc (the second head adds, in the first head's scale)
     auto epi_feat = [&](const f32x16& ap, int e) {
@@ -473,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
     auto set_pend = [&](int l, int dst, int t) {        // the stage that produced the cotangent ab[l] (masked by mask[l + 1]) into buffer dst
       plq = quad[dst] + t * 512;
       pg = gquad + (unsigned)t * 512u;
+      pgw = goct + (unsigned)t * 512u;
       phout = a.ab[l];
     };
     auto ldfeat = [&](int t) {
@@ -482,15 +518,28 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
           nf[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.featc) + (size_t)q * ldp16 + (gquad + (unsigned)t * 512u));
       }
     };
+    HC_STAMP(1);
     // ---- lin4^T: one k-step per tile (the output cotangent has 3 / 6 rows), not pipelined: S -> XA, ab[3]
-    for (int t = 0; t < nt; ++t) {
-      pmask = ldmask(4, t);
-      const uint4 bs = *reinterpret_cast<const uint4*>(frag[2] + t * 512);
+    {
+      unsigned m4[4];               // all masks first: one HBM latency, not one per tile
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
-      acc[0] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wtop), *reinterpret_cast<const bf16x8*>(&bs), acc[0], 0, 0, 0);
-      set_pend(3, 0, t);
-      hc_drain([&](int e) { epi_mask(acc[0], e); });
+      for (int t = 0; t < 4; ++t) m4[t] = t < nt ? ldmask(4, t) : 0u;
+      auto top_mma = [&](f32x16& ac, int t) {
+        const uint4 bs = *reinterpret_cast<const uint4*>(frag[2] + t * 512);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac[r] = 0.0f;
+        ac = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wtop), *reinterpret_cast<const bf16x8*>(&bs), ac, 0, 0, 0);
+      };
+      top_mma(acc[0], 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+          if (t + 1 < nt) top_mma(acc[(t + 1) & 1], t + 1);       // the next tile's MFMA is in flight during this tile's epilogue
+          pmask = m4[t];
+          set_pend(3, 0, t);
+          hc_drain([&](int e) { epi_mask(acc[t & 1], e); });
+        }
+      }
     }
     __syncthreads();
 #define HB_MASK(ACC_) [&](int e) { epi_mask(ACC_, e); }
@@ -516,9 +565,12 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
       pmask = nmask;                                                                                                              \
       __syncthreads();                                                                                                            \
     }
+    HC_STAMP(2);
     HB_LAYER(3, 0, 1, a.Wt[2], wave)      // lin3^T: XA -> XB, ab[2]
+    HC_STAMP(3);
     HB_LAYER(2, 1, 0, a.Wt[1], wave)      // lin2^T: XB -> XA, ab[1]
     HB_LAYER(1, 0, 1, a.Wt[0], wave)      // lin1^T: XA -> XB, ab[0]
+    HC_STAMP(4);
     // ---- lin0^T, feature rows: XB -> featc (no LDS output); the last tile's refill fetches the small-input rows' tile
     for (int pp = 0; pp < np; ++pp) {
       const int t0 = 2 * pp;
@@ -546,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
 #undef HB_LAYER
 #undef HB_MASK
 #undef HB_FEAT
+    HC_STAMP(5);
     // ---- lin0^T, small-input rows (packed rows 256 ..): one (row tile, point tile) unit per wave, fp32 rows out
     if (s_live && stile < nt) {
       hc_stage<16, true, true, 16>(frag[1] + stile * 512, w, acc[0], a.Wt[3], w_off(wave, 16), [](int) {});
@@ -561,6 +614,12 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
       for (int ks = 0; ks < 16; ++ks) w[ks] = hc_ldg(a.Wt[3], o3 + ks * 1024);
     }
     __syncthreads();
+    HC_STAMP(6);
+#if NEAT_HC_TIMING
+    if (blockIdx.x == 0 && it < 3 && tid == 0)
+      printf("hc bwd head %d batch %d (np %d): load %llu lin4T %llu lin3T %llu lin2T+lin1T %llu lin0T %llu small %llu cycles\n", HEAD, it, np,
+             stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5]);
+#endif
   }
 }
 

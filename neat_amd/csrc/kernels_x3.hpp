@@ -62,6 +62,14 @@ __device__ __forceinline__ uint4 x3_ldg(const void* base, unsigned off) {
 #ifndef NEAT_X3_SGB
 #define NEAT_X3_SGB 0         // > 0: sched_group_barrier pattern per k-step with this many VALU instructions per MFMA (probe)
 #endif
+#ifndef NEAT_X3_TIMING
+#define NEAT_X3_TIMING 0      // probe builds only: workgroup 0 prints the cycle counts of its first batches' phases (SDF primal chain)
+#endif
+#if NEAT_X3_TIMING
+#define X3_STAMP(i) do { if (blockIdx.x == 0 && nb_done < 3) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define X3_STAMP(i) do { } while (0)
+#endif
 #ifndef NEAT_X3_ABLATE
 #define NEAT_X3_ABLATE 0      // probe builds only (results are WRONG): 1 = no epilogue, 2 = no MFMAs
 #endif
@@ -222,13 +230,19 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
   }
   __syncthreads();
 
+#if NEAT_X3_TIMING
+  int nb_done = 0;
+  unsigned long long stamp[12];
+#endif
   for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
     const int p0 = batch * BP;
     const bool more = batch + (int)gridDim.x < nbatches;
+    X3_STAMP(0);
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.ldp16 = (unsigned)a.ldp * 16u;
     asm volatile("" : "+v"(L.ldp16));
     if (!PREFETCH) { e_load(batch); e_store(); __syncthreads(); }
+    X3_STAMP(1);
 
     f32x16 acc[2];
     // the bias rows of a quad are read from LDS when its first element comes up (4 registers instead of 16 held over the stage)
@@ -305,8 +319,10 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
 #define X3_EPI(LB_, ACC_, T_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_) [&](int e) { epi_elem(ACC_, e, T_, LB_, ACT_, N_, DST_, TOLDS_, SAVE_, H_, HL_); }
     // lin0: S -> XA
     X3_LAYER(0, 4, 2, SLO, true, true, 16, a.Wp[1], a.Wlo[1], w_off(16, 256), none, X3_EPI(0, acc[0], 0, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]))
+    X3_STAMP(2);
     // lin1: XA -> XB
     X3_LAYER(1, 16, 0, LO, true, false, 16, a.Wp[2], a.Wlo[2], w_off(16, 256), X3_EPI(0, acc[1], 1, true, 256, 0, true, SAVE, a.h[1], a.hlo[1]), X3_EPI(1, acc[0], 0, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]))
+    X3_STAMP(3);
     // lin2: XB -> XA
     X3_LAYER(2, 16, 1, LO, true, false, 16, a.Wp[3], a.Wlo[3], w_off(16, 217), X3_EPI(1, acc[1], 1, true, 256, 1, true, SAVE, a.h[2], a.hlo[2]), X3_EPI(2, acc[0], 0, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]))
     // lin3 (217 rows): XA -> XB like every other layer (wave 7 multiplies a duplicate of tile 0: its rows 224.. do not exist and are
@@ -317,9 +333,11 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     __syncthreads();
     skip_fix();
     __syncthreads();
+    X3_STAMP(4);
     if (PREFETCH && more) e_load(batch + gridDim.x);
     // lin4: XB -> XA
     X3_LAYER(4, 16, 1, LO, true, false, 16, a.Wp[5], a.Wlo[5], w_off(16, 256), none, X3_EPI(4, acc[0], 0, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]))
+    X3_STAMP(5);
     // lin5: XA -> XB
     X3_LAYER(5, 16, 0, LO, true, false, 16, a.Wp[6], a.Wlo[6], w_off(16, 256), X3_EPI(4, acc[1], 1, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]), X3_EPI(5, acc[0], 0, true, 256, 1, true, SAVE, a.h[6], a.hlo[6]))
     // lin6: XB -> XA
@@ -330,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     // drain: h8's second tile
     x3_drain(X3_EPI(7, acc[1], 1, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]));
     __syncthreads();
+    X3_STAMP(6);
     // ---- lin8: the sdf row, split over the waves' k-steps (2 each) and reduced through LDS
     {
       unsigned so = (unsigned)((((VALUES ? 0 : 8) * 16 + 2 * wave) * 64 + lane) * 16);
@@ -382,6 +401,13 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     }
     if (PREFETCH && more) e_store();
     __syncthreads();
+    X3_STAMP(7);
+#if NEAT_X3_TIMING
+    if (blockIdx.x == 0 && nb_done < 3 && tid == 0)
+      printf("x3 primal save %d batch %d: load %llu lin0 %llu lin1 %llu lin2+3 %llu lin4 %llu lin5-7 %llu lin8+end %llu cycles\n", (int)SAVE, nb_done,
+             stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5], stamp[7] - stamp[6]);
+    ++nb_done;
+#endif
   }
 }
 
