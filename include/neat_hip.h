@@ -307,7 +307,10 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *  10 fused primal chain: batches interleaved over the workgroups (default 0)
  *  11 non-temporal accesses, bit mask (default 15): 1 / 2 = aux0 / aux1 fetch of the layer kernels, 4 = weight-gradient operands,
  *     8 = `in` fetch of the layer kernels, 16 = out1 (m_l) store, 32 = out0 store (both stores measured neutral)
- *  12 layer kernels: 1 = 16-byte output stores through v_permlane32_swap (default; measured neutral), 0 = 8-byte stores */
+ *  12 layer kernels: 1 = 16-byte output stores through v_permlane32_swap (default; measured neutral), 0 = 8-byte stores
+ *  13 16-bit builds: the adjoint chain (normals) as one fused launch (default 1), 0 = seed + eight streaming launches
+ *  14 16-bit builds: the two heads as fused chains (kernels_heads.hpp): 2 = forward and backward (default), 1 = forward only,
+ *     0 = one layer_kernel_ws launch per layer */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);
