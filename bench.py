@@ -357,7 +357,9 @@ def main():
     roofline = None
     kernels = {}
     if not args.no_prof:
-        for cls, name in ((0, "layer_kernel"), (1, "wgrad_kernel"), (2, "sdf_fused_kernel")):
+        # launch classes of the library's event brackets: 0 per-layer GEMM launches, 1 weight gradients, 2 fused SDF primal chain,
+        # 3 fused SDF adjoint chain (the normals), 4 the heads' fused chains (forward and backward)
+        for cls, name in ((0, "layer_kernel"), (1, "wgrad_kernel"), (2, "sdf_fused_kernel"), (3, "sdf_adjoint_kernel"), (4, "head_chain_kernel")):
             ms, fl, n, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
             _lib.check(lib.neat_prof_collect(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n), ctypes.byref(by)),
                        "neat_prof_collect")
@@ -379,10 +381,10 @@ def main():
             if os.path.exists(tpath):
                 tj = json.load(open(tpath)).get(args.precision, {})
                 traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
-                if traffic is None and dom == "sdf_fused_kernel" and any(k.endswith("_x3_kernel") for k in tj):
-                    # fp16x3: the class holds three different fused chains; their full-size launches, per step: primal + adjoint + two heads
-                    traffic = (tj["sdf_chain_x3_kernel"]["hbm_bytes_per_launch"] + tj["sdf_adjoint_x3_kernel"]["hbm_bytes_per_launch"] +
-                               2.0 * tj["head_chain_x3_kernel"]["hbm_bytes_per_launch"]) / 4.0
+                if traffic is None and dom == "sdf_fused_kernel":
+                    traffic = tj.get("sdf_chain_x3_kernel", {}).get("hbm_bytes_per_launch")
+                if traffic is None and dom == "sdf_adjoint_kernel":
+                    traffic = tj.get("sdf_adjoint_x3_kernel", {}).get("hbm_bytes_per_launch")
                 if traffic is not None:
                     traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
             # the hot path is bounded by the MFMA roof (fused, it moves ~5 B per ray-sample against 9.1 MFLOP), so the

@@ -290,7 +290,8 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
 
 /* ---- measurement support (bench.py): when enabled, every launch of the two GEMM-class kernels is bracketed by
  * HIP events on the caller's stream.  class 0 = layer_kernel (all MLP chains), class 1 = wgrad_kernel,
- * class 2 = sdf_fused_kernel (bf16 build: PE + lin0..lin8 of the SDF network in one launch).
+ * class 2 = the fused SDF primal chain (16-bit builds: PE + lin0..lin8 of the SDF network in one launch), class 3 = the fused
+ * SDF adjoint chain (the normals), class 4 = the heads' fused chains (forward and backward, one launch per head each).
  * neat_prof_collect synchronises on the recorded events and returns the summed kernel time, the summed
  * ALGORITHMIC flops (2*N*K*P with the true layer dims), the summed ALGORITHMIC HBM bytes (each operand/result row once,
  * weights once) and the launch count since neat_prof_enable(1). */

@@ -658,12 +658,12 @@ hipError_t sdf_adjoint(const Ctx& c, const SdfWs& w, bool save = true) {
     if (c.hx3) {
       for (int l = 0; l < 8; ++l) a.Wlo[l] = reinterpret_cast<const uint4*>(c.packed + L.d[L.tr_lo[l]].offset);
       for (int l = 1; l <= 8; ++l) a.hlo[l] = reinterpret_cast<const u16*>(w.hlo[l].p);
-      ProfSlot* ps3 = prof_begin(c.st, 2, fl, (double)c.P * (2 * 8 * 512.0 + (save ? 8 * 512.0 : 0.0) + 2 * 39 * 4.0) + 4.0 * 589000.0);
+      ProfSlot* ps3 = prof_begin(c.st, 3, fl, (double)c.P * (2 * 8 * 512.0 + (save ? 8 * 512.0 : 0.0) + 2 * 39 * 4.0) + 4.0 * 589000.0);
       hipError_t e3 = launch_sdf_adjoint_x3(c.st, a, c.ldp / X3_BATCH, g_ws_grid, save);
       prof_end(c.st, ps3);
       return e3;
     }
-    ProfSlot* ps = prof_begin(c.st, 2, fl, (double)c.P * (8 * 512.0 + (save ? 8 * 512.0 : 0.0) + 2 * 39 * 4.0) + 2.0 * 589000.0);
+    ProfSlot* ps = prof_begin(c.st, 3, fl, (double)c.P * (8 * 512.0 + (save ? 8 * 512.0 : 0.0) + 2 * 39 * 4.0) + 2.0 * 589000.0);
     hipError_t e = launch_sdf_adjoint_w64(c.st, a, ntiles, nwg, save);
     prof_end(c.st, ps);
     return e;
@@ -1047,7 +1047,7 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = A
       if (save && g_head_chain == 2) for (int l = 1; l <= 4; ++l) a.mask[l] = reinterpret_cast<u16*>(head ? h.ma[l] : h.mr[l]);
       double fl3 = 0.0;
       for (int l = 0; l < 5; ++l) fl3 += 2.0 * kO[base + l] * kI[base + l] * (double)c.P;
-      ProfSlot* ps3 = prof_begin(c.st, 2, fl3, (double)c.P * (2 * 512.0 + a.srows * 4.0 + (save ? 4 * 512.0 : 0.0) + (head ? 24.0 : 12.0)) + 4.0 * 540000.0);
+      ProfSlot* ps3 = prof_begin(c.st, 4, fl3, (double)c.P * (2 * 512.0 + a.srows * 4.0 + (save ? 4 * 512.0 : 0.0) + (head ? 24.0 : 12.0)) + 4.0 * 540000.0);
       e = launch_head_chain_x3(c.st, a, head, c.ldp / X3_BATCH, g_ws_grid, save);
       prof_end(c.st, ps3);
       if (e != hipSuccess) return e;
@@ -1074,7 +1074,7 @@ hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = A
       a.out = head ? h.lin : h.rgb;
       double fl = 0.0;
       for (int l = 0; l < 5; ++l) fl += 2.0 * kO[base + l] * kI[base + l] * (double)c.P;
-      ProfSlot* ps = prof_begin(c.st, 2, fl, (double)c.P * (512.0 + a.srows * 2.0 + (save ? 4 * (512.0 + 64.0) : 0.0) + (head ? 24.0 : 12.0)) + 2.0 * 540000.0);
+      ProfSlot* ps = prof_begin(c.st, 4, fl, (double)c.P * (512.0 + a.srows * 2.0 + (save ? 4 * (512.0 + 64.0) : 0.0) + (head ? 24.0 : 12.0)) + 2.0 * 540000.0);
       e = launch_head_chain(c.st, a, head, c.ldp / 64, g_ws_grid, save);
       prof_end(c.st, ps);
       if (e != hipSuccess) return e;
@@ -1132,7 +1132,7 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
       a.sc = head ? h.sc_a : h.sc_r; a.srows = srows;
       double fl = 0.0;
       for (int l = 0; l < 5; ++l) fl += 2.0 * kO[base + l] * kI[base + l] * (double)c.P;
-      ProfSlot* ps = prof_begin(c.st, 2, fl, (double)c.P * (16.0 + 4 * (512.0 + 64.0) + (head ? 1024.0 : 512.0) + srows * 4.0) + 2.0 * 540000.0);
+      ProfSlot* ps = prof_begin(c.st, 4, fl, (double)c.P * (16.0 + 4 * (512.0 + 64.0) + (head ? 1024.0 : 512.0) + srows * 4.0) + 2.0 * 540000.0);
       e = launch_head_bwd_chain(c.st, a, head, c.ldp / 64, g_ws_grid);
       prof_end(c.st, ps);
       if (e != hipSuccess) return e;

@@ -7,7 +7,8 @@ import csv, json, os, sys
 
 CLASSES = {"layer_kernel": ("layer_kernel_ws", "layer_kernel_h", "layer_kernel<"), "wgrad_kernel": ("wgrad_kernel",),
            "sdf_fused_kernel": ("sdf_fused",), "sdf_adjoint_kernel": ("sdf_adjoint_w64",),
-           "sdf_chain_x3_kernel": ("sdf_chain_x3",), "sdf_adjoint_x3_kernel": ("sdf_adjoint_x3",), "head_chain_x3_kernel": ("head_chain_x3",)}
+           "sdf_chain_x3_kernel": ("sdf_chain_x3",), "sdf_adjoint_x3_kernel": ("sdf_adjoint_x3",),
+           "head_chain_kernel": ("head_chain_kernel", "head_bwd_chain_kernel", "head_chain_x3")}
 
 
 def collect(path, counter):
@@ -19,7 +20,7 @@ def collect(path, counter):
         for cls, pats in CLASSES.items():
             if any(p in name for p in pats):
                 # full-size launches only: persistent kernels have ~256 workgroups of 512 threads, the old ones >= 100k threads
-                big = int(r["Grid_Size"]) >= 100000 or (("_ws" in name or "_h3" in name or "_w64" in name or "_x3" in name) and int(r["Grid_Size"]) >= 100 * 512)
+                big = int(r["Grid_Size"]) >= 100000 or (("_ws" in name or "_h3" in name or "_w64" in name or "_x3" in name or "head_" in name) and int(r["Grid_Size"]) >= 100 * 512)
                 if big:
                     out.setdefault(cls, {}).setdefault(name.split("(")[0], []).append(float(r["Counter_Value"]) * 1024.0)
     return out

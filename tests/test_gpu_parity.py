@@ -930,14 +930,19 @@ def test_fused_head_chains_agree_with_layer_launches(dev, R, S, half):
         torch.manual_seed(7)                  # (the eikonal points of the train-mode main pass)
         rgb, l3, *_ = m._render(c, d, z, False)
         ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        with torch.no_grad():                  # the forward-only variant of the chain (nothing saved, no masks)
+            ev = m._render(c, d, z, False)
+        ev_out[key] = (ev[0].clone(), ev[1].clone())
         return rgb.detach().clone(), l3.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
+    ev_out = {}
     try:
         r0, l0, g0 = run(0)
         r1, l1, g1 = run(1)
         r2, l2, g2 = run(2)
     finally:
         _lib.lib().neat_set_tuning(14, 2)
+    assert torch.equal(ev_out[2][0], r2) and torch.equal(ev_out[2][1], l2)          # saving does not change what is computed
     out_tol = 1e-6 if half == "fp16x3" else (2e-2 if half == "bf16" else 3e-3)      # fp16x3: the forward is the 3-product chain in both
     g_tol = {"bf16": 3e-2, "fp16": 1e-2, "fp16x3": 2e-3}[half]
     close(r2, r0, tol=out_tol, what="fused heads rgb")
