@@ -455,9 +455,14 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
 #ifndef NEAT_X3_ADJ_REVERSE
 #define NEAT_X3_ADJ_REVERSE 0
 #endif
+#if NEAT_X3_TIMING
+  int nb_done = 0;
+  unsigned long long stamp[12];
+#endif
   for (int bi = blockIdx.x; bi < nbatches; bi += gridDim.x) {
     const int batch = NEAT_X3_ADJ_REVERSE ? nbatches - 1 - bi : bi;
     const int p0 = batch * BP;
+    X3_STAMP(0);
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.ldp16 = (unsigned)a.ldp * 16u;
     asm volatile("" : "+v"(L.ldp16));
@@ -510,6 +515,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
     }
     load_h(a.h[7], a.hlo[7], 0);            // what the first epilogue (layer 7, tile 0) needs; every later quad set is requested by an epilogue
     __syncthreads();
+    X3_STAMP(1);
 
     f32x16 acc[2];
     unsigned ph[2], pl[2];
@@ -568,22 +574,33 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
     // were requested before the loop; layer 0's epilogues read no h.)
     ADJ_LAYER(0, a.Wp[6], a.Wlo[6], 256, none,
               ADJ_EPI(acc[0], 0, 0, 1, a.u[6], nullptr, a.h[7], a.hlo[7], 1))                                                     // l = 7: XA -> XB
+    X3_STAMP(2);
     ADJ_LAYER(1, a.Wp[5], a.Wlo[5], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[6], nullptr, a.h[6], a.hlo[6], 0),
               ADJ_EPI(acc[0], 0, 0, 0, a.u[5], nullptr, a.h[6], a.hlo[6], 1))                                                     // l = 6: XB -> XA
+    X3_STAMP(3);
     ADJ_LAYER(0, a.Wp[4], a.Wlo[4], 256, ADJ_EPI(acc[1], 1, 0, 0, a.u[5], nullptr, a.h[5], a.hlo[5], 0),
               ADJ_EPI(acc[0], 0, 0, 1, a.u[4], nullptr, a.h[5], a.hlo[5], 1))                                                     // l = 5
     ADJ_LAYER(1, a.Wp[3], a.Wlo[3], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[4], nullptr, a.h[4], a.hlo[4], 0),
               ADJ_EPI(acc[0], 0, 1, 0, a.u[3], a.es, a.h[4], a.hlo[4], 1))                                                        // l = 4: rows 217.. -> es
+    X3_STAMP(4);
     ADJ_LAYER(0, a.Wp[2], a.Wlo[2], 256, ADJ_EPI(acc[1], 1, 1, 0, a.u[3], a.es, a.h[3], a.hlo[3], 0),
               ADJ_EPI(acc[0], 0, 0, 1, a.u[2], nullptr, a.h[3], a.hlo[3], 1))                                                     // l = 3
     ADJ_LAYER(1, a.Wp[1], a.Wlo[1], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[2], nullptr, a.h[2], a.hlo[2], 0),
               ADJ_EPI(acc[0], 0, 0, 0, a.u[1], nullptr, a.h[2], a.hlo[2], 1))                                                     // l = 2
     ADJ_LAYER(0, a.Wp[0], a.Wlo[0], 39, ADJ_EPI(acc[1], 1, 0, 0, a.u[1], nullptr, a.h[1], a.hlo[1], 0),
               ADJ_EPI(acc[0], 0, 0, 1, a.u[0], nullptr, a.h[1], a.hlo[1], 1))                                                     // l = 1
+    X3_STAMP(5);
     ADJ_LAYER(1, a.Wp[7], a.Wlo[7], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[0], nullptr, nullptr, nullptr, 0),
               ADJ_EPI(acc[0], 0, 2, 0, nullptr, a.e0, nullptr, nullptr, 0))                                                       // l = 0: e0 (fp32)
     x3_drain(ADJ_EPI(acc[1], 1, 2, 0, nullptr, a.e0, nullptr, nullptr, 0));
     __syncthreads();
+    X3_STAMP(6);
+#if NEAT_X3_TIMING
+    if (blockIdx.x == 0 && nb_done < 3 && tid == 0)
+      printf("x3 adjoint save %d batch %d: seed %llu l7 %llu l6 %llu l5+l4 %llu l3..l1 %llu l0 %llu cycles\n", (int)SAVE, nb_done,
+             stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5]);
+    ++nb_done;
+#endif
 #undef ADJ_LAYER
 #undef ADJ_EPI
   }
