@@ -4,7 +4,7 @@ R=$PWD; mkdir -p $R/gpurun_out/hcab
 for n in "$@"; do
   O=$R/gpurun_out/hcab/$n; rm -rf $O; mkdir -p $O
   if [ $n = default ]; then unset NEAT_HIP_LIB; else export NEAT_HIP_LIB=$R/abl_libs/libneat_$n.so; fi
-  (cd /tmp && TMPDIR=/tmp PYTHONPATH=$R rocprofv3 --kernel-trace --stats --output-format csv -d $O -- timeout 60 python $R/scripts/hc_time.py ${HC_PREC:-bf16} ${HC_S:-128} > $O/log.txt 2>&1)
+  (cd /tmp && TMPDIR=/tmp PYTHONPATH=$R rocprofv3 --kernel-trace --stats --output-format csv -d $O -- timeout 60 python $R/scripts/hc_time.py ${HC_PREC:-bf16} ${HC_S:-128} $HC_TUNE > $O/log.txt 2>&1)
   f=$(find $O -name "*kernel_stats.csv" | head -1)
   echo "== $n: $(tail -1 $O/log.txt)"
   python - $f <<'PY'

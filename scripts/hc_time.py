@@ -1,10 +1,13 @@
 """Main pass only (neat_render_forward + neat_render_backward on 1024 rays x S samples + 2048 eikonal points, random cotangents), a few
 times: the fused head chains without the junction block / loss around them (probe builds with wrong results cannot hang a matching).
-Run under rocprofv3 --kernel-trace --stats (scripts/hc_ab.sh).   python scripts/hc_time.py [precision] [samples per ray]"""
+Run under rocprofv3 --kernel-trace --stats (scripts/hc_ab.sh).   python scripts/hc_time.py [precision] [samples per ray] [tuning key=value ...]"""
 import sys
 import torch
 sys.path.insert(0, '.')
-from neat_amd import networks, synth, ops
+from neat_amd import networks, synth, ops, _lib
+for kv in sys.argv[3:]:               # tuning keys: key=value
+    k, v = kv.split('=')
+    _lib.check(_lib.lib().neat_set_tuning(int(k), int(v)), f"tuning {kv}")
 
 dev = torch.device('cuda:0')
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
