@@ -617,7 +617,14 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
           dst[q].x = __uint_as_float(v.x); dst[q].y = __uint_as_float(v.y);
         }
       };
-      float4 hq[2][4 * RT];
+      // Two sets: the quads of a stage's tile are requested one stage before the epilogue that multiplies with them runs.  NEAT_ADJ_HDEPTH = 3
+      // (probe): three sets, requested two stages ahead -- 32 KiB instead of 16 KiB per CU in flight; measured 315 -> 338 us per full-size
+      // launch (the rolling weight refills share the in-order vector-memory counter with the longer queue of h requests)
+#ifndef NEAT_ADJ_HDEPTH
+#define NEAT_ADJ_HDEPTH 2
+#endif
+      constexpr int HD = NEAT_ADJ_HDEPTH;
+      float4 hq[HD][4 * RT];
       // ---- seed: u_7 = w8 (.) phi'(h_8) -> XA (+ HBM)
       {
         float4 wq[4];
@@ -655,33 +662,38 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
       uint4 ring[NEAT_F6_RING];
       constexpr int RD = NEAT_F6_RING;
 #define ADJ_STAGE(S_, T_, SRC_, WC_, E_, H_, TE_, NFR_)                                                                              \
-      f6_stage<NT, RT, FULL, true, 16, SRC_, E_, (16 * (S_)) % RD, ((S_) % 2 == 1)>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], hq[((S_) + 1) & 1], TE_, nt, H_, wave, hi, ring, NFR_);
+      f6_stage<NT, RT, FULL, true, 16, SRC_, E_, (16 * (S_)) % RD, ((S_) % 2 == 1)>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], hq[((S_) + HD - 1) % HD], TE_, nt, H_, wave, hi, ring, NFR_);
 #define ADJ_STAGE_ROLL(S_, T_, SRC_, WC_, E_, H_, TE_, NFR_, WNX_)                                                                   \
-      f6_stage<NT, RT, FULL, true, 16, SRC_, E_, (16 * (S_)) % RD, ((S_) % 2 == 1), true>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], hq[((S_) + 1) & 1], TE_, nt, H_, wave, hi, ring, NFR_, WNX_);
+      f6_stage<NT, RT, FULL, true, 16, SRC_, E_, (16 * (S_)) % RD, ((S_) % 2 == 1), true>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], hq[((S_) + HD - 1) % HD], TE_, nt, H_, wave, hi, ring, NFR_, WNX_);
       // HSRC_: the h array whose phi' multiplies this layer's output (null: none); FPREV_ / FCUR_: fp32 row destinations of the previous / this layer
-#define ADJ_LAYER(S0_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, HAS_H_, HSRC_, NSRC_, FPREV_, FCUR_, WNEXT_, NNEXT_)                           \
+#define ADJ_LAYER(S0_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, HAS_H_, HSRC_, NSRC_, FPREV_, FCUR_, WNEXT_, NNEXT_, HASN_, HNEXT_)             \
       { L.frows = FPREV_;                                                                                                         \
-        if (HAS_H_) load_h(hq[((S0_) + 0) & 1], HSRC_, 0);                                                                         \
+        if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 0) % HD], HSRC_, 0);                                                              \
+        if (HD == 3 && HAS_H_) load_h(hq[((S0_) + 1) % HD], HSRC_, 1);                                                              \
         ADJ_STAGE((S0_) + 0, 0, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512)                                         \
         L.frows = FCUR_;                                                                                                          \
-        if (HAS_H_) load_h(hq[((S0_) + 1) & 1], HSRC_, 1);                                                                         \
+        if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 1) % HD], HSRC_, 1);                                                              \
+        if (HD == 3 && HAS_H_) load_h(hq[((S0_) + 2) % HD], HSRC_, 2);                                                              \
         ADJ_STAGE((S0_) + 1, 1, SRC_, WC_, ECUR_, HCUR_, 0, L.frag[SRC_] + 2 * 512)                                                \
-        if (HAS_H_) load_h(hq[((S0_) + 2) & 1], HSRC_, 2);                                                                         \
+        if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 2) % HD], HSRC_, 2);                                                              \
+        if (HD == 3 && HAS_H_) load_h(hq[((S0_) + 3) % HD], HSRC_, 3);                                                              \
         ADJ_STAGE((S0_) + 2, 2, SRC_, WC_, ECUR_, HCUR_, 1, L.frag[SRC_] + 3 * 512)                                                \
-        if (HAS_H_) load_h(hq[((S0_) + 3) & 1], HSRC_, 3);                                                                         \
+        if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 3) % HD], HSRC_, 3);                                                              \
+        if (HD == 3 && HASN_) load_h(hq[((S0_) + 4) % HD], HNEXT_, 0);                                                              \
         ADJ_STAGE_ROLL((S0_) + 3, 3, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 2 ? L.frag[(NSRC_) < 2 ? (NSRC_) : 0] : nullptr), w_addr(WNEXT_, NNEXT_)) }
 #pragma unroll
       for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[0] + j * 2 * BP * 16);
-      ADJ_LAYER(0, 0, wA, F6NoEpi, R7, nullptr, a.u[6], 1, a.h[7], 1, nullptr, nullptr, a.Wp[6], 256)
-      ADJ_LAYER(4, 1, wA, R7, R6, a.u[6], a.u[5], 1, a.h[6], 0, nullptr, nullptr, a.Wp[5], 256)
-      ADJ_LAYER(8, 0, wA, R6, R5, a.u[5], a.u[4], 1, a.h[5], 1, nullptr, nullptr, a.Wp[4], 256)
-      ADJ_LAYER(12, 1, wA, R5, R4, a.u[4], a.u[3], 1, a.h[4], 0, nullptr, a.es, a.Wp[3], 256)
-      ADJ_LAYER(16, 0, wA, R4, R3, a.u[3], a.u[2], 1, a.h[3], 1, a.es, nullptr, a.Wp[2], 256)
-      ADJ_LAYER(20, 1, wA, R3, R2, a.u[2], a.u[1], 1, a.h[2], 0, nullptr, nullptr, a.Wp[1], 256)
-      ADJ_LAYER(24, 0, wA, R2, R1, a.u[1], a.u[0], 1, a.h[1], 1, nullptr, nullptr, a.Wp[0], 39)
-      ADJ_LAYER(28, 1, wA, R1, R0, a.u[0], nullptr, 0, a.h[1], 2, nullptr, a.e0, a.Wp[7], 256)      // (the next batch starts with W_7 again)
+      if (HD == 3) load_h(hq[0], a.h[7], 0);
+      ADJ_LAYER(0, 0, wA, F6NoEpi, R7, nullptr, a.u[6], 1, a.h[7], 1, nullptr, nullptr, a.Wp[6], 256, 1, a.h[6])
+      ADJ_LAYER(4, 1, wA, R7, R6, a.u[6], a.u[5], 1, a.h[6], 0, nullptr, nullptr, a.Wp[5], 256, 1, a.h[5])
+      ADJ_LAYER(8, 0, wA, R6, R5, a.u[5], a.u[4], 1, a.h[5], 1, nullptr, nullptr, a.Wp[4], 256, 1, a.h[4])
+      ADJ_LAYER(12, 1, wA, R5, R4, a.u[4], a.u[3], 1, a.h[4], 0, nullptr, a.es, a.Wp[3], 256, 1, a.h[3])
+      ADJ_LAYER(16, 0, wA, R4, R3, a.u[3], a.u[2], 1, a.h[3], 1, a.es, nullptr, a.Wp[2], 256, 1, a.h[2])
+      ADJ_LAYER(20, 1, wA, R3, R2, a.u[2], a.u[1], 1, a.h[2], 0, nullptr, nullptr, a.Wp[1], 256, 1, a.h[1])
+      ADJ_LAYER(24, 0, wA, R2, R1, a.u[1], a.u[0], 1, a.h[1], 1, nullptr, nullptr, a.Wp[0], 39, 0, a.h[1])
+      ADJ_LAYER(28, 1, wA, R1, R0, a.u[0], nullptr, 0, a.h[1], 2, nullptr, a.e0, a.Wp[7], 256, 0, a.h[1])      // (the next batch starts with W_7 again)
       // drain: the last tile of the last layer
-      f6_stage<NT, RT, FULL, false, 16, 0, R0, 0, true>(L, wA, 0, acc[0], acc[1], hq[1], NT - 1, nt, nullptr, wave, hi, ring, nullptr);
+      f6_stage<NT, RT, FULL, false, 16, 0, R0, 0, true>(L, wA, 0, acc[0], acc[1], hq[(32 + HD - 1) % HD], NT - 1, nt, nullptr, wave, hi, ring, nullptr);
 #undef ADJ_LAYER
 #undef ADJ_STAGE_ROLL
 #undef ADJ_STAGE
