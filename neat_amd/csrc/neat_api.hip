@@ -211,6 +211,7 @@ int g_wreduce_direct = 2;   // bf16 weight-gradient reduction: 2 = one launch pe
                             // sums + finish (two launches, stage buffer), 1 = one 16-wave pass with 4-byte loads (slowest)
 int g_head_chain = 2;       // 16-bit builds: the heads as fused chains (kernels_heads.hpp): 2 = forward and backward, 1 = forward only, 0 = per-layer
                             // launches of layer_kernel_ws (tuning key 14)
+int g_head_wgrad_order = 1; // fused head backward: a head's weight gradients right after its backward chain (tuning key 15; 0 = after both chains, hidden layers of the two heads batched together)
 int g_fused_adj = 1;        // bf16 build: adjoint chain (normals) as one fused launch (sdf_adjoint_w64_kernel); 0 = seed + eight streaming EPI_REV launches (tuning key 13)
 int g_fused_ws = 3;         // fused primal chain: 4 = phase-staggered kernel (sdf_fused_ph_kernel; measured slower: a matrix wave and a
                             // vector wave on one SIMD do not overlap on this machine, scripts/probes/probe_roles.hip), 3 / 2 = stage-pipelined kernel of kernels_fused.hpp with 8 waves x 32 rows / 4 waves x 64 rows,
@@ -1106,6 +1107,40 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
   hipError_t e;
   const bool oct = oct_operands(c);
   if (oct) oct_pack(c, {{h.zrgb, 3, h.topbf_r}, {h.dlin, 6, h.topbf_a}});      // (the small inputs were packed by heads_forward)
+  const int nb1 = wgrad_batch_size(c.ldp);
+  const bool batch = oct && nb1 && g_wgrad_h3;
+  bool wdone[2] = {false, false};
+  // all weight gradients of one head (per_head_batch: its three hidden layers as one multi-problem launch)
+  auto head_wgrads = [&](int head, bool per_head_batch) -> hipError_t {
+    const int base = head ? L_ATTR : L_REND;
+    const Arr* hh = head ? h.ha : h.hr;
+    const Arr* ab = head ? h.aa : h.ar;
+    const float* top = head ? h.dlin : h.zrgb;
+    const float* small = head ? h.small_a : h.small_r;
+    const int srows = head ? SMALL_A : SMALL_R;
+    hipError_t e2;
+    const bool hb = per_head_batch && batch;
+    if (hb) {
+      WProb pb[3];
+      for (int l = 1; l <= 3; ++l) pb[l - 1] = WProb{base + l, {ab[l], Arr{}}, {256, 0}, {hh[l], Arr{}}};
+      for (int t = 0; t < 3; t += nb1)
+        if ((e2 = wgrad_multi(c, w, pb + t, (3 - t) < nb1 ? (3 - t) : nb1, 1, gr)) != hipSuccess) return e2;
+    }
+    for (int l = 0; l <= 4; ++l) {
+      if ((hb || (!per_head_batch && batch)) && l >= 1 && l <= 3) continue;
+      WPair pr[1] = {};
+      pr[0].A = l == 4 ? (oct ? (head ? h.topbf_a : h.topbf_r) : F(top)) : ab[l]; pr[0].rowsA = kO[base + l];
+      if (l == 0) {
+        pr[0].B[0] = w.feat; pr[0].rowsB[0] = 256;
+        pr[0].B[1] = oct ? (head ? h.smallbf_a : h.smallbf_r) : F(small); pr[0].rowsB[1] = srows;
+      } else {
+        pr[0].B[0] = hh[l]; pr[0].rowsB[0] = 256;
+      }
+      if ((e2 = wgrad(c, w, base + l, pr, 1, kO[base + l], gr)) != hipSuccess) return e2;
+    }
+    wdone[head] = true;
+    return hipSuccess;
+  };
   for (int head = 0; head < 2; ++head) {
     const int base = head ? L_ATTR : L_REND;
     const Arr* hh = head ? h.ha : h.hr;
@@ -1136,6 +1171,7 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
       e = launch_head_bwd_chain(c.st, a, head, c.ldp / 64, g_ws_grid);
       prof_end(c.st, ps);
       if (e != hipSuccess) return e;
+      if (g_head_wgrad_order && (e = head_wgrads(head, true)) != hipSuccess) return e;      // while its cotangents are the last thing written
       continue;
     }
     if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, in(oct ? (head ? h.topbf_a : h.topbf_r) : F(top), top_rows), NOIN, nullptr, 256, ab[3], Arr{}, 1 << 30, hh[4])) != hipSuccess) return e;
@@ -1151,10 +1187,8 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     } else if ((e = layer(c, L.tr[base], EPI_LINEAR, in(ab[0], 256), NOIN, nullptr, 256 + srows, F(w.abar8 + c.ldp),
                           F(head ? h.sc_a : h.sc_r), 256, Arr{}, Arr{}, head)) != hipSuccess) return e;
   }
-  // weight gradients; the hidden layers l = 1..3 of the two heads have identical shapes: one launch per layer for both
-  const int nb1 = wgrad_batch_size(c.ldp);
-  const bool batch = oct && nb1 && g_wgrad_h3;
-  if (batch) {                    // 3 hidden layers x 2 heads: six single-pair problems, g_wgrad_batch per launch
+  // weight gradients not yet launched; the hidden layers l = 1..3 of the two heads have identical shapes: one launch per layer for both
+  if (!wdone[0] && !wdone[1] && batch) {          // 3 hidden layers x 2 heads: six single-pair problems, g_wgrad_batch per launch
     WProb pb[6];
     for (int l = 1; l <= 3; ++l) {
       pb[2 * (l - 1)] = WProb{L_REND + l, {h.ar[l], Arr{}}, {256, 0}, {h.hr[l], Arr{}}};
@@ -1163,26 +1197,8 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     for (int t = 0; t < 6; t += nb1)
       if ((e = wgrad_multi(c, w, pb + t, nb1, 1, gr)) != hipSuccess) return e;
   }
-  for (int head = 0; head < 2; ++head) {
-    const int base = head ? L_ATTR : L_REND;
-    const Arr* hh = head ? h.ha : h.hr;
-    const Arr* ab = head ? h.aa : h.ar;
-    const float* top = head ? h.dlin : h.zrgb;
-    const float* small = head ? h.small_a : h.small_r;
-    const int srows = head ? SMALL_A : SMALL_R;
-    for (int l = 0; l <= 4; ++l) {
-      if (batch && l >= 1 && l <= 3) continue;
-      WPair pr[1] = {};
-      pr[0].A = l == 4 ? (oct ? (head ? h.topbf_a : h.topbf_r) : F(top)) : ab[l]; pr[0].rowsA = kO[base + l];
-      if (l == 0) {
-        pr[0].B[0] = w.feat; pr[0].rowsB[0] = 256;
-        pr[0].B[1] = oct ? (head ? h.smallbf_a : h.smallbf_r) : F(small); pr[0].rowsB[1] = srows;
-      } else {
-        pr[0].B[0] = hh[l]; pr[0].rowsB[0] = 256;
-      }
-      if ((e = wgrad(c, w, base + l, pr, 1, kO[base + l], gr)) != hipSuccess) return e;
-    }
-  }
+  for (int head = 0; head < 2; ++head)
+    if (!wdone[head] && (e = head_wgrads(head, false)) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -1325,6 +1341,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 12 && (value == 0 || value == 1)) { g_ws_wide_store = value; return 0; }
   if (key == 13 && (value == 0 || value == 1)) { g_fused_adj = value; return 0; }
   if (key == 14 && value >= 0 && value <= 2) { g_head_chain = value; return 0; }
+  if (key == 15 && (value == 0 || value == 1)) { g_head_wgrad_order = value; return 0; }
   return -1;
 }
 
