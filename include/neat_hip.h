@@ -311,7 +311,9 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *  12 layer kernels: 1 = 16-byte output stores through v_permlane32_swap (default; measured neutral), 0 = 8-byte stores
  *  13 16-bit builds: the adjoint chain (normals) as one fused launch (default 1), 0 = seed + eight streaming launches
  *  14 16-bit builds: the two heads as fused chains (kernels_heads.hpp): 2 = forward and backward (default), 1 = forward only,
- *     0 = one layer_kernel_ws launch per layer */
+ *     0 = one layer_kernel_ws launch per layer
+ *  15 with the fused head backward: 1 = a head's weight gradients right after its backward chain (default: its cotangents are the
+ *     last 270 MB written, -0.025 ms per step), 0 = after both chains, the two heads' hidden layers batched together */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);
