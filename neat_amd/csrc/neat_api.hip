@@ -1123,8 +1123,7 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     if (hb) {
       WProb pb[3];
       for (int l = 1; l <= 3; ++l) pb[l - 1] = WProb{base + l, {ab[l], Arr{}}, {256, 0}, {hh[l], Arr{}}};
-      for (int t = 0; t < 3; t += nb1)
-        if ((e2 = wgrad_multi(c, w, pb + t, (3 - t) < nb1 ? (3 - t) : nb1, 1, gr)) != hipSuccess) return e2;
+      if ((e2 = wgrad_multi(c, w, pb, 3, 1, gr)) != hipSuccess) return e2;
     }
     for (int l = 0; l <= 4; ++l) {
       if ((hb || (!per_head_batch && batch)) && l >= 1 && l <= 3) continue;
@@ -1171,7 +1170,9 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
       e = launch_head_bwd_chain(c.st, a, head, c.ldp / 64, g_ws_grid);
       prof_end(c.st, ps);
       if (e != hipSuccess) return e;
-      if (g_head_wgrad_order && (e = head_wgrads(head, true)) != hipSuccess) return e;      // while its cotangents are the last thing written
+      // ... while its cotangents are the last thing written (unless the batch size in force splits three problems 2 + 1: a multi-problem
+      // launch takes at least two, and the batch of two is what large point counts want)
+      if (g_head_wgrad_order && (!batch || nb1 >= 3) && (e = head_wgrads(head, true)) != hipSuccess) return e;
       continue;
     }
     if ((e = layer(c, L.tr[base + 4], EPI_BWD_RELU, in(oct ? (head ? h.topbf_a : h.topbf_r) : F(top), top_rows), NOIN, nullptr, 256, ab[3], Arr{}, 1 << 30, hh[4])) != hipSuccess) return e;
