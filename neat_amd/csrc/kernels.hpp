@@ -754,29 +754,50 @@ __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float*
 //   render  (rend_a :235-241): [p(3), PE4(view)(27), normal(3)] = 33 rows
 //   attract (rend_a :175-181): [p(3), view(3), normal(3)]      =  9 rows
 // view dir of point p is dirs[p / S] (S=1: per-point dirs)
+// bf_r / bf_a (16-bit builds; null otherwise): the same rows as octet-major 16-bit copies [5 | 2 octets][ldp][8], zero padded -- what the
+// heads' chains and weight gradients read (a separate oct_pack launch before)
 __global__ void head_inputs_kernel(const float* __restrict__ x_fm, const float* __restrict__ g_fm,
                                    const float* __restrict__ dirs, int P, int S, int ldp,
-                                   float* __restrict__ small_r, float* __restrict__ small_a) {
+                                   float* __restrict__ small_r, float* __restrict__ small_a,
+                                   u16* __restrict__ bf_r, u16* __restrict__ bf_a) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= ldp) return;
   const int r = (p < P ? p : 0) / S;
+  float vr[40], va[16];
+#pragma unroll
+  for (int i = 0; i < 40; ++i) vr[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) va[i] = 0.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float xc = x_fm[(size_t)c * ldp + p], gc = g_fm[(size_t)c * ldp + p];
     const float dc = (p < P) ? dirs[r * 3 + c] : 0.0f;
-    small_r[(size_t)c * ldp + p] = xc;
-    small_r[(size_t)(3 + c) * ldp + p] = dc;
+    vr[c] = xc; vr[3 + c] = dc;
     float f = 1.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      small_r[(size_t)(6 + 6 * k + c) * ldp + p] = sinf(dc * f);
-      small_r[(size_t)(9 + 6 * k + c) * ldp + p] = cosf(dc * f);
+      vr[6 + 6 * k + c] = sinf(dc * f);
+      vr[9 + 6 * k + c] = cosf(dc * f);
       f *= 2.0f;
     }
-    small_r[(size_t)(30 + c) * ldp + p] = gc;
-    small_a[(size_t)c * ldp + p] = xc;
-    small_a[(size_t)(3 + c) * ldp + p] = dc;
-    small_a[(size_t)(6 + c) * ldp + p] = gc;
+    vr[30 + c] = gc;
+    va[c] = xc; va[3 + c] = dc; va[6 + c] = gc;
+  }
+#pragma unroll
+  for (int i = 0; i < 33; ++i) small_r[(size_t)i * ldp + p] = vr[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) small_a[(size_t)i * ldp + p] = va[i];
+  if (bf_r) {
+#pragma unroll
+    for (int o = 0; o < 5; ++o)
+      reinterpret_cast<uint4*>(bf_r)[(size_t)o * ldp + p] = make_uint4(pack2(vr[8 * o], vr[8 * o + 1]), pack2(vr[8 * o + 2], vr[8 * o + 3]),
+                                                                      pack2(vr[8 * o + 4], vr[8 * o + 5]), pack2(vr[8 * o + 6], vr[8 * o + 7]));
+  }
+  if (bf_a) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+      reinterpret_cast<uint4*>(bf_a)[(size_t)o * ldp + p] = make_uint4(pack2(va[8 * o], va[8 * o + 1]), pack2(va[8 * o + 2], va[8 * o + 3]),
+                                                                      pack2(va[8 * o + 4], va[8 * o + 5]), pack2(va[8 * o + 6], va[8 * o + 7]));
   }
 }
 
@@ -845,13 +866,16 @@ __global__ void zero_tail_kernel(float* __restrict__ a, int rows, int p_from, in
   for (int r = 0; r < rows; ++r) a[(size_t)r * ldp + p] = 0.0f;
 }
 // the same for three arrays in one launch (the head cotangents and the sdf cotangent row beyond the ray samples)
+// oct_a / oct_b (null: none): one-octet 16-bit copies of a / b (composite_bwd_kernel's zrgb_oct / dlin_oct), zeroed as well
 __global__ void zero_tail3_kernel(float* __restrict__ a, int rows_a, float* __restrict__ b, int rows_b, float* __restrict__ c, int rows_c,
-                                  int p_from, int ldp) {
+                                  int p_from, int ldp, u16* __restrict__ oct_a, u16* __restrict__ oct_b) {
   const int p = p_from + blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= ldp) return;
   for (int r = 0; r < rows_a; ++r) a[(size_t)r * ldp + p] = 0.0f;
   for (int r = 0; r < rows_b; ++r) b[(size_t)r * ldp + p] = 0.0f;
   for (int r = 0; r < rows_c; ++r) c[(size_t)r * ldp + p] = 0.0f;
+  if (oct_a) reinterpret_cast<uint4*>(oct_a)[p] = make_uint4(0u, 0u, 0u, 0u);
+  if (oct_b) reinterpret_cast<uint4*>(oct_b)[p] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -946,6 +970,8 @@ struct CompositeBwdArgs {
   const float* d_rgb; const float* d_lines3d; const float* d_depth; const float* d_xyz;   // [R,3],[R,6],[R],[R,3] (null = 0)
   float* zrgb_fm;      // [3][ldp]  cotangent of the pre-sigmoid colour logits
   float* dlin_fm;      // [6][ldp]  cotangent of the attraction offsets
+  u16* zrgb_oct = nullptr;   // 16-bit builds: the same two as one zero-padded octet per point [ldp][8] (what the heads' backward chain and
+  u16* dlin_oct = nullptr;   // output-layer weight gradients read; a separate oct_pack launch before)
   float* dsdf_row;     // [ldp]     cotangent of raw sdf (0 where the sphere clamp is active)
   float* dbeta_ray;    // [R]       per-ray partial of d loss / d beta
   const float* cot_slot = nullptr;   // f16 build: the incoming cotangents are scaled on load, d beta is scaled back (cot_scale_of)
@@ -1035,10 +1061,13 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
       const float keep = 1.0f - (a.mask ? a.mask[p] : 0.0f);
       a.dsdf_row[p] = dsig * dsig_ds * keep;
       dbeta += dsig * dsig_db;
+      float zo[3], lo6[6];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a.zrgb_fm[(size_t)c * a.ldp + p] = w * drgb[c] * rgbv[c] * (1.0f - rgbv[c]);
+      for (int c = 0; c < 3; ++c) { zo[c] = w * drgb[c] * rgbv[c] * (1.0f - rgbv[c]); a.zrgb_fm[(size_t)c * a.ldp + p] = zo[c]; }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) a.dlin_fm[(size_t)c * a.ldp + p] = w * dl[c];
+      for (int c = 0; c < 6; ++c) { lo6[c] = w * dl[c]; a.dlin_fm[(size_t)c * a.ldp + p] = lo6[c]; }
+      if (a.zrgb_oct) reinterpret_cast<uint4*>(a.zrgb_oct)[p] = make_uint4(pack2(zo[0], zo[1]), pack2(zo[2], 0.0f), 0u, 0u);
+      if (a.dlin_oct) reinterpret_cast<uint4*>(a.dlin_oct)[p] = make_uint4(pack2(lo6[0], lo6[1]), pack2(lo6[2], lo6[3]), pack2(lo6[4], lo6[5]), 0u);
     }
   }
   dbeta = wave_sum(dbeta);

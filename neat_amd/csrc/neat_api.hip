@@ -1023,8 +1023,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
 hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = Arr{}, bool save = true, int n_main = -1) {
   const PackLayout& L = c.L();
   hipError_t e;
-  // bf16 build: octet-major copies of the small head inputs (the input layers then stream like every other layer)
-  if (c.prec) oct_pack(c, {{h.small_r, SMALL_R, h.smallbf_r}, {h.small_a, SMALL_A, h.smallbf_a}});
+  // (16-bit builds: the octet-major copies of the small head inputs, smallbf_r / smallbf_a, were written by head_inputs_kernel)
   if (c.hx3) {
     // split-precision forward: one fused launch per head (kernels_x3.hpp); the hidden activations stay on chip, their hi planes
     // go to hr / ha for the 16-bit backward (save)
@@ -1106,7 +1105,7 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
   const PackLayout& L = c.L();
   hipError_t e;
   const bool oct = oct_operands(c);
-  if (oct) oct_pack(c, {{h.zrgb, 3, h.topbf_r}, {h.dlin, 6, h.topbf_a}});      // (the small inputs were packed by heads_forward)
+  // (16-bit builds: the octet copies of zrgb / dlin, topbf_r / topbf_a, were written by composite_bwd_kernel and zero_tail3_kernel)
   const int nb1 = wgrad_batch_size(c.ldp);
   const bool batch = oct && nb1 && g_wgrad_h3;
   bool wdone[2] = {false, false};
@@ -1535,7 +1534,8 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
   if (precision) hipLaunchKernelGGL(rm_to_oct_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, reinterpret_cast<u16*>(f_fm),
                                     reinterpret_cast<u16*>(featlo.p));
   else hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, feats, P, 256, c.ldp, f_fm);
-  hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, x_fm, g_fm, view_dirs, P, 1, c.ldp, h.small_r, h.small_a);
+  hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, x_fm, g_fm, view_dirs, P, 1, c.ldp, h.small_r, h.small_a,
+                     reinterpret_cast<u16*>(h.smallbf_r.p), reinterpret_cast<u16*>(h.smallbf_a.p));
   NEAT_CHECK(heads_forward(c, h, feat, featlo));
   if (rgb) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, h.rgb, P, 3, c.ldp, rgb, 0);
   if (lines) hipLaunchKernelGGL(lines_from_offsets_kernel, grid1(P), dim3(256), 0, c.st, h.lin, x_fm, P, c.ldp, lines);   // y = p + offsets (rend_a :195)
@@ -1573,7 +1573,8 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
   FINALIZE_LAUNCH(c, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
                      w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
   // the heads run over every column of the tile grid; only the first R*S columns are consumed
-  hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, Pm, S, c.ldp, h.small_r, h.small_a);
+  hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, Pm, S, c.ldp, h.small_r, h.small_a,
+                     reinterpret_cast<u16*>(h.smallbf_r.p), reinterpret_cast<u16*>(h.smallbf_a.p));
   NEAT_CHECK(heads_forward(c, h, w.feat, w.featlo, !fwd_only, Pm));
   CompositeArgs ca;
   ca.z = z; ca.sdf = w.sdf; ca.dirs = dirs; ca.x_fm = w.x; ca.rgb_fm = h.rgb; ca.lin_fm = h.lin; ca.g_fm = w.g;
@@ -1631,6 +1632,7 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   cb.R = R; cb.S = S; cb.ldp = c.ldp; cb.beta_ptr = beta;
   cb.d_rgb = d_rgb; cb.d_lines3d = d_lines3d; cb.d_depth = d_depth; cb.d_xyz = d_xyz;
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
+  cb.zrgb_oct = reinterpret_cast<u16*>(h.topbf_r.p); cb.dlin_oct = reinterpret_cast<u16*>(h.topbf_a.p);      // (null in the fp32 build)
   const float* slot = cot_scale_begin(c, w.ones, {{d_rgb, 3LL * R}, {d_lines3d, 6LL * R}, {d_depth, (long long)R}, {d_xyz, 3LL * R},
                                                   {d_eik_grad, 3LL * E}});
   // the attraction head's chain in its own scale (only its top cotangent d_lines3d feeds it)
@@ -1641,7 +1643,8 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
     hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, cb);
   if (c.ldp > Pm) {      // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents
-    hipLaunchKernelGGL(zero_tail3_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, h.dlin, 6, w.abar8, 1, Pm, c.ldp);
+    hipLaunchKernelGGL(zero_tail3_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, h.dlin, 6, w.abar8, 1, Pm, c.ldp,
+                       reinterpret_cast<u16*>(h.topbf_r.p), reinterpret_cast<u16*>(h.topbf_a.p));
   }
   NEAT_CHECK(heads_backward(c, h, w, grads, slot, slot_a, Pm));
   hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
