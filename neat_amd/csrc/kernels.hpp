@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void wreduce_direct_kernel(WreduceArgs a) { wr
 // the finish of several layers in one launch (the problems of one batched weight-gradient launch): blockIdx.y = layer.
 // The argument table is read from the kernel-argument segment through a pointer -- indexing the by-value array with
 // blockIdx.y would copy it to scratch.
-constexpr int WREDUCE_BATCH = 6;
+constexpr int WREDUCE_BATCH = 8;
 struct WreduceBatch { WreduceArgs a[WREDUCE_BATCH]; };
 __global__ __launch_bounds__(256) void wreduce_wnorm_batch_kernel(WreduceBatch) {
   const WreduceArgs* tab = (const WreduceArgs*)__builtin_amdgcn_kernarg_segment_ptr();

@@ -11,6 +11,7 @@
 #include "f16_symbols.h"
 #endif
 #include "kernels_bf16.hpp"
+#include "kernels_dw.hpp"
 #include "fused_launch.hpp"
 #include "kernels_sampler.hpp"
 #include "kernels_junction.hpp"
@@ -219,12 +220,34 @@ int g_fused_ws = 3;         // fused primal chain: 4 = phase-staggered kernel (s
 int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whichever balances the CUs better
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
+constexpr int DW_MAXGRID = 256;     // workgroup partials the workspace holds per (layer, pair)
+inline int dw_grid(int ldp) { const int nt = ldp / WSP, g = g_ws_grid < DW_MAXGRID ? g_ws_grid : DW_MAXGRID; return nt < g ? nt : g; }
 int g_ws_aux_nt = 15;       // non-temporal accesses (tuning key 11): bit 0 / 1 = fetch of aux0 / aux1 of the streaming layer kernels, bit 2 =
                             // weight-gradient operands, bit 3 = `in` of the layer kernels, bit 4 = store of out1 (m_l)
 int g_ws_wide_store = 1;    // streaming layer kernels: 16-byte output stores (tuning key 12)
 const int* g_gate = nullptr; int g_gate_value = 0;      // set around one neat_sdf_forward call by neat_sdf_values_gated
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
+int g_dw_ablate = 0;        // probe runs (tuning key 17): see LayerArgsDW::ablate
+int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers 1..7 accumulated inside the tangent / reverse launches
+                            // (kernels_dw.hpp; tuning key 16; 0 = the separate wgrad_kernel_h3 launches of round 3)
+constexpr int DW_NSUB = 8;  // sub-ranges of workgroup partials summed by dw_gather_kernel (= splits per pair seen by the finish)
+template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_wsdw<EPI, FULL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI, 16>::LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  LayerArgsDW d = d0;
+  d.w.ntiles = d.w.ldp / WSP;
+  d.w.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 28);
+  d.ablate = g_dw_ablate;
+  if (FULL && (d.w.N != 256 || d.rowsA != 256)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((layer_kernel_wsdw<EPI, FULL>), dim3(dw_grid(d.w.ldp)), dim3(WST), (WsCfg<EPI, 16>::LDS), st, d);
+  return hipGetLastError();
+}
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -448,8 +471,10 @@ struct SdfWs {
   Arr Ebf, Ebf4, Ehbf, Ehbf4;     // bf16 build: octet-major copies of the PE rows 0..38 / 7..38 and of their tangents
   Arr h[9], feat, u[8], vh[9], m[8];                                                   // big (bf16 in the bf16 build)
   Arr hlo[9], featlo;             // HX3: lo planes of h_1..h_8 (read by the adjoint chain) and of the feature rows (read by the heads)
+  float *dwp, *dwscale, *dwbias;  // 16-bit builds: block-scaled f16 partials of the in-kernel weight gradients (kernels_dw.hpp): 14 jobs
   size_t total;
 };
+constexpr int DW_JOBS = 14;                 // (layer 1..7) x (tangent pair, reverse pair)
 constexpr int WSPLIT = 128;                 // fp32 build: point-splits of the weight-gradient reduction
 constexpr int WLDN = 384, WLDK = 384;       //             partial tile leading dims (>= 296+1, multiple of 128)
 constexpr int W2SPLIT = 256;                // bf16 build (256x256 tiles): splits and leading dims
@@ -490,6 +515,11 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec, int hx3 = 0) {
     if (prec) { w.Ebf = big(20); w.Ebf4 = big(16); w.Ehbf = big(20); w.Ehbf4 = big(16); w.featc = big(256); }
     w.partial = base ? base + off : nullptr;
     off += WPARTIAL_FLOATS;
+    if (prec) {
+      w.dwp = base ? base + off : nullptr; off += (size_t)DW_JOBS * DW_MAXGRID * DW_WG_UINT4 * 4;
+      w.dwscale = base ? base + off : nullptr; off += (size_t)DW_JOBS * DW_MAXGRID * 8;
+      w.dwbias = base ? base + off : nullptr; off += (size_t)DW_JOBS * DW_MAXGRID * 256;
+    }
   }
   if (hx3 && mode != 0) {
     for (int l = 1; l <= 8; ++l) w.hlo[l] = big(128);      // (a 16-bit plane of 256 rows = 128 float rows)
@@ -945,10 +975,48 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   // tangent chain (forward-mode along g^): vh_{l+1} = tangent of h_{l+1}, m_l = extra cotangent of a_l
   // bf16 build: the 217-row arrays of the skip layer carry the first 7 PE rows in the padding of their last octet, so
   // lin4's input is [h4 | PE0..6] (224 rows, octet aligned) + PE7..38 (32 rows) = 256 columns
+  // 16-bit builds: layers 1..7 run on the streaming kernels that also contract the layer's weight gradient on chip (kernels_dw.hpp):
+  // the tangent launch of layer l leaves u_l (x) vhat_l, the reverse launch a^_l (x) in_l (transposed) and the bias gradient, as
+  // block-scaled f16 partials per workgroup; one gather launch and one batched weight-norm finish follow the chains
+  bool dw = c.prec && g_dw_fused && g_layer_ws && g_wgrad_h3 && c.ldp >= 2 * WSP;
+  for (int l = 1; l <= 7; ++l) dw = dw && gr->dv[l] != nullptr && L.d[L.fwd[l]].Kpad == 256 && L.d[L.tr[l]].Kpad == 256;
+  const int dwg = dw_grid(c.ldp);
+  auto dw_job = [&](int l, int pair, LayerArgsDW& d) {
+    const size_t j = (size_t)(2 * (l - 1) + pair);
+    d.partial = reinterpret_cast<uint4*>(w.dwp) + j * DW_MAXGRID * DW_WG_UINT4;
+    d.pscale = w.dwscale + j * DW_MAXGRID * 8;
+    d.pbias = pair ? w.dwbias + j * DW_MAXGRID * 256 : nullptr;
+    d.P = c.P;
+  };
+  auto u16p = [](const Arr& a) { return reinterpret_cast<u16*>(a.p); };
+  auto dw_prof = [&](int N, int rowsA) {
+    const double P = (double)c.P;
+    // the layer (2 N 256 P) + the gradient (2 rowsA 256 P); bytes: input, two epilogue operands, outputs, the partial
+    return prof_begin(c.st, 0, 2.0 * N * 256 * P + 2.0 * rowsA * 256 * P, 256 * P * 2.0 + N * P * 2.0 * 4 + (double)dwg * DW_WG_UINT4 * 16.0);
+  };
   for (int l = 0; l < 8; ++l) {
     In a = l == 0 ? in(c.prec ? w.Ehbf : F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? (c.prec ? 224 : 217) : 256);
     In b = l == 4 ? (c.prec ? in(w.Ehbf4, 32) : in(F(w.Eh), PE_ROWS)) : NOIN;
     const bool fill = c.prec && l == 3;
+    if (dw && l >= 1) {
+      LayerArgsDW d{};
+      LayerArgsWS& s = d.w;
+      const PackDesc2& pd = L.d[L.fwd[l]];
+      s.in = u16p(w.vh[l]); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
+      s.aux0 = u16p(w.h[l + 1]); s.aux1 = u16p(w.u[l]); s.out0 = u16p(w.vh[l + 1]); s.out1 = u16p(w.m[l]);
+      s.N = kO[l]; s.ldp = c.ldp; s.kstride = pd.Kpad / 16; s.n_split = 1 << 30;
+      s.in_octs = 32; s.split_oct = 32;
+      if (l == 4) { s.in2 = u16p(w.Ehbf4); s.split_oct = 28; }
+      if (l == 3) s.padfill = u16p(w.Ehbf);
+      d.auxA2 = nullptr; d.auxA_split = 1 << 30; d.rowsA = kO[l];
+      dw_job(l, 0, d);
+      ProfSlot* ps = dw_prof(kO[l], kO[l]);
+      e = l == 3 ? launch_layer_wsdw<EPI_TAN_PF, false>(c.st, d) : launch_layer_wsdw<EPI_TAN, true>(c.st, d);
+      prof_end(c.st, ps);
+      dbg_sync(c.st, "tangent+dW layer", l, 0, 0);
+      if (e != hipSuccess) return e;
+      continue;
+    }
     if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l], 0, 0, 1 << 30,
                    fill ? w.Eh : nullptr, fill ? 7 : 0, 0, fill ? w.Ehbf : Arr{})) != hipSuccess) return e;
   }
@@ -989,17 +1057,73 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     }
     return wgrad(c, w, l, pr, 2, kO[l], gr);
   };
-  const bool inter = g_wgrad_interleave != 0;
+  const bool inter = g_wgrad_interleave != 0 && !dw;
   if (inter && (e = wgrad_layer(8)) != hipSuccess) return e;
   for (int l = 7; l >= 1; --l) {
     if (inter && (e = wgrad_layer(l)) != hipSuccess) return e;
     const int N = l == 4 ? 217 : kI[l];
+    if (dw) {
+      LayerArgsDW d{};
+      LayerArgsWS& s = d.w;
+      const PackDesc2& pd = L.d[L.tr[l]];
+      s.in = u16p(w.m[l]); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
+      s.aux0 = u16p(w.h[l]); s.aux1 = u16p(w.m[l - 1]); s.out0 = u16p(w.m[l - 1]);
+      s.N = N; s.ldp = c.ldp; s.kstride = pd.Kpad / 16; s.n_split = 1 << 30;
+      s.in_octs = (kO[l] + 7) / 8; s.split_oct = 32;
+      // second gradient operand = the layer's input rows = the aux0 image: h_l, for the skip layer [h4 (217) | PE 0..6 in the padding | PE 7..38]
+      d.auxA2 = l == 4 ? u16p(w.Ebf4) : nullptr; d.auxA_split = l == 4 ? 28 : (1 << 30);
+      // rows of the gradient = rows of a^_l.  lin3's 217: the rows up to 223 of m[3] are zeros and the octets past them are re-reads of
+      // octet 27 (finite), so rows >= 217 of the product are finite garbage that the gather never writes -- no row mask needed
+      d.rowsA = 256;
+      dw_job(l, 1, d);
+      ProfSlot* ps = dw_prof(N, d.rowsA);
+      e = (N == 256 && d.rowsA == 256) ? launch_layer_wsdw<EPI_BWD, true>(c.st, d) : launch_layer_wsdw<EPI_BWD, false>(c.st, d);
+      prof_end(c.st, ps);
+      dbg_sync(c.st, "reverse+dW layer", l, 0, 0);
+      if (e != hipSuccess) return e;
+      continue;
+    }
     if ((e = layer(c, L.tr[l], EPI_BWD, in(w.m[l], kO[l]), NOIN, nullptr, N, w.m[l - 1], Arr{}, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
   }
   if (inter) return wgrad_layer(0);
   bool done[9] = {};
+  if (dw) {
+    // one gather launch: 14 jobs x DW_NSUB sub-ranges of workgroups -> 2 DW_NSUB fp32 splits per layer in the partial-tile format;
+    // then the weight-norm finish of the seven layers in one launch
+    const int K = 256, Kld2 = (K + 1 + 7) / 8 * 8, splits = DW_NSUB;
+    const size_t region = (size_t)256 * splits * Kld2;
+    DwGatherArgs ga{};
+    WreduceBatch wb{};
+    for (int l = 1; l <= 7; ++l) {
+      float* out = w.partial + (size_t)(l - 1) * region;
+      const size_t j0 = (size_t)(2 * (l - 1)), j1 = j0 + 1;          // tangent / reverse partial sets of the layer
+      DwGatherJob& jb = ga.job[l - 1];
+      jb.partial = reinterpret_cast<const uint4*>(w.dwp) + j0 * DW_MAXGRID * DW_WG_UINT4;
+      jb.pscale = w.dwscale + j0 * DW_MAXGRID * 8;
+      jb.partial2 = reinterpret_cast<const uint4*>(w.dwp) + j1 * DW_MAXGRID * DW_WG_UINT4;
+      jb.pscale2 = w.dwscale + j1 * DW_MAXGRID * 8;
+      jb.pbias = w.dwbias + j1 * DW_MAXGRID * 256;
+      jb.nwg = dwg; jb.transposed = 0;
+      jb.out = out; jb.row_stride = (size_t)splits * Kld2; jb.split_stride = Kld2; jb.split0 = 0;
+      jb.bias_col = K; jb.rows = kO[l]; jb.cols = K;
+      const PackDesc2& pd = L.d[L.fwd[l]];
+      WreduceArgs& r = wb.a[l - 1];
+      r.partial = out; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
+      r.O = kO[l]; r.I = kI[l];
+      r.s0 = pd.s0; r.s0p = pd.s0p; r.off0 = pd.off0; r.off1 = pd.off1; r.rot = pd.rot; r.scale = pd.scale;
+      r.v = c.net->v[l]; r.g = c.net->g[l];
+      r.dv = gr->dv[l]; r.dg = gr->dg[l]; r.db = gr->db[l];
+      r.bias_col = K;
+      done[l] = true;
+    }
+    hipLaunchKernelGGL(dw_gather_kernel, dim3(DW_WG_UINT4 / 256, DW_NSUB, 7), dim3(256), 0, c.st, ga);
+    dbg_sync(c.st, "dw gather", 0, 0, 0);
+    hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(256, 7), dim3(WG), 0, c.st, wb);
+    dbg_sync(c.st, "dw finish", 0, 0, 0);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
   const int nb2 = wgrad_batch_size(c.ldp);
-  if (oct && nb2 && g_wgrad_h3) {
+  if (oct && nb2 && g_wgrad_h3 && !dw) {
     // the six hidden layers with 256 packed input columns as six problems (two (A, B) pairs each) of one launch
     const int ls[6] = {1, 2, 3, 5, 6, 7};
     WProb pb[6];
@@ -1342,6 +1466,8 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 13 && (value == 0 || value == 1)) { g_fused_adj = value; return 0; }
   if (key == 14 && value >= 0 && value <= 2) { g_head_chain = value; return 0; }
   if (key == 15 && (value == 0 || value == 1)) { g_head_wgrad_order = value; return 0; }
+  if (key == 16 && (value == 0 || value == 1)) { g_dw_fused = value; return 0; }
+  if (key == 17 && value >= 0 && value <= 7) { g_dw_ablate = value; return 0; }
   return -1;
 }
 

@@ -995,6 +995,49 @@ def test_fused_adjoint_chain_equals_streamed_layers(dev, P, half):
         lib.neat_set_tuning(13, 1)
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16", "fp16x3"])
+@pytest.mark.parametrize("R,S", [(1024, 128), (600, 98), (37, 50), (3, 7)])
+def test_in_kernel_weight_gradients_agree_with_wgrad_launches(dev, R, S, half):
+    """layer_kernel_wsdw (kernels_dw.hpp: the tangent / reverse launches of SDF layers 1..7 contract the layer's weight gradient on
+    chip, block-scaled f16 partials per workgroup, dw_gather_kernel) against the separate wgrad_kernel_h3 launches (tuning key 16 = 0).
+    Same 16-bit operands and fp32 MFMA accumulation; what differs is the summation order and ONE f16 rounding (relative to the
+    block maximum) of each workgroup's partial: every gradient tensor within 1e-3 of its maximum, outputs and every array the
+    chains write identical (the swizzled LDS image must not change the layer).  Sizes: full rounds, ragged tail tiles (P % 32 != 0),
+    fewer tiles than workgroups, one partial tile."""
+    from neat_amd import _lib, rend_util
+    m = build_model(dev, "rough", seed=5, train=True).set_precision(half)
+    sc = synth.synth_scene(seed=5, n_rays=R)
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(5, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(3)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def run(key):
+        _lib.check(_lib.lib().neat_set_tuning(16, key), "neat_set_tuning")
+        m.zero_grad()
+        torch.manual_seed(7)
+        rgb, l3, *_ = m._render(c, d, z, False)
+        ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        return rgb.detach().clone(), l3.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        r0, l0, g0 = run(0)
+        r1, l1, g1 = run(1)
+    finally:
+        _lib.lib().neat_set_tuning(16, 1)
+    assert torch.equal(r0, r1) and torch.equal(l0, l1)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        err = float((g1[k] - g0[k]).abs().max())
+        # layers 0 and 8 and the heads keep their launches, but their gradients depend on nothing the switch changes
+        assert err <= 1e-3 * float(g0[k].abs().max()) + 1e-12, (k, err, float(g0[k].abs().max()))
+        if not any(f"implicit_network.lin{l}." in k for l in range(1, 8)):
+            assert torch.equal(g0[k], g1[k]), k
+
+
 @pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("R,S", [(1024, 128), (37, 50), (3, 7)])
 def test_bf16_wgrad_kernels_agree(dev, R, S, half):
