@@ -1116,9 +1116,12 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       r.bias_col = K;
       done[l] = true;
     }
+    // (accounted with the weight-gradient class: no flops, the partials read once + the fp32 splits written and read once)
+    ProfSlot* psg = prof_begin(c.st, 1, 0.0, 14.0 * dwg * DW_WG_UINT4 * 16.0 + 2.0 * 7 * (double)region * 4.0);
     hipLaunchKernelGGL(dw_gather_kernel, dim3(DW_WG_UINT4 / 256, DW_NSUB, 7), dim3(256), 0, c.st, ga);
     dbg_sync(c.st, "dw gather", 0, 0, 0);
     hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(256, 7), dim3(WG), 0, c.st, wb);
+    prof_end(c.st, psg);
     dbg_sync(c.st, "dw finish", 0, 0, 0);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }

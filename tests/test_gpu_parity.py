@@ -1062,6 +1062,7 @@ def test_bf16_wgrad_kernels_agree(dev, R, S, half):
         return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
     try:
+        _lib.check(_lib.lib().neat_set_tuning(16, 0), "neat_set_tuning")     # every weight gradient through the kernels under test (key 16: SDF layers 1..7 in the chain launches)
         g2, g3 = grads(0), grads(1)
         _lib.check(_lib.lib().neat_set_tuning(8, 0), "neat_set_tuning")      # the two heads' hidden layers as separate launches
         g3_single = grads(1)
@@ -1079,6 +1080,7 @@ def test_bf16_wgrad_kernels_agree(dev, R, S, half):
         _lib.check(_lib.lib().neat_set_tuning(12, 0), "neat_set_tuning")     # 8-byte output stores
         batched["contiguous, temporal, narrow stores"] = grads(1)
     finally:
+        _lib.lib().neat_set_tuning(16, 1)
         _lib.lib().neat_set_tuning(1, 1)
         _lib.lib().neat_set_tuning(8, -1)
         _lib.lib().neat_set_tuning(6, 2)
