@@ -228,7 +228,15 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
         const int q = 2 * j + qq;
         pk0[qq] = make_uint2(0u, 0u); pk1[qq] = make_uint2(0u, 0u);
         const int n0 = wave * 32 + 8 * q + 4 * (int)hi5;
-        if (!fullrows && n0 >= Npad) continue;
+        if (!fullrows && fa) {       // layers with fewer rows: the quad's four gradient MFMAs up front, whether or not it has output rows
+                                     // (the accumulators must not be assigned in alternative branches: the allocator then spills them)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int t = qq * 4 + e;
+            dacc[t] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&fa[t >> 2]), *reinterpret_cast<const bf16x8*>(&fb[t & 3]), dacc[t], 0, 0, 0);
+          }
+        }
+        if (!fullrows && wave * 32 + 8 * q >= Npad) continue;      // (wave-uniform) no output rows in this quad
         const unsigned eoff = dma_off + q * (WSP * 16) + ((l31 ^ ((unsigned)q << 2)) * 16) + hi5 * 8;
         const uint2 r0v = *reinterpret_cast<const uint2*>(slot + AUX0 + eoff);
         const uint2 r1v = *reinterpret_cast<const uint2*>(slot + AUX1 + eoff);
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = acc[4 * q + e];
-          if (fa) {             // one gradient MFMA per output element: the matrix pipe works under this element's vector instructions
+          if (fa && fullrows) {             // one gradient MFMA per output element: the matrix pipe works under this element's vector instructions
             const int t = qq * 4 + e;
             dacc[t] = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&fa[t >> 2]), *reinterpret_cast<const bf16x8*>(&fb[t & 3]), dacc[t], 0, 0, 0);
           }
@@ -283,35 +291,18 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
     // (FULL: no row tests, straight-line code; the hints below ask for one MFMA per DW_VALU_PER_MFMA vector instructions) -- and
     // the fragments of the second k-step requested at the start of the second half.
     uint4 av[2], bv[4];
-    if (FULL) {
-      load_frags(0, av, bv);
-      if (tail) mask_frags(0, av, bv, true);
-      chain();
-      __builtin_amdgcn_sched_barrier(0);
-      dw_mma(av, bv, false);
-      epi_half(0, true, av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frags(1, av, bv);
-      if (tail) mask_frags(1, av, bv, true);
-      dw_mma(av, bv, false);
-      epi_half(1, true, av, bv);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      // layers with fewer rows (lin3's 217): the gradient first, waves without output rows stop there
-      if (!(d.ablate & 2)) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          load_frags(s2, av, bv);
-          mask_frags(s2, av, bv, tail);
-          dw_mma(av, bv);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (!live) continue;
-      chain();
-      epi_half(0, false);
-      epi_half(1, false);
-    }
+    load_frags(0, av, bv);
+    if (!FULL || tail) mask_frags(0, av, bv, tail);
+    if (live) chain();            // (waves without output rows -- lin3's 217 -- keep their share of the gradient: epi_half issues it)
+    __builtin_amdgcn_sched_barrier(0);
+    dw_mma(av, bv, false);
+    epi_half(0, FULL, av, bv);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(1, av, bv);
+    if (!FULL || tail) mask_frags(1, av, bv, tail);
+    dw_mma(av, bv, false);
+    epi_half(1, FULL, av, bv);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- the workgroup's partial: block-scaled f16, one scale per wave

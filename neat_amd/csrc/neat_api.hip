@@ -231,7 +231,7 @@ int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead 
 int g_dw_ablate = 0;        // probe runs (tuning key 17): see LayerArgsDW::ablate
 int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers 1..7 accumulated inside the tangent / reverse launches
                             // (kernels_dw.hpp; tuning key 16; 0 = the separate wgrad_kernel_h3 launches of round 3)
-constexpr int DW_NSUB = 8;  // sub-ranges of workgroup partials summed by dw_gather_kernel (= splits per pair seen by the finish)
+int g_dw_nsub = 8;          // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
 template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -1088,9 +1088,9 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   if (inter) return wgrad_layer(0);
   bool done[9] = {};
   if (dw) {
-    // one gather launch: 14 jobs x DW_NSUB sub-ranges of workgroups -> 2 DW_NSUB fp32 splits per layer in the partial-tile format;
+    // one gather launch: 7 layers (tangent + reverse partial sets each) x g_dw_nsub sub-ranges of workgroups -> g_dw_nsub fp32 splits per layer in the partial-tile format;
     // then the weight-norm finish of the seven layers in one launch
-    const int K = 256, Kld2 = (K + 1 + 7) / 8 * 8, splits = DW_NSUB;
+    const int K = 256, Kld2 = (K + 1 + 7) / 8 * 8, splits = g_dw_nsub;
     const size_t region = (size_t)256 * splits * Kld2;
     DwGatherArgs ga{};
     WreduceBatch wb{};
@@ -1118,7 +1118,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     }
     // (accounted with the weight-gradient class: no flops, the partials read once + the fp32 splits written and read once)
     ProfSlot* psg = prof_begin(c.st, 1, 0.0, 14.0 * dwg * DW_WG_UINT4 * 16.0 + 2.0 * 7 * (double)region * 4.0);
-    hipLaunchKernelGGL(dw_gather_kernel, dim3(DW_WG_UINT4 / 256, DW_NSUB, 7), dim3(256), 0, c.st, ga);
+    hipLaunchKernelGGL(dw_gather_kernel, dim3(DW_WG_UINT4 / 256, g_dw_nsub, 7), dim3(256), 0, c.st, ga);
     dbg_sync(c.st, "dw gather", 0, 0, 0);
     hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(256, 7), dim3(WG), 0, c.st, wb);
     prof_end(c.st, psg);
@@ -1471,6 +1471,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 15 && (value == 0 || value == 1)) { g_head_wgrad_order = value; return 0; }
   if (key == 16 && (value == 0 || value == 1)) { g_dw_fused = value; return 0; }
   if (key == 17 && value >= 0 && value <= 7) { g_dw_ablate = value; return 0; }
+  if (key == 18 && value >= 1 && value <= 16) { g_dw_nsub = value; return 0; }
   return -1;
 }
 
