@@ -163,3 +163,23 @@ def synth_z_vals(seed, n_rays, n_samples, near=0.0, far=6.0):
     edges = np.linspace(near, far, n_samples + 1)
     u = rng.uniform(0.0, 1.0, size=(n_rays, n_samples))
     return (edges[:-1] + (edges[1:] - edges[:-1]) * u).astype(np.float32)
+
+
+def write_scene_fixture(npz_path, root):
+    """tests/golden/scene_abc_00075213_8views.npz (made by tests/golden/make_scene_fixture.py: down-sampled views of the ABC scene the
+    reference ships, as arrays) -> the directory layout the dataset class reads: images/image_%04d.png, cameras.npz, hawp/image_%04d.json.
+    Returns the image resolution."""
+    import json
+    import os
+    from PIL import Image
+    d = np.load(npz_path)
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    os.makedirs(os.path.join(root, "hawp"), exist_ok=True)
+    res = int(d["images"].shape[1])
+    for i, v in enumerate(d["view_ids"].tolist()):
+        Image.fromarray(d["images"][i]).save(os.path.join(root, "images", f"image_{i:04d}.png"))
+        json.dump({"vertices": d[f"wf_{v}_vertices"].tolist(), "vertices-score": d[f"wf_{v}_scores"].tolist(),
+                   "edges": d[f"wf_{v}_edges"].tolist(), "edges-weights": d[f"wf_{v}_weights"].tolist(), "height": res, "width": res},
+                  open(os.path.join(root, "hawp", f"image_{i:04d}.json"), "w"))
+    np.savez(os.path.join(root, "cameras.npz"), intrinsics=d["intrinsics"], extrinsics=d["extrinsics"])
+    return res
