@@ -334,6 +334,30 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     note(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
+    dist_info = None
+    if dist.is_initialized():
+        # what a bad scaling curve would be diagnosed from, in the same line: every rank's own time per step (the headline uses the
+        # MAX), how long each rank's steps take WITHOUT the exchange being waited on (its GPU work), and the gradient all-reduce alone
+        # (the flat 4.9 MB bucket, 20 back-to-back calls between HIP events, after the timed region)
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        tr.bucket._ensure()
+        flat = tr.bucket.flat
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        ar = torch.tensor([e0.elapsed_time(e1) / 20.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        flat.zero_()
+        dist_info = {"backend": dist.get_backend(), "world": world,
+                     "ms_per_step_by_rank": [1e3 * float(t.item()) / args.steps for t in every],
+                     "allreduce_ms": float(ar.item()), "allreduce_bytes": int(flat.numel() * 4),
+                     "allreduce_note": "flat gradient bucket, mean of 20 back-to-back calls after the timed region, max over ranks"}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -424,6 +448,7 @@ def main():
             "step_frac_of_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (peak * world),
             "loss": float(losses["loss"].detach()),
             "roofline": roofline,
+            "dist": dist_info,
         }
         if world == 1 and not args.no_secondary:
             line["secondary"] = secondary_legs(dev, sd, args.precision, args.steps, note)

@@ -14,6 +14,16 @@
 
 namespace neat {
 
+// "Done on the CURRENT device?"  The dynamic-LDS limit of a kernel (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-device
+// attribute: a process-wide flag would leave a second GPU driven by the same process (or a device switched to after the first
+// call) launching 150 KB kernels without it.  Drop-in for the `static bool` of the launch helpers: one bit per device.
+struct DevOnce {
+  unsigned long long mask = 0;
+  static int dev() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) d = 0; return d; }
+  operator bool() const { return ((mask >> dev()) & 1ull) != 0; }
+  DevOnce& operator=(bool v) { if (v) mask |= 1ull << dev(); else mask &= ~(1ull << dev()); return *this; }
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 

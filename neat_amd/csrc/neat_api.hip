@@ -6,6 +6,8 @@
 // NEAT_F16 (precision 3) is this same file compiled a second time with -DNEAT_HALF=1 (build.sh): namespace neat becomes neat_f16, every
 // C entry point gets the prefix f16_ (f16_symbols.h, generated from include/neat_hip.h), bf16_common.hpp switches the 16-bit format
 // to IEEE half.  The primary build's entry points forward precision 3 to that twin as ITS precision 1 (NEAT_F16_FWD below).
+#include <mutex>
+#include <unordered_map>
 #if defined(NEAT_HALF) && NEAT_HALF
 #define neat neat_f16
 #include "f16_symbols.h"
@@ -163,7 +165,7 @@ inline void prof_end(hipStream_t st, ProfSlot* s) { if (s) hipEventRecord(s->e1,
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 template <int EPI> hipError_t launch_layer_f(hipStream_t st, const LayerArgs& a, int ntiles_p) {
-  static bool attr_set = false;
+  static DevOnce attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel<EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -179,7 +181,7 @@ int g_wgrad_h3 = 1;         // bf16 weight gradient of the all-bf16 256x256 laye
 int g_pt_bf16 = 2;          // 32-point column tiles per workgroup in the bf16 layer kernel: 2 (64 pts, higher occupancy) or 4
 
 template <int EPI, int PT, bool OBF> hipError_t launch_layer_h_pt(hipStream_t st, const LayerArgsH& a) {
-  static bool attr_set = false;
+  static DevOnce attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_h<EPI, PT, OBF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -233,7 +235,7 @@ int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers
                             // (kernels_dw.hpp; tuning key 16; 0 = the separate wgrad_kernel_h3 launches of round 3)
 int g_dw_nsub = 8;          // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
 template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
-  static bool attr_set = false;
+  static DevOnce attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_wsdw<EPI, FULL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI, 16>::LDS);
@@ -249,7 +251,7 @@ template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const
   return hipGetLastError();
 }
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
-  static bool attr_set = false;
+  static DevOnce attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_ws<EPI, KS, OUTF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI, KS>::LDS);
@@ -613,7 +615,7 @@ hipError_t sdf_primal(const Ctx& c, const SdfWs& w, bool full, float radius = 0.
     ProfSlot* ps = prof_begin(c.st, 2, fl, fbytes);
     if (g_fused_ws) {
       // weight-stationary persistent kernel: batches of 128 points (64 when that balances the CUs better)
-      static bool attr_done = false;      // raise the dynamic-LDS limit of all variants once (not a stream operation: keep it out of graph capture)
+      static DevOnce attr_done;      // raise the dynamic-LDS limit of all variants once (not a stream operation: keep it out of graph capture)
       if (!attr_done) {
         hipError_t e0 = hipSuccess;
         auto raise = [&](auto kern, int bytes) { if (e0 == hipSuccess) e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
@@ -774,7 +776,7 @@ hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob,
   const int splits = (c.P + chunk - 1) / chunk;
   const size_t region = (size_t)N * splits * Kld2;
   if ((size_t)nprob * region > WPARTIAL_FLOATS - WSTAGE_FLOATS) return hipErrorInvalidValue;
-  static bool attr3 = false;
+  static DevOnce attr3;
   if (!attr3) {
     hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
     if (e0 != hipSuccess) return e0;
@@ -876,7 +878,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     prof_end(c.st, ps);
     r.row_stride = (size_t)splits * WLDK; r.split_stride = WLDK;
   } else {
-    static bool attr_set = false;
+    static DevOnce attr_set;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h2), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
       if (e != hipSuccess) return e;
@@ -897,7 +899,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     const bool two = K > 256;
     if (two && (r0 != 256 || r1 == 0 || r1 > 256)) h3 = false;
     if (h3) {
-      static bool attr3_set = false;
+      static DevOnce attr3_set;
       if (!attr3_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1147,9 +1149,28 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
 // heads
 // ------------------------------------------------------------------------------------------------
 // n_main: points that hold ray samples (the heads' outputs beyond them are never read)
+// Which forward path filled a heads workspace: the fused backward chain reads the ReLU-mask arrays, which only the fused forward
+// chains write (and the split-precision forward only under tuning key 14 == 2).  The switch is a mutable process global; a
+// backward that runs under another setting than its forward (a key changed in between, two models sharing the process) must not
+// read masks that were never written.  Keyed by the first array of the workspace; host-side, so a captured graph records the
+// pairing that was valid at capture.
+std::mutex g_head_path_mutex;
+std::unordered_map<const void*, int> g_head_path;      // workspace -> 1: masks written by the forward of this workspace
+void note_head_path(const HeadWs& h, bool masks_written) {
+  std::lock_guard<std::mutex> lock(g_head_path_mutex);
+  if (g_head_path.size() > 4096) g_head_path.clear();  // (workspaces come and go with the caller's allocator)
+  g_head_path[h.small_r] = masks_written ? 1 : 0;
+}
+bool head_masks_written(const HeadWs& h) {
+  std::lock_guard<std::mutex> lock(g_head_path_mutex);
+  auto it = g_head_path.find(h.small_r);
+  return it != g_head_path.end() && it->second == 1;
+}
+
 hipError_t heads_forward(const Ctx& c, const HeadWs& h, Arr feat, Arr featlo = Arr{}, bool save = true, int n_main = -1) {
   const PackLayout& L = c.L();
   hipError_t e;
+  note_head_path(h, save && c.prec && ((c.hx3 && g_head_chain == 2) || (!c.hx3 && g_head_chain != 0)));
   // (16-bit builds: the octet-major copies of the small head inputs, smallbf_r / smallbf_a, were written by head_inputs_kernel)
   if (c.hx3) {
     // split-precision forward: one fused launch per head (kernels_x3.hpp); the hidden activations stay on chip, their hi planes
@@ -1274,8 +1295,9 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     const int top_rows = head ? 6 : 3;
     const float* small = head ? h.small_a : h.small_r;
     const int srows = head ? SMALL_A : SMALL_R;
-    if (oct && g_head_chain == 2) {
-      // fused backward chain (kernels_heads.hpp): the ReLU masks come from the forward chain of this step
+    if (oct && g_head_chain == 2 && head_masks_written(h)) {
+      // fused backward chain (kernels_heads.hpp): the ReLU masks come from the forward chain of this step (a forward that took
+      // another path leaves none: per-layer launches below, which read the saved activations)
       HeadBwdArgs a{};
       a.P = c.P; a.ldp = c.ldp;
       a.nvalid = ((n_main < 0 ? c.P : n_main) + 63) / 64;
@@ -2049,7 +2071,7 @@ int neat_lsap(const float* cost, int nr, int nc, const unsigned char* row_mask, 
   constexpr size_t LSAP_LDS_MAX = 156 * 1024;
   a.cost_lds_off = -1;
   if (dbytes + ibytes <= LSAP_LDS_MAX) {
-    static bool attr_set = false;
+    static DevOnce attr_set;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX);
       if (e != hipSuccess) return (int)e;

@@ -19,8 +19,13 @@ def init_from_env(backend=None):
     force = os.environ.get("NEAT_FORCE_DIST") == "1"      # world size 1 with a real process group: exercises RCCL on a single GPU
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29577")      # (forced single-rank group: nothing else needs to find it)
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            # forced single-rank group: nothing else needs to find it, so any free port will do -- a fixed one collides when two such
+            # processes share a host (bench.py's RCCL world-1 leg next to the pytest RCCL check)
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or os.environ.get("NEAT_DIST_BACKEND") or None      # gloo on GPUs: functional checks with ranks sharing a device
         if backend is None:
@@ -90,8 +95,11 @@ class FlatGradBucket:
         src = [p.grad for p, h in zip(self.params, have) if h]
         if src:
             torch._foreach_copy_([v for v, h in zip(self._views, have) if h], src)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.mul_(1.0 / world)
+        if dist.get_backend(self.group) == "nccl":         # RCCL averages in the collective: one launch less than sum + scale
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.mul_(1.0 / world)
         for p, v in zip(self.params, self._views):
             p.grad = v
 

@@ -1,6 +1,7 @@
 """One training step of the hot path as the reference trainer runs it (code/training/volsdf_train.py:361-374,408):
 forward -> loss -> zero_grad/backward -> [gradient all-reduce] -> Adam step -> per-iteration ExponentialLR."""
 import torch
+import torch.distributed as dist
 
 from . import networks, synth
 from .dp import FlatGradBucket
@@ -127,7 +128,13 @@ class Trainer:
         if entry.static_z is not None:
             self.model.z_vals_override = entry.static_z
         ok = False
-        finished = 0                                        # optimizer steps taken so far by this call
+        finished = 0                                        # gradient all-reduces issued so far by this call: what the other ranks
+                                                            # count on -- an exception AFTER the exchange of a warm-up step (say, in
+                                                            # optimizer.step) must not make this rank issue one collective more
+
+        def count_collective():
+            nonlocal finished
+            finished += 1
         torch.cuda.synchronize()                            # (captures are rare: start from an idle device)
         try:
             if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
@@ -138,8 +145,7 @@ class Trainer:
                 for _ in range(warmup):                     # (real optimizer steps on this batch)
                     self._refill_randoms(entry)
                     self._fwd_bwd(entry)
-                    self._finish_step(None)
-                    finished += 1
+                    self._finish_step(None, on_collective=count_collective)
                 if not entry.randoms:                       # no warm-up step ran (auto-capture of a layout that already ran eagerly):
                     rng = torch.get_rng_state()             # one forward registers the draw sites, without consuming the CPU stream
                     with torch.no_grad():
@@ -183,7 +189,9 @@ class Trainer:
             self._finish_step(entry)                        # the capture pass itself does not execute: replay it once
             self.replays += 1
             self._last = entry
-        elif warmup > 0:
+        else:
+            self._last = None                               # check_nan() reads the loss's own flag again, not the previous layout's
+        if not ok and warmup > 0:
             self.optimizer.zero_grad(set_to_none=True)      # (whatever a half-finished attempt left in .grad)
             for _ in range(warmup + 1 - finished):          # the steps the successful path would have taken
                 self.step_eager(model_input, ground_truth)
@@ -198,13 +206,15 @@ class Trainer:
         losses["loss"].backward()
         return out, losses
 
-    def _finish_step(self, entry):
+    def _finish_step(self, entry, on_collective=None):
         if entry is not None:
             for p, g in entry.static_grads:                 # another graph or an eager step re-pointed .grad: this graph writes ITS tensors
                 if p.grad is not g:
                     p.grad = g
             entry.graph.replay()
         self.bucket.all_reduce_mean()
+        if on_collective is not None:
+            on_collective()
         self.optimizer.step()
         self.scheduler.step()
 
@@ -228,8 +238,16 @@ class Trainer:
     def check_nan(self):
         """Graph mode keeps the line-loss NaN flag on the device (loss.nan_check == "off"); this reads it (one sync)."""
         flag = self._last.nan_flag if self._last is not None else self.loss.nan_flag
-        if flag is not None and bool(flag.item()):
-            raise FloatingPointError("line loss is NaN (the reference drops into pdb here, loss_wfr.py:66-67)")
+        bad = flag is not None and bool(flag.item())
+        # data parallel: the flag belongs to THIS rank's batch.  The ranks agree before anyone raises -- a rank that stopped alone would
+        # leave the others blocked in the next gradient all-reduce until the watchdog tears the job down.  (Every rank calls this at
+        # the same iterations: the runner's log interval and checkpoint epochs.)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([1.0 if bad else 0.0], device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bad = bool(t.item() > 0.0)
+        if bad:
+            raise FloatingPointError("line loss is NaN on at least one rank (the reference drops into pdb here, loss_wfr.py:66-67)")
 
     def _load_batch(self, entry, model_input, ground_truth):
         """Every tensor of the fresh batch is copied into the captured tensors, in ONE multi-tensor launch (a few KB per step).  No

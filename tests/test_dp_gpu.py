@@ -43,3 +43,29 @@ def test_rccl_all_reduce_on_one_gpu():
                          timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "RCCL world-1 check OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_bench_line_with_the_collective_agrees_with_the_plain_line():
+    """The N = 1 line of a scaling run must agree with the plain bench line (VERDICT r3 #7a): `bench.py --gpus 1` with a forced
+    world-size-1 RCCL group -- the flat gradient bucket through a real all-reduce after every replay -- against the same run without
+    a group: value within 3 %; the forced run's line carries the per-rank step time and the all-reduce time (`dist`)."""
+    import json
+
+    def run(extra_env):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NEAT_FORCE_DIST")}
+        env.update(extra_env)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "3", "--no-secondary",
+                            "--no-cpu-baseline", "--no-prof"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+
+    plain = run({})
+    forced = run({"NEAT_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert plain["dist"] is None and forced["dist"]["backend"] == "nccl" and forced["dist"]["world"] == 1
+    assert len(forced["dist"]["ms_per_step_by_rank"]) == 1 and forced["dist"]["allreduce_bytes"] == 4 * 1219274
+    assert 0.0 < forced["dist"]["allreduce_ms"] < 1.0, forced["dist"]
+    assert abs(forced["value"] / plain["value"] - 1.0) <= 0.03, (forced["value"], plain["value"], forced["dist"])
