@@ -557,6 +557,9 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
 // (training: the tangent chain and the weight gradient read u_l), writes u_{l-1} once: 2 streams per layer where the streaming
 // EPI_REV launches move 3 (in, aux, out) -- and 8 launches + the seed kernel become one.
 // ===============================================================================================================
+#ifndef NEAT_ADJ_SINGLE
+#define NEAT_ADJ_SINGLE 1      // 1: the ragged end of a workgroup's tile range goes tile by tile through chain_single (0: as one partial pipeline batch)
+#endif
 template <bool SAVE>
 __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int ntiles, int nwg) {
   constexpr int NT = 4, RT = 1;
@@ -596,9 +599,14 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
   __syncthreads();
 
   const int t_begin = (int)(((long long)blockIdx.x * ntiles) / nwg), t_end = (int)(((long long)(blockIdx.x + 1) * ntiles) / nwg);
+  // A batch = NT tiles through the stage pipeline.  What is left of a workgroup's range (1 .. NT-1 tiles: at 133 120 points 64 of the
+  // 256 workgroups own 17 tiles) goes tile by tile through `chain_single` below: a pipeline batch costs its full latency whatever it
+  // holds, a single tile about a sixth of it (round 4; the primal chain has had this path since round 2).
   for (int tile0 = t_begin; tile0 < t_end; tile0 += NT) {
-    const int p0 = tile0 * 32;
-    const int nt = min(NT, t_end - tile0);
+   const int ntb = min(NT, t_end - tile0);
+   for (int sub = 0; sub < ((ntb == NT || !NEAT_ADJ_SINGLE) ? 1 : ntb); ++sub) {
+    const int p0 = (tile0 + sub) * 32;
+    const int nt = (ntb == NT || !NEAT_ADJ_SINGLE) ? ntb : 1;
     L.gquad = ((unsigned)(4 * RT * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.fcol = (unsigned)(p0 + (lane & 31));
     // the row stride as an opaque per-batch VGPR: with a loop-invariant stride the 64 (array, quad) row bases of the sixteen h / u
@@ -698,15 +706,71 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
 #undef ADJ_STAGE_ROLL
 #undef ADJ_STAGE
     };
+    // ---- one tile: per layer the 16 k-steps (the next layer's weight slice rolls into the registers behind them), then the whole
+    // epilogue, then the barrier that publishes the tile
+    auto chain_single = [&]() {
+      constexpr bool FULL = false;
+      auto load_h = [&](float4 (&dst)[4 * RT], const u16* hsrc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)q * L.ldp16 + L.gquad));
+          dst[q].x = __uint_as_float(v.x); dst[q].y = __uint_as_float(v.y);
+        }
+      };
+      float4 hq[4 * RT];
+      {
+        float4 wq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(L.bias + (8 * q) * 4);
+        load_h(hq, a.h[8]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned h0 = __float_as_uint(hq[q].x), h1 = __float_as_uint(hq[q].y);
+          const uint2 v = make_uint2(pack2(wq[q].x * dphi_fast(bf_lo(h0)), wq[q].y * dphi_fast(bf_hi(h0))),
+                                     pack2(wq[q].z * dphi_fast(bf_lo(h1)), wq[q].w * dphi_fast(bf_hi(h1))));
+          *reinterpret_cast<uint2*>(L.quad[0] + (q * BP) * 16) = v;
+          if (SAVE) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.u[7]) + ((unsigned)q * L.ldp16 + L.gquad)) = v;
+        }
+      }
+      __syncthreads();
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R7;
+      typedef F6RevCfg<SAVE, 256, 0, 1 << 30> R6;
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R5;
+      typedef F6RevCfg<SAVE, 256, 0, 217> R4;
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R3;
+      typedef F6RevCfg<SAVE, 256, 0, 1 << 30> R2;
+      typedef F6RevCfg<SAVE, 256, 1, 1 << 30> R1;
+      typedef F6RevCfg<false, 39, 0, 0> R0;
+      f32x16 acc[2][RT];
+      uint4 ring[NEAT_F6_RING];
+      constexpr int RD = NEAT_F6_RING;
+#define ADJ_LAYER1(SRC_, ECUR_, HCUR_, HAS_H_, HSRC_, FCUR_, WNEXT_, NNEXT_)                                                          \
+      { _Pragma("unroll") for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[SRC_] + j * 2 * BP * 16);  \
+        if (HAS_H_) load_h(hq, HSRC_);                                                                                              \
+        L.frows = FCUR_;                                                                                                            \
+        f6_stage<NT, RT, FULL, true, 16, SRC_, F6NoEpi, 0, false, true>(L, wA, 0, acc[0], acc[1], hq, 0, 1, nullptr, wave, hi, ring, nullptr, w_addr(WNEXT_, NNEXT_)); \
+        f6_stage<NT, RT, FULL, false, 16, 0, ECUR_, 0, true>(L, wA, 0, acc[1], acc[0], hq, 0, 1, HCUR_, wave, hi, ring, nullptr); }
+      ADJ_LAYER1(0, R7, a.u[6], 1, a.h[7], nullptr, a.Wp[6], 256)
+      ADJ_LAYER1(1, R6, a.u[5], 1, a.h[6], nullptr, a.Wp[5], 256)
+      ADJ_LAYER1(0, R5, a.u[4], 1, a.h[5], nullptr, a.Wp[4], 256)
+      ADJ_LAYER1(1, R4, a.u[3], 1, a.h[4], a.es, a.Wp[3], 256)
+      ADJ_LAYER1(0, R3, a.u[2], 1, a.h[3], nullptr, a.Wp[2], 256)
+      ADJ_LAYER1(1, R2, a.u[1], 1, a.h[2], nullptr, a.Wp[1], 256)
+      ADJ_LAYER1(0, R1, a.u[0], 1, a.h[1], nullptr, a.Wp[0], 39)
+      ADJ_LAYER1(1, R0, nullptr, 0, a.h[1], a.e0, a.Wp[7], 256)       // (the next tile or batch starts with W_7 again)
+#undef ADJ_LAYER1
+    };
 #ifndef NEAT_ADJ_ONE_VARIANT
 #define NEAT_ADJ_ONE_VARIANT 1
 #endif
     // one variant of the chain for full and partial batches (per-tile `t < nt` predicates on the loads / stores): with a second,
     // predicate-free copy for full batches the rolling weight registers are carried into both copies and the allocator spills them
-    if (NEAT_ADJ_ONE_VARIANT) chain(std::false_type{});
+    if (NEAT_ADJ_SINGLE && ntb != NT) chain_single();
+    else if (NEAT_ADJ_ONE_VARIANT) chain(std::false_type{});
     else if (nt == NT) chain(std::true_type{});
     else chain(std::false_type{});
     __syncthreads();
+   }
   }
 }
 
