@@ -313,7 +313,10 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *  14 16-bit builds: the two heads as fused chains (kernels_heads.hpp): 2 = forward and backward (default), 1 = forward only,
  *     0 = one layer_kernel_ws launch per layer
  *  15 with the fused head backward: 1 = a head's weight gradients right after its backward chain (default: its cotangents are the
- *     last 270 MB written, -0.025 ms per step), 0 = after both chains, the two heads' hidden layers batched together */
+ *     last 270 MB written, -0.025 ms per step), 0 = after both chains, the two heads' hidden layers batched together
+ *  16 16-bit builds: weight gradients of the SDF layers 1..7 contracted inside the tangent / reverse launches that hold both
+ *     operands in LDS (kernels_dw.hpp): 1 = from 49 152 points on (default), 2 = always, 0 = never (separate launches)
+ *  17 probe switch of those launches (4 = no partial stores: wrong results)      18 sub-ranges of their gather launch (default 8) */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);

@@ -115,6 +115,11 @@ def lib():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l
+        # A/B switches from the environment (probe scripts; the defaults are what the tests and the bench run):
+        # NEAT_TUNING="16=0,18=4" -> neat_set_tuning(16, 0), neat_set_tuning(18, 4)
+        for kv in filter(None, os.environ.get("NEAT_TUNING", "").split(",")):
+            k, v = kv.split("=")
+            check(l.neat_set_tuning(int(k), int(v)), f"NEAT_TUNING {kv}")
     return _lib
 
 

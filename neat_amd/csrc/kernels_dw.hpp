@@ -36,7 +36,7 @@ struct LayerArgsDW {
   uint4* partial;                      // [grid][8 waves][8 column blocks][2][64 lanes] x 8 f16
   float* pscale;                       // [grid][8]: factor that takes the stored values back
   float* pbias;                        // reverse launches: [grid][256] row sums of the input tile (bias gradient); else null
-  int ablate;                          // probe runs only (results WRONG): 2 = no gradient at all (every stage takes the plain path), 4 = no partial stores, 8 = plain path with the gradient
+  int ablate;                          // probe runs only (results WRONG; tuning key 17): 4 = no partial stores
 };
 
 constexpr int DW_WG_UINT4 = 8 * 8 * 2 * 64;      // uint4 per workgroup partial (128 KiB)

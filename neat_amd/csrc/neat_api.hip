@@ -232,7 +232,10 @@ int g_fused_interleave = 0; // fused primal chain: batches interleaved over the 
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
 int g_dw_ablate = 0;        // probe runs (tuning key 17): see LayerArgsDW::ablate
 int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers 1..7 accumulated inside the tangent / reverse launches
-                            // (kernels_dw.hpp; tuning key 16; 0 = the separate wgrad_kernel_h3 launches of round 3)
+                            // (kernels_dw.hpp; tuning key 16): 1 = where it pays (>= DW_MIN_POINTS points: the partials and their gather cost
+                            // the same ~1 GB of traffic per pass whatever the point count, the operand reads they replace scale with it),
+                            // 2 = always, 0 = never (the separate wgrad_kernel_h3 launches of round 3)
+constexpr int DW_MIN_POINTS = 49152;
 int g_dw_nsub = 8;          // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
 template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
   static DevOnce attr_set;
@@ -980,7 +983,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   // 16-bit builds: layers 1..7 run on the streaming kernels that also contract the layer's weight gradient on chip (kernels_dw.hpp):
   // the tangent launch of layer l leaves u_l (x) vhat_l, the reverse launch a^_l (x) in_l (transposed) and the bias gradient, as
   // block-scaled f16 partials per workgroup; one gather launch and one batched weight-norm finish follow the chains
-  bool dw = c.prec && g_dw_fused && g_layer_ws && g_wgrad_h3 && c.ldp >= 2 * WSP;
+  bool dw = c.prec && g_dw_fused && g_layer_ws && g_wgrad_h3 && c.ldp >= 2 * WSP && (g_dw_fused == 2 || c.ldp >= DW_MIN_POINTS);
   for (int l = 1; l <= 7; ++l) dw = dw && gr->dv[l] != nullptr && L.d[L.fwd[l]].Kpad == 256 && L.d[L.tr[l]].Kpad == 256;
   const int dwg = dw_grid(c.ldp);
   auto dw_job = [&](int l, int pair, LayerArgsDW& d) {
@@ -1491,7 +1494,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 13 && (value == 0 || value == 1)) { g_fused_adj = value; return 0; }
   if (key == 14 && value >= 0 && value <= 2) { g_head_chain = value; return 0; }
   if (key == 15 && (value == 0 || value == 1)) { g_head_wgrad_order = value; return 0; }
-  if (key == 16 && (value == 0 || value == 1)) { g_dw_fused = value; return 0; }
+  if (key == 16 && value >= 0 && value <= 2) { g_dw_fused = value; return 0; }
   if (key == 17 && value >= 0 && value <= 7) { g_dw_ablate = value; return 0; }
   if (key == 18 && value >= 1 && value <= 16) { g_dw_nsub = value; return 0; }
   return -1;

@@ -5,7 +5,7 @@
 usage: python scripts/make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [precision]"""
 import csv, json, os, sys
 
-CLASSES = {"layer_kernel": ("layer_kernel_ws", "layer_kernel_h", "layer_kernel<"), "wgrad_kernel": ("wgrad_kernel",),
+CLASSES = {"layer_kernel": ("layer_kernel_ws", "layer_kernel_h", "layer_kernel<"), "wgrad_kernel": ("wgrad_kernel", "dw_gather"),
            "sdf_fused_kernel": ("sdf_fused",), "sdf_adjoint_kernel": ("sdf_adjoint_w64",),
            "sdf_chain_x3_kernel": ("sdf_chain_x3",), "sdf_adjoint_x3_kernel": ("sdf_adjoint_x3",),
            "head_chain_kernel": ("head_chain_kernel", "head_bwd_chain_kernel", "head_chain_x3")}

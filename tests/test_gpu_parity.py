@@ -1016,7 +1016,7 @@ def test_in_kernel_weight_gradients_agree_with_wgrad_launches(dev, R, S, half):
     cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
 
     def run(key):
-        _lib.check(_lib.lib().neat_set_tuning(16, key), "neat_set_tuning")
+        _lib.check(_lib.lib().neat_set_tuning(16, 2 * key), "neat_set_tuning")     # 2 = at every size (1, the default: from 49 152 points on)
         m.zero_grad()
         torch.manual_seed(7)
         rgb, l3, *_ = m._render(c, d, z, False)
