@@ -114,7 +114,7 @@ def secondary_legs(dev, sd, headline_precision, steps, note):
             tr.step(inp, gt)
         graphed = tr.capture(inp, gt)
         # untimed: the first ~20 replays of the first sampler graph of a process run 0.6-1.2 ms slow (host-side enqueue of the refilled
-        # random draws next to a cold launch path; scripts/sampler_first_steps.py), a one-time 20 ms that is not the steady state
+        # random draws next to a cold launch path; scripts/probes/sampler_first_steps.py), a one-time 20 ms that is not the steady state
         for _ in range(20):
             tr.step(inp, gt)
         torch.cuda.synchronize()

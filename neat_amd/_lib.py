@@ -9,7 +9,7 @@ NUM_LAYERS = 19
 ABI_VERSION = 9
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "fp16x3": 4}
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/abl_build.sh)
+LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/probes/abl_build.sh)
 
 c_fp = ctypes.c_void_p      # device float* (passed as integer addresses)
 

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
 // ===============================================================================================================
 // Phase-staggered fused primal chain (generation 4).
 //
-// What the ablations of the stage-pipelined kernel above showed (scripts/probe_fused_abl.py, values mode, P = 133 120):
+// What the ablations of the stage-pipelined kernel above showed (scripts/probes/probe_fused_abl.py, values mode, P = 133 120):
 // MFMAs + B-fragment reads alone 81 us (4 waves x 64 rows) = the matrix-pipe time; the epilogue alone 74 us; both in one
 // instruction stream 236 us -- more than their sum, whatever the interleave (fine, per 2 / 4 / 16 k-steps), the fragment
 // ring depth, the accumulator register class or the barrier count.  A wave that mixes MFMAs with VALU / LDS work runs

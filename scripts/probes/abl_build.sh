@@ -1,5 +1,5 @@
 #!/bin/bash
-# Probe builds of libneat_hip.so with extra -D flags:  scripts/abl_build.sh NAME -DNEAT_F6_ABLATE=9 ...   -> abl_libs/libneat_NAME.so
+# Probe builds of libneat_hip.so with extra -D flags:  scripts/probes/abl_build.sh NAME -DNEAT_F6_ABLATE=9 ...   -> abl_libs/libneat_NAME.so
 # The flags go to ONE translation unit: NAME starting with "f": the fused chains' unit (primary build); "x": the f16 TWIN of the fused
 # chains' unit (the split-precision chains of kernels_x3.hpp run there); otherwise neat_api.hip (primary).  The other units are
 # compiled once without flags and cached in abl_libs/ (delete abl_libs/*.o after editing sources).

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel averages of the C2 train step for every library in abl_libs/:   bash scripts/abl_step.sh PATTERN [PATTERN ...]
+# per-kernel averages of the C2 train step for every library in abl_libs/:   bash scripts/probes/abl_step.sh PATTERN [PATTERN ...]
 R=$PWD; O=$R/gpurun_out/abl_step; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp PYTHONPATH=$R
 for lib in $R/abl_libs/libneat_*.so; do
   n=$(basename $lib .so)

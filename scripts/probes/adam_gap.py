@@ -1,4 +1,4 @@
-"""GPU-side duration of graph replay and of the Adam launch that follows it (HIP events), given depths vs sampler.  python scripts/adam_gap.py [sampler]"""
+"""GPU-side duration of graph replay and of the Adam launch that follows it (HIP events), given depths vs sampler.  python scripts/probes/adam_gap.py [sampler]"""
 import sys, torch
 sys.path.insert(0, '.')
 from neat_amd import synth

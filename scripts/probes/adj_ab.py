@@ -1,6 +1,6 @@
 """Fused adjoint chain (tuning key 13 = 1) against the seed + eight streaming launches (key 13 = 0): normals and the full train-step
 gradients must agree bit for bit (same bf16 products, same k order, same epilogue arithmetic); then the times.
-    python scripts/adj_ab.py [P]"""
+    python scripts/probes/adj_ab.py [P]"""
 import sys
 import torch
 sys.path.insert(0, '.')

@@ -1,7 +1,7 @@
 #!/bin/bash
-# kernel times of get_outputs with the fused / streamed adjoint chain:  bash scripts/adj_prof.sh
+# kernel times of get_outputs with the fused / streamed adjoint chain:  bash scripts/probes/adj_prof.sh
 R=$PWD; O=$R/gpurun_out/adjp; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R; cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/s -- python $R/scripts/adj_ab.py > $O/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/s -- python $R/scripts/probes/adj_ab.py > $O/run.log 2>&1
 tail -6 $O/run.log
 python - "$(find $O/s -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv, sys

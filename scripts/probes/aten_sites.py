@@ -1,5 +1,5 @@
 """Which Python lines of neat_amd issue ATen operators on CUDA tensors during one C2 train step (forward + loss; the backward pass
-runs their derivatives)?  TorchDispatchMode sees every operator call with its Python stack.   python scripts/aten_sites.py"""
+runs their derivatives)?  TorchDispatchMode sees every operator call with its Python stack.   python scripts/probes/aten_sites.py"""
 import sys, traceback, collections
 import torch
 sys.path.insert(0, '.')

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel effect of the persistent grid size (tuning key 3) on the streaming layer launches:  bash scripts/grid_probe.sh "256 512 128"
+# per-kernel effect of the persistent grid size (tuning key 3) on the streaming layer launches:  bash scripts/probes/grid_probe.sh "256 512 128"
 R=$PWD; O=$R/gpurun_out/gridp; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R; cd $R
 for v in ${1:-256 512}; do
   rocprofv3 --kernel-trace --output-format csv -d $O/v$v -- python $R/scripts/bench_tune.py 3=$v -- --steps 4 --warmup 2 --no-cpu-baseline --no-prof --no-graph > $O/v$v.log 2>&1

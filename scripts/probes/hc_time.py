@@ -1,6 +1,6 @@
 """Main pass only (neat_render_forward + neat_render_backward on 1024 rays x S samples + 2048 eikonal points, random cotangents), a few
 times: the fused head chains without the junction block / loss around them (probe builds with wrong results cannot hang a matching).
-Run under rocprofv3 --kernel-trace --stats (scripts/hc_ab.sh).   python scripts/hc_time.py [precision] [samples per ray] [tuning key=value ...]"""
+Run under rocprofv3 --kernel-trace --stats (scripts/probes/hc_ab.sh).   python scripts/probes/hc_time.py [precision] [samples per ray] [tuning key=value ...]"""
 import sys
 import torch
 sys.path.insert(0, '.')

@@ -1,6 +1,6 @@
 """Fused head chains (tuning key 14: 2 = forward + backward, 1 = forward, 0 = per-layer launches) against the per-layer path on the same
 build: one C2-shaped train step (1024 rays x S samples + 2048 eikonal points), outputs and all gradients; then the step times.
-  python scripts/head_chain_check.py [precision] [samples per ray]"""
+  python scripts/probes/head_chain_check.py [precision] [samples per ray]"""
 import sys, time
 import torch
 sys.path.insert(0, '.')

@@ -1,5 +1,5 @@
 """Where does the host spend the eager train step with the sampler on?  Per-step wall times with and without the cyclic GC, then a
-cProfile of 10 steps.  usage: python scripts/host_stall.py"""
+cProfile of 10 steps.  usage: python scripts/probes/host_stall.py"""
 import cProfile, gc, pstats, sys, time
 import torch
 sys.path.insert(0, '.')

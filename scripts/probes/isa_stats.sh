@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/isa_stats.sh <mangled-name-regex>   -- builds with -save-temps and prints register/spill stats
+# usage: scripts/probes/isa_stats.sh <mangled-name-regex>   -- builds with -save-temps and prints register/spill stats
 cd /root/repo/neat_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I. neat_api.hip -o /tmp/isa_stats_scratch.so -save-temps=obj 2>&1 | grep -E "error|warning: v" | head
 python3 - "$1" <<'PY'
 import re,sys

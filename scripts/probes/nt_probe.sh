@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel effect of the non-temporal fetch bits (tuning key 11) on the full-size streaming layer launches:  bash scripts/nt_probe.sh "15 14 11 10 0"
+# per-kernel effect of the non-temporal fetch bits (tuning key 11) on the full-size streaming layer launches:  bash scripts/probes/nt_probe.sh "15 14 11 10 0"
 R=$PWD; O=$R/gpurun_out/ntp; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R; cd $R
 for v in ${1:-15 14 11 10 0}; do
   rocprofv3 --kernel-trace --output-format csv -d $O/v$v -- python $R/scripts/bench_tune.py 11=$v -- --steps 4 --warmup 2 --no-cpu-baseline --no-prof --no-graph > $O/v$v.log 2>&1

@@ -1,10 +1,10 @@
-# PMC passes over the fused primal kernels.  usage: bash scripts/pmc_fused.sh "GENS" "MODES"   (default "2" "values save")
+# PMC passes over the fused primal kernels.  usage: bash scripts/probes/pmc_fused.sh "GENS" "MODES"   (default "2" "values save")
 GENS=${1:-2}; MODES=${2:-values save}
 R=$PWD; O=$R/gpurun_out/pmc_fused; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp PYTHONPATH=$R
 for g in $GENS; do for m in $MODES; do
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $O/a$g$m -- python $R/scripts/probe_fused_pmc.py $g $m > $O/a$g$m.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_SALU --output-format csv -d $O/b$g$m -- python $R/scripts/probe_fused_pmc.py $g $m > $O/b$g$m.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $O/c$g$m -- python $R/scripts/probe_fused_pmc.py $g $m > $O/c$g$m.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $O/a$g$m -- python $R/scripts/probes/probe_fused_pmc.py $g $m > $O/a$g$m.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_SALU --output-format csv -d $O/b$g$m -- python $R/scripts/probes/probe_fused_pmc.py $g $m > $O/b$g$m.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $O/c$g$m -- python $R/scripts/probes/probe_fused_pmc.py $g $m > $O/c$g$m.log 2>&1
 done; done
 python - <<PY
 import csv, glob, collections

@@ -1,4 +1,4 @@
-"""Time the fused primal kernel (values mode) of an ablated library build: NEAT_LIB=path python scripts/probe_fused_abl.py GEN"""
+"""Time the fused primal kernel (values mode) of an ablated library build: NEAT_LIB=path python scripts/probes/probe_fused_abl.py GEN"""
 import os, sys, torch
 sys.path.insert(0, '.')
 from neat_amd import _lib

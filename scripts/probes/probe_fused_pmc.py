@@ -1,11 +1,11 @@
 """One fused-primal kernel generation in a loop (values mode or save mode), for rocprofv3 --pmc runs.
-    python scripts/probe_fused_pmc.py GEN MODE [P]      MODE: values | save"""
+    python scripts/probes/probe_fused_pmc.py GEN MODE [P]      MODE: values | save"""
 import os, sys
 import torch
 sys.path.insert(0, '.')
 from neat_amd import _lib
 if os.environ.get('NEAT_LIB'):
-    _lib.LIB_PATH = os.environ['NEAT_LIB']      # a probe build from scripts/abl_build.sh
+    _lib.LIB_PATH = os.environ['NEAT_LIB']      # a probe build from scripts/probes/abl_build.sh
 from neat_amd import networks, synth
 gen, mode = int(sys.argv[1]), sys.argv[2]
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 133120

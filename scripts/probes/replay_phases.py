@@ -1,5 +1,5 @@
 """Where a replayed step spends its time: the HIP graph alone, graph + Adam, the whole Trainer.step.
-    python scripts/replay_phases.py [sampler]      (sampler: depths from the ErrorBoundSampler instead of given depths)"""
+    python scripts/probes/replay_phases.py [sampler]      (sampler: depths from the ErrorBoundSampler instead of given depths)"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from neat_amd import synth

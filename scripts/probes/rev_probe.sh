@@ -1,5 +1,5 @@
 #!/bin/bash
-# does the adjoint (REV) layer time depend on which fused primal kernel ran before it?   bash scripts/rev_probe.sh
+# does the adjoint (REV) layer time depend on which fused primal kernel ran before it?   bash scripts/probes/rev_probe.sh
 R=$PWD; O=$R/gpurun_out/revp; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R; cd $R
 for g in 1 3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/g$g -- python $R/scripts/bench_tune.py 4=$g -- --steps 4 --warmup 2 --no-cpu-baseline --no-prof --no-graph > $O/g$g.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel averages of the train step at several batch sizes (how do the streaming kernels scale with P?):  bash scripts/size_sweep.sh "256 512 1024 2048"
+# per-kernel averages of the train step at several batch sizes (how do the streaming kernels scale with P?):  bash scripts/probes/size_sweep.sh "256 512 1024 2048"
 R=$PWD; O=$R/gpurun_out/sweep; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp PYTHONPATH=$R
 for n in ${1:-256 512 1024 2048}; do
   NEAT_BENCH_RAYS=$n rocprofv3 --kernel-trace --stats --output-format csv -d $O/r$n -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prof --no-graph > $O/r$n.log 2>&1

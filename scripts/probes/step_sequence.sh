@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel sequence of one eager C2 train step (names + durations), from a rocprofv3 kernel trace:  bash scripts/step_sequence.sh
+# kernel sequence of one eager C2 train step (names + durations), from a rocprofv3 kernel trace:  bash scripts/probes/step_sequence.sh
 R=$PWD; O=$R/gpurun_out/seq; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp PYTHONPATH=$R
 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph > $O/run.log 2>&1
 python - "$(find $O/t -name '*kernel_trace.csv' | head -1)" <<'PY'

@@ -1,6 +1,6 @@
 """Fused SDF primal chain: the kernel generations against each other at the C2 size (P = 133 120 points).
 Agreement (same bf16 products, fp32 accumulation in the same k order) and device time per launch (HIP events).
-    python scripts/time_fused.py [P]
+    python scripts/probes/time_fused.py [P]
 """
 import sys
 import torch

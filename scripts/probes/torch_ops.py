@@ -1,5 +1,5 @@
 """Which torch ops (not neat_hip launches) does one eager training step issue, and from where?
-python scripts/torch_ops.py   (on the GPU box)"""
+python scripts/probes/torch_ops.py   (on the GPU box)"""
 import sys, collections, traceback, torch
 sys.path.insert(0, '.')
 from torch.utils._python_dispatch import TorchDispatchMode

@@ -1,6 +1,6 @@
 """Forward pass of the C2 workload (1024 rays x 128 samples + 2048 eikonal points, train mode: everything saved) under precision
 fp16x3, a few times; run it under rocprofv3 --kernel-trace --stats to get the per-launch times of the split-precision chains
-(scripts/x3_ab.sh does, for a list of probe builds)."""
+(scripts/probes/x3_ab.sh does, for a list of probe builds)."""
 import sys
 import torch
 sys.path.insert(0, '.')

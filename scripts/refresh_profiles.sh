@@ -21,3 +21,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_x3
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_x3 -- python $R/bench.py --precision fp16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-prof --no-graph > $O/pmc_write_x3.log 2>&1
 find $O -name "*kernel_trace*" -delete
 du -sh $O; find $O -type f | head -40
+# SQ counters of the step's kernels (two passes)
+cd $R && bash scripts/pmc_sq.sh > $O/pmc_sq.log 2>&1; python scripts/pmc_summary.py gpurun_out/pmc2 wsdw layer_kernel_ws wgrad_kernel_h3 dw_gather sdf_adjoint sdf_fused head_chain head_bwd > $O/sq_counters.txt 2>&1

@@ -95,7 +95,7 @@ def close_sampler(z, ref, what, max_frac=0.003):
     err = np.abs(z.detach().cpu().numpy() - ref)
     assert err.shape == ref.shape
     frac = float((err > 2e-4).mean())
-    # Measured with the fp64 CDF scans of sampler_resample_kernel: 0 .. 0.18 % (scripts/sampler_flips.py).  The flips are not a
+    # Measured with the fp64 CDF scans of sampler_resample_kernel: 0 .. 0.18 % (scripts/probes/sampler_flips.py).  The flips are not a
     # summation-order artefact: tests/test_oracle_golden.py::test_sampler_is_ill_conditioned shows that the reference algorithm
     # itself moves a sample by a whole bin when ONE ulp of noise is put on the SDF values it reads.
     print(f"{what}: {frac:.4%} of the samples off by more than 2e-4 (allowed {max_frac:.2%})")
