@@ -696,12 +696,16 @@ __global__ void adjoint_seed_kernel(const float* __restrict__ v8, const float* _
 // normals + sphere clamp:  g = J^T (e0 + eskip) ; sdf = min(raw, scale (radius - |x|))  (rend_a :111-129)
 // FAST (bf16 build): hardware sin/cos (|arg| <= 96, abs error ~1e-6); the fp32 build keeps libm's for the 1e-4 parity bar.
 // E (optional): the PE rows [39][ldp] of the same points (posenc6_kernel: sin / cos by libm) -- read instead of recomputed
+// hin (main pass; small_r == null: off): the heads' small inputs of the same point in the same launch (what head_inputs_kernel,
+// below, does in a launch of its own for the stand-alone heads entry): render [p(3), PE4(view)(27), normal(3)], attraction
+// [p(3), view(3), normal(3)], fp32 rows + octet-major 16-bit copies
+struct HeadInArgs { const float* dirs; int P, S; float* small_r; float* small_a; u16* bf_r; u16* bf_a; };
 template <bool FAST>
 __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float* __restrict__ out8,
                                     const float* __restrict__ e0, const float* __restrict__ es, int P, int ldp,
                                     float radius, float scale, float* __restrict__ sdf, float* __restrict__ g_fm,
                                     float* __restrict__ mask, float* __restrict__ sdf_rm, float* __restrict__ g_rm,
-                                    int n_clamp, float* __restrict__ g_extra_rm, const float* __restrict__ E = nullptr) {
+                                    int n_clamp, float* __restrict__ g_extra_rm, const float* __restrict__ E, HeadInArgs hin) {
   // points [0, n_clamp) get the bounding-sphere clamp (get_outputs); points [n_clamp, P) are eikonal points:
   // raw network gradient (ImplicitNetwork.gradient), written to g_extra_rm
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -739,6 +743,45 @@ __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float*
   sdf[p] = s;
   if (mask) mask[p] = m;
   if (g_fm) { g_fm[p] = gv[0]; g_fm[(size_t)ldp + p] = gv[1]; g_fm[(size_t)2 * ldp + p] = gv[2]; }
+  if (hin.small_r) {
+    const int r = (p < hin.P ? p : 0) / hin.S;
+    float vr[40], va[16];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) vr[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) va[i] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xc = xv[c], gc = gv[c];
+      const float dc = (p < hin.P) ? hin.dirs[r * 3 + c] : 0.0f;
+      vr[c] = xc; vr[3 + c] = dc;
+      float f = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        vr[6 + 6 * k + c] = sinf(dc * f);
+        vr[9 + 6 * k + c] = cosf(dc * f);
+        f *= 2.0f;
+      }
+      vr[30 + c] = gc;
+      va[c] = xc; va[3 + c] = dc; va[6 + c] = gc;
+    }
+#pragma unroll
+    for (int i = 0; i < 33; ++i) hin.small_r[(size_t)i * ldp + p] = vr[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) hin.small_a[(size_t)i * ldp + p] = va[i];
+    if (hin.bf_r) {
+#pragma unroll
+      for (int o = 0; o < 5; ++o)
+        reinterpret_cast<uint4*>(hin.bf_r)[(size_t)o * ldp + p] = make_uint4(pack2(vr[8 * o], vr[8 * o + 1]), pack2(vr[8 * o + 2], vr[8 * o + 3]),
+                                                                            pack2(vr[8 * o + 4], vr[8 * o + 5]), pack2(vr[8 * o + 6], vr[8 * o + 7]));
+    }
+    if (hin.bf_a) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+        reinterpret_cast<uint4*>(hin.bf_a)[(size_t)o * ldp + p] = make_uint4(pack2(va[8 * o], va[8 * o + 1]), pack2(va[8 * o + 2], va[8 * o + 3]),
+                                                                            pack2(va[8 * o + 4], va[8 * o + 5]), pack2(va[8 * o + 6], va[8 * o + 7]));
+    }
+  }
   if (p < P) {
     if (p < n_clamp) {
       if (sdf_rm) sdf_rm[p] = s;
@@ -865,19 +908,6 @@ __global__ void zero_tail_kernel(float* __restrict__ a, int rows, int p_from, in
   if (p >= ldp) return;
   for (int r = 0; r < rows; ++r) a[(size_t)r * ldp + p] = 0.0f;
 }
-// the same for three arrays in one launch (the head cotangents and the sdf cotangent row beyond the ray samples)
-// oct_a / oct_b (null: none): one-octet 16-bit copies of a / b (composite_bwd_kernel's zrgb_oct / dlin_oct), zeroed as well
-__global__ void zero_tail3_kernel(float* __restrict__ a, int rows_a, float* __restrict__ b, int rows_b, float* __restrict__ c, int rows_c,
-                                  int p_from, int ldp, u16* __restrict__ oct_a, u16* __restrict__ oct_b) {
-  const int p = p_from + blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= ldp) return;
-  for (int r = 0; r < rows_a; ++r) a[(size_t)r * ldp + p] = 0.0f;
-  for (int r = 0; r < rows_b; ++r) b[(size_t)r * ldp + p] = 0.0f;
-  for (int r = 0; r < rows_c; ++r) c[(size_t)r * ldp + p] = 0.0f;
-  if (oct_a) reinterpret_cast<uint4*>(oct_a)[p] = make_uint4(0u, 0u, 0u, 0u);
-  if (oct_b) reinterpret_cast<uint4*>(oct_b)[p] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 // ---------------------------------------------------------------------------------------------
 // compositing (rend_a :540-554 volume_rendering, :406-426 integrals); one wave per ray
 // ---------------------------------------------------------------------------------------------
@@ -978,10 +1008,23 @@ struct CompositeBwdArgs {
   const float* cot_slot_a = nullptr; // f16 build: the attraction head's backward chain runs in its own power-of-two scale (its cotangents,
                                      // line-loss weight 0.01 and detached weights, are orders of magnitude below the colour ones: in the
                                      // common scale they sit in f16's subnormal range); null = the common one
+  int tail_from = 0;                 // > 0: the workgroups behind the rays' zero the columns [tail_from, ldp) of zrgb / dlin / dsdf_row and of the
+                                     // octet copies (eikonal points, padding: no head cotangents) -- what zero_tail3_kernel did in a launch of its own
 };
 
 __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
   const int lane = threadIdx.x & 63;
+  const int ray_blocks = (a.R + 3) / 4;
+  if ((int)blockIdx.x >= ray_blocks) {
+    const int p = a.tail_from + ((int)blockIdx.x - ray_blocks) * WG + (int)threadIdx.x;
+    if (a.tail_from <= 0 || p >= a.ldp) return;
+    for (int c = 0; c < 3; ++c) a.zrgb_fm[(size_t)c * a.ldp + p] = 0.0f;
+    for (int c = 0; c < 6; ++c) a.dlin_fm[(size_t)c * a.ldp + p] = 0.0f;
+    a.dsdf_row[p] = 0.0f;
+    if (a.zrgb_oct) reinterpret_cast<uint4*>(a.zrgb_oct)[p] = make_uint4(0u, 0u, 0u, 0u);
+    if (a.dlin_oct) reinterpret_cast<uint4*>(a.dlin_oct)[p] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.R) return;
   const float dn = sqrtf(a.dirs[r * 3] * a.dirs[r * 3] + a.dirs[r * 3 + 1] * a.dirs[r * 3 + 1] + a.dirs[r * 3 + 2] * a.dirs[r * 3 + 2]);

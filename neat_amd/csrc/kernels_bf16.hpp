@@ -1267,6 +1267,69 @@ __global__ void oct_pack_kernel(OctPackArgs a) {
   }
 }
 
+// Prologue of the SDF backward pass of the 16-bit builds in ONE launch per point (round 4: a launch costs ~5 us inside a replayed
+// graph whatever it does): the cotangent of the normals (normal_cotangent_kernel), its PE tangent E^ = J g^ (posenc6_tangent_kernel)
+// and the octet-major 16-bit copies of the PE rows and their tangents that the streaming kernels read (oct_pack_kernel: rows 0..38
+// and rows 7..38 of each) -- same arithmetic, three launches less.
+struct BwdPrologueArgs {
+  const float* sc_r; const float* sc_a; const float* extra_rm; const float* mask; const float* d_tail_rm;
+  const float* cot_slot; const float* cot_slot_a;
+  int P, ldp, P_main;
+  const float* x_fm; const float* E;          // points, their PE rows [39][ldp] (saved by the forward pass)
+  float* gh; float* Eh;                       // fp32 feature-major outputs [3][ldp], [39][ldp]
+  u16* Ebf; u16* Ebf4; u16* Ehbf; u16* Ehbf4; // octet-major copies: rows 0..38 (5 octets) / rows 7..38 (4 octets)
+};
+__global__ void bwd_prologue_kernel(BwdPrologueArgs a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.ldp) return;
+  const size_t ldp = (size_t)a.ldp;
+  const float ext_scale = cot_scale_of(a.cot_slot);
+  const float rho_a = a.cot_slot_a ? ext_scale / cot_scale_of(a.cot_slot_a) : 1.0f;
+  const float keep = (p < a.P) ? 1.0f - (a.mask ? a.mask[p] : 0.0f) : 0.0f;
+  float eh[40], ev[40];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = 0.0f;
+    if (p < a.P_main) {
+      if (a.sc_r) v += a.sc_r[(size_t)(30 + c) * ldp + p];
+      if (a.sc_a) v += a.sc_a[(size_t)(6 + c) * ldp + p] * rho_a;
+      if (a.extra_rm) v += a.extra_rm[p * 3 + c] * ext_scale;
+    } else if (p < a.P && a.d_tail_rm) {
+      v = a.d_tail_rm[(p - a.P_main) * 3 + c] * ext_scale;
+    }
+    const float gc = v * keep;
+    a.gh[(size_t)c * ldp + p] = gc;
+    const float xc = a.x_fm[(size_t)c * ldp + p];
+    eh[c] = gc;
+    float f = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      eh[3 + 6 * k + c] = f * __cosf(xc * f) * gc;
+      eh[6 + 6 * k + c] = -f * __sinf(xc * f) * gc;
+      f *= 2.0f;
+    }
+  }
+  eh[39] = 0.0f; ev[39] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 39; ++j) { a.Eh[(size_t)j * ldp + p] = eh[j]; ev[j] = a.E[(size_t)j * ldp + p]; }
+  auto octet = [](const float (&v)[40], int r0) {      // rows r0 .. r0 + 7 (rows >= 39: zero)
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (r0 + e < 39) ? v[r0 + e] : 0.0f;
+    return make_uint4(pack2(t[0], t[1]), pack2(t[2], t[3]), pack2(t[4], t[5]), pack2(t[6], t[7]));
+  };
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    reinterpret_cast<uint4*>(a.Ebf)[(size_t)o * ldp + p] = octet(ev, 8 * o);
+    reinterpret_cast<uint4*>(a.Ehbf)[(size_t)o * ldp + p] = octet(eh, 8 * o);
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    reinterpret_cast<uint4*>(a.Ebf4)[(size_t)o * ldp + p] = octet(ev, 7 + 8 * o);
+    reinterpret_cast<uint4*>(a.Ehbf4)[(size_t)o * ldp + p] = octet(eh, 7 + 8 * o);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // wgrad_kernel_h3: the all-bf16 256x256 case (hidden layers: both operands octet-major, K = 256, N <= 256).
 // No register staging, no second LDS image, no v_perm transposes:
@@ -1580,6 +1643,31 @@ __global__ void oct_to_rm_kernel(const u16* __restrict__ src, int P, int C, int 
   for (int j = 0; j < 4; ++j) {
     if (o * 8 + 2 * j < C) d[2 * j] = bf_lo(w4[j]) + bf_lo(l4[j]);
     if (o * 8 + 2 * j + 1 < C) d[2 * j + 1] = bf_hi(w4[j]) + bf_hi(l4[j]);
+  }
+}
+// the lin8 output of the stand-alone SDF entry in ONE launch: raw sdf -> out257[:, 0], the 256 feature rows (octet-major, + the low
+// plane of a hi/lo split) -> out257[:, 1:] and / or feat [P, 256]
+__global__ void export_out8_kernel(const float* __restrict__ sdfraw, const u16* __restrict__ src, const u16* __restrict__ srclo, int P, int ldp,
+                                   float* __restrict__ out257, float* __restrict__ feat) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
+  if (p >= P) return;
+  const uint4 v = reinterpret_cast<const uint4*>(src)[(size_t)o * ldp + p];
+  uint4 vl = make_uint4(0u, 0u, 0u, 0u);
+  if (srclo) vl = reinterpret_cast<const uint4*>(srclo)[(size_t)o * ldp + p];
+  const unsigned w4[4] = {v.x, v.y, v.z, v.w}, l4[4] = {vl.x, vl.y, vl.z, vl.w};
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = bf_lo(w4[j]) + bf_lo(l4[j]); f[2 * j + 1] = bf_hi(w4[j]) + bf_hi(l4[j]); }
+  if (out257) {
+    float* d = out257 + (size_t)p * 257 + 1 + o * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = f[j];
+    if (o == 0) out257[(size_t)p * 257] = sdfraw[p];
+  }
+  if (feat) {
+    float* d = feat + (size_t)p * 256 + o * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = f[j];
   }
 }
 // (dstlo: also write the low plane of the hi/lo split)

@@ -362,12 +362,13 @@ hipError_t dispatch_h(hipStream_t st, int epi, const LayerArgsH& a, int nt) { EP
 
 // sdf_finalize_kernel<FAST>: hardware sin/cos in the bf16 build
 // (the split-precision forward has the PE rows of the points in w.E -- libm's sin / cos, posenc6_kernel -- and reads them back)
-#define FINALIZE_LAUNCH(c, ...)                                                                                         \
+#define FINALIZE_LAUNCH_H(c, hin, ...)                                                                                  \
   do {                                                                                                                   \
-    if ((c).hx3) hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)w.E); \
-    else if ((c).prec) hipLaunchKernelGGL(sdf_finalize_kernel<true>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)nullptr); \
-    else hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)nullptr); \
+    if ((c).hx3) hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)w.E, hin); \
+    else if ((c).prec) hipLaunchKernelGGL(sdf_finalize_kernel<true>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)nullptr, hin); \
+    else hipLaunchKernelGGL(sdf_finalize_kernel<false>, grid1((c).ldp), dim3(256), 0, (c).st, __VA_ARGS__, (const float*)nullptr, hin); \
   } while (0)
+#define FINALIZE_LAUNCH(c, ...) FINALIZE_LAUNCH_H(c, HeadInArgs{}, __VA_ARGS__)
 
 struct Ctx {
   hipStream_t st;
@@ -969,14 +970,29 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
 }
 
 // double backward + backward: w.gh (cotangent of normals, masked) and w.abar8 (cotangent of lin8 output) are set
-hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grads* gr) {
+// nc: the cotangent of the normals still has to be formed (its arguments); null = w.gh is set
+struct NormalCot { const float* sc_r; const float* sc_a; const float* extra_rm; int P_main; const float* d_tail_rm; const float* slot; const float* slot_a; };
+hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grads* gr, const NormalCot* nc = nullptr) {
   const PackLayout& L = c.L();
   hipError_t e;
-  if (c.prec) hipLaunchKernelGGL(posenc6_tangent_kernel<true>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
-  else hipLaunchKernelGGL(posenc6_tangent_kernel<false>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
+  if (c.prec && nc) {
+    // 16-bit builds: normal cotangent + PE tangent + the octet-major copies the streaming kernels read, one launch (bwd_prologue_kernel)
+    BwdPrologueArgs a{};
+    a.sc_r = nc->sc_r; a.sc_a = nc->sc_a; a.extra_rm = nc->extra_rm; a.mask = w.mask; a.d_tail_rm = nc->d_tail_rm;
+    a.cot_slot = nc->slot; a.cot_slot_a = nc->slot_a; a.P = c.P; a.ldp = c.ldp; a.P_main = nc->P_main;
+    a.x_fm = w.x; a.E = w.E; a.gh = w.gh; a.Eh = w.Eh;
+    a.Ebf = reinterpret_cast<u16*>(w.Ebf.p); a.Ebf4 = reinterpret_cast<u16*>(w.Ebf4.p);
+    a.Ehbf = reinterpret_cast<u16*>(w.Ehbf.p); a.Ehbf4 = reinterpret_cast<u16*>(w.Ehbf4.p);
+    hipLaunchKernelGGL(bwd_prologue_kernel, grid1(c.ldp), dim3(256), 0, c.st, a);
+  } else {
+    if (nc) hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, nc->sc_r, nc->sc_a, nc->extra_rm, w.mask, c.P, c.ldp,
+                               w.gh, nc->P_main, nc->d_tail_rm, nc->slot, nc->slot_a);
+    if (c.prec) hipLaunchKernelGGL(posenc6_tangent_kernel<true>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
+    else hipLaunchKernelGGL(posenc6_tangent_kernel<false>, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.gh, c.ldp, w.Eh);
+    // bf16 build: octet-major copies of the PE rows and their tangents for the streaming kernels (skip layer, lin0 / lin4 gradients)
+    if (c.prec) oct_pack(c, {{w.E, PE_ROWS, w.Ebf}, {w.E + 7 * (size_t)c.ldp, 32, w.Ebf4}, {w.Eh, PE_ROWS, w.Ehbf}, {w.Eh + 7 * (size_t)c.ldp, 32, w.Ehbf4}});
+  }
   if (!c.prec) hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, c.P, c.ldp);
-  // bf16 build: octet-major copies of the PE rows and their tangents for the streaming kernels (skip layer, lin0 / lin4 gradients)
-  if (c.prec) oct_pack(c, {{w.E, PE_ROWS, w.Ebf}, {w.E + 7 * (size_t)c.ldp, 32, w.Ebf4}, {w.Eh, PE_ROWS, w.Ehbf}, {w.Eh + 7 * (size_t)c.ldp, 32, w.Ehbf4}});
   // tangent chain (forward-mode along g^): vh_{l+1} = tangent of h_{l+1}, m_l = extra cotangent of a_l
   // bf16 build: the 217-row arrays of the skip layer carry the first 7 PE rows in the padding of their last octet, so
   // lin4's input is [h4 | PE0..6] (224 rows, octet aligned) + PE7..38 (32 rows) = 256 columns
@@ -1256,7 +1272,7 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
   const PackLayout& L = c.L();
   hipError_t e;
   const bool oct = oct_operands(c);
-  // (16-bit builds: the octet copies of zrgb / dlin, topbf_r / topbf_a, were written by composite_bwd_kernel and zero_tail3_kernel)
+  // (16-bit builds: the octet copies of zrgb / dlin, topbf_r / topbf_a, were written by composite_bwd_kernel, tail columns included)
   const int nb1 = wgrad_batch_size(c.ldp);
   const bool batch = oct && nb1 && g_wgrad_h3;
   bool wdone[2] = {false, false};
@@ -1438,13 +1454,9 @@ void grad_unscale(const Ctx& c, const neat_net_grads* gr, int first, int count, 
 void export_out8(const Ctx& c, const SdfWs& w, float* out257, float* feat) {
   const int P = c.P;
   if (c.prec) {
-    if (out257) {
-      hipLaunchKernelGGL(fm_col_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, out257, 257, 0);
-      hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, out257, 257, 1,
-                         reinterpret_cast<const u16*>(w.featlo.p));
-    }
-    if (feat) hipLaunchKernelGGL(oct_to_rm_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, reinterpret_cast<const u16*>(w.feat.p), P, 256, c.ldp, feat, 256, 0,
-                                 reinterpret_cast<const u16*>(w.featlo.p));
+    if (out257 || feat)
+      hipLaunchKernelGGL(export_out8_kernel, dim3((P + 255) / 256, 32), dim3(256), 0, c.st, (const float*)w.sdfraw, reinterpret_cast<const u16*>(w.feat.p),
+                         reinterpret_cast<const u16*>(w.featlo.p), P, c.ldp, out257, feat);
   } else {
     if (out257) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.sdfraw, P, 257, c.ldp, out257, 0);
     if (feat) hipLaunchKernelGGL(fm_to_rm_kernel, grid1(P), dim3(256), 0, c.st, w.feat.f(), P, 256, c.ldp, feat, 0);
@@ -1650,9 +1662,8 @@ int neat_sdf_backward(const float* packed, const neat_net_params* net, float* ws
   const float* slot = cot_scale_begin(c, w.ones, {{d_out257, 257LL * P}, {d_sdf, (long long)P}, {d_feat, 256LL * P}, {d_grad, 3LL * P}});
   hipLaunchKernelGGL(build_abar8_kernel, dim3((c.ldp + 255) / 256, 257), dim3(256), 0, c.st, d_out257, d_sdf, d_feat, w.mask, P, c.ldp, w.abar8, slot);
   if (precision) oct_pack(c, {{w.abar8 + c.ldp, 256, w.featc}});
-  hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, (const float*)nullptr, (const float*)nullptr,
-                     d_grad, w.mask, P, c.ldp, w.gh, P, (const float*)nullptr, slot);
-  NEAT_CHECK(sdf_backward_chains(c, w, grads));
+  const NormalCot nc{nullptr, nullptr, d_grad, P, nullptr, slot, nullptr};
+  NEAT_CHECK(sdf_backward_chains(c, w, grads, &nc));
   grad_unscale(c, grads, 0, 9, slot);
   return (int)hipGetLastError();
 }
@@ -1725,11 +1736,11 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
   hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, origins, dirs, z, R, S, c.ldp, w.x, points, eik_points, E);
   NEAT_CHECK(sdf_primal(c, w, true));
   NEAT_CHECK(sdf_adjoint(c, w, !fwd_only));
-  FINALIZE_LAUNCH(c, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
-                     w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
-  // the heads run over every column of the tile grid; only the first R*S columns are consumed
-  hipLaunchKernelGGL(head_inputs_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.x, w.g, dirs, Pm, S, c.ldp, h.small_r, h.small_a,
-                     reinterpret_cast<u16*>(h.smallbf_r.p), reinterpret_cast<u16*>(h.smallbf_a.p));
+  // normals + sphere clamp, and in the same launch the heads' small inputs (the heads run over every column of the tile grid; only
+  // the first R*S columns are consumed)
+  const HeadInArgs hin{dirs, Pm, S, h.small_r, h.small_a, reinterpret_cast<u16*>(h.smallbf_r.p), reinterpret_cast<u16*>(h.smallbf_a.p)};
+  FINALIZE_LAUNCH_H(c, hin, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
+                    w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
   NEAT_CHECK(heads_forward(c, h, w.feat, w.featlo, !fwd_only, Pm));
   CompositeArgs ca;
   ca.z = z; ca.sdf = w.sdf; ca.dirs = dirs; ca.x_fm = w.x; ca.rgb_fm = h.rgb; ca.lin_fm = h.lin; ca.g_fm = w.g;
@@ -1796,15 +1807,12 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   cb.cot_slot = slot; cb.cot_slot_a = slot_a;
   if (!c.prec)      // the ones row is the bias column of the fp32 weight-gradient kernel; the bf16 kernels sum the rows of A themselves
     hipLaunchKernelGGL(ones_kernel, grid1(c.ldp), dim3(256), 0, c.st, w.ones, P, c.ldp);
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, cb);
-  if (c.ldp > Pm) {      // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents
-    hipLaunchKernelGGL(zero_tail3_kernel, grid1(c.ldp - Pm), dim3(256), 0, c.st, h.zrgb, 3, h.dlin, 6, w.abar8, 1, Pm, c.ldp,
-                       reinterpret_cast<u16*>(h.topbf_r.p), reinterpret_cast<u16*>(h.topbf_a.p));
-  }
+  // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents: zeroed by extra workgroups of the same launch
+  cb.tail_from = c.ldp > Pm ? Pm : 0;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4 + (c.ldp > Pm ? (c.ldp - Pm + WG - 1) / WG : 0)), dim3(WG), 0, c.st, cb);
   NEAT_CHECK(heads_backward(c, h, w, grads, slot, slot_a, Pm));
-  hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, h.sc_r, h.sc_a, (const float*)nullptr, w.mask, P, c.ldp,
-                     w.gh, Pm, d_eik_grad, slot, slot_a);
-  NEAT_CHECK(sdf_backward_chains(c, w, grads));
+  const NormalCot nc{h.sc_r, h.sc_a, nullptr, Pm, d_eik_grad, slot, slot_a};
+  NEAT_CHECK(sdf_backward_chains(c, w, grads, &nc));
   if (slot_a) { grad_unscale(c, grads, 0, L_ATTR, slot); grad_unscale(c, grads, L_ATTR, NLAYERS - L_ATTR, slot_a); }
   else grad_unscale(c, grads, 0, NLAYERS, slot);
   return (int)hipGetLastError();
