@@ -56,7 +56,7 @@ class VolSDFLoss(nn.Module):
                 raise FloatingPointError("line loss is NaN (the reference drops into pdb here, loss_wfr.py:66-67)")
             return
         if self.nan_check == "off":
-            self.nan_flag = torch.isnan(line_loss.detach()).reshape(1)
+            self.nan_flag = line_loss.detach().reshape(1)      # the value itself (a view: no launch); whoever polls tests it for NaN
             return
         flag = torch.empty(1, dtype=torch.bool).pin_memory()
         flag.copy_(torch.isnan(line_loss.detach()).reshape(1), non_blocking=True)

@@ -238,7 +238,8 @@ class Trainer:
     def check_nan(self):
         """Graph mode keeps the line-loss NaN flag on the device (loss.nan_check == "off"); this reads it (one sync)."""
         flag = self._last.nan_flag if self._last is not None else self.loss.nan_flag
-        bad = flag is not None and bool(flag.item())
+        # (graph mode keeps the line loss itself as the flag -- testing it on the device every step would be one more launch)
+        bad = flag is not None and bool((torch.isnan(flag).any() if flag.is_floating_point() else flag.any()).item())
         # data parallel: the flag belongs to THIS rank's batch.  The ranks agree before anyone raises -- a rank that stopped alone would
         # leave the others blocked in the next gradient all-reduce until the watchdog tears the job down.  (Every rank calls this at
         # the same iterations: the runner's log interval and checkpoint epochs.)

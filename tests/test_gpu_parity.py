@@ -1532,6 +1532,26 @@ def test_graph_per_view_cache_equals_eager(dev):
     tr_g.check_nan()
 
 
+def test_graph_replay_reports_a_nan_line_loss(dev):
+    """Graph mode keeps the NaN flag of the line loss (the reference drops into pdb there, loss_wfr.py:66-67) on the device -- since round 4
+    as the loss value itself, tested when Trainer.check_nan() polls it: a replay fed a NaN ground-truth segment must be reported, a clean one not."""
+    from neat_amd.train import Trainer, synthetic_batch
+    torch.manual_seed(5)
+    tr = Trainer(device=dev, state_dict={k: T(v) for k, v in synth.synth_state_dict(5, "rough").items()})
+    _, inp, gt = synthetic_batch(31, 64, dev)
+    tr.model.z_vals_override = T(synth.synth_z_vals(31, 64, 32)).to(dev)
+    assert tr.capture(inp, gt), tr.capture_error
+    tr.step(inp, gt)
+    tr.check_nan()
+    bad = dict(gt)
+    bad["lines2d"] = gt["lines2d"].clone()
+    bad["lines2d"][..., 4] = float("nan")
+    tr.step(inp, bad)
+    assert tr.replays >= 2
+    with pytest.raises(FloatingPointError):
+        tr.check_nan()
+
+
 def test_graph_falls_back_for_other_batches(dev):
     """A captured step only replays for batches with the captured layout; another view (other wireframe object) or another
     ray count runs eagerly, and the next matching batch replays again."""
