@@ -1348,8 +1348,17 @@ __global__ void bwd_prologue_kernel(BwdPrologueArgs a) {
 #define NEAT_W3_ABLATE 0
 #endif
 constexpr int W3T = 512, W3P = 32, W3NS = 4;
-constexpr int W3_STAGE = 2 * 256 * W3P * 2;          // bytes per stage: A | B, each 8 quads x 32 points x 64 B
-constexpr int W3_LDS_BYTES = W3NS * W3_STAGE;
+// NCB = 32-column blocks of the output per wave: 4 (K <= 256 packed columns) or 5 (K <= 320: the heads' input layers [256 feature | <= 64
+// small rows] in ONE launch instead of two that each read the whole A operand; round 4)
+template <int NCB> struct W3Cfg {
+  static constexpr int QA = 8, QB = 2 * NCB;           // 32-row quads of the A / B operand in a stage
+  static constexpr int STAGE = (QA + QB) * 2048;       // bytes per stage: A quads, then B quads, each 32 points x 64 B
+  static constexpr int LDS = W3NS * STAGE;
+  static constexpr int QPW = NCB == 4 ? 2 : 3;         // quads a wave moves per stage (NCB = 5: 18 quads over 8 waves x 3, the surplus re-reads the last)
+  static constexpr int G = 2 * QPW;                    // LDS-DMA instructions per stage and wave
+};
+constexpr int W3_STAGE = W3Cfg<4>::STAGE;
+constexpr int W3_LDS_BYTES = W3Cfg<4>::LDS;
 constexpr int W3_SLOTS = 12;         // up to 6 problems x 2 pairs per launch
 struct WgradArgsH3 {
   const unsigned short* A[W3_SLOTS]; const unsigned short* B[W3_SLOTS]; int rowsA[W3_SLOTS];   // operand set of (problem p, pair q) at p * npairs + q
@@ -1364,13 +1373,15 @@ struct WgradArgsH3 {
 };
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
+template <int NCB>
 __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
+  typedef W3Cfg<NCB> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char w3lds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef __attribute__((address_space(3))) v4s16* lds_v4;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 128;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 32 * NCB;
   // point stages of this workgroup: one contiguous chunk, or (interleave) stages y, y + splits, ... -- at any moment the
   // machine then sweeps one contiguous window of every operand array
   const int nsplit = gridDim.y;
@@ -1380,29 +1391,33 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   const int nsteps = a.interleave ? ((a.P + W3P - 1) / W3P - (int)blockIdx.y + nsplit - 1) / nsplit : (pend - pbeg + W3P - 1) / W3P;
   const int prob = a.nprob > 1 ? (int)blockIdx.x : 0;
   const int T = nsteps * a.npairs;
-  bool liveR[2], liveC[4];
+  bool liveR[2], liveC[NCB];
 #pragma unroll
   for (int i = 0; i < 2; ++i) liveR[i] = wr + 32 * i < a.N;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) liveC[j] = wc + 32 * j < a.K;
-  f32x16 acc[2][4];
+  for (int j = 0; j < NCB; ++j) liveC[j] = wc + 32 * j < a.K;
+  f32x16 acc[2][NCB];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NCB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   float rsum[2] = {0.0f, 0.0f};
 
-  // DMA role of this wave: operand (A: waves 0-3, B: 4-7), quads 2(w&3), 2(w&3)+1, two 16-point halves each
-  const int dop = wave >> 2, dq0 = 2 * (wave & 3);
+  // DMA role of this wave: QPW of the stage's QA + QB quads (global quad g: A quads first), two 16-point halves each
   const int dl_oct = lane & 3, dl_pt = lane >> 2;
   // The DMA is issued from inline asm so that hipcc's waitcnt pass does not know about it: otherwise it puts
   // `s_waitcnt vmcnt(0)` in front of every ds_read that follows an LDS-DMA and the ring never holds more than one stage.
   const unsigned lds_base = (unsigned)(size_t)(lds_ptr)w3lds;
-  // operand set of (this problem, pair q) for this wave's DMA role, selected ONCE with compile-time kernarg indices (a runtime
+  // operand set of (this problem, pair q) per quad of this wave, selected ONCE with compile-time kernarg indices (a runtime
   // index would go through scratch; selecting inside the streaming loop costs ~150 scalar instructions per stage)
-  const unsigned short* opbase[2]; const unsigned short* opbase2[2]; int opmax[2];
+  const unsigned short* opbase[2][C::QPW]; const unsigned short* opbase2[2]; int opmax[2][C::QPW]; int opq[C::QPW]; bool opB[C::QPW];
+#pragma unroll
+  for (int hq = 0; hq < C::QPW; ++hq) {
+    const int g = min(C::QPW * wave + hq, C::QA + C::QB - 1);
+    opB[hq] = g >= C::QA; opq[hq] = opB[hq] ? g - C::QA : g;
+  }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int idx = prob * a.npairs + q;
@@ -1411,26 +1426,29 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
 #pragma unroll
     for (int k = 1; k < W3_SLOTS; ++k)
       if (idx == k) { pA = a.A[k]; pB = a.B[k]; p2 = a.B2[k]; rA = a.rowsA[k]; }
-    opbase[q] = dop ? pB : pA; opbase2[q] = p2; opmax[q] = dop ? a.octsB - 1 : (rA + 7) / 8 - 1;
+    opbase2[q] = p2;
+#pragma unroll
+    for (int hq = 0; hq < C::QPW; ++hq) { opbase[q][hq] = opB[hq] ? pB : pA; opmax[q][hq] = opB[hq] ? a.octsB - 1 : (rA + 7) / 8 - 1; }
   }
   auto issue = [&](int tau) {
     const int q = tau >= nsteps ? 1 : 0;
     const int st = tau - q * nsteps;
     if (NEAT_W3_ABLATE == 4) return;
-    const unsigned short* base = q ? opbase[1] : opbase[0];
     const unsigned short* base2 = q ? opbase2[1] : opbase2[0];
-    const int maxoct = q ? opmax[1] : opmax[0];
-    const unsigned slot = lds_base + (tau % W3NS) * W3_STAGE + dop * (W3_STAGE / 2);
+    const unsigned stage = lds_base + (tau % W3NS) * C::STAGE;
 #pragma unroll
-    for (int hq = 0; hq < 2; ++hq) {
-      const int oct = min(4 * (dq0 + hq) + dl_oct, maxoct);       // rows past the array: re-read a valid octet (dropped later)
-      const bool second = dop && oct >= a.splitB;
+    for (int hq = 0; hq < C::QPW; ++hq) {
+      const unsigned short* base = q ? opbase[1][hq] : opbase[0][hq];
+      const int maxoct = q ? opmax[1][hq] : opmax[0][hq];
+      const int oct = min(4 * opq[hq] + dl_oct, maxoct);       // rows past the array: re-read a valid octet (dropped later)
+      const bool second = opB[hq] && oct >= a.splitB;
       const uint4* seg = reinterpret_cast<const uint4*>(second ? base2 : base) + (size_t)(second ? oct - a.splitB : oct) * a.ldp;
+      const int g = min(C::QPW * wave + hq, C::QA + C::QB - 1);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int p = pbeg + st * pstep + 16 * i + dl_pt;
         const uint4* src = seg + p;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (dq0 + hq) * 2048 + i * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(stage + g * 2048 + i * 1024);
         unsigned keep;
         if (a.nt_loads)      // operands are read once, long after they were written: keep them out of the way of the partial tiles
           asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
@@ -1453,18 +1471,18 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
   for (int tau = 0; tau < T; ++tau) {
     // stage tau has landed when at most the 2 x 4 newer DMA instructions of this wave are outstanding; the barrier
     // then publishes every wave's part and retires the reads of stage tau-1 (whose slot is refilled next)
-    if (tau + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else if (tau + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    if (tau + 2 < T) { if (C::G == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory"); }
+    else if (tau + 1 < T) { if (C::G == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (tau + W3NS - 1 < T) issue(tau + W3NS - 1);
-    const unsigned char* slot = w3lds + (tau % W3NS) * W3_STAGE;
+    const unsigned char* slot = w3lds + (tau % W3NS) * C::STAGE;
     const int st = tau >= nsteps ? tau - nsteps : tau;
     const int pb = pbeg + st * pstep;
     const bool tail = pb + W3P > pend;
     const bool bias_now = do_bias && tau < nsteps;
 #pragma unroll
     for (int s2 = 0; s2 < W3P / 16; ++s2) {
-      uint4 av[2], bv[4];
+      uint4 av[2], bv[NCB];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (NEAT_W3_ABLATE == 2) { av[i] = make_uint4(lane, tau, i, s2); continue; }
@@ -1474,9 +1492,9 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
         av[i] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NCB; ++j) {
         if (NEAT_W3_ABLATE == 2) { bv[j] = make_uint4(lane, tau, j, s2); continue; }
-        const unsigned char* bp = slot + W3_STAGE / 2 + ((wc >> 5) + j) * 2048 + s2 * 1024 + frag_off;
+        const unsigned char* bp = slot + C::QA * 2048 + ((wc >> 5) + j) * 2048 + s2 * 1024 + frag_off;
         const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(bp));
         const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(bp + 256));
         bv[j] = make_uint4(((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]);
@@ -1495,7 +1513,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) mask4(av[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mask4(bv[j]);
+        for (int j = 0; j < NCB; ++j) mask4(bv[j]);
       }
       if (bias_now) {
 #pragma unroll
@@ -1511,7 +1529,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       for (int i = 0; i < 2; ++i) {
         if (!liveR[i]) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NCB; ++j)
           if (liveC[j]) {
             if (NEAT_W3_ABLATE == 1) { asm volatile("" :: "v"(av[i].x), "v"(av[i].w), "v"(bv[j].x), "v"(bv[j].w)); continue; }
             acc[i][j] = NEAT_MFMA16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]), acc[i][j], 0, 0, 0);
@@ -1532,7 +1550,7 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       const int n = wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (n >= a.N) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NCB; ++j) {
         const int k = wc + 32 * j + (lane & 31);
         if (liveC[j] && k < a.K) put(dstp + (size_t)n * a.row_stride + a.col_off + k, acc[i][j][r]);
       }

@@ -230,6 +230,7 @@ int g_ws_wide_store = 1;    // streaming layer kernels: 16-byte output stores (t
 const int* g_gate = nullptr; int g_gate_value = 0;      // set around one neat_sdf_forward call by neat_sdf_values_gated
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
+int g_wgrad_k320 = 1;       // 16-bit builds: the heads' input layers (K = 256 + <= 64) as one five-column-block weight-gradient launch (tuning key 19)
 int g_dw_ablate = 0;        // probe runs (tuning key 17): see LayerArgsDW::ablate
 int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers 1..7 accumulated inside the tangent / reverse launches
                             // (kernels_dw.hpp; tuning key 16): 1 = where it pays (>= DW_MIN_POINTS points: the partials and their gather cost
@@ -782,7 +783,7 @@ hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob,
   if ((size_t)nprob * region > WPARTIAL_FLOATS - WSTAGE_FLOATS) return hipErrorInvalidValue;
   static DevOnce attr3;
   if (!attr3) {
-    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
     if (e0 != hipSuccess) return e0;
     attr3 = true;
   }
@@ -801,7 +802,7 @@ hipError_t wgrad_multi(const Ctx& c, const SdfWs& w, const WProb* pb, int nprob,
   a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.col_off = 0; a.bias_col = K;
   a.nprob = nprob; a.prob_stride = region; a.interleave = g_ws_interleave != 0; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
   ProfSlot* ps = prof_begin(c.st, 1, flops, bytes + (double)nprob * splits * N * (K + 1) * 4.0);
-  hipLaunchKernelGGL(wgrad_kernel_h3, dim3(nprob, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
+  hipLaunchKernelGGL(wgrad_kernel_h3<4>, dim3(nprob, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
   prof_end(c.st, ps);
   hipError_t e = hipGetLastError();
   if (splits <= 2 * WGROUPS || nprob > WREDUCE_BATCH) {        // few points: finish each layer on its own
@@ -900,12 +901,15 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
            s.rowsB[0] == pairs_in[0].rowsB[0] && s.rowsB[1] == pairs_in[0].rowsB[1];
     }
     const int r0 = pairs_in[0].rowsB[0], r1 = pairs_in[0].rowsB[1];
-    const bool two = K > 256;
+    // [256 | r1 <= 64 rows] (the heads' input layers): ONE launch of the five-column-block variant (g_wgrad_k320, tuning key 19) -- two
+    // launches, [256] and [r1] into disjoint partial columns, each read the whole A operand
+    const bool wide = h3 && g_wgrad_k320 && K > 256 && K <= 320 && r0 == 256 && r1 > 0 && r1 <= 64;
+    const bool two = K > 256 && !wide;
     if (two && (r0 != 256 || r1 == 0 || r1 > 256)) h3 = false;
     if (h3) {
       static DevOnce attr3_set;
       if (!attr3_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr3_set = true;
       }
@@ -914,6 +918,14 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
       splits = (c.P + chunk - 1) / chunk;
       chunk_used = chunk;
       ProfSlot* ps = prof_begin(c.st, 1, wflops, wbytes + (double)splits * N * (K + 1) * 4.0);
+      if (wide) {
+        static DevOnce attr5_set;
+        if (!attr5_set) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3<5>), hipFuncAttributeMaxDynamicSharedMemorySize, W3Cfg<5>::LDS);
+          if (e != hipSuccess) return e;
+          attr5_set = true;
+        }
+      }
       for (int part = 0; part < (two ? 2 : 1); ++part) {
         WgradArgsH3 a{};
         for (int q = 0; q < npairs; ++q) {
@@ -925,7 +937,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
         }
         if (part == 0) {
           a.K = two ? 256 : K;
-          a.splitB = (!two && r1 > 0) ? r0 / 8 : 32;
+          a.splitB = wide ? 32 : ((!two && r1 > 0) ? r0 / 8 : 32);
           a.col_off = 0; a.bias_col = K;
         } else {
           a.K = r1; a.splitB = 32; a.col_off = 256; a.bias_col = -1;
@@ -933,7 +945,8 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
         a.octsB = (a.K + 7) / 8;
         a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
         a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.interleave = g_ws_interleave != 0; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
-        hipLaunchKernelGGL(wgrad_kernel_h3, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
+        if (wide) hipLaunchKernelGGL(wgrad_kernel_h3<5>, dim3(1, splits), dim3(W3T), W3Cfg<5>::LDS, c.st, a);
+        else hipLaunchKernelGGL(wgrad_kernel_h3<4>, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
       }
       prof_end(c.st, ps);
       r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
@@ -1509,6 +1522,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 16 && value >= 0 && value <= 2) { g_dw_fused = value; return 0; }
   if (key == 17 && value >= 0 && value <= 7) { g_dw_ablate = value; return 0; }
   if (key == 18 && value >= 1 && value <= 16) { g_dw_nsub = value; return 0; }
+  if (key == 19 && (value == 0 || value == 1)) { g_wgrad_k320 = value; return 0; }
   return -1;
 }
 
