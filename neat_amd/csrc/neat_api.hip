@@ -231,6 +231,7 @@ const int* g_gate = nullptr; int g_gate_value = 0;      // set around one neat_s
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
 int g_wgrad_k320 = 1;       // 16-bit builds: the heads' input layers (K = 256 + <= 64) as one five-column-block weight-gradient launch (tuning key 19)
+int g_head_l4_batched = 1;  // a head's output-layer weight gradient as a fourth problem of its hidden layers' launch (tuning key 20)
 int g_dw_ablate = 0;        // probe runs (tuning key 17): see LayerArgsDW::ablate
 int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers 1..7 accumulated inside the tangent / reverse launches
                             // (kernels_dw.hpp; tuning key 16): 1 = where it pays (>= DW_MIN_POINTS points: the partials and their gather cost
@@ -1299,13 +1300,19 @@ hipError_t heads_backward(const Ctx& c, const HeadWs& h, const SdfWs& w, const n
     const int srows = head ? SMALL_A : SMALL_R;
     hipError_t e2;
     const bool hb = per_head_batch && batch;
+    bool l4_batched = false;
     if (hb) {
-      WProb pb[3];
+      // the three hidden layers and (16-bit operands) the output layer -- 3 / 6 rows against the same kind of 256-row B operand -- as
+      // problems of one launch: one weight-gradient launch and one finish less per head
+      WProb pb[4];
       for (int l = 1; l <= 3; ++l) pb[l - 1] = WProb{base + l, {ab[l], Arr{}}, {256, 0}, {hh[l], Arr{}}};
-      if ((e2 = wgrad_multi(c, w, pb, 3, 1, gr)) != hipSuccess) return e2;
+      l4_batched = oct && g_head_l4_batched;
+      if (l4_batched) pb[3] = WProb{base + 4, {head ? h.topbf_a : h.topbf_r, Arr{}}, {kO[base + 4], 0}, {hh[4], Arr{}}};
+      if ((e2 = wgrad_multi(c, w, pb, l4_batched ? 4 : 3, 1, gr)) != hipSuccess) return e2;
     }
     for (int l = 0; l <= 4; ++l) {
       if ((hb || (!per_head_batch && batch)) && l >= 1 && l <= 3) continue;
+      if (l == 4 && l4_batched) continue;
       WPair pr[1] = {};
       pr[0].A = l == 4 ? (oct ? (head ? h.topbf_a : h.topbf_r) : F(top)) : ab[l]; pr[0].rowsA = kO[base + l];
       if (l == 0) {
@@ -1523,6 +1530,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 17 && value >= 0 && value <= 7) { g_dw_ablate = value; return 0; }
   if (key == 18 && value >= 1 && value <= 16) { g_dw_nsub = value; return 0; }
   if (key == 19 && (value == 0 || value == 1)) { g_wgrad_k320 = value; return 0; }
+  if (key == 20 && (value == 0 || value == 1)) { g_head_l4_batched = value; return 0; }
   return -1;
 }
 
