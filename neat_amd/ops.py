@@ -635,7 +635,8 @@ class LossTailFn(torch.autograd.Function):
         R, E = rgb_c.shape[0], 0 if gth_c is None else gth_c.shape[0]
         K = 0 if loc3_c is None else loc3_c.shape[0]
         J = 0 if glo3_c is None else glo3_c.shape[0]
-        scal = torch.zeros(8, device=dev)
+        # (with junction pairs the two launches write all seven scalars the caller reads: no fill launch)
+        scal = torch.empty(8, device=dev) if (K and J) else torch.zeros(8, device=dev)
         # every gradient the two launches produce lives in ONE flat buffer, so that backward is two multiplies (per-element
         # loss weight x upstream gradient, then x buffer) instead of one or two per tensor
         have_pairs = bool(K and J)
