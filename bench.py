@@ -339,9 +339,10 @@ def main():
         # what a bad scaling curve would be diagnosed from, in the same line: every rank's own time per step (the headline uses the
         # MAX), how long each rank's steps take WITHOUT the exchange being waited on (its GPU work), and the gradient all-reduce alone
         # (the flat 4.9 MB bucket, 20 back-to-back calls between HIP events, after the timed region)
-        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
+        every_t = torch.zeros(world, device=dev, dtype=torch.float64)      # (as an all-reduce of one-hot rows: gloo has no all_gather for device tensors)
+        every_t[rank] = elapsed
+        dist.all_reduce(every_t, op=dist.ReduceOp.SUM)
+        every = list(every_t)
         tr.bucket._ensure()
         flat = tr.bucket.flat
         barrier()

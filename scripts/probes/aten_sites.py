@@ -34,5 +34,7 @@ class Log(TorchDispatchMode):
 with Log():
     out = tr.model(inp)
     losses = tr.loss(out, gt)
+    tr.optimizer.zero_grad(set_to_none=True)
+    losses["loss"].backward()
 for (name, where), n in sorted(sites.items(), key=lambda kv: kv[0][1]):
     print(f"{n:3d} x {name:40s} {where}")
