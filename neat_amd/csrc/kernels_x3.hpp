@@ -18,6 +18,7 @@
 #pragma once
 #include "bf16_common.hpp"
 #include "fused_launch.hpp"
+#include <type_traits>
 
 namespace neat {
 
@@ -69,6 +70,9 @@ __device__ __forceinline__ uint4 x3_ldg(const void* base, unsigned off) {
 #define X3_STAMP(i) do { if (blockIdx.x == 0 && nb_done < 3) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define X3_STAMP(i) do { } while (0)
+#endif
+#ifndef NEAT_X3_HALF
+#define NEAT_X3_HALF 1        // the ragged last round of the two SDF chains as half batches (0: whole batches, as in round 3)
 #endif
 #ifndef NEAT_X3_ABLATE
 #define NEAT_X3_ABLATE 0      // probe builds only (results are WRONG): 1 = no epilogue, 2 = no MFMAs
@@ -194,16 +198,17 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
   // layer's rolling refill in both modes.
   constexpr bool PREFETCH = VALUES;
   float en[5];
-  auto e_load = [&](int b) {
+  auto e_load = [&](int pfirst, bool half) {      // half: only the first 32 points exist for this workgroup
     int te = tid;
     asm volatile("" : "+v"(te));
     const int p = te & (BP - 1), g = te >> 6;
-    unsigned pvo = (unsigned)(b * BP + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
+    unsigned pvo = (unsigned)(pfirst + p) * 4u, ldp4 = (unsigned)a.ldp * 4u;
     asm volatile("" : "+v"(pvo), "+v"(ldp4));
+    const bool live = !half || p < 32;
 #pragma unroll
     for (int jj = 0; jj < 5; ++jj) {
       const int j = g + 8 * jj;
-      en[jj] = j < 39 ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.E) + ((unsigned)j * ldp4 + pvo)) : 0.0f;
+      en[jj] = (j < 39 && live) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.E) + ((unsigned)j * ldp4 + pvo)) : 0.0f;
     }
   };
   auto e_store = [&]() {
@@ -226,22 +231,29 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     const unsigned o0 = w_off(4, 256);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { wh[ks] = x3_ldg(a.Wp[0], o0 + ks * 1024); wl[ks] = x3_ldg(a.Wlo[0], o0 + ks * 1024); }
-    if (PREFETCH) { e_load(blockIdx.x); e_store(); }
   }
   __syncthreads();
+  // The ragged last round.  nbatches over G workgroups leaves rem = nbatches % G batches for a last round that would keep G - rem
+  // workgroups idle for a whole batch; when 2 rem <= G the round is run as 2 rem HALF batches (one tile of 32 points per workgroup:
+  // per layer the k-steps, then the epilogue, one barrier -- no pipeline, about half a batch's latency).
+  const int G = (int)gridDim.x;
+  int nfull = nbatches, nhalf = 0;
+  if (NEAT_X3_HALF && nbatches > G) {
+    const int rem = nbatches % G;
+    if (rem > 0 && 2 * rem <= G) { nfull = nbatches - rem; nhalf = rem; }
+  }
 
 #if NEAT_X3_TIMING
   int nb_done = 0;
   unsigned long long stamp[12];
 #endif
-  for (int batch = blockIdx.x; batch < nbatches; batch += gridDim.x) {
-    const int p0 = batch * BP;
-    const bool more = batch + (int)gridDim.x < nbatches;
+  auto run_batch = [&](const int p0, const bool more, const int pnext, auto half_c) {
+    constexpr bool HALF = decltype(half_c)::value;
     X3_STAMP(0);
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.ldp16 = (unsigned)a.ldp * 16u;
     asm volatile("" : "+v"(L.ldp16));
-    if (!PREFETCH) { e_load(batch); e_store(); __syncthreads(); }
+    if (!PREFETCH || HALF) { e_load(p0, HALF); e_store(); __syncthreads(); }
     X3_STAMP(1);
 
     f32x16 acc[2];
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
         const unsigned h216 = dst->x & 0xFFFFu;
         const uint4 v = make_uint4(h216 | (e.x << 16), (e.x >> 16) | (e.y << 16), (e.y >> 16) | (e.z << 16), (e.z >> 16) | (e.w << 16));
         *dst = v;
-        if (SAVE) {
+        if (SAVE && (!HALF || p2 < 32)) {
           u16* arr = pl2 ? a.hlo[4] : a.h[4];
           *reinterpret_cast<uint4*>(reinterpret_cast<char*>(arr) + ((unsigned)27 * (unsigned)a.ldp + (unsigned)(p0 + p2)) * 16u) = v;
         }
@@ -307,7 +319,11 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     // One layer = 2 stages.  SRC / DST: input / output LDS buffer (0 = XA, 1 = XB, 2 = S); the epilogue of the previous stage
     // belongs to layer LP (activated, NP rows, written to buffer SRC -- this layer's input buffer is the previous layer's output).
 #define X3_LAYER(LCUR, KS_, SRC_, SRCLO_, LIVE_, FIRST_, NKS_, WNH_, WNL_, NOFF_, PREV_EPI0_, CUR_EPI_)                                   \
-    {                                                                                                                               \
+    if (HALF) {                                                                                                                     \
+      x3_stage<KS_, SRCLO_, true, true, NKS_>(L.frag[SRC_], wh, wl, acc[0], WNH_, WNL_, NOFF_, none);                               \
+      x3_drain(CUR_EPI_);                                                                                                           \
+      __syncthreads();                                                                                                              \
+    } else {                                                                                                                        \
       if (LIVE_) x3_stage<KS_, SRCLO_, true, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI0_);             \
       else x3_drain(PREV_EPI0_);                                                                                                   \
       __syncthreads();                                                                                                              \
@@ -329,12 +345,14 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     // overwritten below; nothing of it is stored), drained, then the PE rows complete lin4's input (skip_fix)
     const bool w7 = wave != 7;
     X3_LAYER(3, 16, 0, LO, true, false, 16, a.Wp[4], a.Wlo[4], w_off(16, 256), X3_EPI(2, acc[1], 1, true, 256, 0, true, SAVE, a.h[3], a.hlo[3]), X3_EPI(3, acc[0], 0, true, 217, 1, true, SAVE && w7, a.h[4], a.hlo[4]))
-    x3_drain(X3_EPI(3, acc[1], 1, true, 217, 1, true, SAVE && w7, a.h[4], a.hlo[4]));
-    __syncthreads();
+    if (!HALF) {
+      x3_drain(X3_EPI(3, acc[1], 1, true, 217, 1, true, SAVE && w7, a.h[4], a.hlo[4]));
+      __syncthreads();
+    }
     skip_fix();
     __syncthreads();
     X3_STAMP(4);
-    if (PREFETCH && more) e_load(batch + gridDim.x);
+    if (PREFETCH && more) e_load(pnext, false);
     // lin4: XB -> XA
     X3_LAYER(4, 16, 1, LO, true, false, 16, a.Wp[5], a.Wlo[5], w_off(16, 256), none, X3_EPI(4, acc[0], 0, true, 256, 0, true, SAVE, a.h[5], a.hlo[5]))
     X3_STAMP(5);
@@ -346,8 +364,10 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     // macro refills anyway -- from lin8's pack, which exists in both modes)
     X3_LAYER(7, 16, 0, LO, true, false, (VALUES ? 4 : 16), a.Wp[VALUES ? 0 : 8], a.Wlo[VALUES ? 0 : 8], w_off(VALUES ? 4 : 16, 256), X3_EPI(6, acc[1], 1, true, 256, 0, true, SAVE, a.h[7], a.hlo[7]), X3_EPI(7, acc[0], 0, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]))
     // drain: h8's second tile
-    x3_drain(X3_EPI(7, acc[1], 1, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]));
-    __syncthreads();
+    if (!HALF) {
+      x3_drain(X3_EPI(7, acc[1], 1, true, 256, 1, true, SAVE, a.h[8], a.hlo[8]));
+      __syncthreads();
+    }
     X3_STAMP(6);
     // ---- lin8: the sdf row, split over the waves' k-steps (2 each) and reduced through LDS
     {
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
       for (int j = 0; j < 2; ++j) { sh[j] = x3_ldg(a.Wp[8], so + j * 1024); sl[j] = x3_ldg(a.Wlo[8], so + j * 1024); }
       const unsigned char* fr = L.frag[1] + (unsigned)(2 * wave) * C::KSTEP;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < (HALF ? 1 : 2); ++t) {
         f32x16 accs;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
@@ -375,16 +395,21 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
     }
     if (SAVE) {
       // ---- the 256 feature rows of lin8 (linear): XB -> HBM only
-      x3_stage<16, LO, true, false, 16>(L.frag[1], wh, wl, acc[0], nullptr, nullptr, 0u, none);
-      x3_stage<16, LO, true, true, 4>(L.frag[1] + 512, wh, wl, acc[1], a.Wp[0], a.Wlo[0], w_off(4, 256), X3_EPI(8, acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));      // (rolls in lin0 of the next batch)
-      x3_drain(X3_EPI(8, acc[1], 1, false, 256, 0, false, true, a.feat, a.featlo));
+      if (HALF) {
+        x3_stage<16, LO, true, true, 4>(L.frag[1], wh, wl, acc[0], a.Wp[0], a.Wlo[0], w_off(4, 256), none);
+        x3_drain(X3_EPI(8, acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));
+      } else {
+        x3_stage<16, LO, true, false, 16>(L.frag[1], wh, wl, acc[0], nullptr, nullptr, 0u, none);
+        x3_stage<16, LO, true, true, 4>(L.frag[1] + 512, wh, wl, acc[1], a.Wp[0], a.Wlo[0], w_off(4, 256), X3_EPI(8, acc[0], 0, false, 256, 0, false, true, a.feat, a.featlo));      // (rolls in lin0 of the next batch)
+        x3_drain(X3_EPI(8, acc[1], 1, false, 256, 0, false, true, a.feat, a.featlo));
+      }
     }
     __syncthreads();
 #undef X3_EPI
 #undef X3_LAYER
     int tf = tid;
     asm volatile("" : "+v"(tf));
-    if (tf < BP) {
+    if (tf < (HALF ? 32 : BP)) {
       float sv = biasl[8 * 256 + (VALUES ? 0 : 256)];
 #pragma unroll
       for (int w = 0; w < 8; ++w) sv += red[w * BP + tf];
@@ -408,7 +433,12 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
              stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5], stamp[7] - stamp[6]);
     ++nb_done;
 #endif
-  }
+  };
+  // (the half batch FIRST: behind the loop it would keep its pointers alive through the loop)
+  if ((int)blockIdx.x < 2 * nhalf) run_batch((nfull + ((int)blockIdx.x >> 1)) * BP + 32 * ((int)blockIdx.x & 1), false, 0, std::true_type{});
+  if (PREFETCH && (int)blockIdx.x < nfull) { e_load(blockIdx.x * BP, false); e_store(); __syncthreads(); }
+  for (int batch = blockIdx.x; batch < nfull; batch += G)
+    run_batch(batch * BP, batch + G < nfull, (batch + G) * BP, std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -459,9 +489,15 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
   int nb_done = 0;
   unsigned long long stamp[12];
 #endif
-  for (int bi = blockIdx.x; bi < nbatches; bi += gridDim.x) {
-    const int batch = NEAT_X3_ADJ_REVERSE ? nbatches - 1 - bi : bi;
-    const int p0 = batch * BP;
+  // the ragged last round as half batches: see sdf_chain_x3_kernel
+  const int G = (int)gridDim.x;
+  int nfull = nbatches, nhalf = 0;
+  if (NEAT_X3_HALF && !NEAT_X3_ADJ_REVERSE && nbatches > G) {
+    const int rem = nbatches % G;
+    if (rem > 0 && 2 * rem <= G) { nfull = nbatches - rem; nhalf = rem; }
+  }
+  auto run_batch = [&](const int p0, auto half_c) {
+    constexpr bool HALF = decltype(half_c)::value;
     X3_STAMP(0);
     L.gquad = ((unsigned)(4 * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
     L.ldp16 = (unsigned)a.ldp * 16u;
@@ -479,6 +515,10 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
     uint2 hqh[4], hql[4];
     auto load_hq = [&](int q, const u16* hs, const u16* ls, int t) {
       const unsigned off = (unsigned)q * L.ldp16 + L.gquad + t * 512;
+#ifdef NEAT_X3_ADJ_NOLOAD     // probe (results are WRONG): what the adjoint chain costs without its h loads
+      hqh[q] = make_uint2(off, off); hql[q] = make_uint2(off >> 8, off >> 9);
+      return;
+#endif
       hqh[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hs) + off);
       hql[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ls) + off);
     };
@@ -497,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
 #pragma unroll
       for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(L.bias + (8 * q) * 4);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < (HALF ? 1 : 2); ++t) {
         load_h(a.h[8], a.hlo[8], t);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -555,15 +595,23 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
       const uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
       *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
       *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
+#ifndef NEAT_X3_ADJ_NOSTORE   // probe (results are WRONG): what the adjoint chain costs without its u stores
       if (SAVE && (MODE == 0 || wave < 7)) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(uout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+#endif
     };
     auto none = [](int) {};
     // ADJ_EPI(accumulators, tile, mode, destination buffer, u array, fp32 rows, [h planes, tile] of the NEXT epilogue's quads)
 #define ADJ_EPI(ACC_, T_, MODE_, DST_, U_, F_, NH_, NL_, NT_) [&](int e) { epi_elem(ACC_, e, T_, MODE_, DST_, U_, F_, NH_, NL_, NT_); }
     // one layer: stage (tile 0) with the previous layer's tile-1 epilogue, stage (tile 1, rolling in the next layer's weights) with
     // this layer's tile-0 epilogue.  HS / HL: the h planes whose phi' multiplies THIS layer's output (requested a stage ahead).
-#define ADJ_LAYER(SRC_, WNH_, WNL_, NNEXT_, PREV_EPI_, CUR_EPI_)                                                                     \
-    {                                                                                                                             \
+    // HALF (one tile): the k-steps, then the next layer's weights are requested and the tile's epilogue HALF_EPI_ runs -- CUR_EPI_
+    // with the h quads of the NEXT layer's tile 0 as its refill.
+#define ADJ_LAYER(SRC_, WNH_, WNL_, NNEXT_, PREV_EPI_, CUR_EPI_, HALF_EPI_)                                                          \
+    if (HALF) {                                                                                                                   \
+      x3_stage<16, LO, true, true, 16>(L.frag[SRC_], wh, wl, acc[0], WNH_, WNL_, w_off(NNEXT_), none);                            \
+      x3_drain(HALF_EPI_);                                                                                                        \
+      __syncthreads();                                                                                                            \
+    } else {                                                                                                                      \
       x3_stage<16, LO, true, false, 16>(L.frag[SRC_], wh, wl, acc[0], nullptr, nullptr, 0u, PREV_EPI_);                           \
       __syncthreads();                                                                                                            \
       x3_stage<16, LO, true, true, 16>(L.frag[SRC_] + 512, wh, wl, acc[1], WNH_, WNL_, w_off(NNEXT_), CUR_EPI_);                  \
@@ -573,27 +621,37 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
     // epilogue of (l, tile 0), whose quads make room for (l, tile 1)'s.  (The first stage has no epilogue: its successor's quads
     // were requested before the loop; layer 0's epilogues read no h.)
     ADJ_LAYER(0, a.Wp[6], a.Wlo[6], 256, none,
-              ADJ_EPI(acc[0], 0, 0, 1, a.u[6], nullptr, a.h[7], a.hlo[7], 1))                                                     // l = 7: XA -> XB
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[6], nullptr, a.h[7], a.hlo[7], 1),
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[6], nullptr, a.h[6], a.hlo[6], 0))                                                     // l = 7: XA -> XB
     X3_STAMP(2);
     ADJ_LAYER(1, a.Wp[5], a.Wlo[5], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[6], nullptr, a.h[6], a.hlo[6], 0),
-              ADJ_EPI(acc[0], 0, 0, 0, a.u[5], nullptr, a.h[6], a.hlo[6], 1))                                                     // l = 6: XB -> XA
+              ADJ_EPI(acc[0], 0, 0, 0, a.u[5], nullptr, a.h[6], a.hlo[6], 1),
+              ADJ_EPI(acc[0], 0, 0, 0, a.u[5], nullptr, a.h[5], a.hlo[5], 0))                                                     // l = 6: XB -> XA
     X3_STAMP(3);
     ADJ_LAYER(0, a.Wp[4], a.Wlo[4], 256, ADJ_EPI(acc[1], 1, 0, 0, a.u[5], nullptr, a.h[5], a.hlo[5], 0),
-              ADJ_EPI(acc[0], 0, 0, 1, a.u[4], nullptr, a.h[5], a.hlo[5], 1))                                                     // l = 5
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[4], nullptr, a.h[5], a.hlo[5], 1),
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[4], nullptr, a.h[4], a.hlo[4], 0))                                                     // l = 5
     ADJ_LAYER(1, a.Wp[3], a.Wlo[3], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[4], nullptr, a.h[4], a.hlo[4], 0),
-              ADJ_EPI(acc[0], 0, 1, 0, a.u[3], a.es, a.h[4], a.hlo[4], 1))                                                        // l = 4: rows 217.. -> es
+              ADJ_EPI(acc[0], 0, 1, 0, a.u[3], a.es, a.h[4], a.hlo[4], 1),
+              ADJ_EPI(acc[0], 0, 1, 0, a.u[3], a.es, a.h[3], a.hlo[3], 0))                                                        // l = 4: rows 217.. -> es
     X3_STAMP(4);
     ADJ_LAYER(0, a.Wp[2], a.Wlo[2], 256, ADJ_EPI(acc[1], 1, 1, 0, a.u[3], a.es, a.h[3], a.hlo[3], 0),
-              ADJ_EPI(acc[0], 0, 0, 1, a.u[2], nullptr, a.h[3], a.hlo[3], 1))                                                     // l = 3
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[2], nullptr, a.h[3], a.hlo[3], 1),
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[2], nullptr, a.h[2], a.hlo[2], 0))                                                     // l = 3
     ADJ_LAYER(1, a.Wp[1], a.Wlo[1], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[2], nullptr, a.h[2], a.hlo[2], 0),
-              ADJ_EPI(acc[0], 0, 0, 0, a.u[1], nullptr, a.h[2], a.hlo[2], 1))                                                     // l = 2
+              ADJ_EPI(acc[0], 0, 0, 0, a.u[1], nullptr, a.h[2], a.hlo[2], 1),
+              ADJ_EPI(acc[0], 0, 0, 0, a.u[1], nullptr, a.h[1], a.hlo[1], 0))                                                     // l = 2
     ADJ_LAYER(0, a.Wp[0], a.Wlo[0], 39, ADJ_EPI(acc[1], 1, 0, 0, a.u[1], nullptr, a.h[1], a.hlo[1], 0),
-              ADJ_EPI(acc[0], 0, 0, 1, a.u[0], nullptr, a.h[1], a.hlo[1], 1))                                                     // l = 1
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[0], nullptr, a.h[1], a.hlo[1], 1),
+              ADJ_EPI(acc[0], 0, 0, 1, a.u[0], nullptr, nullptr, nullptr, 0))                                                     // l = 1
     X3_STAMP(5);
     ADJ_LAYER(1, a.Wp[7], a.Wlo[7], 256, ADJ_EPI(acc[1], 1, 0, 1, a.u[0], nullptr, nullptr, nullptr, 0),
+              ADJ_EPI(acc[0], 0, 2, 0, nullptr, a.e0, nullptr, nullptr, 0),
               ADJ_EPI(acc[0], 0, 2, 0, nullptr, a.e0, nullptr, nullptr, 0))                                                       // l = 0: e0 (fp32)
-    x3_drain(ADJ_EPI(acc[1], 1, 2, 0, nullptr, a.e0, nullptr, nullptr, 0));
-    __syncthreads();
+    if (!HALF) {
+      x3_drain(ADJ_EPI(acc[1], 1, 2, 0, nullptr, a.e0, nullptr, nullptr, 0));
+      __syncthreads();
+    }
     X3_STAMP(6);
 #if NEAT_X3_TIMING
     if (blockIdx.x == 0 && nb_done < 3 && tid == 0)
@@ -603,7 +661,9 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
 #endif
 #undef ADJ_LAYER
 #undef ADJ_EPI
-  }
+  };
+  if ((int)blockIdx.x < 2 * nhalf) run_batch((nfull + ((int)blockIdx.x >> 1)) * BP + 32 * ((int)blockIdx.x & 1), std::true_type{});
+  for (int bi = blockIdx.x; bi < nfull; bi += G) run_batch((NEAT_X3_ADJ_REVERSE ? nbatches - 1 - bi : bi) * BP, std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -995,6 +995,31 @@ def test_fused_adjoint_chain_equals_streamed_layers(dev, P, half):
         lib.neat_set_tuning(13, 1)
 
 
+@pytest.mark.parametrize("P", [133120, 64 * 288, 64 * 257 - 5, 64 * 300 + 1])
+def test_x3_chains_ragged_round_as_half_batches(dev, P):
+    """sdf_chain_x3_kernel / sdf_adjoint_x3_kernel run the ragged last round of a launch (nbatches % workgroups batches, when they are
+    at most half the workgroups) as half batches -- one 32-point tile per workgroup, no stage pipeline.  A tile's arithmetic does
+    not depend on which path it takes: the points of that round must come out bit-identical to a launch that holds them in whole
+    batches (at most as many batches as workgroups), for get_outputs (save mode: sdf, features, normals) and get_sdf_vals (values
+    mode), and the points before them must not change either."""
+    G = 256                                                # persistent workgroups of the chains (neat_api.hip: g_ws_grid)
+    m = build_model(dev, "rough", precision="fp16x3")
+    x = (torch.rand(P, 3, generator=torch.Generator().manual_seed(P)) * 4 - 2).to(dev)
+    nb = (P + 63) // 64
+    first = (nb - nb % G) * 64 if nb > G else 0            # first point of the last round
+    with torch.no_grad():
+        full = [t.clone() for t in m.implicit_network.get_outputs(x)]
+        tail = [t.clone() for t in m.implicit_network.get_outputs(x[first:].contiguous())]
+        head = [t.clone() for t in m.implicit_network.get_outputs(x[:G * 64].contiguous())]
+        v_full = m.implicit_network.get_sdf_vals(x).clone()
+        v_tail = m.implicit_network.get_sdf_vals(x[first:].contiguous()).clone()
+    for a, b, c in zip(full, tail, head):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a[first:], b)
+        assert torch.equal(a[:G * 64], c)
+    assert torch.isfinite(v_full).all() and torch.equal(v_full[first:], v_tail)
+
+
 @pytest.mark.parametrize("half", ["bf16", "fp16", "fp16x3"])
 @pytest.mark.parametrize("R,S", [(1024, 128), (600, 98), (37, 50), (3, 7)])
 def test_in_kernel_weight_gradients_agree_with_wgrad_launches(dev, R, S, half):
