@@ -1348,13 +1348,14 @@ __global__ void bwd_prologue_kernel(BwdPrologueArgs a) {
 #define NEAT_W3_ABLATE 0
 #endif
 constexpr int W3T = 512, W3P = 32, W3NS = 4;
-// NCB = 32-column blocks of the output per wave: 4 (K <= 256 packed columns) or 5 (K <= 320: the heads' input layers [256 feature | <= 64
-// small rows] in ONE launch instead of two that each read the whole A operand; round 4)
+// NCB = 32-column blocks of the output per wave: 4 (K <= 256 packed columns), 5 (K <= 320: the heads' input layers [256 feature | <= 64
+// small rows] in ONE launch instead of two that each read the whole A operand; round 4) or 1 (K <= 64: lin0, whose B operand is the 39 PE
+// rows -- the 4-block variant moves 32 octets of B per stage whatever K is)
 template <int NCB> struct W3Cfg {
   static constexpr int QA = 8, QB = 2 * NCB;           // 32-row quads of the A / B operand in a stage
   static constexpr int STAGE = (QA + QB) * 2048;       // bytes per stage: A quads, then B quads, each 32 points x 64 B
   static constexpr int LDS = W3NS * STAGE;
-  static constexpr int QPW = NCB == 4 ? 2 : 3;         // quads a wave moves per stage (NCB = 5: 18 quads over 8 waves x 3, the surplus re-reads the last)
+  static constexpr int QPW = NCB == 5 ? 3 : 2;         // quads a wave moves per stage (NCB = 5: 18 quads over 8 waves x 3, NCB = 1: 10 over 8 x 2; the surplus re-reads the last)
   static constexpr int G = 2 * QPW;                    // LDS-DMA instructions per stage and wave
 };
 constexpr int W3_STAGE = W3Cfg<4>::STAGE;

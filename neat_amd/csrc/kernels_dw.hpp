@@ -39,6 +39,7 @@ struct LayerArgsDW {
   int ablate;                          // probe runs only (results WRONG; tuning key 17): 4 = no partial stores
 };
 
+constexpr int DW_XLDS = 1024;                     // bytes behind the ring: lin8's sdf weight row (EPI_BWD8)
 constexpr int DW_WG_UINT4 = 8 * 8 * 2 * 64;      // uint4 per workgroup partial (128 KiB)
 #ifndef DW_VALU_PER_MFMA
 #define DW_VALU_PER_MFMA 14
@@ -115,12 +116,10 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
   uint4 wreg[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) wreg[ks] = live ? a.Wp[((size_t)wave * a.kstride + ks) * 64 + lane0] : make_uint4(0u, 0u, 0u, 0u);
-  float bias8[16];            // EPI_BWD8 only: the sdf row of lin8 (effective weight) in accumulator layout
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane0 >> 5);
-    bias8[r] = (EPI == EPI_BWD8 && n < a.N) ? a.wrow[n] * a.wrow_scale[0] : 0.0f;
-  }
+  // EPI_BWD8 only: the sdf row of lin8 (effective weight), 256 floats behind the ring (16 more registers per lane would spill); the
+  // first stage's barrier publishes it
+  float* w8 = reinterpret_cast<float*>(wslds + C::LDS);
+  if (EPI == EPI_BWD8 && threadIdx.x < 256) w8[threadIdx.x] = (int)threadIdx.x < a.N ? a.wrow[threadIdx.x] * a.wrow_scale[0] : 0.0f;
   const int Npad = (a.N + 7) & ~7;
 
   f32x16 dacc[8];
@@ -243,6 +242,9 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
         const float x0[4] = {bf_lo(r0v.x), bf_hi(r0v.x), bf_lo(r0v.y), bf_hi(r0v.y)};
         const float x1[4] = {bf_lo(r1v.x), bf_hi(r1v.x), bf_lo(r1v.y), bf_hi(r1v.y)};
         float o0[4], o1[4];
+        float4 b8 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI == EPI_BWD8) b8 = *reinterpret_cast<const float4*>(w8 + n0);
+        const float bias8q[4] = {b8.x, b8.y, b8.z, b8.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = acc[4 * q + e];
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
           float r0 = 0.0f, r1 = 0.0f;
           if (TANK) { const float sg = dphi_fast(x0[e]); r0 = v * sg; r1 = v * x1[e] * (100.0f * (1.0f - sg)); }
           else if (EPI == EPI_BWD) r0 = v * dphi_fast(x0[e]) + x1[e];
-          else if (EPI == EPI_BWD8) r0 = (v + bias8[4 * q + e] * sp) * dphi_fast(x0[e]) + x1[e];
+          else if (EPI == EPI_BWD8) r0 = (v + bias8q[e] * sp) * dphi_fast(x0[e]) + x1[e];
           if (!fullrows && n0 + e >= a.N) {
             r0 = 0.0f; r1 = 0.0f;
             if (C::HAS_PF && n0 + e < a.N + 7)
@@ -356,6 +358,8 @@ struct DwGatherJob {
   float* out; size_t row_stride, split_stride; int split0;       // sub-range y writes split split0 + y
   int bias_col;
   int rows, cols;                                                 // valid packed rows n / packed columns k (others are not written)
+  const float* xrow; int xrow_n; size_t xrow_stride;              // one more packed row `rows` (lin8: the sdf row, rowdot_kernel's xrow_n block
+                                                                  // partials of cols + 1 values -- bias column included); null: none
 };
 constexpr int DW_MAXJOBS = 16;
 struct DwGatherArgs { DwGatherJob job[DW_MAXJOBS]; };
@@ -404,6 +408,16 @@ __global__ __launch_bounds__(256) void dw_gather_kernel(DwGatherArgs) {
     if (jb.pbias)
       for (int g = g0; g < g1; ++g) t += jb.pbias[g * 256 + n];
     if (n < jb.rows) out[(size_t)n * jb.row_stride + jb.bias_col] = t;
+  }
+  if (jb.xrow && blockIdx.x == 1) {                            // extra row: this sub-range's share of the block partials, in block order
+    const int perx = (jb.xrow_n + nsub - 1) / nsub;
+    const int b0 = sub * perx, b1 = min(jb.xrow_n, b0 + perx);
+    for (int k = threadIdx.x; k <= jb.cols; k += 256) {
+      float t = 0.0f;
+#pragma unroll 8
+      for (int b = b0; b < b1; ++b) t += jb.xrow[(size_t)b * jb.xrow_stride + k];
+      out[(size_t)jb.rows * jb.row_stride + k] = t;
+    }
   }
 }
 

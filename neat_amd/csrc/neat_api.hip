@@ -230,6 +230,7 @@ int g_ws_wide_store = 1;    // streaming layer kernels: 16-byte output stores (t
 const int* g_gate = nullptr; int g_gate_value = 0;      // set around one neat_sdf_forward call by neat_sdf_values_gated
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
+int g_wgrad_narrow = 1;     // 16-bit builds: lin0's weight gradient (K = 39) on the one-column-block variant of wgrad_kernel_h3 (tuning key 21)
 int g_wgrad_k320 = 1;       // 16-bit builds: the heads' input layers (K = 256 + <= 64) as one five-column-block weight-gradient launch (tuning key 19)
 int g_head_l4_batched = 1;  // a head's output-layer weight gradient as a fourth problem of its hidden layers' launch (tuning key 20)
 int g_dw_ablate = 0;        // probe runs (tuning key 17): see LayerArgsDW::ablate
@@ -238,12 +239,14 @@ int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers
                             // the same ~1 GB of traffic per pass whatever the point count, the operand reads they replace scale with it),
                             // 2 = always, 0 = never (the separate wgrad_kernel_h3 launches of round 3)
 constexpr int DW_MIN_POINTS = 49152;
+constexpr int DW8_XBLOCKS = 512;     // block partials of the sdf row of dW8 (rowdot_kernel)
+int g_dw_lin8 = 1;          // with key 16: lin8's feature-row gradient (featc x h8) inside its reverse launch too (tuning key 22)
 int g_dw_nsub = 8;          // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
 template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
   static DevOnce attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_wsdw<EPI, FULL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI, 16>::LDS);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WsCfg<EPI, 16>::LDS + DW_XLDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -252,7 +255,7 @@ template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const
   d.w.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 28);
   d.ablate = g_dw_ablate;
   if (FULL && (d.w.N != 256 || d.rowsA != 256)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((layer_kernel_wsdw<EPI, FULL>), dim3(dw_grid(d.w.ldp)), dim3(WST), (WsCfg<EPI, 16>::LDS), st, d);
+  hipLaunchKernelGGL((layer_kernel_wsdw<EPI, FULL>), dim3(dw_grid(d.w.ldp)), dim3(WST), (WsCfg<EPI, 16>::LDS + DW_XLDS), st, d);
   return hipGetLastError();
 }
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
@@ -482,7 +485,7 @@ struct SdfWs {
   float *dwp, *dwscale, *dwbias;  // 16-bit builds: block-scaled f16 partials of the in-kernel weight gradients (kernels_dw.hpp): 14 jobs
   size_t total;
 };
-constexpr int DW_JOBS = 14;                 // (layer 1..7) x (tangent pair, reverse pair)
+constexpr int DW_JOBS = 15;                 // (layer 1..7) x (tangent pair, reverse pair) + lin8's reverse pair
 constexpr int WSPLIT = 128;                 // fp32 build: point-splits of the weight-gradient reduction
 constexpr int WLDN = 384, WLDK = 384;       //             partial tile leading dims (>= 296+1, multiple of 128)
 constexpr int W2SPLIT = 256;                // bf16 build (256x256 tiles): splits and leading dims
@@ -907,6 +910,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
     const bool wide = h3 && g_wgrad_k320 && K > 256 && K <= 320 && r0 == 256 && r1 > 0 && r1 <= 64;
     const bool two = K > 256 && !wide;
     if (two && (r0 != 256 || r1 == 0 || r1 > 256)) h3 = false;
+    const bool narrow = h3 && g_wgrad_narrow && K <= 64 && r1 == 0;      // lin0: one 32-column block per wave (tuning key 21)
     if (h3) {
       static DevOnce attr3_set;
       if (!attr3_set) {
@@ -914,7 +918,9 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
         if (e != hipSuccess) return e;
         attr3_set = true;
       }
-      int chunk = ((c.ldp + W2SPLIT - 1) / W2SPLIT + W3P - 1) / W3P * W3P;
+      // (narrow: 80 KB of LDS per workgroup -> two co-resident workgroups per CU when there are twice as many splits)
+      const int nsplit_target = narrow ? W2SPLIT * g_wgrad_narrow : W2SPLIT;
+      int chunk = ((c.ldp + nsplit_target - 1) / nsplit_target + W3P - 1) / W3P * W3P;
       if (chunk < 2 * W3P) chunk = 2 * W3P;
       splits = (c.P + chunk - 1) / chunk;
       chunk_used = chunk;
@@ -925,6 +931,14 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3<5>), hipFuncAttributeMaxDynamicSharedMemorySize, W3Cfg<5>::LDS);
           if (e != hipSuccess) return e;
           attr5_set = true;
+        }
+      }
+      if (narrow) {
+        static DevOnce attr1_set;
+        if (!attr1_set) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel_h3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, W3Cfg<1>::LDS);
+          if (e != hipSuccess) return e;
+          attr1_set = true;
         }
       }
       for (int part = 0; part < (two ? 2 : 1); ++part) {
@@ -947,6 +961,7 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
         a.npairs = npairs; a.N = N; a.P = c.P; a.ldp = c.ldp; a.chunk = chunk;
         a.partial = w.partial; a.row_stride = (size_t)splits * Kld2; a.split_stride = Kld2; a.interleave = g_ws_interleave != 0; a.nt_loads = (g_ws_aux_nt >> 2) & 1;
         if (wide) hipLaunchKernelGGL(wgrad_kernel_h3<5>, dim3(1, splits), dim3(W3T), W3Cfg<5>::LDS, c.st, a);
+        else if (narrow) hipLaunchKernelGGL(wgrad_kernel_h3<1>, dim3(1, splits), dim3(W3T), W3Cfg<1>::LDS, c.st, a);
         else hipLaunchKernelGGL(wgrad_kernel_h3<4>, dim3(1, splits), dim3(W3T), W3_LDS_BYTES, c.st, a);
       }
       prof_end(c.st, ps);
@@ -1016,6 +1031,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   bool dw = c.prec && g_dw_fused && g_layer_ws && g_wgrad_h3 && c.ldp >= 2 * WSP && (g_dw_fused == 2 || c.ldp >= DW_MIN_POINTS);
   for (int l = 1; l <= 7; ++l) dw = dw && gr->dv[l] != nullptr && L.d[L.fwd[l]].Kpad == 256 && L.d[L.tr[l]].Kpad == 256;
   const int dwg = dw_grid(c.ldp);
+  const bool dw8 = dw && g_dw_lin8 && gr->dv[8] != nullptr && L.d[L.tr[8]].Kpad >= 256 && w.featc.bf16;
   auto dw_job = [&](int l, int pair, LayerArgsDW& d) {
     const size_t j = (size_t)(2 * (l - 1) + pair);
     d.partial = reinterpret_cast<uint4*>(w.dwp) + j * DW_MAXGRID * DW_WG_UINT4;
@@ -1057,6 +1073,38 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   }
   // reverse chain: a^_{l-1} = (W_l^T a^_l) phi'(a_{l-1}) + m_{l-1}   (in place in m)
   if (!c.prec) e = layer(c, L.tr[8], EPI_BWD, in(F(w.abar8), 257), NOIN, nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
+  else if (dw8) {
+    // the sdf row of dW8 first: its operands h8 and vh8 are what the last tangent launch just read / wrote (Infinity Cache)
+    {
+      const int K = 256, Kld2 = (K + 1 + 7) / 8 * 8, splits = g_dw_nsub;
+      const size_t region = (size_t)256 * splits * Kld2, region8 = (size_t)257 * splits * Kld2;
+      float* xrow = w.partial + (size_t)7 * region + region8;
+      const int xchunk = ((c.ldp + DW8_XBLOCKS - 1) / DW8_XBLOCKS + 31) / 32 * 32;
+      const int xn = (c.P + xchunk - 1) / xchunk;
+      if ((size_t)7 * region + region8 + (size_t)DW8_XBLOCKS * Kld2 > WPARTIAL_FLOATS) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(rowdot_kernel, dim3(xn), dim3(256), 0, c.st, w.abar8, reinterpret_cast<const u16*>(w.h[8].p),
+                         reinterpret_cast<const u16*>(w.vh[8].p), c.P, c.ldp, xchunk, xrow, (size_t)Kld2);
+    }
+    // lin8's reverse launch contracts featc (x) h8 (the 256 feature rows of dW8) and the row sums of featc on chip as well
+    LayerArgsDW d{};
+    LayerArgsWS& s = d.w;
+    const PackDesc2& pd = L.d[L.tr[8]];
+    s.in = u16p(w.featc); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
+    s.aux0 = u16p(w.h[8]); s.aux1 = u16p(w.m[7]); s.out0 = u16p(w.m[7]);
+    s.srow = w.abar8; s.wrow = c.net->v[8]; s.wrow_scale = c.rowscale(8);
+    s.N = 256; s.ldp = c.ldp; s.kstride = pd.Kpad / 16; s.n_split = 1 << 30;
+    s.in_octs = 32; s.split_oct = 32;
+    d.auxA2 = nullptr; d.auxA_split = 1 << 30; d.rowsA = 256;
+    const size_t j = 14;
+    d.partial = reinterpret_cast<uint4*>(w.dwp) + j * DW_MAXGRID * DW_WG_UINT4;
+    d.pscale = w.dwscale + j * DW_MAXGRID * 8;
+    d.pbias = w.dwbias + j * DW_MAXGRID * 256;
+    d.P = c.P;
+    ProfSlot* ps = dw_prof(256, 256);
+    e = launch_layer_wsdw<EPI_BWD8, true>(c.st, d);
+    prof_end(c.st, ps);
+    dbg_sync(c.st, "reverse+dW layer", 8, 0, 0);
+  }
   else if (g_layer_ws) e = layer_ws(c, L.tr[8], EPI_BWD8, w.featc, 256, w.m[7], w.h[8], w.m[7], w.abar8, c.net->v[8], c.rowscale(8));
   else e = layer(c, L.tr[8], EPI_BWD, in(w.featc, 256), in(F(w.abar8), 1), nullptr, 256, w.m[7], Arr{}, 1 << 30, w.h[8], w.m[7]);
   if (e != hipSuccess) return e;
@@ -1151,11 +1199,41 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       r.bias_col = K;
       done[l] = true;
     }
+    int njobs = 7;
+    if (dw8) {
+      // lin8: packed rows 0..255 = the feature rows (one partial set, reverse launch only), packed row 256 = the sdf row: cotangent abar8
+      // row 0 against h8, plus the plain row sums of vh8 (second-order part, the adjoint seed being 1), from rowdot_kernel's block partials
+      float* out = w.partial + (size_t)7 * region;
+      const size_t region8 = (size_t)257 * splits * Kld2;
+      float* xrow = out + region8;
+      const int xchunk = ((c.ldp + DW8_XBLOCKS - 1) / DW8_XBLOCKS + 31) / 32 * 32;
+      const int xn = (c.P + xchunk - 1) / xchunk;
+      const size_t j = 14;
+      DwGatherJob& jb = ga.job[7];
+      jb.partial = reinterpret_cast<const uint4*>(w.dwp) + j * DW_MAXGRID * DW_WG_UINT4;
+      jb.pscale = w.dwscale + j * DW_MAXGRID * 8;
+      jb.partial2 = nullptr; jb.pscale2 = nullptr;
+      jb.pbias = w.dwbias + j * DW_MAXGRID * 256;
+      jb.nwg = dwg; jb.transposed = 0;
+      jb.out = out; jb.row_stride = (size_t)splits * Kld2; jb.split_stride = Kld2; jb.split0 = 0;
+      jb.bias_col = K; jb.rows = 256; jb.cols = K;
+      jb.xrow = xrow; jb.xrow_n = xn; jb.xrow_stride = Kld2;
+      const PackDesc2& pd = L.d[L.fwd[8]];
+      WreduceArgs& r = wb.a[7];
+      r.partial = out; r.splits = splits; r.row_stride = (size_t)splits * Kld2; r.split_stride = Kld2;
+      r.O = kO[8]; r.I = kI[8];
+      r.s0 = pd.s0; r.s0p = pd.s0p; r.off0 = pd.off0; r.off1 = pd.off1; r.rot = pd.rot; r.scale = pd.scale;
+      r.v = c.net->v[8]; r.g = c.net->g[8];
+      r.dv = gr->dv[8]; r.dg = gr->dg[8]; r.db = gr->db[8];
+      r.bias_col = K;
+      done[8] = true;
+      njobs = 8;
+    }
     // (accounted with the weight-gradient class: no flops, the partials read once + the fp32 splits written and read once)
-    ProfSlot* psg = prof_begin(c.st, 1, 0.0, 14.0 * dwg * DW_WG_UINT4 * 16.0 + 2.0 * 7 * (double)region * 4.0);
-    hipLaunchKernelGGL(dw_gather_kernel, dim3(DW_WG_UINT4 / 256, g_dw_nsub, 7), dim3(256), 0, c.st, ga);
+    ProfSlot* psg = prof_begin(c.st, 1, 0.0, (14.0 + (dw8 ? 1.0 : 0.0)) * dwg * DW_WG_UINT4 * 16.0 + 2.0 * njobs * (double)region * 4.0);
+    hipLaunchKernelGGL(dw_gather_kernel, dim3(DW_WG_UINT4 / 256, g_dw_nsub, njobs), dim3(256), 0, c.st, ga);
     dbg_sync(c.st, "dw gather", 0, 0, 0);
-    hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(256, 7), dim3(WG), 0, c.st, wb);
+    hipLaunchKernelGGL(wreduce_wnorm_batch_kernel, dim3(dw8 ? 257 : 256, njobs), dim3(WG), 0, c.st, wb);
     prof_end(c.st, psg);
     dbg_sync(c.st, "dw finish", 0, 0, 0);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1531,6 +1609,8 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 18 && value >= 1 && value <= 16) { g_dw_nsub = value; return 0; }
   if (key == 19 && (value == 0 || value == 1)) { g_wgrad_k320 = value; return 0; }
   if (key == 20 && (value == 0 || value == 1)) { g_head_l4_batched = value; return 0; }
+  if (key == 21 && value >= 0 && value <= 4) { g_wgrad_narrow = value; return 0; }
+  if (key == 22 && (value == 0 || value == 1)) { g_dw_lin8 = value; return 0; }
   return -1;
 }
 

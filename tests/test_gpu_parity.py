@@ -1057,10 +1057,89 @@ def test_in_kernel_weight_gradients_agree_with_wgrad_launches(dev, R, S, half):
     for k in g0:
         assert torch.isfinite(g1[k]).all(), k
         err = float((g1[k] - g0[k]).abs().max())
-        # layers 0 and 8 and the heads keep their launches, but their gradients depend on nothing the switch changes
+        # layer 0 and the heads keep their launches, but their gradients depend on nothing the switch changes
         assert err <= 1e-3 * float(g0[k].abs().max()) + 1e-12, (k, err, float(g0[k].abs().max()))
-        if not any(f"implicit_network.lin{l}." in k for l in range(1, 8)):
+        if not any(f"implicit_network.lin{l}." in k for l in range(1, 9)):
             assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("R,S", [(1024, 128), (600, 98), (37, 50)])
+def test_lin8_in_kernel_weight_gradient(dev, R, S, half):
+    """lin8's reverse launch as layer_kernel_wsdw<EPI_BWD8> (tuning key 22): the 256 feature rows of dW8 = featc (x) h8 and their bias
+    gradient contracted on chip, the sdf row from rowdot_kernel's block partials summed by the gather launch -- against the separate
+    wgrad_kernel_h3 + rowdot + wreduce_direct launches.  The reverse chain itself (m7 and everything downstream) must not change:
+    every other gradient identical; lin8's within 1e-3 of its maximum (block-scaled f16 partials, another summation order)."""
+    from neat_amd import _lib, rend_util
+    m = build_model(dev, "rough", seed=6, train=True).set_precision(half)
+    sc = synth.synth_scene(seed=6, n_rays=R)
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(6, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(4)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def run(key):
+        _lib.check(_lib.lib().neat_set_tuning(22, key), "neat_set_tuning")
+        m.zero_grad()
+        torch.manual_seed(7)
+        rgb, l3, *_ = m._render(c, d, z, False)
+        ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        _lib.check(_lib.lib().neat_set_tuning(16, 2), "neat_set_tuning")
+        g0, g1 = run(0), run(1)
+    finally:
+        _lib.lib().neat_set_tuning(16, 1)
+        _lib.lib().neat_set_tuning(22, 1)
+    seen = 0
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        if "implicit_network.lin8." in k:
+            seen += 1
+            mx = float(g0[k].abs().max())
+            assert mx > 0, k
+            err = float((g1[k] - g0[k]).abs().max())
+            assert err <= 1e-3 * mx + 1e-12, (k, err, mx)
+        else:
+            assert torch.equal(g0[k], g1[k]), k
+    assert seen == 3
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("R,S", [(1024, 128), (37, 50), (3, 7)])
+def test_lin0_narrow_wgrad_is_bit_identical(dev, R, S, half):
+    """lin0's weight gradient (K = 39 PE columns) on wgrad_kernel_h3<1> (one 32-column block per wave, two B quads per stage instead
+    of eight; tuning key 21) against the four-block variant: same stages, same MFMA order per output element -> every gradient identical."""
+    from neat_amd import _lib, rend_util
+    m = build_model(dev, "rough", seed=4, train=True).set_precision(half)
+    sc = synth.synth_scene(seed=4, n_rays=R)
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(4, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(2)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def grads(key):
+        _lib.check(_lib.lib().neat_set_tuning(21, key), "neat_set_tuning")
+        m.zero_grad()
+        torch.manual_seed(7)
+        rgb, l3, *_ = m._render(c, d, z, False)
+        ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        g0, g1 = grads(0), grads(1)
+    finally:
+        _lib.lib().neat_set_tuning(21, 1)
+    assert float(g0["implicit_network.lin0.weight_v"].abs().max()) > 0
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
 
 
 @pytest.mark.parametrize("half", ["bf16", "fp16"])
