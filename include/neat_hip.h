@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 9 */
+int neat_abi_version(void);      /* 10 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -217,6 +217,13 @@ int neat_encode_lines(const float* lines, int N, int H, int W, float* lmap, int*
 int neat_gather_batch(const int* pool, int npool, const long long* draw, int n, int W, const float* att, const float* rgb, const int* labels,
                       const float* lines, int nlines, float* uv, float* uv_proj, float* rgb_out, float* lines_out, long long* labels_out,
                       long long* pixel_out, void* stream);
+
+/* ---- step prefix: the fresh batch's tensors (datasets' collate output, training/volsdf_train.py:361-364 `model_input[...] = ...cuda()`)
+ * and the step's CPU-drawn randoms (the reference draws on the host: model/ray_sampler.py:86-93,132; neat_wfr_rend_a.py:330-335) into the
+ * persistent tensors a captured step reads, as ONE launch: copy i moves nbytes[i] bytes from src[i] to dst[i] (n <= 16).  A source may be
+ * device memory or pinned host memory (hipHostMalloc: the kernel reads it over the bus -- no separate copy-engine transfer and none of
+ * the idle gaps between a copy and the next kernel).  Pointers 4-byte aligned, sizes multiples of 4. */
+int neat_copy_batch(const void* const* src, void* const* dst, const long long* nbytes, int n, void* stream);
 
 /* ---- a11 / a14 glue as single launches.  neat_project2d = VolSDFNetwork.project2D (model/networks/neat_wfr_rend_a.py:317-326):
  * K [3,3] and w2c [3,4] = [R|T] row-major on the device, X [N,3] -> uv [N,2]; its backward gives d_X from d_uv.

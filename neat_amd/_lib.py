@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 9
+ABI_VERSION = 10
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "fp16x3": 4}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/probes/abl_build.sh)
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_gather_batch": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int,
                                          c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "neat_copy_batch": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
     "neat_ffn_forward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 10),
     "neat_ffn_backward": (ctypes.c_int, [c_fp, ctypes.c_int] + [c_fp] * 15),
     "neat_l3d": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),

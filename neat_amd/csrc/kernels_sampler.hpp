@@ -464,6 +464,21 @@ __global__ void gather_batch_kernel(GatherBatchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Step prefix (neat_copy_batch): up to COPY_BATCH_MAX small copies as one launch; blockIdx.y = the copy, sources in device memory or in
+// pinned host memory (read over the bus by the kernel itself).
+// ---------------------------------------------------------------------------------------------
+constexpr int COPY_BATCH_MAX = 16;
+struct CopyBatchArgs { const unsigned* src[COPY_BATCH_MAX]; unsigned* dst[COPY_BATCH_MAX]; long long words[COPY_BATCH_MAX]; int n; };
+__global__ __launch_bounds__(256) void copy_batch_kernel(CopyBatchArgs) {
+  const CopyBatchArgs* a = (const CopyBatchArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int i = blockIdx.y;
+  const unsigned* __restrict__ s = a->src[i];
+  unsigned* __restrict__ d = a->dst[i];
+  const long long w = a->words[i];
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < w; k += (long long)gridDim.x * 256) d[k] = s[k];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dataset-side attraction field: replacement for the un-vendored `hawp.base._C.encodels`
 // (call sites: datasets/blender_hawp_dataset.py:96, scene_hawp_dataset.py:95).  Per pixel: the nearest of the N
 // 2-D segments (distance to the segment, projection clamped to its ends); outputs, as the call sites consume them,

@@ -1582,7 +1582,7 @@ NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated)
 
 extern "C" {
 
-int neat_abi_version(void) { return 9; }
+int neat_abi_version(void) { return 10; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
 #if !NEAT_HALF
@@ -2021,6 +2021,23 @@ int neat_gather_batch(const int* pool, int npool, const long long* draw, int n, 
   if (!draw || !uv || !uv_proj || !rgb_out || !lines_out || !labels_out || !pixel_out) return -1;
   GatherBatchArgs a{pool, draw, n, W, npool, att, rgb, labels, lines, nlines, uv, uv_proj, rgb_out, lines_out, labels_out, pixel_out};
   hipLaunchKernelGGL(gather_batch_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_copy_batch(const void* const* src, void* const* dst, const long long* nbytes, int n, void* stream) {
+  if (n < 0 || n > COPY_BATCH_MAX) return -1;
+  if (n == 0) return 0;
+  if (!src || !dst || !nbytes) return -1;
+  CopyBatchArgs a{};
+  long long mx = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!src[i] || !dst[i] || nbytes[i] < 0 || (nbytes[i] & 3) || ((size_t)src[i] & 3) || ((size_t)dst[i] & 3)) return -1;
+    a.src[i] = (const unsigned*)src[i]; a.dst[i] = (unsigned*)dst[i]; a.words[i] = nbytes[i] >> 2;
+    mx = nbytes[i] > mx ? nbytes[i] : mx;
+  }
+  a.n = n;
+  const int by = (int)((mx / 4 + 1023) / 1024);          // 256 threads x 4 words per block
+  hipLaunchKernelGGL(copy_batch_kernel, dim3(by < 1 ? 1 : (by > 1024 ? 1024 : by), n), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

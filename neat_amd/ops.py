@@ -25,6 +25,27 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def copy_batch(pairs):
+    """[(dst, src), ...] -> one launch per 16 copies (neat_copy_batch): dst device tensors, src device or PINNED host tensors of the same
+    byte size, both contiguous.  The step prefix of a replayed graph: the fresh batch and the CPU-drawn randoms go into the captured
+    tensors without a multi-tensor ATen launch and without copy-engine transfers (each of which idles the GPU for ~6 us before the next kernel)."""
+    lib = _lib.lib()
+    for i0 in range(0, len(pairs), 16):
+        chunk = pairs[i0:i0 + 16]
+        n = len(chunk)
+        src = (ctypes.c_void_p * n)(*[s.data_ptr() for _, s in chunk])
+        dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
+        nb = (ctypes.c_longlong * n)(*[d.numel() * d.element_size() for d, _ in chunk])
+        _lib.check(lib.neat_copy_batch(src, dst, nb, n, _stream()), "neat_copy_batch")
+
+
+def copy_batch_ok(dst, src):
+    """Can (dst, src) ride in copy_batch?  Same dtype and element count, contiguous, 4-byte granular; src on dst's device or pinned."""
+    return (dst.dtype == src.dtype and dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+            and (dst.numel() * dst.element_size()) % 4 == 0 and dst.data_ptr() % 4 == 0 and src.data_ptr() % 4 == 0
+            and dst.numel() > 0 and (src.device == dst.device or (src.device.type == "cpu" and src.is_pinned())))
+
+
 def _f32c(t):
     if t is None:
         return None

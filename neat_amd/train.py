@@ -3,7 +3,7 @@ forward -> loss -> zero_grad/backward -> [gradient all-reduce] -> Adam step -> p
 import torch
 import torch.distributed as dist
 
-from . import networks, synth
+from . import networks, ops, synth
 from .dp import FlatGradBucket
 from .loss import VolSDFLoss
 from .wireframe import WireframeGraph
@@ -218,9 +218,12 @@ class Trainer:
         self.optimizer.step()
         self.scheduler.step()
 
-    def _refill_randoms(self, entry):
-        """Fresh CPU draws, in the forward's draw order, into the layout's persistent device tensors (pinned staging ring)."""
+    def _refill_randoms(self, entry, collect=None):
+        """Fresh CPU draws, in the forward's draw order, into the layout's persistent device tensors (pinned staging ring).
+        collect (a list): the (device tensor, pinned buffer) pairs are appended for ONE copy_batch launch by the caller, who records the
+        returned events after it; None: one asynchronous copy per draw site, here."""
         slots = sorted(entry.randoms.values(), key=lambda s: s["order"])
+        events = []
         for slot in slots:
             ring = slot.get("ring")
             if ring is None:
@@ -231,9 +234,14 @@ class Trainer:
             pinned, ev = ring[self._ring_pos % 4]
             ev.synchronize()                                # the copy that last used this staging buffer is long done
             pinned.copy_(slot["draw"]())
-            slot["dev"].copy_(pinned, non_blocking=True)
-            ev.record()
+            if collect is not None and ops.copy_batch_ok(slot["dev"], pinned):
+                collect.append((slot["dev"], pinned))
+                events.append(ev)
+            else:
+                slot["dev"].copy_(pinned, non_blocking=True)
+                ev.record()
         self._ring_pos += 1
+        return events
 
     def check_nan(self):
         """Graph mode keeps the line-loss NaN flag on the device (loss.nan_check == "off"); this reads it (one sync)."""
@@ -250,7 +258,7 @@ class Trainer:
         if bad:
             raise FloatingPointError("line loss is NaN on at least one rank (the reference drops into pdb here, loss_wfr.py:66-67)")
 
-    def _load_batch(self, entry, model_input, ground_truth):
+    def _load_batch(self, entry, model_input, ground_truth, collect=None):
         """Every tensor of the fresh batch is copied into the captured tensors, in ONE multi-tensor launch (a few KB per step).  No
         "unchanged?" shortcut on (data_ptr, _version): a new batch uploaded with .to(device) usually lands on the block the allocator
         just freed, with version 0, and would be mistaken for the previous one."""
@@ -266,12 +274,24 @@ class Trainer:
         zo = getattr(self.model, "z_vals_override", None)
         if entry.static_z is not None and zo is not entry.static_z:
             dst.append(entry.static_z); src.append(zo)
-        if dst:
+        if collect is not None:
+            for d, s_ in zip(dst, src):
+                if ops.copy_batch_ok(d, s_):
+                    collect.append((d, s_))
+                else:
+                    d.copy_(s_, non_blocking=True)
+        elif dst:
             torch._foreach_copy_(dst, src)
 
     def _replay(self, entry, model_input, ground_truth):
-        self._load_batch(entry, model_input, ground_truth)
-        self._refill_randoms(entry)
+        # the step's prefix as ONE launch: fresh batch tensors and the CPU-drawn randoms (read from their pinned buffers by the kernel)
+        pairs = []
+        self._load_batch(entry, model_input, ground_truth, collect=pairs)
+        events = self._refill_randoms(entry, collect=pairs)
+        if pairs:
+            ops.copy_batch(pairs)
+        for ev in events:
+            ev.record()
         self._finish_step(entry)
         self._last = entry
         self.replays += 1

@@ -1926,3 +1926,29 @@ def test_degenerate_sizes_give_empty_results(dev, precision):
     with pytest.raises(RuntimeError):
         ops.line_loss(z0(0, 4), z0(0, 4), z0(0))
     torch.cuda.synchronize()
+
+
+def test_copy_batch_device_and_pinned_sources(dev):
+    """neat_copy_batch (the replayed step's prefix): 19 copies -> two launches; device and pinned-host sources, sizes from 4 bytes to
+    a few hundred KB, int64 and float32; destinations equal sources afterwards and neighbouring memory is untouched."""
+    from neat_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    pairs, guards = [], []
+    for i in range(19):
+        n = [1, 3, 64, 1024, 2048 * 3, 98 * 1024, 7, 257, 65536][i % 9]
+        if i % 4 == 3:
+            src = torch.randint(0, 1 << 40, (n,), generator=gen, dtype=torch.int64)
+        else:
+            src = torch.randn(n, generator=gen)
+        src = src.pin_memory() if i % 2 else src.to(dev)
+        buf = torch.full((n + 2,), -7, dtype=src.dtype, device=dev)
+        pairs.append((buf[1:n + 1], src))
+        guards.append(buf)
+        assert ops.copy_batch_ok(*pairs[-1])
+    ops.copy_batch(pairs)
+    torch.cuda.synchronize()
+    for (d, s_), buf in zip(pairs, guards):
+        assert torch.equal(d.cpu(), s_.cpu())
+        assert float(buf[0]) == -7 and float(buf[-1]) == -7
+    assert not ops.copy_batch_ok(torch.zeros(4, device=dev), torch.zeros(4))            # pageable host memory
+    assert not ops.copy_batch_ok(torch.zeros(4, 4, device=dev).t(), torch.zeros(4, 4, device=dev))
