@@ -323,7 +323,7 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *     last 270 MB written, -0.025 ms per step), 0 = after both chains, the two heads' hidden layers batched together
  *  16 16-bit builds: weight gradients of the SDF layers 1..7 contracted inside the tangent / reverse launches that hold both
  *     operands in LDS (kernels_dw.hpp): 1 = from 49 152 points on (default), 2 = always, 0 = never (separate launches)
- *  17 probe switch of those launches (4 = no partial stores: wrong results)      18 sub-ranges of their gather launch (default 8)
+ *  17 probe switch of those launches (4 = no partial stores: wrong results)      18 sub-ranges of their gather launch (default 16)
  *  19 16-bit builds: the heads' input layers ([256 feature | <= 64 small] columns) as ONE five-column-block weight-gradient launch
  *     (default 1; 0 = two launches that each read the whole cotangent array)
  *  20 a head's output-layer weight gradient as a fourth problem of its hidden layers' launch (default 1)

@@ -645,34 +645,71 @@ __global__ __launch_bounds__(256) void ffn_dense_kernel(const float* __restrict_
   }
 }
 
-// blockIdx.y: 0: dW0 = d_a1^T x, db0 ; 1: dW1 = d_a2^T h1, db1 ; 2 (rows 0..2): dW2 = dy^T h2, db2.  blockIdx.x = output row.
-__global__ __launch_bounds__(FFN_H) void ffn_backward_weights_kernel(const float* __restrict__ x, const float* __restrict__ h1,
+// blockIdx.y: 0: dW0 = d_a1^T x, db0 ; 1: dW1 = d_a2^T h1, db1 ; 2 (rows 0..2): dW2 = dy^T h2, db2.  blockIdx.x = FFN_RN output rows.
+// 1024 threads = 16 wavefronts: wavefront g sums ITS sixteenth of the J rows (a lane = four columns of the block's output rows: one 16-byte load
+// per row of the input, eight rows in flight), the sixteen partial sums are combined in group order (deterministic).  One thread per
+// output over all J rows was a chain of J dependent trips to L2 with every block re-reading the whole input: 87 us at the J = 1024
+// latents of the DTU / BlendedMVS confs.
+constexpr int FFN_JG = 16, FFN_RN = 4;       // wavefronts (row groups) per block, output rows per block
+__global__ __launch_bounds__(64 * FFN_JG) void ffn_backward_weights_kernel(const float* __restrict__ x, const float* __restrict__ h1,
     const float* __restrict__ h2, const float* __restrict__ d_a1, const float* __restrict__ d_a2, const float* __restrict__ dy, int J,
     float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
     float* __restrict__ db2) {
-  const int k = threadIdx.x, n = blockIdx.x, which = blockIdx.y;
-  if (which == 2 && n >= 3) return;
+  __shared__ __attribute__((aligned(16))) float red[FFN_JG][FFN_RN][FFN_H];
+  __shared__ float bred[FFN_JG][FFN_RN];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, which = blockIdx.y;
+  const int n0 = FFN_RN * blockIdx.x;
+  const int N = which == 2 ? 3 : FFN_H;
+  if (n0 >= N) return;
   const float* d = which == 0 ? d_a1 : (which == 1 ? d_a2 : dy);
   const float* in = which == 0 ? x : (which == 1 ? h1 : h2);
   const int ldd = which == 2 ? 3 : FFN_H;
-  float acc = 0.0f, bsum = 0.0f;
-  int j = 0;
-  for (; j + 4 <= J; j += 4) {              // four rows in flight (the sum order stays j = 0, 1, 2, ...)
-    float dv[4], xv[4];
+  const int per = (J + FFN_JG - 1) / FFN_JG;
+  const int jb = min(J, grp * per), je = min(J, jb + per);
+  float4 a[FFN_RN]; float bs[FFN_RN];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { dv[t] = d[(size_t)(j + t) * ldd + n]; xv[t] = in[(size_t)(j + t) * FFN_H + k]; }
+  for (int r = 0; r < FFN_RN; ++r) { a[r] = make_float4(0.f, 0.f, 0.f, 0.f); bs[r] = 0.0f; }
+  int j = jb;
+  for (; j + 4 <= je; j += 4) {               // four rows of the input in flight (the sum order of a group stays j = jb, jb + 1, ...)
+    float dv[4][FFN_RN]; float4 xv[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { acc += dv[t] * xv[t]; bsum += dv[t]; }
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int r = 0; r < FFN_RN; ++r) dv[t][r] = n0 + r < N ? d[(size_t)(j + t) * ldd + n0 + r] : 0.0f;
+      xv[t] = *reinterpret_cast<const float4*>(in + (size_t)(j + t) * FFN_H + 4 * lane);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < FFN_RN; ++r) {
+        a[r].x += dv[t][r] * xv[t].x; a[r].y += dv[t][r] * xv[t].y; a[r].z += dv[t][r] * xv[t].z; a[r].w += dv[t][r] * xv[t].w;
+        bs[r] += dv[t][r];
+      }
   }
-  for (; j < J; ++j) {
-    const float dv = d[(size_t)j * ldd + n];
-    acc += dv * in[(size_t)j * FFN_H + k];
-    bsum += dv;
+  for (; j < je; ++j) {
+    const float4 xv = *reinterpret_cast<const float4*>(in + (size_t)j * FFN_H + 4 * lane);
+#pragma unroll
+    for (int r = 0; r < FFN_RN; ++r) {
+      const float dv = n0 + r < N ? d[(size_t)j * ldd + n0 + r] : 0.0f;
+      a[r].x += dv * xv.x; a[r].y += dv * xv.y; a[r].z += dv * xv.z; a[r].w += dv * xv.w;
+      bs[r] += dv;
+    }
   }
+#pragma unroll
+  for (int r = 0; r < FFN_RN; ++r) {
+    *reinterpret_cast<float4*>(&red[grp][r][4 * lane]) = a[r];
+    if (lane == 0) bred[grp][r] = bs[r];
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 8, k = threadIdx.x & (FFN_H - 1);       // 1024 threads = FFN_RN rows x 256 columns
+  if (n0 + r >= N) return;
+  float v = 0.0f, b = 0.0f;
+#pragma unroll
+  for (int g = 0; g < FFN_JG; ++g) { v += red[g][r][k]; b += bred[g][r]; }
   float* dW = which == 0 ? dW0 : (which == 1 ? dW1 : dW2);
   float* db = which == 0 ? db0 : (which == 1 ? db1 : db2);
-  dW[(size_t)n * FFN_H + k] = acc;
-  if (k == 0) db[n] = bsum;
+  dW[(size_t)(n0 + r) * FFN_H + k] = v;
+  if (k == 0) db[n0 + r] = b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,7 +760,7 @@ __global__ void dbscan_union_kernel(const float* __restrict__ pts, int n, double
 constexpr int DBSCAN_MAXN = 8192;
 __global__ __launch_bounds__(1024) void dbscan_finish_kernel(const float* __restrict__ pts, int n, int* __restrict__ parent,
                                                              const int* __restrict__ has_nb, float* __restrict__ centres,
-                                                             unsigned char* __restrict__ valid, int* __restrict__ count) {
+                                                             unsigned char* __restrict__ valid, int* __restrict__ count, int pts_in_lds) {
   __shared__ int lab[DBSCAN_MAXN];
   __shared__ int s_wave[16], s_base;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -749,15 +786,33 @@ __global__ __launch_bounds__(1024) void dbscan_finish_kernel(const float* __rest
     __syncthreads();
   }
   const int nclu = s_base;
+  // the points next to the labels (dynamic LDS, 12 n bytes when the launcher could provide them): the member loop below is one
+  // thread per cluster walking ALL points -- from global memory that was a chain of n dependent loads (87 us at n = 1024)
+  extern __shared__ float dbscan_pts[];
+  const float* P = pts;
+  if (pts_in_lds) {
+    for (int i = tid; i < 3 * n; i += nt) dbscan_pts[i] = pts[i];
+    P = dbscan_pts;
+  }
   __syncthreads();
-  for (int k = tid; k < nclu; k += nt) {                      // mean of the members in index order
+  // mean of a cluster's members: one wavefront per cluster, lane l sums members r + l, r + l + 64, ... in index order, the 64 partial
+  // sums are combined by a fixed shuffle tree (deterministic).  (One thread per cluster walking all points: 87 us at n = 1024.)
+  for (int k = wave; k < nclu; k += nw) {
     const int r = replist[k];
     float sx = 0.f, sy = 0.f, sz = 0.f; int cnt = 0;
-    for (int j = r; j < n; ++j)
-      if (lab[j] == r) { sx += pts[3 * j]; sy += pts[3 * j + 1]; sz += pts[3 * j + 2]; ++cnt; }
-    const float inv = 1.0f / (float)cnt;
-    centres[3 * k] = sx * inv; centres[3 * k + 1] = sy * inv; centres[3 * k + 2] = sz * inv;
-    valid[k] = 1;
+    for (int j = r + lane; j < n; j += 64) {
+      const bool m = lab[j] == r;
+      sx += m ? P[3 * j] : 0.0f; sy += m ? P[3 * j + 1] : 0.0f; sz += m ? P[3 * j + 2] : 0.0f; cnt += m ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off); cnt += __shfl_xor(cnt, off);
+    }
+    if (lane == 0) {
+      const float inv = 1.0f / (float)cnt;
+      centres[3 * k] = sx * inv; centres[3 * k + 1] = sy * inv; centres[3 * k + 2] = sz * inv;
+      valid[k] = 1;
+    }
   }
   if (tid == 0) *count = nclu;
 }

@@ -241,7 +241,7 @@ int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers
 constexpr int DW_MIN_POINTS = 49152;
 constexpr int DW8_XBLOCKS = 512;     // block partials of the sdf row of dW8 (rowdot_kernel)
 int g_dw_lin8 = 1;          // with key 16: lin8's feature-row gradient (featc x h8) inside its reverse launch too (tuning key 22)
-int g_dw_nsub = 8;          // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
+int g_dw_nsub = 16;         // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
 template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
   static DevOnce attr_set;
   if (!attr_set) {
@@ -2099,7 +2099,7 @@ int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, c
     hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a2, J, FFN_H, FFN_H, W1, nobias, h1, 0, d_a1, noy2);
     hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a1, J, FFN_H, FFN_H, W0, nobias, nogate, 0, dx, noy2);
   }
-  hipLaunchKernelGGL(ffn_backward_weights_kernel, dim3(FFN_H, 3), dim3(FFN_H), 0, (hipStream_t)stream, x, h1, h2, d_a1, d_a2, dy, J, dW0, db0,
+  hipLaunchKernelGGL(ffn_backward_weights_kernel, dim3(FFN_H / FFN_RN, 3), dim3(64 * FFN_JG), 0, (hipStream_t)stream, x, h1, h2, d_a1, d_a2, dy, J, dW0, db0,
                      dW1, db1, dW2, db2);
   return (int)hipGetLastError();
 }
@@ -2225,7 +2225,20 @@ int neat_dbscan_means(const float* points, int n, double eps, float* centres, un
   int* parent = (int*)ws; int* has_nb = parent + n;
   hipLaunchKernelGGL(dbscan_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, parent, has_nb, n);
   hipLaunchKernelGGL(dbscan_union_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, points, n, eps * eps, parent, has_nb);
-  hipLaunchKernelGGL(dbscan_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, points, n, parent, has_nb, centres, valid, count);
+  // the points in LDS next to the 32 KB of labels when they fit (12 n bytes)
+  const size_t pbytes = (size_t)n * 12;
+  int in_lds = 0;
+  if (pbytes <= 96 * 1024) {
+    static DevOnce attr_set;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dbscan_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    in_lds = 1;
+  }
+  hipLaunchKernelGGL(dbscan_finish_kernel, dim3(1), dim3(1024), in_lds ? pbytes : 0, (hipStream_t)stream, points, n, parent, has_nb, centres, valid,
+                     count, in_lds);
   return (int)hipGetLastError();
 }
 
