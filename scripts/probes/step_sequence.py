@@ -2,8 +2,9 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-# a step ends with adam_flat_kernel
-ends = [i for i, e in enumerate(ev) if "adam_flat" in e[2]]
+# a step ends with adam_flat_kernel (eval: a forward ends with the last junction_gate / composite kernel)
+marker = "adam_flat" if not (len(sys.argv) > 2 and sys.argv[2] == "eval") else "composite_fwd"
+ends = [i for i, e in enumerate(ev) if marker in e[2]]
 lo, hi = ends[-3] + 1, ends[-2] + 1
 tot = 0
 for i in range(lo, hi):
