@@ -1516,9 +1516,14 @@ __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const flo
 // f16 build: cotangent normalisation (kernels.hpp: cot_scale_of).  cot_scale_begin reduces max |cotangent| over the caller's arrays
 // into `slot` (a float of the workspace: the `ones` row, which only the fp32 build uses); the kernels that read the caller's
 // cotangents scale by 2^k; grad_unscale takes the factor out of the finished parameter gradients.  Other builds: slot = nullptr.
+// (a kernel, not hipMemsetAsync: inside a captured graph every memset node cost 35-45 us of idle GPU before the next kernel node --
+// two of them per f16 / fp16x3 step, found in the step's launch-ordered trace)
+__global__ void zero_word_kernel(float* p) { if (threadIdx.x == 0) *p = 0.0f; }
 const float* cot_scale_begin(const Ctx& c, float* slot, std::initializer_list<std::pair<const float*, long long>> arrays) {
   if (!NEAT_HALF) return nullptr;
-  (void)hipMemsetAsync(slot, 0, sizeof(float), c.st);
+  static const bool use_memset = getenv("NEAT_COT_MEMSET") != nullptr;      // probe: the memset node of rounds 2-4
+  if (use_memset) (void)hipMemsetAsync(slot, 0, sizeof(float), c.st);
+  else hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(64), 0, c.st, slot);
   CotMaxArgs a{};
   long long total = 0;
   for (const auto& it : arrays) { a.p[a.narr] = it.first; a.n[a.narr] = it.first ? it.second : 0; total += a.n[a.narr]; ++a.narr; }
