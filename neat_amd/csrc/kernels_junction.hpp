@@ -760,7 +760,7 @@ __global__ void dbscan_union_kernel(const float* __restrict__ pts, int n, double
 constexpr int DBSCAN_MAXN = 8192;
 __global__ __launch_bounds__(1024) void dbscan_finish_kernel(const float* __restrict__ pts, int n, int* __restrict__ parent,
                                                              const int* __restrict__ has_nb, float* __restrict__ centres,
-                                                             unsigned char* __restrict__ valid, int* __restrict__ count, int pts_in_lds) {
+                                                             unsigned char* __restrict__ valid, int* __restrict__ count, int mode) {
   __shared__ int lab[DBSCAN_MAXN];
   __shared__ int s_wave[16], s_base;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -786,17 +786,45 @@ __global__ __launch_bounds__(1024) void dbscan_finish_kernel(const float* __rest
     __syncthreads();
   }
   const int nclu = s_base;
-  // the points next to the labels (dynamic LDS, 12 n bytes when the launcher could provide them): the member loop below is one
-  // thread per cluster walking ALL points -- from global memory that was a chain of n dependent loads (87 us at n = 1024)
-  extern __shared__ float dbscan_pts[];
+  extern __shared__ __attribute__((aligned(8))) unsigned char dbscan_dyn[];
+  if (mode == 2) {
+    // O(n): every member adds its coordinates to its cluster's sums with LDS atomics -- in 2^-32 FIXED POINT, so that the sums do not depend
+    // on the order of the additions (deterministic; 2.3e-10 per coordinate, three orders below the float32 mean's own rounding; |x| < 2^19).
+    // rank[r] = cluster number of representative r.  (One wavefront per cluster walking all points, below, is O(clusters x n): 133 us at
+    // the 4096 line end points of a 2048-ray batch.)
+    long long* sx = reinterpret_cast<long long*>(dbscan_dyn);
+    long long* sy = sx + maxc; long long* sz = sy + maxc;
+    int* cnt = reinterpret_cast<int*>(sz + maxc);
+    int* rank = cnt + maxc;
+    for (int k = tid; k < nclu; k += nt) { sx[k] = 0; sy[k] = 0; sz[k] = 0; cnt[k] = 0; rank[replist[k]] = k; }
+    __syncthreads();
+    for (int j = tid; j < n; j += nt) {
+      if (has_nb[j] == 0) continue;                  // noise: a component of one point
+      const int k = rank[lab[j]];
+      atomicAdd(reinterpret_cast<unsigned long long*>(&sx[k]), (unsigned long long)__double2ll_rn((double)pts[3 * j] * 4294967296.0));
+      atomicAdd(reinterpret_cast<unsigned long long*>(&sy[k]), (unsigned long long)__double2ll_rn((double)pts[3 * j + 1] * 4294967296.0));
+      atomicAdd(reinterpret_cast<unsigned long long*>(&sz[k]), (unsigned long long)__double2ll_rn((double)pts[3 * j + 2] * 4294967296.0));
+      atomicAdd(&cnt[k], 1);
+    }
+    __syncthreads();
+    for (int k = tid; k < nclu; k += nt) {
+      const double inv = 1.0 / (4294967296.0 * (double)cnt[k]);
+      centres[3 * k] = (float)((double)sx[k] * inv); centres[3 * k + 1] = (float)((double)sy[k] * inv); centres[3 * k + 2] = (float)((double)sz[k] * inv);
+      valid[k] = 1;
+    }
+    if (tid == 0) *count = nclu;
+    return;
+  }
+  // the points next to the labels (dynamic LDS, 12 n bytes, mode 1)
+  float* dbscan_pts = reinterpret_cast<float*>(dbscan_dyn);
   const float* P = pts;
-  if (pts_in_lds) {
+  if (mode == 1) {
     for (int i = tid; i < 3 * n; i += nt) dbscan_pts[i] = pts[i];
     P = dbscan_pts;
   }
   __syncthreads();
   // mean of a cluster's members: one wavefront per cluster, lane l sums members r + l, r + l + 64, ... in index order, the 64 partial
-  // sums are combined by a fixed shuffle tree (deterministic).  (One thread per cluster walking all points: 87 us at n = 1024.)
+  // sums are combined by a fixed shuffle tree (deterministic)
   for (int k = wave; k < nclu; k += nw) {
     const int r = replist[k];
     float sx = 0.f, sy = 0.f, sz = 0.f; int cnt = 0;

@@ -2230,20 +2230,20 @@ int neat_dbscan_means(const float* points, int n, double eps, float* centres, un
   int* parent = (int*)ws; int* has_nb = parent + n;
   hipLaunchKernelGGL(dbscan_init_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, parent, has_nb, n);
   hipLaunchKernelGGL(dbscan_union_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, points, n, eps * eps, parent, has_nb);
-  // the points in LDS next to the 32 KB of labels when they fit (12 n bytes)
-  const size_t pbytes = (size_t)n * 12;
-  int in_lds = 0;
-  if (pbytes <= 96 * 1024) {
+  // mode 2 (18 n bytes of dynamic LDS fit next to the 32 KB of labels): O(n) fixed-point sums; else one wavefront per cluster over all
+  // points, read from LDS (mode 1: 12 n bytes fit) or from global memory (mode 0)
+  const size_t acc_bytes = (size_t)(n / 2) * 28 + (size_t)n * 4, pbytes = (size_t)n * 12;
+  const int mode = acc_bytes <= 96 * 1024 ? 2 : (pbytes <= 96 * 1024 ? 1 : 0);
+  if (mode) {
     static DevOnce attr_set;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dbscan_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    in_lds = 1;
   }
-  hipLaunchKernelGGL(dbscan_finish_kernel, dim3(1), dim3(1024), in_lds ? pbytes : 0, (hipStream_t)stream, points, n, parent, has_nb, centres, valid,
-                     count, in_lds);
+  hipLaunchKernelGGL(dbscan_finish_kernel, dim3(1), dim3(1024), mode == 2 ? acc_bytes : (mode == 1 ? pbytes : 0), (hipStream_t)stream, points, n,
+                     parent, has_nb, centres, valid, count, mode);
   return (int)hipGetLastError();
 }
 
