@@ -136,3 +136,42 @@ def test_draw_rules_of_the_device_batches():
         assert int(r.min()) >= 0 and int(r.max()) < npool
     counts = Counter(tuple(s.draw_rays(4, 2).tolist()) for _ in range(12000))
     assert len(counts) == 12 and min(counts.values()) > 800 and max(counts.values()) < 1200      # 12 ordered pairs, 1000 expected each
+
+
+def test_quat_to_rot_matches_scipy():
+    """rend_util.quat_to_rot (reference: utils/rend_util.py:111-128, (w, x, y, z) order, normalised first) against scipy's Rotation
+    (an independent implementation; (x, y, z, w) order) on random, un-normalised quaternions."""
+    import numpy as np
+    import torch
+    from scipy.spatial.transform import Rotation
+    from neat_amd import rend_util
+    rng = np.random.default_rng(3)
+    q = rng.normal(size=(64, 4)) * rng.uniform(0.1, 5.0, size=(64, 1))
+    got = rend_util.quat_to_rot(torch.tensor(q)).numpy()
+    ref = Rotation.from_quat(q[:, [1, 2, 3, 0]]).as_matrix()
+    assert np.abs(got - ref).max() < 1e-12
+    assert np.abs(got @ got.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_quaternion_pose_gives_the_matrix_pose_rays():
+    """get_camera_params with the reference's quaternion pose form [1,7] (rend_util.py:56-61) = the same rays as the 4x4 matrix of the
+    same camera through the HIP ray kernel."""
+    import numpy as np
+    import torch
+    from scipy.spatial.transform import Rotation
+    from neat_amd import rend_util
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    rot = Rotation.from_rotvec(rng.normal(size=3))
+    c = rng.uniform(-2, 2, size=3)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = rot.as_matrix()
+    pose[:3, 3] = c
+    qx = rot.as_quat()                                   # (x, y, z, w)
+    pose7 = np.concatenate([[qx[3]], qx[:3], c]).astype(np.float32)[None]
+    K = np.array([[500.0, 0.5, 256.0, 0], [0, 480.0, 250.0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)[None]
+    uv = torch.tensor(rng.uniform(0, 512, size=(1, 300, 2)).astype(np.float32)).to(dev)
+    d0, c0 = rend_util.get_camera_params(uv, torch.tensor(pose[None]).to(dev), torch.tensor(K).to(dev))
+    d1, c1 = rend_util.get_camera_params(uv, torch.tensor(pose7).to(dev), torch.tensor(K).to(dev))
+    assert float((d0 - d1).abs().max()) < 2e-6 and float((c0 - c1).abs().max()) < 1e-6
