@@ -48,6 +48,26 @@ def test_workspace_queries_are_consistent():
     assert lib.neat_sdf_ws_floats(100, 1, 3) == lib.neat_sdf_ws_floats(100, 1, 1) and lib.neat_heads_ws_floats(100, 3) == lib.neat_heads_ws_floats(100, 1)
 
 
+def test_copy_batch_rejects_bad_arguments_before_any_launch():
+    """neat_copy_batch validates on the host: more than 16 copies, null tables, misaligned pointers and sizes that are not multiples of 4
+    return -1 without touching a device (so this runs without a GPU); zero copies is a no-op."""
+    from neat_amd import _lib
+    lib = _lib.lib()
+    buf = (ctypes.c_float * 16)()
+    base = ctypes.addressof(buf)
+    def call(srcs, dsts, sizes):
+        n = len(srcs)
+        return lib.neat_copy_batch((ctypes.c_void_p * n)(*srcs), (ctypes.c_void_p * n)(*dsts), (ctypes.c_longlong * n)(*sizes), n, None)
+    assert lib.neat_copy_batch(None, None, None, 0, None) == 0
+    assert lib.neat_copy_batch(None, None, None, 3, None) == -1
+    assert call([base] * 17, [base + 32] * 17, [4] * 17) == -1            # at most 16 per launch (ops.copy_batch chunks)
+    assert call([base + 2], [base + 32], [4]) == -1                        # source not 4-byte aligned
+    assert call([base], [base + 33], [4]) == -1                            # destination not 4-byte aligned
+    assert call([base], [base + 32], [6]) == -1                            # size not a multiple of 4
+    assert call([base], [base + 32], [-4]) == -1
+    assert call([base, 0], [base + 32, base + 48], [4, 4]) == -1           # a null source
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from neat_amd import networks, synth
