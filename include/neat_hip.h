@@ -329,7 +329,8 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *  20 a head's output-layer weight gradient as a fourth problem of its hidden layers' launch (default 1)
  *  21 16-bit builds: lin0's weight gradient (K = 39 PE columns) on the one-column-block variant of the streaming kernel: 0 = off,
  *     n = 1..4: on, with n times the point splits (default 1; 2 and 4 measured no faster)
- *  22 with key 16: the feature rows of lin8's weight gradient contracted inside lin8's reverse launch as well (default 1) */
+ *  22 with key 16: the feature rows of lin8's weight gradient contracted inside lin8's reverse launch as well (default 1)
+ *  23 workgroups (= partials per set) of the launches of key 16, 16..256 (default 256; C4's shape: 192 the same, 128 +7 %) */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);

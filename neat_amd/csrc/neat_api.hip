@@ -223,7 +223,13 @@ int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whi
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
 constexpr int DW_MAXGRID = 256;     // workgroup partials the workspace holds per (layer, pair)
-inline int dw_grid(int ldp) { const int nt = ldp / WSP, g = g_ws_grid < DW_MAXGRID ? g_ws_grid : DW_MAXGRID; return nt < g ? nt : g; }
+int g_dw_grid = DW_MAXGRID;  // workgroups (= partials per set) of the launches that contract weight gradients on chip (tuning key 23)
+inline int dw_grid(int ldp) {
+  int g = g_ws_grid < DW_MAXGRID ? g_ws_grid : DW_MAXGRID;
+  g = g < g_dw_grid ? g : g_dw_grid;
+  const int nt = ldp / WSP;
+  return nt < g ? nt : g;
+}
 int g_ws_aux_nt = 15;       // non-temporal accesses (tuning key 11): bit 0 / 1 = fetch of aux0 / aux1 of the streaming layer kernels, bit 2 =
                             // weight-gradient operands, bit 3 = `in` of the layer kernels, bit 4 = store of out1 (m_l)
 int g_ws_wide_store = 1;    // streaming layer kernels: 16-byte output stores (tuning key 12)
@@ -1616,6 +1622,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 20 && (value == 0 || value == 1)) { g_head_l4_batched = value; return 0; }
   if (key == 21 && value >= 0 && value <= 4) { g_wgrad_narrow = value; return 0; }
   if (key == 22 && (value == 0 || value == 1)) { g_dw_lin8 = value; return 0; }
+  if (key == 23 && value >= 16 && value <= DW_MAXGRID) { g_dw_grid = value; return 0; }
   return -1;
 }
 
