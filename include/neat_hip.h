@@ -330,7 +330,9 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *  21 16-bit builds: lin0's weight gradient (K = 39 PE columns) on the one-column-block variant of the streaming kernel: 0 = off,
  *     n = 1..4: on, with n times the point splits (default 1; 2 and 4 measured no faster)
  *  22 with key 16: the feature rows of lin8's weight gradient contracted inside lin8's reverse launch as well (default 1)
- *  23 workgroups (= partials per set) of the launches of key 16, 16..256 (default 256; C4's shape: 192 the same, 128 +7 %) */
+ *  23 workgroups (= partials per set) of the launches of key 16, 16..256 (default 256; C4's shape: 192 the same, 128 +7 %)
+ *  24 with keys 16 and 22: the chain variables of those launches (tangents of h_2..h_7, cotangents of a_6..a_1) alternate between two
+ *     buffers each instead of one array per layer (default 1; results bit-identical, fewer HBM write-backs) */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);

@@ -247,6 +247,9 @@ int g_dw_fused = 1;         // 16-bit builds: weight gradients of the SDF layers
 constexpr int DW_MIN_POINTS = 49152;
 constexpr int DW8_XBLOCKS = 512;     // block partials of the sdf row of dW8 (rowdot_kernel)
 int g_dw_lin8 = 1;          // with key 16: lin8's feature-row gradient (featc x h8) inside its reverse launch too (tuning key 22)
+int g_chain_pp = 1;         // with key 16: the chain variables of the tangent / reverse launches (vhat_2..7, a^_6..1) ping-pong between two buffers each
+                            // instead of one array per layer: since the weight gradients are contracted in the launch that holds them no later
+                            // kernel reads them, and a line rewritten while it is still in the Infinity Cache never costs an HBM write (tuning key 24)
 int g_dw_nsub = 16;         // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
 template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
   static DevOnce attr_set;
@@ -1046,6 +1049,11 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     d.P = c.P;
   };
   auto u16p = [](const Arr& a) { return reinterpret_cast<u16*>(a.p); };
+  // chain variables of the in-kernel-gradient launches: vhat_1 (lin0's launch) and vhat_8 (rowdot_kernel reads it) keep their arrays, vhat_2..7
+  // alternate between vh[2] / vh[3]; the reverse chain's a^_7..1 alternate between vh[4] / vh[5] (free in this mode), a^_0 lands in m[0] (lin0's gradient)
+  const bool pp = dw && g_chain_pp;
+  auto VH = [&](int l) -> const Arr& { return (pp && l >= 2 && l <= 7) ? w.vh[2 + (l & 1)] : w.vh[l]; };
+  auto RB = [&](int l) -> const Arr& { return (pp && l >= 1 && l <= 7) ? w.vh[4 + (l & 1)] : w.m[l]; };
   auto dw_prof = [&](int N, int rowsA) {
     const double P = (double)c.P;
     // the layer (2 N 256 P) + the gradient (2 rowsA 256 P); bytes: input, two epilogue operands, outputs, the partial
@@ -1059,8 +1067,8 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       LayerArgsDW d{};
       LayerArgsWS& s = d.w;
       const PackDesc2& pd = L.d[L.fwd[l]];
-      s.in = u16p(w.vh[l]); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
-      s.aux0 = u16p(w.h[l + 1]); s.aux1 = u16p(w.u[l]); s.out0 = u16p(w.vh[l + 1]); s.out1 = u16p(w.m[l]);
+      s.in = u16p(VH(l)); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
+      s.aux0 = u16p(w.h[l + 1]); s.aux1 = u16p(w.u[l]); s.out0 = u16p(VH(l + 1)); s.out1 = u16p(w.m[l]);
       s.N = kO[l]; s.ldp = c.ldp; s.kstride = pd.Kpad / 16; s.n_split = 1 << 30;
       s.in_octs = 32; s.split_oct = 32;
       if (l == 4) { s.in2 = u16p(w.Ehbf4); s.split_oct = 28; }
@@ -1096,7 +1104,7 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     LayerArgsWS& s = d.w;
     const PackDesc2& pd = L.d[L.tr[8]];
     s.in = u16p(w.featc); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
-    s.aux0 = u16p(w.h[8]); s.aux1 = u16p(w.m[7]); s.out0 = u16p(w.m[7]);
+    s.aux0 = u16p(w.h[8]); s.aux1 = u16p(w.m[7]); s.out0 = u16p(RB(7));
     s.srow = w.abar8; s.wrow = c.net->v[8]; s.wrow_scale = c.rowscale(8);
     s.N = 256; s.ldp = c.ldp; s.kstride = pd.Kpad / 16; s.n_split = 1 << 30;
     s.in_octs = 32; s.split_oct = 32;
@@ -1155,8 +1163,8 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       LayerArgsDW d{};
       LayerArgsWS& s = d.w;
       const PackDesc2& pd = L.d[L.tr[l]];
-      s.in = u16p(w.m[l]); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
-      s.aux0 = u16p(w.h[l]); s.aux1 = u16p(w.m[l - 1]); s.out0 = u16p(w.m[l - 1]);
+      s.in = u16p(dw8 ? RB(l) : w.m[l]); s.Wp = reinterpret_cast<const uint4*>(c.packed + pd.offset);
+      s.aux0 = u16p(w.h[l]); s.aux1 = u16p(w.m[l - 1]); s.out0 = u16p(dw8 ? RB(l - 1) : w.m[l - 1]);
       s.N = N; s.ldp = c.ldp; s.kstride = pd.Kpad / 16; s.n_split = 1 << 30;
       s.in_octs = (kO[l] + 7) / 8; s.split_oct = 32;
       // second gradient operand = the layer's input rows = the aux0 image: h_l, for the skip layer [h4 (217) | PE 0..6 in the padding | PE 7..38]
@@ -1623,6 +1631,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 21 && value >= 0 && value <= 4) { g_wgrad_narrow = value; return 0; }
   if (key == 22 && (value == 0 || value == 1)) { g_dw_lin8 = value; return 0; }
   if (key == 23 && value >= 16 && value <= DW_MAXGRID) { g_dw_grid = value; return 0; }
+  if (key == 24 && (value == 0 || value == 1)) { g_chain_pp = value; return 0; }
   return -1;
 }
 

@@ -1063,6 +1063,44 @@ def test_in_kernel_weight_gradients_agree_with_wgrad_launches(dev, R, S, half):
             assert torch.equal(g0[k], g1[k]), k
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16", "fp16x3"])
+@pytest.mark.parametrize("R,S", [(1024, 128), (600, 98)])
+def test_chain_variables_in_two_buffers_change_nothing(dev, R, S, half):
+    """Tuning key 24 (round 5): the tangent / reverse launches with in-kernel weight gradients write their chain variables into two
+    alternating buffers instead of one array per layer (no later kernel reads them).  Same launches, same arithmetic: outputs and
+    EVERY gradient bit-identical to the one-array-per-layer run."""
+    from neat_amd import _lib, rend_util
+    m = build_model(dev, "rough", seed=8, train=True).set_precision(half)
+    sc = synth.synth_scene(seed=8, n_rays=R)
+    d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+    d = d.reshape(-1, 3)
+    c = c.expand(R, 3).contiguous()
+    z = T(synth.synth_z_vals(8, R, S)).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    cot_rgb = torch.randn(R, 3, generator=gen).to(dev)
+    cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
+
+    def run(key):
+        _lib.check(_lib.lib().neat_set_tuning(24, key), "neat_set_tuning")
+        m.zero_grad()
+        torch.manual_seed(7)
+        rgb, l3, *_ = m._render(c, d, z, False)
+        ((rgb * cot_rgb).sum() + (l3 * cot_l).sum()).backward()
+        return rgb.detach().clone(), l3.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        _lib.check(_lib.lib().neat_set_tuning(16, 2), "neat_set_tuning")
+        r0, l0, g0 = run(0)
+        r1, l1, g1 = run(1)
+    finally:
+        _lib.lib().neat_set_tuning(16, 1)
+        _lib.lib().neat_set_tuning(24, 1)
+    assert torch.equal(r0, r1) and torch.equal(l0, l1)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g0[k], g1[k]), k
+
+
 @pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("R,S", [(1024, 128), (600, 98), (37, 50)])
 def test_lin8_in_kernel_weight_gradient(dev, R, S, half):
