@@ -98,6 +98,48 @@ def cpu_baseline(seed):
                             "a few tens of threads; the 1-thread figure is the reference runner's own configuration"}
 
 
+def dtu_switches_conf():
+    """C3 / C4 name DTU scan24: confs/dtu.conf differs from abc-neat-a in the model switches dbscan_enabled = True, use_median = False and
+    1024 global junction latents (the scene itself is not in /root/reference, the rays are synthetic)."""
+    import copy
+    from neat_amd import synth
+    conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+    conf.update(dbscan_enabled=True, use_median=False)
+    conf["global_junctions"] = dict(conf["global_junctions"], num_junctions=1024)
+    return conf
+
+
+C4_GLOBAL_RAYS = 4096
+
+
+def make_workload(name, rank, world, dev, precision):
+    """The trainer, its batch and the description of a headline workload on this rank.
+      c2 (default): BASELINE configs[1] -- 1024 rays x 128 given samples PER GPU (weak scaling);
+      c4: BASELINE configs[3] -- 4096 rays per step in total, split evenly over the ranks (512 per rank at 8 GPUs), DTU model
+          switches, full losses, RCCL gradient all-reduce (strong scaling)."""
+    from neat_amd import dp, synth
+    from neat_amd.train import Trainer, synthetic_batch
+    seed = dp.rank_seed(42, rank)
+    torch.manual_seed(seed)
+    if name == "c4":
+        rays = dp.shard_rays(C4_GLOBAL_RAYS, world)
+        sd = {k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough", num_junctions=1024).items()}
+        tr = Trainer(model_conf=dtu_switches_conf(), device=dev, state_dict=sd)
+        what = (f"C4: DTU model switches (device DBSCAN, 1024 junction latents), {C4_GLOBAL_RAYS} rays per step in total = {rays} per GPU "
+                f"x {S_SAMPLES} given samples, full losses")
+        scaling = "strong"
+    else:
+        rays = R_RAYS
+        sd = {k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()}      # same weights on every rank
+        tr = Trainer(device=dev, state_dict=sd)
+        what = f"C2: abc-neat-a networks, {rays} rays x {S_SAMPLES} samples per GPU, depth samples given"
+        scaling = "weak"
+    _, inp, gt = synthetic_batch(seed, rays, dev, view=rank)
+    tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(seed, rays, S_SAMPLES)).to(dev)
+    tr.model.set_precision(precision)
+    return tr, inp, gt, rays, what, scaling, sd
+
+
 def secondary_legs(dev, sd, headline_precision, steps, note):
     """Timed AFTER the headline, on the same GPU, same clock discipline (warm-up, graph capture, `steps` steps between
     synchronisations); rank 0 of a single-GPU run only.  VERDICT r2 #3:
@@ -109,7 +151,7 @@ def secondary_legs(dev, sd, headline_precision, steps, note):
     from neat_amd.train import Trainer, synthetic_batch
     legs = {}
 
-    def timed(tr, inp, gt, label):
+    def timed(tr, inp, gt, label, rays=R_RAYS):
         for _ in range(3):
             tr.step(inp, gt)
         graphed = tr.capture(inp, gt)
@@ -126,10 +168,10 @@ def secondary_legs(dev, sd, headline_precision, steps, note):
         if graphed:
             tr.check_nan()
         pts = out["points"]
-        S = pts.shape[0] // R_RAYS if pts.dim() == 2 else pts.shape[1]
+        S = pts.shape[0] // rays if pts.dim() == 2 else pts.shape[1]
         note(f"secondary leg {label}: {1e3 * dt:.3f} ms/step")
-        return {"ms_per_step": 1e3 * dt, "samples_per_ray": int(S), "value": R_RAYS * S / dt, "unit": "ray-samples/s",
-                "rays_per_s": R_RAYS / dt, "launch": "hip graph replay" if graphed else f"eager ({tr.capture_error!r})",
+        return {"ms_per_step": 1e3 * dt, "samples_per_ray": int(S), "value": rays * S / dt, "unit": "ray-samples/s",
+                "rays_per_s": rays / dt, "launch": "hip graph replay" if graphed else f"eager ({tr.capture_error!r})",
                 "loss": float(lo["loss"].detach()), "steps": steps}
 
     _, inp, gt = synthetic_batch(42, R_RAYS, dev)
@@ -164,6 +206,61 @@ def secondary_legs(dev, sd, headline_precision, steps, note):
                workload="train step with the conf-default ErrorBoundSampler, its SDF queries in one-product f16 (hip_sampler_fast_values)")
     legs[f"sampler_step_{parity}_fast_values"] = leg
     del tr
+    # ---- the other BASELINE configs under the same clock; single GPU, HIP-graph replay, synthetic rays
+    sd_dtu = {k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough", num_junctions=1024).items()}
+    for label, rays, precs, what, parity_note in (
+            ("c3_dtu_2048x128", 2048, dict.fromkeys((headline_precision, parity)),
+             "C3: DTU model switches (device DBSCAN, use_median off, 1024 junction latents), 2048 rays x 128 given samples, full losses (RGB + eikonal + attraction + junctions)",
+             "G11 (the reference's train step with these switches) at the fp32 bars for fp16x3; full-size oracle comparison test_c3_full_size_dtu_step"),
+            ("c4_rank_shape_512x128", 512, dict.fromkeys((headline_precision, parity)),
+             "C4's per-rank shape: 512 rays x 128 given samples (4096 rays over 8 ranks), DTU switches, world size 1 here (no all-reduce)",
+             "test_c4_rank_shape_step_vs_oracle")):
+        for prec in precs:
+            torch.manual_seed(42)
+            tr = Trainer(model_conf=dtu_switches_conf(), device=dev, state_dict=sd_dtu)
+            tr.model.set_precision(prec)
+            _, inp_w, gt_w = synthetic_batch(42, rays, dev)
+            tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(42, rays, S_SAMPLES)).to(dev)
+            leg = timed(tr, inp_w, gt_w, f"{label}_{prec}", rays=rays)
+            leg.update(precision=prec, workload=what, parity=parity_note)
+            legs[f"{label}_{prec}"] = leg
+            del tr
+    # C5: hierarchical 64 coarse + 64 fine depths, "fp16 MFMA with fp32 accumulate" (BASELINE configs[4]); per-rank shape 1024 rays
+    import copy
+    conf5 = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+    conf5.update(hip_sampler="hierarchical", hip_sampler_coarse=64, hip_sampler_fine=64)
+    for prec in ("fp16", parity):
+        torch.manual_seed(42)
+        tr = Trainer(model_conf=conf5, device=dev, state_dict=sd)
+        tr.model.set_precision(prec)
+        leg = timed(tr, inp, gt, f"c5_hierarchical_64+64_{prec}")
+        leg.update(precision=prec, workload="C5: 1024 rays, hierarchical sampler (64 coarse -> SDF values -> weights -> 64 fine = 128 samples per ray) feeding the main pass, abc model",
+                   parity="G12 (the reference's hierarchical train step): f16-grade bars for fp16 (test_c5_fp16_train_step_vs_reference_golden), fp32 bars for fp16x3; "
+                          "full size: test_c5_full_size_hierarchical_step")
+        legs[f"c5_hierarchical_64+64_{prec}"] = leg
+        del tr
+    # eval chunk as neat-final-parsing.py drives the model (:203-218): forward only, 2048 rays, conf-default sampler in eval mode
+    for prec in dict.fromkeys((headline_precision, parity)):
+        tr = Trainer(device=dev, state_dict=sd)
+        tr.model.set_precision(prec)
+        tr.model.eval()
+        _, inp_e, _ = synthetic_batch(43, 2048, dev)
+        with torch.no_grad():
+            for _ in range(3):
+                o = tr.model(inp_e)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                o = tr.model(inp_e)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        S_e = o["points"].shape[0] // 2048 if o["points"].dim() == 2 else o["points"].shape[1]
+        note(f"secondary leg eval_chunk_2048_{prec}: {1e3 * dt:.3f} ms/chunk")
+        legs[f"eval_chunk_2048_{prec}"] = {"ms_per_step": 1e3 * dt, "samples_per_ray": int(S_e), "value": 2048 * S_e / dt, "unit": "ray-samples/s",
+                                           "rays_per_s": 2048 / dt, "launch": "eager (host decides the sampler's rounds, as the reference)", "steps": steps,
+                                           "precision": prec, "workload": "eval forward of one 2048-ray chunk (sampler + render + junction block), neat-final-parsing.py:203-218",
+                                           "parity": "G7 (the reference's eval forward, all keys): test_eval_chunks_like_final_parsing"}
+        del tr
     return legs
 
 
@@ -192,7 +289,9 @@ def dry_run(args):
     rank, world, _ = dp.init_from_env(backend="gloo")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    model = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    c4 = args.workload == "c4"
+    model = networks.VolSDFNetwork(dtu_switches_conf() if c4 else synth.ABC_NEAT_A_MODEL_CONF)
+    rays = dp.shard_rays(C4_GLOBAL_RAYS, world) if c4 else R_RAYS
     params = [p for p in model.parameters() if p.requires_grad]
     n = sum(p.numel() for p in params)
     flat = torch.full((n,), float(rank + 1))
@@ -201,18 +300,26 @@ def dry_run(args):
     for _ in range(args.steps):
         flat.fill_(float(rank + 1))
         bucket.all_reduce_mean(flat)
+        # the packed path of a replayed step (Trainer._finish_step): gradients -> flat bucket -> ONE collective -> .grad = views
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1) * (1 + (i % 3)))
+        bucket.pack()
+        if bucket.active():
+            bucket.reduce_packed()
+        packed_ok = all(torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2.0 * (1 + (i % 3)))) for i, p in enumerate(params)) \
+            if bucket.active() else True
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     expect = (world + 1) / 2.0
-    ok = bool(torch.allclose(flat, torch.full_like(flat, expect)))
+    ok = bool(torch.allclose(flat, torch.full_like(flat, expect))) and (packed_ok if args.steps else True)
     if rank == 0:
         print(json.dumps({"metric": "ray-samples/s (train step) on ABC-neat-a", "value": 0.0, "unit": "ray-samples/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "strong" if c4 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "dry_run": True, "backend": "gloo", "world_size": world, "allreduce_elements": n, "allreduce_ok": ok,
                           "config": {"workload": "DRY RUN (no GPU): launcher + gloo rendezvous + flat gradient all-reduce only",
-                                     "rays_per_gpu": R_RAYS, "samples_per_ray": S_SAMPLES, "parallelism": f"dp{world}"}}), flush=True)
+                                     "rays_per_gpu": rays, "global_rays": world * rays, "samples_per_ray": S_SAMPLES, "parallelism": f"dp{world}"}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     if not ok:
@@ -231,6 +338,9 @@ def main():
                     help="run the timed steps eagerly (default: forward+loss+backward of the step replayed from a HIP graph)")
     ap.add_argument("--pt", type=int, default=0, help="(tuning) bf16 layer-kernel point tile: 2 = 64 points, 4 = 128 points")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launcher + gloo rendezvous + gradient all-reduce only (CPU test)")
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
+                    help="c2 (default, BASELINE configs[1]): 1024 rays x 128 samples per GPU, weak scaling; c4 (configs[3]): 4096 rays per step "
+                         "in total split over the ranks, DTU model switches, strong scaling")
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "fp16", "fp16x3"], default=DEFAULT_PRECISION,
                     help="GEMM build: fp32 = exact-f32 MFMA (parity build); bf16 = bf16 MFMA, fp32 accumulate (BASELINE config 2)")
     args = ap.parse_args()
@@ -265,13 +375,7 @@ def main():
     if args.pt:
         _lib.check(lib.neat_set_tuning(0, args.pt), "neat_set_tuning")
 
-    seed = dp.rank_seed(42, rank)
-    torch.manual_seed(seed)
-    sd = {k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough").items()}      # same weights on every rank
-    tr = Trainer(device=dev, state_dict=sd)
-    _, inp, gt = synthetic_batch(seed, R_RAYS, dev, view=rank)
-    tr.model.z_vals_override = torch.tensor(synth.synth_z_vals(seed, R_RAYS, S_SAMPLES)).to(dev)
-    tr.model.set_precision(args.precision)
+    tr, inp, gt, rays, workload_text, scaling, sd = make_workload(args.workload, rank, world, dev, args.precision)
     peak = PEAK_TFLOPS[args.precision]
 
     def barrier():
@@ -355,7 +459,17 @@ def main():
         ar = torch.tensor([e0.elapsed_time(e1) / 20.0], device=dev, dtype=torch.float64)
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
         flat.zero_()
-        dist_info = {"backend": dist.get_backend(), "world": world,
+        # host time of a step: what the Python side needs to enqueue one step (batch prefix, graph replay, all-reduce, Adam), with
+        # nothing waited on -- as long as it stays below the GPU's time per step the ranks are never host-bound
+        barrier()
+        th = time.perf_counter()
+        for _ in range(10):
+            tr.step(inp, gt)
+        host_ms = 1e2 * (time.perf_counter() - th)
+        barrier()
+        dist_info = {"backend": dist.get_backend(), "world": world, "ranks": world, "host_ms_per_step": host_ms,
+                     "step_sequence": ("graph replay (ends with the gradient pack) -> all-reduce -> Adam on the flat buffer, one stream"
+                                       if graphed and getattr(tr._last, "packed", False) else "eager step + pack + all-reduce + Adam"),
                      "ms_per_step_by_rank": [1e3 * float(t.item()) / args.steps for t in every],
                      "allreduce_ms": float(ar.item()), "allreduce_bytes": int(flat.numel() * 4),
                      "allreduce_note": "flat gradient bucket, mean of 20 back-to-back calls after the timed region, max over ranks"}
@@ -430,28 +544,29 @@ def main():
                         "all_kernels": kernels}
 
     if rank == 0:
-        samples = world * R_RAYS * S_SAMPLES * args.steps
+        samples = world * rays * S_SAMPLES * args.steps
         value = samples / elapsed
         line = {
             "metric": "ray-samples/s (train step) on ABC-neat-a", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": {"fp32": "f32", "fp16": "f16", "fp16x3": "f16x3 forward / f16 backward"}.get(args.precision, "bf16"), "data": "synthetic",
-            "config": {"workload": "C2: abc-neat-a networks, 1024 rays x 128 samples per GPU, depth samples given, "
-                                   "train step = forward + loss + backward + Adam" +
+            "config": {"workload": workload_text + ", train step = forward + loss + backward + Adam" +
                                    ((" + RCCL grad all-reduce" if dist.get_backend() == "nccl" else " + gloo grad all-reduce (functional check)") if dist.is_initialized() else ""),
-                       "rays_per_gpu": R_RAYS, "samples_per_ray": S_SAMPLES, "global_rays": world * R_RAYS,
+                       "rays_per_gpu": rays, "samples_per_ray": S_SAMPLES, "global_rays": world * rays,
                        "parallelism": f"dp{world}", "weights": "synthetic 'rough' (seed 42)",
                        "launch": "hip graph replay (forward+loss+backward) + eager all-reduce/Adam" if graphed else "eager" + graph_note,
                        "dist_backend": (dist.get_backend() if dist.is_initialized() else None)},
-            "rays_per_s": world * R_RAYS * args.steps / elapsed,
+            "rays_per_s": world * rays * args.steps / elapsed,
             "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,
             "step_frac_of_mfma_peak": value * FLOP_PER_RAY_SAMPLE / 1e12 / (peak * world),
             "loss": float(losses["loss"].detach()),
             "roofline": roofline,
             "dist": dist_info,
         }
-        if world == 1 and not args.no_secondary:
+        if _lib.tuning_overrides:
+            line["config"]["tuning_overrides"] = list(_lib.tuning_overrides)      # NEAT_TUNING was set: not the default kernels
+        if world == 1 and not args.no_secondary and args.workload == "c2":
             line["secondary"] = secondary_legs(dev, sd, args.precision, args.steps, note)
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle (cpu_baseline)")

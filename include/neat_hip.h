@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 10 */
+int neat_abi_version(void);      /* 11 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -120,13 +120,13 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
  * the SDF network only; eik_grad [E,3] receives ImplicitNetwork.gradient (:98-109, no sphere clamp) at those points.
  * This removes ~66 latency-bound small launches per training step (the 2R eikonal points of :515-527).
  *
- * Backward of neat_render_forward.  Cotangents d_rgb [R,3], d_lines3d [R,6], d_depth [R], d_xyz [R,3], d_eik_grad [E,3]
- * (NULL = zero).  lines3d uses detached weights exactly as :410.  Writes all 19 layers' grads and the
+ * Backward of neat_render_forward.  Cotangents d_rgb [R,3], d_lines3d [R,6], d_depth [R], d_xyz [R,3], d_eik_grad [E,3],
+ * d_acc [R] = cotangent of the ray's opacity acc_map = sum_i w_i (the white_bkgd term of :411-413; ABI v11) (NULL = zero).  lines3d uses detached weights exactly as :410.  Writes all 19 layers' grads and the
  * per-ray partial derivative wrt beta, dbeta_ray [R] (sum it, times sign(density.beta)). */
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs,
                          const float* z, int R, int S, int E, int precision, const float* beta,
                          const float* d_rgb, const float* d_lines3d, const float* d_depth, const float* d_xyz,
-                         const float* d_eik_grad, const neat_net_grads* grads, float* dbeta_ray, void* stream);
+                         const float* d_eik_grad, const float* d_acc, const neat_net_grads* grads, float* dbeta_ray, void* stream);
 
 /* Forward-only variant for eval / inference callers (code/neat-final-parsing.py:203-218 drives `model(s)` in 2048-ray chunks under
  * model.eval(); training/volsdf_train.py:312-320 renders validation images the same way): same arguments and results as

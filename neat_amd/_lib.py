@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 10
+ABI_VERSION = 11
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "fp16x3": 4}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/probes/abl_build.sh)
@@ -45,7 +45,7 @@ _SIGNATURES = {
                                                 c_fp, ctypes.c_float, ctypes.c_float, c_fp,
                                                 c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                            ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
+                                            ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
     "neat_sampler_bound": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp,
                                           ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_sampler_resample": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_float,
@@ -104,6 +104,9 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+tuning_overrides = []      # the NEAT_TUNING key=value pairs applied when the library was loaded (bench.py records them)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -118,9 +121,16 @@ def lib():
         _lib = l
         # A/B switches from the environment (probe scripts; the defaults are what the tests and the bench run):
         # NEAT_TUNING="16=0,18=4" -> neat_set_tuning(16, 0), neat_set_tuning(18, 4)
+        applied = []
         for kv in filter(None, os.environ.get("NEAT_TUNING", "").split(",")):
             k, v = kv.split("=")
             check(l.neat_set_tuning(int(k), int(v)), f"NEAT_TUNING {kv}")
+            applied.append(kv)
+        if applied:       # never silent: a stray variable changes what the tests and the bench measure
+            import sys
+            print(f"[neat_amd] NEAT_TUNING overrides applied: {','.join(applied)}", file=sys.stderr, flush=True)
+        global tuning_overrides
+        tuning_overrides = applied
     return _lib
 
 

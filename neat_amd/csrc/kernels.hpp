@@ -858,7 +858,8 @@ __device__ __forceinline__ float cot_scale_of(const float* slot) {
   e = e < -100 ? -100 : (e > 100 ? 100 : e);
   return ldexpf(1.0f, 1 - e);
 }
-struct CotMaxArgs { const float* p[5]; long long n[5]; int narr; float* slot; };
+constexpr int COT_MAX_ARRAYS = 8;
+struct CotMaxArgs { const float* p[COT_MAX_ARRAYS]; long long n[COT_MAX_ARRAYS]; int narr; float* slot; };
 __global__ __launch_bounds__(256) void cot_max_kernel(CotMaxArgs a) {
   float m = 0.0f;
   for (int q = 0; q < a.narr; ++q) {
@@ -998,6 +999,7 @@ struct CompositeBwdArgs {
   const float* x_fm; const float* rgb_fm;
   int R, S, ldp; const float* beta_ptr;
   const float* d_rgb; const float* d_lines3d; const float* d_depth; const float* d_xyz;   // [R,3],[R,6],[R],[R,3] (null = 0)
+  const float* d_acc = nullptr;   // [R] cotangent of the ray's opacity sum_i w_i (white_bkgd, rend_a :411-413); null = 0
   float* zrgb_fm;      // [3][ldp]  cotangent of the pre-sigmoid colour logits
   float* dlin_fm;      // [6][ldp]  cotangent of the attraction offsets
   u16* zrgb_oct = nullptr;   // 16-bit builds: the same two as one zero-padded octet per point [ldp][8] (what the heads' backward chain and
@@ -1040,6 +1042,7 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
 #pragma unroll
   for (int c = 0; c < 6; ++c) if (a.d_lines3d) dl[c] = a.d_lines3d[r * 6 + c] * cs_a;
   const float ddepth = a.d_depth ? a.d_depth[r] * cs : 0.0f;
+  const float dacc = a.d_acc ? a.d_acc[r] * cs : 0.0f;
   // pass 1 (forward over the ray): transmittance needs the exclusive prefix of E.  Park T_i and w^_i w_i in the
   // output rows (same thread reads them back in pass 2, so no hazard).
   const int nchunk = (a.S + 63) / 64;
@@ -1057,7 +1060,7 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
     const float T = expf(-(carry + excl));
     const float w = ok ? (1.0f - expf(-e)) * T : 0.0f;
     carry += __shfl(incl, 63);
-    float wh = ddepth * fabsf(zi) * dn;
+    float wh = ddepth * fabsf(zi) * dn + dacc;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       wh += drgb[c] * a.rgb_fm[(size_t)c * a.ldp + p] + dxyz[c] * a.x_fm[(size_t)c * a.ldp + p];

@@ -224,6 +224,10 @@ int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
 constexpr int DW_MAXGRID = 256;     // workgroup partials the workspace holds per (layer, pair)
 int g_dw_grid = DW_MAXGRID;  // workgroups (= partials per set) of the launches that contract weight gradients on chip (tuning key 23)
+inline int dw_slots(int ldp) {          // workgroup partials the workspace holds per (layer, pair): what dw_grid() can reach at this size
+  const int nt = ldp / WSP;
+  return nt < DW_MAXGRID ? (nt > 0 ? nt : 1) : DW_MAXGRID;
+}
 inline int dw_grid(int ldp) {
   int g = g_ws_grid < DW_MAXGRID ? g_ws_grid : DW_MAXGRID;
   g = g < g_dw_grid ? g : g_dw_grid;
@@ -536,9 +540,11 @@ SdfWs sdf_ws(float* base, int ldp, int mode, int prec, int hx3 = 0) {
     w.partial = base ? base + off : nullptr;
     off += WPARTIAL_FLOATS;
     if (prec) {
-      w.dwp = base ? base + off : nullptr; off += (size_t)DW_JOBS * DW_MAXGRID * DW_WG_UINT4 * 4;
-      w.dwscale = base ? base + off : nullptr; off += (size_t)DW_JOBS * DW_MAXGRID * 8;
-      w.dwbias = base ? base + off : nullptr; off += (size_t)DW_JOBS * DW_MAXGRID * 256;
+      // (sized by the workgroups a launch can have at this point count, not by the machine: a 2048-point step reserves 120 MB, not 480)
+      const size_t slots = (size_t)dw_slots(ldp);
+      w.dwp = base ? base + off : nullptr; off += (size_t)DW_JOBS * slots * DW_WG_UINT4 * 4;
+      w.dwscale = base ? base + off : nullptr; off += (size_t)DW_JOBS * slots * 8;
+      w.dwbias = base ? base + off : nullptr; off += (size_t)DW_JOBS * slots * 256;
     }
   }
   if (hx3 && mode != 0) {
@@ -1043,9 +1049,9 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   const bool dw8 = dw && g_dw_lin8 && gr->dv[8] != nullptr && L.d[L.tr[8]].Kpad >= 256 && w.featc.bf16;
   auto dw_job = [&](int l, int pair, LayerArgsDW& d) {
     const size_t j = (size_t)(2 * (l - 1) + pair);
-    d.partial = reinterpret_cast<uint4*>(w.dwp) + j * DW_MAXGRID * DW_WG_UINT4;
-    d.pscale = w.dwscale + j * DW_MAXGRID * 8;
-    d.pbias = pair ? w.dwbias + j * DW_MAXGRID * 256 : nullptr;
+    d.partial = reinterpret_cast<uint4*>(w.dwp) + j * dw_slots(c.ldp) * DW_WG_UINT4;
+    d.pscale = w.dwscale + j * dw_slots(c.ldp) * 8;
+    d.pbias = pair ? w.dwbias + j * dw_slots(c.ldp) * 256 : nullptr;
     d.P = c.P;
   };
   auto u16p = [](const Arr& a) { return reinterpret_cast<u16*>(a.p); };
@@ -1110,9 +1116,9 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     s.in_octs = 32; s.split_oct = 32;
     d.auxA2 = nullptr; d.auxA_split = 1 << 30; d.rowsA = 256;
     const size_t j = 14;
-    d.partial = reinterpret_cast<uint4*>(w.dwp) + j * DW_MAXGRID * DW_WG_UINT4;
-    d.pscale = w.dwscale + j * DW_MAXGRID * 8;
-    d.pbias = w.dwbias + j * DW_MAXGRID * 256;
+    d.partial = reinterpret_cast<uint4*>(w.dwp) + j * dw_slots(c.ldp) * DW_WG_UINT4;
+    d.pscale = w.dwscale + j * dw_slots(c.ldp) * 8;
+    d.pbias = w.dwbias + j * dw_slots(c.ldp) * 256;
     d.P = c.P;
     ProfSlot* ps = dw_prof(256, 256);
     e = launch_layer_wsdw<EPI_BWD8, true>(c.st, d);
@@ -1195,11 +1201,11 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       float* out = w.partial + (size_t)(l - 1) * region;
       const size_t j0 = (size_t)(2 * (l - 1)), j1 = j0 + 1;          // tangent / reverse partial sets of the layer
       DwGatherJob& jb = ga.job[l - 1];
-      jb.partial = reinterpret_cast<const uint4*>(w.dwp) + j0 * DW_MAXGRID * DW_WG_UINT4;
-      jb.pscale = w.dwscale + j0 * DW_MAXGRID * 8;
-      jb.partial2 = reinterpret_cast<const uint4*>(w.dwp) + j1 * DW_MAXGRID * DW_WG_UINT4;
-      jb.pscale2 = w.dwscale + j1 * DW_MAXGRID * 8;
-      jb.pbias = w.dwbias + j1 * DW_MAXGRID * 256;
+      jb.partial = reinterpret_cast<const uint4*>(w.dwp) + j0 * dw_slots(c.ldp) * DW_WG_UINT4;
+      jb.pscale = w.dwscale + j0 * dw_slots(c.ldp) * 8;
+      jb.partial2 = reinterpret_cast<const uint4*>(w.dwp) + j1 * dw_slots(c.ldp) * DW_WG_UINT4;
+      jb.pscale2 = w.dwscale + j1 * dw_slots(c.ldp) * 8;
+      jb.pbias = w.dwbias + j1 * dw_slots(c.ldp) * 256;
       jb.nwg = dwg; jb.transposed = 0;
       jb.out = out; jb.row_stride = (size_t)splits * Kld2; jb.split_stride = Kld2; jb.split0 = 0;
       jb.bias_col = K; jb.rows = kO[l]; jb.cols = K;
@@ -1224,10 +1230,10 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       const int xn = (c.P + xchunk - 1) / xchunk;
       const size_t j = 14;
       DwGatherJob& jb = ga.job[7];
-      jb.partial = reinterpret_cast<const uint4*>(w.dwp) + j * DW_MAXGRID * DW_WG_UINT4;
-      jb.pscale = w.dwscale + j * DW_MAXGRID * 8;
+      jb.partial = reinterpret_cast<const uint4*>(w.dwp) + j * dw_slots(c.ldp) * DW_WG_UINT4;
+      jb.pscale = w.dwscale + j * dw_slots(c.ldp) * 8;
       jb.partial2 = nullptr; jb.pscale2 = nullptr;
-      jb.pbias = w.dwbias + j * DW_MAXGRID * 256;
+      jb.pbias = w.dwbias + j * dw_slots(c.ldp) * 256;
       jb.nwg = dwg; jb.transposed = 0;
       jb.out = out; jb.row_stride = (size_t)splits * Kld2; jb.split_stride = Kld2; jb.split0 = 0;
       jb.bias_col = K; jb.rows = 256; jb.cols = K;
@@ -1283,7 +1289,12 @@ std::mutex g_head_path_mutex;
 std::unordered_map<const void*, int> g_head_path;      // workspace -> 1: masks written by the forward of this workspace
 void note_head_path(const HeadWs& h, bool masks_written) {
   std::lock_guard<std::mutex> lock(g_head_path_mutex);
-  if (g_head_path.size() > 4096) g_head_path.clear();  // (workspaces come and go with the caller's allocator)
+  // (workspaces come and go with the caller's allocator: bound the table by dropping ONE other entry -- never the whole table, which
+  // could take the entry of a forward whose backward has not run yet and send that backward down the per-layer path)
+  if (g_head_path.size() > 4096 && g_head_path.find(h.small_r) == g_head_path.end()) {
+    auto victim = g_head_path.begin();
+    g_head_path.erase(victim);
+  }
   g_head_path[h.small_r] = masks_written ? 1 : 0;
 }
 bool head_masks_written(const HeadWs& h) {
@@ -1535,12 +1546,13 @@ __global__ void build_abar8_kernel(const float* __restrict__ d_out257, const flo
 __global__ void zero_word_kernel(float* p) { if (threadIdx.x == 0) *p = 0.0f; }
 const float* cot_scale_begin(const Ctx& c, float* slot, std::initializer_list<std::pair<const float*, long long>> arrays) {
   if (!NEAT_HALF) return nullptr;
+  if (arrays.size() > (size_t)COT_MAX_ARRAYS) abort();      // (a programming error: enlarge COT_MAX_ARRAYS)
   static const bool use_memset = getenv("NEAT_COT_MEMSET") != nullptr;      // probe: the memset node of rounds 2-4
   if (use_memset) (void)hipMemsetAsync(slot, 0, sizeof(float), c.st);
   else hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(64), 0, c.st, slot);
   CotMaxArgs a{};
   long long total = 0;
-  for (const auto& it : arrays) { a.p[a.narr] = it.first; a.n[a.narr] = it.first ? it.second : 0; total += a.n[a.narr]; ++a.narr; }
+  for (const auto& it : arrays) { if (a.narr >= COT_MAX_ARRAYS) break; a.p[a.narr] = it.first; a.n[a.narr] = it.first ? it.second : 0; total += a.n[a.narr]; ++a.narr; }
   a.slot = slot;
   const int blocks = (int)std::min<long long>(1024, (total + 2047) / 2048);
   if (blocks > 0) hipLaunchKernelGGL(cot_max_kernel, dim3(blocks), dim3(256), 0, c.st, a);
@@ -1601,7 +1613,7 @@ NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated)
 
 extern "C" {
 
-int neat_abi_version(void) { return 10; }
+int neat_abi_version(void) { return 11; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
 #if !NEAT_HALF
@@ -1903,9 +1915,9 @@ int neat_render_forward_eval(const float* packed, const neat_net_params* net, co
 
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs, const float* z,
                          int R, int S, int E, int precision, const float* beta, const float* d_rgb, const float* d_lines3d,
-                         const float* d_depth, const float* d_xyz, const float* d_eik_grad, const neat_net_grads* grads,
-                         float* dbeta_ray, void* stream) {
-  NEAT_F16_FWD(neat_render_backward(packed, net, ws, dirs, z, R, S, E, precision, beta, d_rgb, d_lines3d, d_depth, d_xyz, d_eik_grad, grads, dbeta_ray, stream))
+                         const float* d_depth, const float* d_xyz, const float* d_eik_grad, const float* d_acc,
+                         const neat_net_grads* grads, float* dbeta_ray, void* stream) {
+  NEAT_F16_FWD(neat_render_backward(packed, net, ws, dirs, z, R, S, E, precision, beta, d_rgb, d_lines3d, d_depth, d_xyz, d_eik_grad, d_acc, grads, dbeta_ray, stream))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
   if (hx3 == 2) return -1;
@@ -1919,11 +1931,11 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   CompositeBwdArgs cb;
   cb.z = z; cb.sdf = w.sdf; cb.dirs = dirs; cb.mask = w.mask; cb.x_fm = w.x; cb.rgb_fm = h.rgb;
   cb.R = R; cb.S = S; cb.ldp = c.ldp; cb.beta_ptr = beta;
-  cb.d_rgb = d_rgb; cb.d_lines3d = d_lines3d; cb.d_depth = d_depth; cb.d_xyz = d_xyz;
+  cb.d_rgb = d_rgb; cb.d_lines3d = d_lines3d; cb.d_depth = d_depth; cb.d_xyz = d_xyz; cb.d_acc = d_acc;
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
   cb.zrgb_oct = reinterpret_cast<u16*>(h.topbf_r.p); cb.dlin_oct = reinterpret_cast<u16*>(h.topbf_a.p);      // (null in the fp32 build)
   const float* slot = cot_scale_begin(c, w.ones, {{d_rgb, 3LL * R}, {d_lines3d, 6LL * R}, {d_depth, (long long)R}, {d_xyz, 3LL * R},
-                                                  {d_eik_grad, 3LL * E}});
+                                                  {d_eik_grad, 3LL * E}, {d_acc, (long long)R}});
   // the attraction head's chain in its own scale (only its top cotangent d_lines3d feeds it)
   static const bool one_scale = getenv("NEAT_ONE_COT_SCALE") != nullptr;      // probe: the attraction head in the common scale
   const float* slot_a = (slot && d_lines3d && !one_scale) ? cot_scale_begin(c, w.ones + 1, {{d_lines3d, 6LL * R}}) : nullptr;

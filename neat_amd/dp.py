@@ -77,6 +77,35 @@ class FlatGradBucket:
                 self._views.append(self.flat[off:off + p.numel()].view(p.shape))
                 off += p.numel()
 
+    def active(self):
+        """True when a step has to exchange gradients (a process group with more than one rank, or the forced single-rank group)."""
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force_collective)
+
+    def pack(self):
+        """The gradients into the flat buffer, one multi-tensor launch.  Capturable: Trainer.capture() records it at the end of the step's
+        HIP graph, so that a replayed step goes from the graph straight into the collective (`reduce_packed`) with no host work between."""
+        self._ensure()
+        have = [p.grad is not None and p.grad is not v for p, v in zip(self.params, self._views)]
+        for p, v in zip(self.params, self._views):
+            if p.grad is None:
+                v.zero_()               # (rare: a parameter without a gradient on this rank this step)
+        src = [p.grad for p, h in zip(self.params, have) if h]
+        if src:
+            torch._foreach_copy_([v for v, h in zip(self._views, have) if h], src)
+
+    def reduce_packed(self, repoint=True):
+        """ONE all-reduce (mean) of the packed flat buffer on the current stream; afterwards the parameters' .grad are views of it."""
+        world = dist.get_world_size(self.group)
+        if dist.get_backend(self.group) == "nccl":         # RCCL averages in the collective: one launch less than sum + scale
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.mul_(1.0 / world)
+        if repoint:
+            for p, v in zip(self.params, self._views):
+                if p.grad is not v:
+                    p.grad = v
+
     def all_reduce_mean(self, flat_grad=None):
         """grad_i <- mean over ranks of grad_i (a parameter with no gradient on this rank contributes zeros).
         `flat_grad`: the gradients already live in this flat buffer -> reduced in place."""
@@ -87,21 +116,8 @@ class FlatGradBucket:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.mul_(1.0 / world)
             return
-        self._ensure()
-        have = [p.grad is not None and p.grad is not v for p, v in zip(self.params, self._views)]
-        for p, v in zip(self.params, self._views):
-            if p.grad is None:
-                v.zero_()               # (rare: a parameter without a gradient on this rank this step)
-        src = [p.grad for p, h in zip(self.params, have) if h]
-        if src:
-            torch._foreach_copy_([v for v, h in zip(self._views, have) if h], src)
-        if dist.get_backend(self.group) == "nccl":         # RCCL averages in the collective: one launch less than sum + scale
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / world)
-        for p, v in zip(self.params, self._views):
-            p.grad = v
+        self.pack()
+        self.reduce_packed()
 
 
 def all_reduce_scalars(values, group=None):

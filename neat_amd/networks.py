@@ -328,9 +328,7 @@ class VolSDFNetwork(_HipModule):
     def _render(self, cam_loc, ray_dirs, z_vals, want_normal_map, eik_points=None, with_eik=False):
         rgb, lines3d, depth, xyz, eik_grad, weights, sdf, points, nmap = ops.render_rays(
             self.handle(), cam_loc, ray_dirs, z_vals, self.density.get_beta(), self._sphere(),
-            self.implicit_network.sphere_scale, want_normal_map, eik_points)
-        if self.white_bkgd:
-            rgb = rgb + (1.0 - weights.sum(-1, keepdim=True)) * self.bg_color.unsqueeze(0)
+            self.implicit_network.sphere_scale, want_normal_map, eik_points, self.bg_color if self.white_bkgd else None)
         if with_eik:
             return rgb, lines3d, depth, xyz, weights, sdf, points, nmap, eik_grad
         return rgb, lines3d, depth, xyz, weights, sdf, points, nmap

@@ -222,7 +222,7 @@ class RenderRaysFn(torch.autograd.Function):
     return its raw gradient (the eikonal term, :515-527).  Differentiable wrt all 57 network parameters and beta."""
 
     @staticmethod
-    def forward(ctx, handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, *params):
+    def forward(ctx, handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, bg_color, *params):
         lib = _lib.lib()
         ctx.set_materialize_grads(False)
         origins, dirs, z = (_f32c(t.detach()) for t in (origins, dirs, z))
@@ -249,6 +249,11 @@ class RenderRaysFn(torch.autograd.Function):
                                            _p(eik_grad) if E else None, _stream()), "neat_render_forward")
         ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, (R, S, E), ws, packed, netp, prec
         ctx.dirs, ctx.z, ctx.beta_d, ctx.beta_shape = dirs, z, beta_d, beta.shape
+        # white_bkgd (rend_a :411-413): what the weights leave of a ray is filled with the background colour; the backward pass sends
+        # the cotangent of the opacity, -(d_rgb . bg), through the compositing kernel (d_acc)
+        ctx.bg = None if bg_color is None else _f32c(bg_color.detach().reshape(3))
+        if ctx.bg is not None:
+            rgb = rgb + (1.0 - weights.sum(-1, keepdim=True)) * ctx.bg.unsqueeze(0)
         if nmap is None:
             nmap = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(weights, sdf, points, nmap)
@@ -263,12 +268,13 @@ class RenderRaysFn(torch.autograd.Function):
         gr, views, _ = _grad_buffers(h, 0, _lib.NUM_LAYERS, dev)
         d_rgb, d_lines3d, d_depth, d_xyz, d_eik = (_f32c(t) for t in (d_rgb, d_lines3d, d_depth, d_xyz, d_eik))
         dbeta_ray = torch.empty(R, device=dev)
+        d_acc = None if ctx.bg is None or d_rgb is None else _f32c(-(d_rgb @ ctx.bg))
         _lib.check(lib.neat_render_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), _p(ctx.dirs), _p(ctx.z), R, S, E,
                                             ctx.prec, _p(ctx.beta_d), _p(d_rgb), _p(d_lines3d), _p(d_depth), _p(d_xyz),
-                                            _p(d_eik) if E else None, ctypes.byref(gr), _p(dbeta_ray), _stream()),
+                                            _p(d_eik) if E else None, _p(d_acc), ctypes.byref(gr), _p(dbeta_ray), _stream()),
                    "neat_render_backward")
         ctx.ws = None
-        return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, None, *views)
+        return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, None, None, *views)
 
 
 def render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False):
@@ -294,13 +300,16 @@ def render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_
     return rgb, lines3d, depth, xyz, torch.empty(0, 3, device=dev), weights, sdf, points, nmap
 
 
-def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False, eik_points=None):
+def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False, eik_points=None, bg_color=None):
     """-> rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], eik_grad [E,3], weights, sdf, points, normal_map"""
     if not handle.has_heads():
         raise RuntimeError("render_rays needs the SDF network and both heads attached to the NetHandle")
     if not torch.is_grad_enabled() and eik_points is None:
-        return render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map)
-    return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, *handle.tensors())
+        out = render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map)
+        if bg_color is not None:           # white_bkgd (rend_a :411-413)
+            out = (out[0] + (1.0 - out[5].sum(-1, keepdim=True)) * bg_color.reshape(1, 3),) + tuple(out[1:])
+        return out
+    return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, bg_color, *handle.tensors())
 
 
 def camera_rays(uv, pose, intrinsics, with_origins=False):

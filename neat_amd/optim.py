@@ -42,24 +42,39 @@ class FlatAdam(torch.optim.Optimizer):
                              "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape)}
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, flat_grad=None):
+        """flat_grad: ALL gradients live in this flat fp32 buffer, laid out like the parameters (dp.FlatGradBucket.flat after the
+        all-reduce): the pointer table is built once per buffer, no per-parameter host work in the step."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         group = self.param_groups[0]
         self._realias()
-        ptrs = (ctypes.c_void_p * len(self._params))()
         keep = []                                  # non-contiguous / non-fp32 gradients are normalised first (not the usual case)
-        for i, p in enumerate(self._params):
-            g = p.grad
-            if g is None:
-                continue
-            if g.dtype != torch.float32 or not g.is_contiguous():
-                g = g.float().contiguous()
-                keep.append(g)
-            ptrs[i] = g.data_ptr()
-            self._steps[i] += 1
+        if flat_grad is not None:
+            if flat_grad.numel() != self.numel or flat_grad.dtype != torch.float32 or flat_grad.device != self.flat_param.device:
+                raise ValueError("FlatAdam.step(flat_grad=...): one fp32 buffer with the parameters' layout on their device")
+            cache = getattr(self, "_flat_ptrs", None)
+            if cache is None or cache[0] != flat_grad.data_ptr():
+                tab = (ctypes.c_void_p * len(self._params))()
+                for i in range(len(self._params)):
+                    tab[i] = flat_grad.data_ptr() + 4 * self._offsets[i]
+                cache = self._flat_ptrs = (flat_grad.data_ptr(), tab)
+            ptrs = cache[1]
+            for i in range(len(self._params)):
+                self._steps[i] += 1
+        else:
+            ptrs = (ctypes.c_void_p * len(self._params))()
+            for i, p in enumerate(self._params):
+                g = p.grad
+                if g is None:
+                    continue
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                    keep.append(g)
+                ptrs[i] = g.data_ptr()
+                self._steps[i] += 1
         b1, b2 = group["betas"]
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         _lib.check(_lib.lib().neat_adam_step(P(self.flat_param), ptrs, self._offsets, self._steps, len(self._params), P(self.exp_avg),
@@ -67,9 +82,18 @@ class FlatAdam(torch.optim.Optimizer):
                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "neat_adam_step")
         # the parameters changed behind autograd's back: bump their version counters (packed-weight caches key on them)
         torch._C._increment_version(self._params)
-        for i, p in enumerate(self._params):
-            self.state[p]["step"] = torch.tensor(float(self._steps[i]))
+        self._steps_dirty = True                   # state[p]["step"] is refreshed when somebody reads it (state_dict), not 65 tensors per step
         return loss
+
+    def _sync_steps(self):
+        if getattr(self, "_steps_dirty", False):
+            for i, p in enumerate(self._params):
+                self.state[p]["step"] = torch.tensor(float(self._steps[i]))
+            self._steps_dirty = False
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
 
     def _realias(self):
         """The kernel updates `flat_param`; the module reads its parameters.  They are the same memory as long as nobody rebinds
@@ -87,6 +111,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._steps_dirty = False
         for i, p in enumerate(self._params):
             st = self.state[p]
             off, n = self._offsets[i], p.numel()

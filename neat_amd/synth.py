@@ -183,3 +183,19 @@ def write_scene_fixture(npz_path, root):
                   open(os.path.join(root, "hawp", f"image_{i:04d}.json"), "w"))
     np.savez(os.path.join(root, "cameras.npz"), intrinsics=d["intrinsics"], extrinsics=d["extrinsics"])
     return res
+
+
+def hocon_text(d, indent=0):
+    """A nested dict as HOCON text (what neat_amd.conf reads back): conf files for tests and scripts that drive the runner."""
+    pad = "    " * indent
+    out = []
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.append(f"{pad}{k}{{\n{hocon_text(v, indent + 1)}{pad}}}")
+        elif isinstance(v, bool):
+            out.append(f"{pad}{k} = {'True' if v else 'False'}")
+        elif isinstance(v, (list, tuple)):
+            out.append(f"{pad}{k} = [{', '.join(str(x) for x in v)}]")
+        else:
+            out.append(f"{pad}{k} = {v}")
+    return "\n".join(out) + "\n"

@@ -162,7 +162,7 @@ def render_rays_backward(ws: Tensor, dirs: Tensor, z: Tensor, beta: Tensor, para
     dbeta_ray = torch.empty(R, device=dev)
     _lib.check(lib.neat_render_backward(ops._p(packed), ops.ctypes.byref(netp), ops._p(ws), ops._p(dirs), ops._p(z), R, S, E, h.precision,
                                         ops._p(beta_d), ops._p(d_rgb), ops._p(d_lines3d), ops._p(d_depth), ops._p(d_xyz),
-                                        ops._p(d_eik) if E else None, ops.ctypes.byref(gr), ops._p(dbeta_ray), ops._stream()),
+                                        ops._p(d_eik) if E else None, None, ops.ctypes.byref(gr), ops._p(dbeta_ray), ops._stream()),
                "neat_render_backward")
     return [dbeta_ray.sum().reshape(beta.shape)] + [v.clone() for v in views]
 

@@ -168,6 +168,11 @@ class Trainer:
                 out, losses = self._fwd_bwd(entry, zero=False)
                 entry.outputs = (_detached(out), _detached(losses))
                 del out, losses
+                # data parallel: the gradients go into the flat bucket INSIDE the graph -- a replayed step then runs graph ->
+                # all-reduce -> Adam (reading the flat buffer) with no host work between the replay and the collective
+                entry.packed = self.bucket.active() and self.device.type == "cuda" and hasattr(self.optimizer, "flat_param")
+                if entry.packed:
+                    self.bucket.pack()
             entry.graph = graph
             entry.static_grads = [(p, p.grad) for p in self.model.parameters()]
             entry.nan_flag = self.loss.nan_flag
@@ -191,6 +196,8 @@ class Trainer:
             self._last = entry
         else:
             self._last = None                               # check_nan() reads the loss's own flag again, not the previous layout's
+            self.loss.nan_flag = None                       # ... and that flag must not be a tensor of the aborted capture (never executed)
+                                                            # or a stale warm-up value: the eager steps below publish their own
         if not ok and warmup > 0:
             self.optimizer.zero_grad(set_to_none=True)      # (whatever a half-finished attempt left in .grad)
             for _ in range(warmup + 1 - finished):          # the steps the successful path would have taken
@@ -207,6 +214,14 @@ class Trainer:
         return out, losses
 
     def _finish_step(self, entry, on_collective=None):
+        if entry is not None and entry.packed:
+            entry.graph.replay()                            # ... ends with the pack of its own gradient tensors into bucket.flat
+            self.bucket.reduce_packed()
+            if on_collective is not None:
+                on_collective()
+            self.optimizer.step(flat_grad=self.bucket.flat)
+            self.scheduler.step()
+            return
         if entry is not None:
             for p, g in entry.static_grads:                 # another graph or an eager step re-pointed .grad: this graph writes ITS tensors
                 if p.grad is not g:
@@ -246,6 +261,8 @@ class Trainer:
     def check_nan(self):
         """Graph mode keeps the line-loss NaN flag on the device (loss.nan_check == "off"); this reads it (one sync)."""
         flag = self._last.nan_flag if self._last is not None else self.loss.nan_flag
+        if self._last is None and hasattr(self.loss, "_check_deferred"):
+            self.loss._check_deferred()                     # eager steps publish through the loss's own deferred flag
         # (graph mode keeps the line loss itself as the flag -- testing it on the device every step would be one more launch)
         bad = flag is not None and bool((torch.isnan(flag).any() if flag.is_floating_point() else flag.any()).item())
         # data parallel: the flag belongs to THIS rank's batch.  The ranks agree before anyone raises -- a rank that stopped alone would
@@ -310,6 +327,7 @@ def _detached(d):
 class _Captured:
     """One captured batch layout: the graph, its static input tensors, its outputs and the gradient tensors it writes."""
     graph = static_in = static_gt = static_z = outputs = static_grads = randoms = nan_flag = None
+    packed = False          # the graph ends with the pack of its gradients into the data-parallel bucket (dp.FlatGradBucket.pack)
 
 
 def synthetic_batch(seed, n_rays, device, view=0):

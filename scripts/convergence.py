@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from neat_amd import synth
 from neat_amd.runner import TrainRunner
-from tests.test_runner import _hocon
+from neat_amd.synth import hocon_text as _hocon
 
 
 def run(prec, iters, rays, tmp, res, views):

@@ -4,7 +4,8 @@ import sys, time, tempfile, pathlib, torch
 sys.path.insert(0, '.')
 from neat_amd import synth
 from neat_amd.runner import TrainRunner
-from tests.test_runner import _toy_scene, _hocon
+from tests.test_runner import _toy_scene
+from neat_amd.synth import hocon_text as _hocon
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 views = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 tmp = pathlib.Path(tempfile.mkdtemp())

@@ -6,7 +6,8 @@ import numpy as np, torch
 sys.path.insert(0, '.')
 from neat_amd import synth, rend_util
 from neat_amd.runner import TrainRunner
-from tests.test_runner import _toy_scene, _hocon
+from tests.test_runner import _toy_scene
+from neat_amd.synth import hocon_text as _hocon
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rays = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 views, res = 4, 128

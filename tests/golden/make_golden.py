@@ -258,6 +258,35 @@ def extra_goldens():
     save("g12_train_step_hierarchical", **arrs)
 
 
+
+def switch_goldens():
+    """G14 / G15 / G16 (round 5): the three model switches that neat_amd implements but no shipped conf sets --
+    white_bkgd (rend_a :263-265,411-413), use_l3d (:461-465), junction_eikonal (:524-525) -- each as ONE train step of the reference
+    (rough weights, 64 rays, its own random draws recorded), like G8."""
+    install_shims()
+    torch.set_default_dtype(torch.float32)
+    WG = load_wireframe_cls()
+    for tag, switch, seed, view in (("g14_train_step_white_bkgd", dict(white_bkgd=True, bg_color=[1.0, 0.9, 0.8]), 31, 1),
+                                    ("g15_train_step_use_l3d", dict(use_l3d=True), 33, 2),
+                                    ("g16_train_step_junction_eikonal", dict(junction_eikonal=True), 35, 3)):
+        conf = dict(synth.ABC_NEAT_A_MODEL_CONF)
+        conf.update(switch)
+        net = build_model("rough", conf=conf)
+        net.train()
+        sc, inp, gt = scene_inputs(WG, seed=seed, n_rays=64, view=view)
+        rec = {}
+        inner = net.ray_sampler.get_z_vals
+
+        def recording(*a, _inner=inner, _rec=rec, **k):
+            _rec["z"], _rec["z_eik"] = _inner(*a, **k)
+            return _rec["z"], _rec["z_eik"]
+        net.ray_sampler.get_z_vals = recording
+        arrs, tape = train_step_arrays(net, sc, inp, gt, ["rand", "randint", "rand", "randperm", "randint", "uniform_"])
+        arrs.update(z_vals=np_(rec["z"]), z_eik=np_(rec["z_eik"]))
+        arrs.update(t_rand=np_(tape[0][1]), u_final=np_(tape[2][1]), perm=np_(tape[3][1]), eik_idx=np_(tape[4][1]), eik_uniform=np_(tape[5][1]))
+        save(tag, **arrs)
+
+
 def real_scene_golden():
     """G13 (round 3): view 0 of the scene BASELINE configs 1 / 2 name, ABC 00075213, as bundled with the reference:
     K / pose from data/abc/00075213/cameras.npz, the HAWP wireframe from hawp/image_0000.json through the reference's own
@@ -468,9 +497,12 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":      # only the round-2 fixtures (G11, G12); the others are left untouched
         extra_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "switches":   # only the round-5 fixtures (G14-G16)
+        switch_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "real":     # only the round-3 fixture (G13)
         real_scene_golden()
     else:
         main()
         extra_goldens()
         real_scene_golden()
+        switch_goldens()

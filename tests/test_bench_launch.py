@@ -29,3 +29,12 @@ def test_bench_spawns_its_own_ranks_dry_run():
 def test_bench_single_rank_dry_run():
     line = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run"])
     assert line["n_gpus"] == 1 and line["allreduce_ok"] is True
+
+
+def test_bench_c4_workload_splits_the_global_batch_dry_run():
+    """--workload c4 (BASELINE configs[3]): 4096 rays per step in TOTAL, 2048 per rank at world 2 (512 at 8), strong scaling; DTU model
+    (1024 junction latents: 1 465 034... the bucket follows the model's parameter list) and the packed exchange of a replayed step."""
+    line = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--workload", "c4"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["allreduce_ok"] is True
+    assert line["config"]["rays_per_gpu"] == 2048 and line["config"]["global_rays"] == 4096
+    assert line["allreduce_elements"] == 1219274 + (1024 - 64) * 256

@@ -87,7 +87,7 @@ def test_volume_rendering_and_camera_golden(dev, golden):
         close(c, g["cam" + tag], tol=0, what="cam" + tag)
 
 
-def close_sampler(z, ref, what, max_frac=0.003):
+def close_sampler(z, ref, what, max_frac=0.003, bin_width=6.0 / 127):
     """The inverse-CDF step is discontinuous: a sample with u at a CDF knot (notably u = 1.0, the last linspace
     value, against cdf[-1] = 1 +- 1ulp) lands one coarse bin away when the cumsum rounds differently (device scan
     vs the CPU's sequential sum).  Everything else must agree to 2e-4; at most 0.5% of the samples may sit one bin
@@ -101,7 +101,7 @@ def close_sampler(z, ref, what, max_frac=0.003):
     print(f"{what}: {frac:.4%} of the samples off by more than 2e-4 (allowed {max_frac:.2%})")
     assert frac <= max_frac, f"{what}: {frac:.4%} of samples differ by more than 2e-4"
     # a flipped sample moves by one bin of the *current* grid: <= 2 * 6/127 with stratified jitter (training)
-    assert float(err.max()) <= 2 * 6.0 / 127 + 1e-3, f"{what}: max err {err.max():.3e} exceeds one coarse bin"
+    assert float(err.max()) <= 2 * bin_width + 1e-3, f"{what}: max err {err.max():.3e} exceeds one coarse bin"
 
 
 def scene_inputs(g, dev):
@@ -229,7 +229,7 @@ def test_real_scene_abc_00075213_vs_reference_golden(dev, golden, prec):
     _check_golden_train_step(m, g, dev, out, keys, l3d_tol=l3d_tol)
 
 
-def _check_golden_train_step(m, g, dev, out, keys, loss_conf=None, l3d_tol=3e-4):
+def _check_golden_train_step(m, g, dev, out, keys, loss_conf=None, l3d_tol=3e-4, loose=None, grad_bar=2e-3):
     from tests.golden.make_golden import GRAD_STRIDE
     from neat_amd.loss import VolSDFLoss
     for k in keys:
@@ -246,8 +246,9 @@ def _check_golden_train_step(m, g, dev, out, keys, loss_conf=None, l3d_tol=3e-4)
         gr = prm.grad.detach().cpu().reshape(-1).numpy()
         ref, (nrm, _) = g["grad_" + k], g["gradnorm_" + k]
         scale = max(float(np.abs(ref).max()), 1e-6)
-        assert float(np.abs(gr[::GRAD_STRIDE] - ref).max()) <= 2e-3 * scale + 1e-7, k
-        assert abs(float(np.sqrt((gr.astype(np.float64) ** 2).sum())) - nrm) <= 2e-3 * nrm + 1e-7, k
+        bar = (loose or {}).get(k, grad_bar)
+        assert float(np.abs(gr[::GRAD_STRIDE] - ref).max()) <= bar * scale + 1e-7, k
+        assert abs(float(np.sqrt((gr.astype(np.float64) ** 2).sum())) - nrm) <= bar * nrm + 1e-7, k
 
 
 def test_train_step_dtu_switches_vs_reference_golden(dev, golden, prec):
@@ -272,6 +273,39 @@ def test_train_step_dtu_switches_vs_reference_golden(dev, golden, prec):
     _check_golden_train_step(m, g, dev, out, ("rgb_values", "depth", "xyz", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
                                               "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "l3d"),
                              l3d_tol=1e-3 if prec == "bf16x3" else 3e-4)
+
+
+@pytest.mark.parametrize("name,switch", [("g14_train_step_white_bkgd", dict(white_bkgd=True, bg_color=[1.0, 0.9, 0.8])),
+                                         ("g15_train_step_use_l3d", dict(use_l3d=True)),
+                                         ("g16_train_step_junction_eikonal", dict(junction_eikonal=True))])
+def test_train_step_model_switches_vs_reference_golden(dev, golden, prec, name, switch):
+    """G14-G16 (round 5): the model switches no shipped conf sets -- white_bkgd (rend_a :263-265,411-413: no sphere
+    clamp, background colour), use_l3d (:461-465: junction candidates filtered by the l3d score), junction_eikonal (:524-525: the
+    global junctions join the eikonal points) -- as full train steps against fixtures made by the reference: outputs, loss scalars,
+    every gradient at the fp32 bars."""
+    from tests.util_replay import RngReplay
+    from neat_amd import networks
+    g = golden(name)
+    conf = dict(synth.ABC_NEAT_A_MODEL_CONF)
+    conf.update(switch)
+    m = networks.VolSDFNetwork(conf)
+    m.load_state_dict({k: T(v) for k, v in synth.synth_state_dict(42, "rough").items()}, strict=True)
+    m.to(dev).train().set_precision(prec)
+    m.z_vals_override = T(g["z_vals"]).to(dev)        # (the sampler has its own golden tests)
+    with RngReplay([("randint", T(g["eik_idx"])), ("uniform_", T(g["eik_uniform"]))]):
+        out = m(scene_inputs(g, dev))
+    if "junction_eikonal" in switch:
+        assert out["grad_theta"].shape[0] == 3 * 64
+    # white_bkgd: d rgb / d w_i = rgb_i - bg makes the two gradients that are plain sums of the sdf cotangents over all samples -- the sdf
+    # bias lin8.bias[0] and density.beta -- differences of large numbers: the reference's own fp32 result is 1.8 % / 3.1 % away from the
+    # same algorithm in fp64 (tests/test_oracle_golden.py::test_white_bkgd_sums_are_ill_conditioned; the HIP build lands on the fp64 value)
+    loose = {"implicit_network.lin8.bias": 5e-2, "density.beta": 8e-2} if "white_bkgd" in switch else None
+    _check_golden_train_step(m, g, dev, out, ("rgb_values", "depth", "xyz", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+                                              "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median", "l3d"),
+                             l3d_tol=1e-3 if prec == "bf16x3" else 3e-4, loose=loose,
+                             # NEAT_BF16X3's 17-bit products flip the sign of a few ReLU pre-activations of the heads: a thin tensor (a head
+                             # bias: 5.4e-3 on G15) carries that, as at full size (test_full_size_train_step_vs_oracle: 1.3e-2, bar 2e-2)
+                             grad_bar=1e-2 if prec == "bf16x3" else 2e-3)
 
 
 def test_train_step_hierarchical_vs_reference_golden(dev, golden, prec):
@@ -686,6 +720,11 @@ def _full_size_case(cfg):
         sc = synth.synth_scene(seed=seed, n_rays=R, view=1)
         z = T(synth.synth_z_vals(seed, R, S))
         kw = {}
+    elif cfg == "c5":      # BASELINE configs[4]: hierarchical 64 coarse + 64 fine depths (per-rank shape 1024 rays), the oracle draws the depths itself
+        R, seed, nj = 1024, 13, 64
+        sc = synth.synth_scene(seed=seed, n_rays=R, view=3)
+        z = None
+        kw = dict(sampler="hierarchical")
     else:
         R, seed, nj = 2048, 12, 1024
         sc = synth.synth_scene(seed=seed, n_rays=R // 2, view=2)
@@ -698,12 +737,18 @@ def _full_size_case(cfg):
     gen = torch.Generator().manual_seed(seed)
     eik_idx = torch.randint(S, (R,), generator=gen)
     eik_uniform = torch.empty(R, 3).uniform_(-3, 3, generator=gen)
+    rand = {"eik_idx": eik_idx, "eik_uniform": eik_uniform}
+    if cfg == "c5":
+        rand["t_rand"] = torch.rand(R, 64, generator=gen)          # the stratified jitter of the coarse depths (ray_sampler.py:87)
     p = O.params_from_numpy(sd, requires_grad=True)
     wf = WireframeGraph(T(sc["wf_vertices"]), T(sc["wf_vconf"]), T(sc["wf_edges"]), T(sc["wf_weights"]), 512, 512)
     before = torch.get_num_threads()
     torch.set_num_threads(max(before, 16))          # (the oracle is the slow part of this test)
     ref = O.full_forward(p, {k: T(sc[k]) for k in ("intrinsics", "pose", "uv", "uv_proj")}, wf.line_segments(), wf.vertices, training=True,
-                         rand={"eik_idx": eik_idx, "eik_uniform": eik_uniform}, z_vals=z, **kw)
+                         rand=rand, z_vals=z, **kw)
+    if z is None:
+        z = ref["z_vals"].detach()
+        sc = dict(sc, t_rand=rand["t_rand"])
     lo = O.neat_loss(ref, T(sc["gt_rgb"]), T(sc["gt_lines2d"]))
     lo["loss"].backward()
     torch.set_num_threads(before)
@@ -712,6 +757,15 @@ def _full_size_case(cfg):
     grads = {k: (v.grad.detach().clone() if v.grad is not None else None) for k, v in p.items()}
     _FULL_SIZE_ORACLE[cfg] = (sd, sc, z, eik_idx, eik_uniform, ref, lo, grads)
     return _FULL_SIZE_ORACLE[cfg]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "fp16"])
+def test_c5_full_size_hierarchical_step(dev, precision):
+    """BASELINE configs[4] at its per-rank size: 1024 rays, hierarchical 64 coarse + 64 fine depths feeding the main pass.
+    (i) the device sampler (uniform_depths_kernel -> fused SDF values -> weights scan -> sample_pdf_kernel) on the oracle's jitter
+    draws against the oracle's depths (inverse-CDF sampling is ill-conditioned: a small fraction of depths may land in a neighbouring
+    bin) + its size-independent properties; (ii) the train step on the oracle's depths against the oracle's VALUES, like C2 / C3."""
+    test_full_size_train_step_vs_oracle(dev, "c5", precision)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3", "fp16", "bf16"])
@@ -723,9 +777,23 @@ def test_full_size_train_step_vs_oracle(dev, cfg, precision):
     from neat_amd.loss import VolSDFLoss
     from tests.util_replay import RngReplay
     sd, sc, z, eik_idx, eik_uniform, ref, ref_lo, ref_g = _full_size_case(cfg)
-    m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF if cfg == "c2" else _dtu_conf())
+    conf = synth.ABC_NEAT_A_MODEL_CONF if cfg == "c2" else _dtu_conf()
+    if cfg == "c5":
+        conf = dict(synth.ABC_NEAT_A_MODEL_CONF, hip_sampler="hierarchical", hip_sampler_coarse=64, hip_sampler_fine=64)
+    m = networks.VolSDFNetwork(conf)
     m.load_state_dict({k: T(v) for k, v in sd.items()})
     m.to(dev).train().set_precision(precision)
+    if cfg == "c5":
+        from neat_amd import rend_util
+        d, c = rend_util.get_camera_params(T(sc["uv"]).to(dev), T(sc["pose"]).to(dev), T(sc["intrinsics"]).to(dev))
+        d = d.reshape(-1, 3)
+        with RngReplay([("rand", sc["t_rand"]), ("randint", None), ("randint", eik_idx)]):
+            zs, z_eik = m.ray_sampler.get_z_vals(d, c.expand(d.shape[0], 3).contiguous(), m)
+        assert zs.shape == (1024, 128) and z_eik.shape == (1024, 1)
+        assert bool((zs[:, 1:] >= zs[:, :-1]).all()) and float(zs.min()) >= 0.0 and float(zs.max()) <= 6.0
+        assert torch.equal(z_eik.cpu(), torch.gather(zs.cpu(), 1, eik_idx[:, None]))
+        # fp32-grade SDF queries reproduce the oracle's depths up to the ill-conditioned inverse-CDF rule; the f16 build only their distribution
+        close_sampler(zs, z.numpy(), what="c5 full-size hierarchical depths", max_frac=0.01 if precision in FP32_GRADE else 0.5, bin_width=6.0 / 63)
     m.z_vals_override = z.to(dev)
     with RngReplay([("randint", eik_idx), ("uniform_", eik_uniform)]):
         out = m(scene_inputs(sc, dev))

@@ -184,6 +184,58 @@ def test_train_step_dtu_switches(golden):
                                       "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib"))
 
 
+SWITCH_GOLDENS = [("g14_train_step_white_bkgd", dict(white_bkgd=True, bg_color=(1.0, 0.9, 0.8))),
+                  ("g15_train_step_use_l3d", dict(use_l3d=True)),
+                  ("g16_train_step_junction_eikonal", dict(junction_eikonal=True))]
+
+
+@pytest.mark.parametrize("name,switch", SWITCH_GOLDENS)
+def test_train_step_model_switches(golden, name, switch):
+    """G14-G16 (round 5): white_bkgd (rend_a :263-265,411-413), use_l3d (:461-465), junction_eikonal (:524-525) -- reference train steps."""
+    g = golden(name)
+    p = params("rough", grad=True)
+    lines, verts = _wf(g)
+    rand = {k: T(g[k]) for k in ("t_rand", "u_final", "perm", "eik_idx", "eik_uniform")}
+    out = O.full_forward(p, _inp(g), lines, verts, training=True, rand=rand, **switch)
+    close(out["z_vals"], g["z_vals"], 2e-5, "z_vals")
+    if "junction_eikonal" in switch:
+        assert out["grad_theta"].shape[0] == 2 * 64 + 64
+    lo = O.neat_loss(out, T(g["gt_rgb"]), T(g["gt_lines2d"]))
+    _check_train_step(g, p, out, lo, ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+                                      "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median"))
+
+
+def test_white_bkgd_sums_are_ill_conditioned(golden):
+    """Why the GPU test of G14 holds lin8.bias and density.beta to 5e-2 / 8e-2 instead of 2e-3: with white_bkgd the cotangent of every
+    weight is d_rgb . (rgb_i - bg), and the two gradients that are plain sums of the sdf cotangents over all samples cancel to a small
+    remainder.  The SAME algorithm (the oracle, pinned to the reference at 2e-4 in fp32 above) evaluated in fp64 moves them by 1.8 % and
+    3.1 %: that is the reference's own rounding, not a property of any build."""
+    g = golden("g14_train_step_white_bkgd")
+    vals = {}
+    for dt in (torch.float32, torch.float64):
+      try:
+        torch.set_default_dtype(dt)          # (the oracle creates its constants -- eye(3), epsilons -- in the default dtype)
+        sd = synth.synth_state_dict(42, "rough")
+        p = {k: torch.tensor(np.asarray(v), dtype=dt, requires_grad=True) for k, v in sd.items()}
+        lines, verts = _wf(g)
+        inp = {k: v.to(dt) for k, v in _inp(g).items()}
+        out = O.full_forward(p, inp, lines.to(dt), verts.to(dt), training=True,
+                             rand={"eik_idx": T(g["eik_idx"]), "eik_uniform": T(g["eik_uniform"]).to(dt)}, z_vals=T(g["z_vals"]).to(dt),
+                             white_bkgd=True, bg_color=(1.0, 0.9, 0.8))
+        lo = O.neat_loss(out, T(g["gt_rgb"]).to(dt), T(g["gt_lines2d"]).to(dt))
+        lo["loss"].backward()
+      finally:
+        torch.set_default_dtype(torch.float32)
+      if True:
+        vals[dt] = (float(p["implicit_network.lin8.bias"].grad[0]), float(p["density.beta"].grad))
+    ref = (float(g["grad_implicit_network.lin8.bias"][0]), float(g["grad_density.beta"].reshape(-1)[0]))
+    for i, name in enumerate(("lin8.bias[0]", "density.beta")):
+        assert abs(vals[torch.float32][i] - ref[i]) <= 2e-3 * abs(ref[i]), name          # fp32 oracle = reference
+        rel = abs(vals[torch.float64][i] - ref[i]) / abs(ref[i])
+        print(f"{name}: reference fp32 {ref[i]:.6e}, same algorithm in fp64 {vals[torch.float64][i]:.6e} ({rel:.2%})")
+        assert 5e-3 < rel < 8e-2, (name, rel)
+
+
 def test_train_step_hierarchical(golden):
     """G12: C5, hierarchical 64 coarse + 64 fine depths feeding the main pass."""
     g = golden("g12_train_step_hierarchical")

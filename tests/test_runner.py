@@ -8,19 +8,7 @@ import pytest
 import torch
 
 
-def _hocon(d, indent=0):
-    pad = "    " * indent
-    out = []
-    for k, v in d.items():
-        if isinstance(v, dict):
-            out.append(f"{pad}{k}{{\n{_hocon(v, indent + 1)}{pad}}}")
-        elif isinstance(v, bool):
-            out.append(f"{pad}{k} = {'True' if v else 'False'}")
-        elif isinstance(v, (list, tuple)):
-            out.append(f"{pad}{k} = [{', '.join(str(x) for x in v)}]")
-        else:
-            out.append(f"{pad}{k} = {v}")
-    return "\n".join(out) + "\n"
+from neat_amd.synth import hocon_text as _hocon      # (shared with scripts/: convergence.py, runner_rate.py, train_curves.py)
 
 
 def _toy_scene(root, res=64, n_views=3):

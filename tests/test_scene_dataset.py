@@ -75,7 +75,7 @@ def test_scene_dataset_and_runner(tmp_path):
     from neat_amd import synth
     from neat_amd.datasets import SceneDataset
     from neat_amd.runner import TrainRunner
-    from tests.test_runner import _hocon
+    from neat_amd.synth import hocon_text as _hocon
     cams = _toy_scan(tmp_path / "data")
     ds = SceneDataset("DTU", [48, 64], scan_id=7, data_root=str(tmp_path / "data"))
     assert len(ds) == 3 and ds.total_pixels == 48 * 64
