@@ -533,6 +533,9 @@ def main():
             step_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in kernels.values()) / max(steps_prof, 1)
             roofline = {"bound": "mfma", "kernel": dom, "achieved": k["tflops"], "peak": peak, "unit": "TFLOP/s",
                         "frac": k["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_source,
+                        # PMC bytes against the library's own algorithmic bytes of the same launches: wasted re-reads show as > 1, a stale
+                        # traffic.json as a jump (scripts/check_traffic.py fails the profile refresh beyond +-10 %)
+                        "traffic_vs_algorithmic_bytes": (traffic / k["bytes_per_launch"]) if traffic else None,
                         "avg_launch_us": k["avg_us"], "launches": k["launches"], "flop_per_launch": k["flop_per_launch"],
                         "flop_per_byte": k["flop_per_byte"],
                         "hbm": {"achieved_gbytes_per_s": k["gbytes_per_s"], "peak_gbytes_per_s": PEAK_HBM_GBS,

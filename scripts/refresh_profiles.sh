@@ -23,3 +23,10 @@ find $O -name "*kernel_trace*" -delete
 du -sh $O; find $O -type f | head -40
 # SQ counters of the step's kernels (two passes)
 cd $R && bash scripts/pmc_sq.sh > $O/pmc_sq.log 2>&1; python scripts/pmc_summary.py gpurun_out/pmc2 wsdw layer_kernel_ws wgrad_kernel_h3 dw_gather sdf_adjoint sdf_fused head_chain head_bwd > $O/sq_counters.txt 2>&1
+
+# PMC traffic against the library's algorithmic bytes (fails the refresh beyond +-10 % on the layer class)
+cd $R && python scripts/make_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) bf16 > $O/traffic_bf16.txt 2>&1
+python scripts/make_traffic.py $(find $O/pmc_fetch_x3 -name "*counter_collection.csv" | head -1) $(find $O/pmc_write_x3 -name "*counter_collection.csv" | head -1) fp16x3 > $O/traffic_fp16x3.txt 2>&1
+cp profiles/traffic.json $O/traffic.json
+python scripts/check_traffic.py $O/bench_bf16.json bf16 > $O/traffic_check.txt 2>&1 || echo "TRAFFIC CHECK FAILED" >> $O/traffic_check.txt
+cat $O/traffic_check.txt

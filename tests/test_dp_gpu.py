@@ -69,3 +69,28 @@ def test_bench_line_with_the_collective_agrees_with_the_plain_line():
     assert len(forced["dist"]["ms_per_step_by_rank"]) == 1 and forced["dist"]["allreduce_bytes"] == 4 * 1219274
     assert 0.0 < forced["dist"]["allreduce_ms"] < 1.0, forced["dist"]
     assert abs(forced["value"] / plain["value"] - 1.0) <= 0.03, (forced["value"], plain["value"], forced["dist"])
+
+
+@pytest.mark.gpu
+def test_c4_workload_line_with_the_collective():
+    """`bench.py --workload c4` (BASELINE configs[3]: 4096 rays per step in total, DTU switches, RCCL gradient all-reduce) on the one
+    GPU a test box has: forced world-size-1 RCCL group, so the whole of C4 lands on this rank.  The line says strong scaling, the
+    replayed step ends with the gradient pack (graph -> all-reduce -> Adam on the flat buffer) and `dist` reports the ranks, the
+    all-reduce time and the host's time per step, which must stay below the step time (the ranks are never host-bound)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NEAT_FORCE_DIST")}
+    env.update({"NEAT_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "10", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-prof"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["scaling"] == "strong" and line["config"]["rays_per_gpu"] == 4096 and line["config"]["global_rays"] == 4096
+    assert line["config"]["workload"].startswith("C4") and "secondary" not in line
+    d = line["dist"]
+    assert d["backend"] == "nccl" and d["ranks"] == 1 and d["allreduce_bytes"] == 4 * (1219274 + 960 * 256)
+    assert "gradient pack" in d["step_sequence"], d
+    assert 0.0 < d["host_ms_per_step"] < line["ms_per_step"], (d["host_ms_per_step"], line["ms_per_step"])
+    assert line["value"] > 2.0e7, line["value"]
