@@ -77,9 +77,17 @@ __device__ int lsap_compact(int n, F flag, int* out, int* s_wave, int* s_base) {
 }
 
 __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
+  // scipy's shortest-augmenting-path algorithm with its tie rules (remaining-list order, "prefer an unassigned column among equal
+  // costs"), one workgroup.  Round 5: the phases of a row search were cut from five barriers to two per scan --
+  //   * the FIRST scan of a row initialises the row's work arrays (shortest path costs, predecessor, remaining list) as it goes
+  //     instead of a pass of its own;
+  //   * the dual update touches the rows / columns the search VISITED (a handful: kept as two short lists) and runs, with the
+  //     augmentation, inside thread 0's serial section of the scan that found the sink -- no parallel pass, no extra barriers;
+  //   * without masks the row / column lists are the identity (no compaction passes).
+  // Same arithmetic per element, same results (tests/test_lsap.py: scipy, ties, masks, non-finite costs).
   __shared__ int s_wave[LSAP_WG / 64], s_base;
   __shared__ LsapKey s_key[LSAP_WG / 64];
-  __shared__ int s_i, s_sink, s_nrem, s_fail;
+  __shared__ int s_i, s_nrem, s_fail, s_done, s_nvis;
   __shared__ double s_minval;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const int kmax = min(a.nr, a.nc);
@@ -91,50 +99,87 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
   double* wsd = a.use_lds ? reinterpret_cast<double*>(lsap_lds) : a.wsd;
   int* wsi = a.use_lds ? reinterpret_cast<int*>(lsap_lds + a.lds_int_off) : a.wsi;
   int* rowlist = wsi;
-  const unsigned char* mask = a.row_mask;
-  const int n_eff = lsap_compact(a.nr, [&](int i) { return mask ? mask[i] != 0 : true; }, rowlist, s_wave, &s_base);
   int* collist = rowlist + a.nr;
+  const unsigned char* mask = a.row_mask;
   const unsigned char* cmask = a.col_mask;
-  const int c_eff = lsap_compact(a.nc, [&](int j) { return cmask ? cmask[j] != 0 : true; }, collist, s_wave, &s_base);
+  int n_eff, c_eff;
+  if (!mask && !cmask) {
+    for (int i = tid; i < a.nr; i += nt) rowlist[i] = i;
+    for (int j = tid; j < a.nc; j += nt) collist[j] = j;
+    n_eff = a.nr; c_eff = a.nc;
+  } else {
+    n_eff = lsap_compact(a.nr, [&](int i) { return mask ? mask[i] != 0 : true; }, rowlist, s_wave, &s_base);
+    c_eff = lsap_compact(a.nc, [&](int j) { return cmask ? cmask[j] != 0 : true; }, collist, s_wave, &s_base);
+  }
   const bool T = c_eff < n_eff;
   const int N = T ? c_eff : n_eff, M = T ? n_eff : c_eff;
   if (N == 0) { if (tid == 0) *a.n_match = 0; return; }
   double* u = wsd; double* v = u + N; double* sp = v + M;
   int* path = collist + a.nc; int* col4row = path + M; int* row4col = col4row + N; int* remaining = row4col + M;
-  int* SR = remaining + M; int* SC = SR + N; int* tmp = SC + M;
+  int* vis_row = remaining + M;      // (the SR region: rows scanned by the current search, in order; at most N)
+  int* vis_col = vis_row + N;        // (the SC region: columns taken out of the remaining list by it; at most N)
+  int* tmp = vis_col + M;
   const float* C = a.cost;
   const int nc0 = a.nc;
   const bool staged = a.use_lds && a.cost_lds_off >= 0;
   const float* Cl = reinterpret_cast<const float*>(lsap_lds + (staged ? a.cost_lds_off : 0));
   if (staged) {
+    // the cost matrix into LDS: four independent 16-byte loads in flight per thread (a plain element loop is a chain of dependent
+    // L2 round trips: 16 of them for the 8 x 2048 matrix of a training step)
     float* dst = reinterpret_cast<float*>(lsap_lds + a.cost_lds_off);
-    for (int e = tid; e < a.nr * a.nc; e += nt) dst[e] = C[e];
+    const int total = a.nr * a.nc;
+    const int total4 = ((reinterpret_cast<size_t>(C) & 15) == 0) ? (total >> 2) : 0;
+    const float4* C4 = reinterpret_cast<const float4*>(C);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int e = tid; e < total4; e += 4 * nt) {
+      float4 x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (e + q * nt < total4) x[q] = C4[e + q * nt];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (e + q * nt < total4) d4[e + q * nt] = x[q];
+    }
+    for (int e = 4 * total4 + tid; e < total; e += nt) dst[e] = C[e];
   }
+  const bool ident = !mask && !cmask;          // identity row / column lists: no index indirection in the scans
   auto cost = [&](int i, int j) -> double {
-    const int idx = T ? rowlist[j] * nc0 + collist[i] : rowlist[i] * nc0 + collist[j];
+    const int idx = ident ? (T ? j * nc0 + i : i * nc0 + j) : (T ? rowlist[j] * nc0 + collist[i] : rowlist[i] * nc0 + collist[j]);
     return (double)(staged ? Cl[idx] : C[idx]);
   };
   for (int i = tid; i < N; i += nt) { u[i] = 0.0; col4row[i] = -1; }
   for (int j = tid; j < M; j += nt) { v[j] = 0.0; row4col[j] = -1; }
-  if (tid == 0) s_fail = 0;
+  if (tid == 0) { s_fail = 0; s_done = 0; s_i = 0; s_nrem = M; s_minval = 0.0; s_nvis = 0; }
   __syncthreads();
 
   for (int cur = 0; cur < N; ++cur) {
-    for (int j = tid; j < M; j += nt) { remaining[j] = M - j - 1; SC[j] = 0; sp[j] = INFINITY; }
-    for (int i = tid; i < N; i += nt) SR[i] = 0;
-    if (tid == 0) { s_i = cur; s_sink = -1; s_nrem = M; s_minval = 0.0; }
-    __syncthreads();
+    bool first = true;
     while (true) {
       const int i = s_i, nrem = s_nrem;
       const double minval = s_minval, ui = u[i];
       LsapKey best{INFINITY, -1, 0};
-      for (int it = tid; it < nrem; it += nt) {
-        const int j = remaining[it];
-        const double r = minval + cost(i, j) - ui - v[j];
-        double spj = sp[j];
-        if (r < spj) { path[j] = i; sp[j] = r; spj = r; }
-        LsapKey k{spj, it, row4col[j] == -1 ? 1 : 0};
-        if (spj < INFINITY && lsap_better(k, best)) best = k;
+      if (first) {
+        // first scan of the row (i = cur, minval = 0, every column remaining in scipy's initial order M-1 .. 0): the pass that set
+        // sp = inf / remaining / the visited flags is folded in
+        for (int it = tid; it < M; it += nt) {
+          const int j = M - 1 - it;
+          const double r = minval + cost(i, j) - ui - v[j];
+          const bool lower = r < INFINITY;
+          const double spj = lower ? r : INFINITY;
+          sp[j] = spj;
+          if (lower) path[j] = i;
+          remaining[it] = j;
+          LsapKey k{spj, it, row4col[j] == -1 ? 1 : 0};
+          if (spj < INFINITY && lsap_better(k, best)) best = k;
+        }
+        first = false;
+      } else {
+        for (int it = tid; it < nrem; it += nt) {
+          const int j = remaining[it];
+          const double r = minval + cost(i, j) - ui - v[j];
+          double spj = sp[j];
+          if (r < spj) { path[j] = i; sp[j] = r; spj = r; }
+          LsapKey k{spj, it, row4col[j] == -1 ? 1 : 0};
+          if (spj < INFINITY && lsap_better(k, best)) best = k;
+        }
       }
       for (int m = 32; m >= 1; m >>= 1) {
         LsapKey o = lsap_shfl_xor(best, m);
@@ -145,38 +190,40 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
       if (tid == 0) {
         LsapKey b = s_key[0];
         for (int w = 1; w < nw; ++w) if (lsap_better(s_key[w], b)) b = s_key[w];
-        SR[i] = 1;
-        if (b.it < 0) { s_fail = 1; s_sink = -2; }
+        int nvis = s_nvis;
+        vis_row[nvis] = i;
+        if (b.it < 0) { s_fail = 1; s_done = N; }
         else {
-          s_minval = b.val;
+          const double mv = b.val;
           const int j = remaining[b.it];
-          if (row4col[j] == -1) s_sink = j; else s_i = row4col[j];
-          SC[j] = 1;
+          vis_col[nvis] = j;
+          ++nvis;
           remaining[b.it] = remaining[nrem - 1];
-          s_nrem = nrem - 1;
+          if (row4col[j] != -1) { s_i = row4col[j]; s_minval = mv; s_nrem = nrem - 1; s_nvis = nvis; }
+          else {
+            // sink found: dual update over the visited rows / columns (scipy: u[cur] += minVal; u[i] += minVal - sp[col4row[i]] for the
+            // other scanned rows; v[j] -= minVal - sp[j] for the scanned columns), then the augmentation along the path
+            for (int q = 0; q < nvis; ++q) {
+              const int r_ = vis_row[q];
+              if (r_ == cur) u[r_] += mv;
+              else u[r_] += mv - sp[col4row[r_]];
+            }
+            for (int q = 0; q < nvis; ++q) { const int c_ = vis_col[q]; v[c_] -= mv - sp[c_]; }
+            int jj = j;
+            while (true) {
+              const int ii = path[jj];
+              row4col[jj] = ii;
+              const int t = col4row[ii]; col4row[ii] = jj; jj = t;
+              if (ii == cur) break;
+            }
+            s_done = cur + 1; s_i = cur + 1; s_nrem = M; s_minval = 0.0; s_nvis = 0;      // the next row's search starts clean
+          }
         }
       }
       __syncthreads();
-      if (s_sink != -1) break;
+      if (s_done > cur) break;
     }
     if (s_fail) break;
-    const double minval = s_minval;
-    for (int i = tid; i < N; i += nt) {
-      if (i == cur) u[i] += minval;
-      else if (SR[i]) u[i] += minval - sp[col4row[i]];
-    }
-    for (int j = tid; j < M; j += nt) if (SC[j]) v[j] -= minval - sp[j];
-    __syncthreads();
-    if (tid == 0) {
-      int j = s_sink;
-      while (true) {
-        const int i = path[j];
-        row4col[j] = i;
-        const int t = col4row[i]; col4row[i] = j; j = t;
-        if (i == cur) break;
-      }
-    }
-    __syncthreads();
   }
   if (s_fail) { if (tid == 0) *a.n_match = -1; return; }
   if (!T) {

@@ -28,4 +28,7 @@ class LaplaceDensity(Density):
         return (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta)) / beta
 
     def get_beta(self):
+        # (no per-step cache of this two-launch expression: a cached tensor keeps its autograd graph -- and with it the parameter's
+        # AccumulateGrad node, bound to the stream of the step that built it -- alive into the next step; a HIP-graph capture that then
+        # reuses the node records a wait on that other stream and hipStreamEndCapture dies on the unjoined fork.  Tried in round 5.)
         return self.beta.abs() + self.beta_min
