@@ -68,8 +68,6 @@ class ImplicitNetwork(_HipModule):
     def __init__(self, feature_vector_size, sdf_bounding_sphere, d_in, d_out, dims, geometric_init=True, bias=1.0,
                  skip_in=(), weight_norm=True, multires=0, sphere_scale=1.0, inside_out=False):
         super().__init__()
-        if inside_out:
-            raise NotImplementedError("inside_out is not used by any shipped conf")
         self.sdf_bounding_sphere, self.sphere_scale = sdf_bounding_sphere, sphere_scale
         self.skip_in, self.inside_out = tuple(skip_in), inside_out
         pe_dim = d_in * (1 + 2 * multires) if multires > 0 else d_in
@@ -100,9 +98,27 @@ class ImplicitNetwork(_HipModule):
             setattr(self, f"lin{l}", _wrap_wn(lin))
         self.softplus = nn.Softplus(beta=100)
 
+    def triples(self):
+        """(weight_v, weight_g, bias) of the nine layers as the kernels see them.  inside_out (rend_a :94-95: `x[:, :1] = -x[:, :1]` after
+        the last layer) = the sdf row of lin8 with the opposite sign: gain and bias row 0 are negated on the way in (two small launches
+        per forward; their gradients come back through the same products)."""
+        tr = _triples(self, 9)
+        if self.inside_out:
+            v, g, b = tr[8]
+            sign = self.__dict__.get("_sdf_sign")
+            if sign is None or sign.device != g.device:
+                sign = torch.ones(g.shape[0], device=g.device, dtype=g.dtype)
+                sign[0] = -1.0
+                self.__dict__["_sdf_sign"] = sign
+            g2, b2 = g * sign.view_as(g), b * sign
+            g2._neat_key = (g.data_ptr(), g._version, "inside_out")
+            b2._neat_key = (b.data_ptr(), b._version, "inside_out")
+            tr[8] = (v, g2, b2)
+        return tr
+
     def handle(self):
         h = self._handle()
-        h.set_layers(0, _triples(self, 9))
+        h.set_layers(0, self.triples())
         return h
 
     def _outputs(self, x, radius):
@@ -130,18 +146,39 @@ class _Head(_HipModule):
 
     def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0, expect_in=None):
         super().__init__()
-        if mode != "idr":
-            raise NotImplementedError("only mode='idr' (all shipped confs)")
+        if mode not in ("idr", "nerf"):
+            raise NotImplementedError(f"head mode {mode!r}: the reference knows 'idr' and 'nerf'")
         self.mode = mode
         in_dim = d_in + feature_vector_size + (6 * multires_view if multires_view > 0 else 0)
         widths = [in_dim] + list(dims) + [d_out]
+        # mode = 'nerf' (rend_a :180-181,240-241): the input is [view, feature] -- no point, no normal; d_in = 3.  The kernels keep their
+        # [p | view | normal | feature] input layout; the parameter's columns are spread into it with zero weights for p and the normal
+        if mode == "nerf":
+            expect_in -= 6
         if in_dim != expect_in or list(dims) != [256] * 4:
             raise NotImplementedError(f"HIP path implements {expect_in}->256x4->{d_out}, got {widths}")
+        self.full_in = expect_in + (6 if mode == "nerf" else 0)
         self.num_layers = len(widths)
         self.multires_view = multires_view
         for l in range(self.num_layers - 1):
             setattr(self, f"lin{l}", _wrap_wn(_wn_linear(widths[l], widths[l + 1], weight_norm)))
         self.relu, self.sigmoid = nn.ReLU(), nn.Sigmoid()
+
+    def triples(self):
+        """(weight_v, weight_g, bias) of the five layers as the kernels see them: lin0's weight_v spread over the kernels' input columns
+        when mode = 'nerf' (zeros + one index_copy per forward; weight norm divides by the row norm, which the zero columns leave alone)."""
+        tr = _triples(self, 5)
+        if self.mode == "nerf":
+            v, g, b = tr[0]
+            nv = v.shape[1] - 256                        # view columns: 27 (PE-4) or 3
+            idx = self.__dict__.get("_nerf_cols")
+            if idx is None or idx.device != v.device:
+                idx = torch.cat([torch.arange(3, 3 + nv), torch.arange(6 + nv, 6 + nv + 256)]).to(v.device)
+                self.__dict__["_nerf_cols"] = idx
+            v2 = torch.zeros(v.shape[0], self.full_in, device=v.device, dtype=v.dtype).index_copy(1, idx, v)
+            v2._neat_key = (v.data_ptr(), v._version, "nerf")
+            tr[0] = (v2, g, b)
+        return tr
 
     def _standalone(self, points, normals, view_dirs, feature_vectors):
         owner = self.__dict__.get("_neat_owner")
@@ -316,9 +353,9 @@ class VolSDFNetwork(_HipModule):
 
     def handle(self):
         h = self._handle()
-        h.set_layers(0, _triples(self.implicit_network, 9))
-        h.set_layers(9, _triples(self.rendering_network, 5))
-        h.set_layers(14, _triples(self.attraction_network, 5))
+        h.set_layers(0, self.implicit_network.triples())
+        h.set_layers(9, self.rendering_network.triples())
+        h.set_layers(14, self.attraction_network.triples())
         self.implicit_network.__dict__["_neat_handle"] = h      # share the pack cache with the sub-module API
         return h
 

@@ -90,7 +90,9 @@ class NetHandle:
     def packed(self):
         """Returns (packed weights tensor, NetParams).  Re-packs (2 kernel launches) whenever a parameter changed."""
         present = [t for l in self.layers if l is not None for t in l]
-        key = (self.precision,) + tuple((t.data_ptr(), t._version) for t in present)
+        # a tensor DERIVED from a parameter per forward (heads with mode = 'nerf', inside_out: neat_amd.networks) is keyed by its source
+        # parameter: a fresh tensor may land on the address a previous one had, with version 0 again
+        key = (self.precision,) + tuple(getattr(t, "_neat_key", None) or (t.data_ptr(), t._version) for t in present)
         if key != self._key:
             lib = _lib.lib()
             netp = _lib.NetParams()
@@ -157,6 +159,7 @@ class SdfOutputsFn(torch.autograd.Function):
         _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 1, prec, float(radius), float(scale), _p(ws),
                                         _p(out), _p(sdf), _p(feat), _p(grad), _stream()), "neat_sdf_forward")
         ctx.handle, ctx.P, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, P, ws, packed, netp, prec
+        ctx.keep = params          # netp holds raw pointers: tensors derived per forward (networks: nerf heads, inside_out) must outlive the backward
         return out, sdf, feat, grad
 
     @staticmethod
@@ -248,6 +251,7 @@ class RenderRaysFn(torch.autograd.Function):
                                            _p(lines3d), _p(depth), _p(xyz), _p(nmap), _p(eik) if E else None, E,
                                            _p(eik_grad) if E else None, _stream()), "neat_render_forward")
         ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, (R, S, E), ws, packed, netp, prec
+        ctx.keep = params          # (see SdfOutputsFn)
         ctx.dirs, ctx.z, ctx.beta_d, ctx.beta_shape = dirs, z, beta_d, beta.shape
         # white_bkgd (rend_a :411-413): what the weights leave of a ray is filled with the background colour; the backward pass sends
         # the cotangent of the opacity, -(d_rgb . bg), through the compositing kernel (d_acc)

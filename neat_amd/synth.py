@@ -106,6 +106,17 @@ def synth_state_dict(seed=42, variant="init", num_junctions=64):
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()}
 
 
+def nerf_heads_state_dict(sd):
+    """The same weights for heads built with mode = 'nerf' (rend_a :180-181,240-241: the input is [view, feature] without the point and
+    the normal): the point / normal columns of the two input layers are dropped ([256, 289] -> [256, 283], [256, 265] -> [256, 259])."""
+    out = dict(sd)
+    v = sd["rendering_network.lin0.weight_v"]
+    out["rendering_network.lin0.weight_v"] = np.ascontiguousarray(np.concatenate([v[:, 3:30], v[:, 33:]], axis=1))
+    v = sd["attraction_network.lin0.weight_v"]
+    out["attraction_network.lin0.weight_v"] = np.ascontiguousarray(np.concatenate([v[:, 3:6], v[:, 9:]], axis=1))
+    return out
+
+
 def look_at_pose(cam_pos, target=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0)):
     """Camera-to-world 4x4 (OpenCV convention: +z forward, +y down), float32."""
     c = np.asarray(cam_pos, dtype=np.float64)

@@ -11,6 +11,7 @@ so the oracle / HIP path can replay them.  Only DATA (inputs + outputs) is writt
 no reference source travels to the GPU box.
 """
 import importlib.util
+import copy
 import os
 import sys
 import types
@@ -117,11 +118,14 @@ class RngTape:
         torch.Tensor.uniform_ = self._orig["uniform_"]
 
 
-def build_model(variant, seed=42, conf=None, num_junctions=64):
+def build_model(variant, seed=42, conf=None, num_junctions=64, sd_fn=None):
     from model.networks.neat_wfr_rend_a import VolSDFNetwork
     torch.manual_seed(0)
     net = VolSDFNetwork(to_tree(conf or synth.ABC_NEAT_A_MODEL_CONF))
-    sd = {k: torch.tensor(v) for k, v in synth.synth_state_dict(seed, variant, num_junctions=num_junctions).items()}
+    sd_np = synth.synth_state_dict(seed, variant, num_junctions=num_junctions)
+    if sd_fn is not None:
+        sd_np = sd_fn(sd_np)
+    sd = {k: torch.tensor(v) for k, v in sd_np.items()}
     net.load_state_dict(sd, strict=True)
     return net
 
@@ -262,16 +266,29 @@ def extra_goldens():
 def switch_goldens():
     """G14 / G15 / G16 (round 5): the three model switches that neat_amd implements but no shipped conf sets --
     white_bkgd (rend_a :263-265,411-413), use_l3d (:461-465), junction_eikonal (:524-525) -- each as ONE train step of the reference
-    (rough weights, 64 rays, its own random draws recorded), like G8."""
+    (rough weights, 64 rays, its own random draws recorded), like G8.  G17 / G18: the architecture switches mode = 'nerf' of the two
+    heads and inside_out of the SDF network."""
     install_shims()
     torch.set_default_dtype(torch.float32)
     WG = load_wireframe_cls()
     for tag, switch, seed, view in (("g14_train_step_white_bkgd", dict(white_bkgd=True, bg_color=[1.0, 0.9, 0.8]), 31, 1),
                                     ("g15_train_step_use_l3d", dict(use_l3d=True), 33, 2),
-                                    ("g16_train_step_junction_eikonal", dict(junction_eikonal=True), 35, 3)):
-        conf = dict(synth.ABC_NEAT_A_MODEL_CONF)
-        conf.update(switch)
-        net = build_model("rough", conf=conf)
+                                    ("g16_train_step_junction_eikonal", dict(junction_eikonal=True), 35, 3),
+                                    # G17 / G18: architecture switches -- both heads with mode = 'nerf' (:180-181,240-241: input = [view, feature]),
+                                    # and the SDF network with inside_out (:94-95)
+                                    ("g17_train_step_nerf_heads", "nerf", 37, 0),
+                                    ("g18_train_step_inside_out", "inside_out", 39, 1)):
+        conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+        sd_fn = None
+        if switch == "nerf":
+            conf["rendering_network"].update(mode="nerf", d_in=3)
+            conf["attraction_network"].update(mode="nerf", d_in=3)
+            sd_fn = synth.nerf_heads_state_dict
+        elif switch == "inside_out":
+            conf["implicit_network"]["inside_out"] = True
+        else:
+            conf.update(switch)
+        net = build_model("rough", conf=conf, sd_fn=sd_fn)
         net.train()
         sc, inp, gt = scene_inputs(WG, seed=seed, n_rays=64, view=view)
         rec = {}

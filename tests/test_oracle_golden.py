@@ -186,14 +186,20 @@ def test_train_step_dtu_switches(golden):
 
 SWITCH_GOLDENS = [("g14_train_step_white_bkgd", dict(white_bkgd=True, bg_color=(1.0, 0.9, 0.8))),
                   ("g15_train_step_use_l3d", dict(use_l3d=True)),
-                  ("g16_train_step_junction_eikonal", dict(junction_eikonal=True))]
+                  ("g16_train_step_junction_eikonal", dict(junction_eikonal=True)),
+                  ("g17_train_step_nerf_heads", dict(render_mode="nerf", attraction_mode="nerf")),
+                  ("g18_train_step_inside_out", dict(inside_out=True))]
 
 
 @pytest.mark.parametrize("name,switch", SWITCH_GOLDENS)
 def test_train_step_model_switches(golden, name, switch):
-    """G14-G16 (round 5): white_bkgd (rend_a :263-265,411-413), use_l3d (:461-465), junction_eikonal (:524-525) -- reference train steps."""
+    """G14-G16 (round 5): white_bkgd (rend_a :263-265,411-413), use_l3d (:461-465), junction_eikonal (:524-525) -- reference train steps.
+    G17 / G18: heads with mode = 'nerf' (:180-181,240-241), SDF network with inside_out (:94-95)."""
     g = golden(name)
-    p = params("rough", grad=True)
+    sd = synth.synth_state_dict(42, "rough")
+    if "render_mode" in switch:
+        sd = synth.nerf_heads_state_dict(sd)
+    p = O.params_from_numpy(sd, requires_grad=True)
     lines, verts = _wf(g)
     rand = {k: T(g[k]) for k in ("t_rand", "u_final", "perm", "eik_idx", "eik_uniform")}
     out = O.full_forward(p, _inp(g), lines, verts, training=True, rand=rand, **switch)
@@ -201,8 +207,8 @@ def test_train_step_model_switches(golden, name, switch):
     if "junction_eikonal" in switch:
         assert out["grad_theta"].shape[0] == 2 * 64 + 64
     lo = O.neat_loss(out, T(g["gt_rgb"]), T(g["gt_lines2d"]))
-    _check_train_step(g, p, out, lo, ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
-                                      "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median"))
+    _check_train_step(g, p, out, lo, [k for k in ("rgb_values", "depth", "xyz", "l3d", "points3d", "lines3d", "lines2d_calib", "sdf", "grad_theta",
+                                                  "j3d_local", "j3d_global", "j2d_global_calib", "j2d_local_calib", "median") if "out_" + k in g])
 
 
 def test_white_bkgd_sums_are_ill_conditioned(golden):
