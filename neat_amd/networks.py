@@ -117,6 +117,11 @@ class ImplicitNetwork(_HipModule):
         return tr
 
     def handle(self):
+        owner = self.__dict__.get("_neat_owner")
+        if owner is not None and owner() is not None:
+            # attached to a VolSDFNetwork: one handle for all three networks, refreshed as a whole (its heads may be represented by
+            # tensors derived per forward, which must not go stale when only this sub-module is called)
+            return owner().handle()
         h = self._handle()
         h.set_layers(0, self.triples())
         return h
@@ -334,7 +339,7 @@ class VolSDFNetwork(_HipModule):
         self.junction_eikonal = conf.get_bool("junction_eikonal", default=False)
         self.use_l3d = conf.get_bool("use_l3d", default=False)
         import weakref
-        for head in (self.rendering_network, self.attraction_network):
+        for head in (self.rendering_network, self.attraction_network, self.implicit_network):
             head.__dict__["_neat_owner"] = weakref.ref(self)
         self.static_randoms = None        # see _cpu_random
         self.use_side_stream = int(os.environ.get("NEAT_SIDE_STREAMS", "0"))   # forward(): bit 0: ffn(latents), bit 1: get_outputs(points3d) on a second stream

@@ -87,31 +87,41 @@ class NetHandle:
     def has_heads(self):
         return all(l is not None for l in self.layers)
 
+    def _fill_netp(self):
+        netp = _lib.NetParams()
+        dev = None
+        for l, tr in enumerate(self.layers):
+            if tr is None:
+                continue
+            v, g, b = (x.detach() for x in tr)
+            if tuple(v.shape) != (LAYER_OUT[l], LAYER_IN[l]) or g.numel() != LAYER_OUT[l] or b.numel() != LAYER_OUT[l]:
+                raise RuntimeError(f"layer {l}: unsupported shape {tuple(v.shape)} (the HIP path implements the "
+                                   "architecture of the shipped confs: 8x256 SDF MLP, PE-6/PE-4, 4x256 heads)")
+            for t in (v, g, b):
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise RuntimeError("parameters must be contiguous CUDA float32 (call model.cuda())")
+            netp.v[l], netp.g[l], netp.b[l] = v.data_ptr(), g.data_ptr(), b.data_ptr()
+            dev = v.device
+        return netp, dev
+
     def packed(self):
         """Returns (packed weights tensor, NetParams).  Re-packs (2 kernel launches) whenever a parameter changed."""
         present = [t for l in self.layers if l is not None for t in l]
         # a tensor DERIVED from a parameter per forward (heads with mode = 'nerf', inside_out: neat_amd.networks) is keyed by its source
         # parameter: a fresh tensor may land on the address a previous one had, with version 0 again
-        key = (self.precision,) + tuple(getattr(t, "_neat_key", None) or (t.data_ptr(), t._version) for t in present)
+        ptrs = tuple(t.data_ptr() for t in present)
+        key = (self.precision,) + tuple(getattr(t, "_neat_key", None) or (p_, t._version) for t, p_ in zip(present, ptrs))
         if key != self._key:
             lib = _lib.lib()
-            netp = _lib.NetParams()
-            dev = None
-            for l, tr in enumerate(self.layers):
-                if tr is None:
-                    continue
-                v, g, b = (x.detach() for x in tr)
-                if tuple(v.shape) != (LAYER_OUT[l], LAYER_IN[l]) or g.numel() != LAYER_OUT[l] or b.numel() != LAYER_OUT[l]:
-                    raise RuntimeError(f"layer {l}: unsupported shape {tuple(v.shape)} (the HIP path implements the "
-                                       "architecture of the shipped confs: 8x256 SDF MLP, PE-6/PE-4, 4x256 heads)")
-                for t in (v, g, b):
-                    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-                        raise RuntimeError("parameters must be contiguous CUDA float32 (call model.cuda())")
-                netp.v[l], netp.g[l], netp.b[l] = v.data_ptr(), g.data_ptr(), b.data_ptr()
-                dev = v.device
+            netp, dev = self._fill_netp()
             packed = torch.empty(lib.neat_packed_floats(self.precision), device=dev, dtype=torch.float32)
             _lib.check(lib.neat_pack_weights(ctypes.byref(netp), _p(packed), self.precision, _stream()), "neat_pack_weights")
-            self._key, self._packed, self._netp = key, packed, netp
+            self._key, self._packed, self._netp, self._ptrs = key, packed, netp, ptrs
+        elif ptrs != getattr(self, "_ptrs", None):
+            # same values (same source parameters), other tensors: the kernels also read biases, gains and weight_v through NetParams'
+            # raw pointers -- they must follow the derived tensors that are alive NOW, not the ones the pack was made from
+            self._netp, _ = self._fill_netp()
+            self._ptrs = ptrs
         return self._packed, self._netp
 
 

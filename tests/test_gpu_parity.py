@@ -323,6 +323,48 @@ def test_train_step_model_switches_vs_reference_golden(dev, golden, prec, name, 
                              grad_bar=1e-2 if prec == "bf16x3" else 2e-3)
 
 
+def test_derived_layer_tensors_follow_every_call(dev):
+    """inside_out / nerf heads hand the kernels tensors derived from the parameters per forward (networks.triples); the C ABI reads
+    biases, gains and weight_v through raw pointers (NetParams).  A second call with unchanged parameters hits the packed-weight cache --
+    its pointers must follow the tensors that are alive NOW: the first call's derived tensors are freed and their memory is overwritten
+    here before the second call."""
+    import copy
+    from neat_amd import networks
+    conf = copy.deepcopy(synth.ABC_NEAT_A_MODEL_CONF)
+    conf["implicit_network"]["inside_out"] = True
+    conf["rendering_network"].update(mode="nerf", d_in=3)
+    conf["attraction_network"].update(mode="nerf", d_in=3)
+    m = networks.VolSDFNetwork(conf)
+    m.load_state_dict({k: T(v) for k, v in synth.nerf_heads_state_dict(synth.synth_state_dict(42, "rough")).items()}, strict=True)
+    m.to(dev).eval()
+    x = torch.rand(500, 3, device=dev) * 2 - 1
+    with torch.no_grad():
+        a = m.implicit_network.get_sdf_vals(x).clone()
+        plain = copy.deepcopy(conf)
+        junk = [torch.full((257,), float("nan"), device=dev) for _ in range(64)]       # whatever the allocator hands out next: poisoned
+        junk += [torch.full((256, 289), float("nan"), device=dev) for _ in range(8)]
+        del junk
+        b = m.implicit_network.get_sdf_vals(x)
+        sc = synth.synth_scene(seed=3, n_rays=32)
+        inp = scene_inputs(sc, dev)
+        m.z_vals_override = T(synth.synth_z_vals(3, 32, 64)).to(dev)
+        o1 = m(inp)["rgb_values"].clone()
+        junk = [torch.full((256, 289), float("nan"), device=dev) for _ in range(8)] + [torch.full((257,), float("nan"), device=dev) for _ in range(64)]
+        del junk
+        o2 = m(inp)["rgb_values"]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.isfinite(o1).all() and torch.equal(o1, o2)
+    # and the sign: inside_out negates the raw sdf of the same weights
+    conf2 = copy.deepcopy(conf)
+    conf2["implicit_network"]["inside_out"] = False
+    m2 = networks.VolSDFNetwork(conf2)
+    m2.load_state_dict(m.state_dict(), strict=True)
+    m2.to(dev).eval()
+    with torch.no_grad():
+        close(m.implicit_network(x)[:, :1], -m2.implicit_network(x)[:, :1], what="inside_out = -sdf")
+        close(m.implicit_network(x)[:, 1:], m2.implicit_network(x)[:, 1:], what="inside_out keeps the features")
+
+
 def test_train_step_hierarchical_vs_reference_golden(dev, golden, prec):
     """C5: hierarchical 64 coarse + 64 fine depths feeding the main pass (model.hip_sampler = hierarchical), a full train step
     against fixture G12 in which the reference's own UniformSampler / get_z_vals_fine / get_sdf_vals / volume_rendering were composed."""
