@@ -332,7 +332,10 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *  22 with key 16: the feature rows of lin8's weight gradient contracted inside lin8's reverse launch as well (default 1)
  *  23 workgroups (= partials per set) of the launches of key 16, 16..256 (default 256; C4's shape: 192 the same, 128 +7 %)
  *  24 with keys 16 and 22: the chain variables of those launches (tangents of h_2..h_7, cotangents of a_6..a_1) alternate between two
- *     buffers each instead of one array per layer (default 1; results bit-identical, fewer HBM write-backs) */
+ *     buffers each instead of one array per layer (default 1; results bit-identical, fewer HBM write-backs)
+ *  25 with key 16: consecutive layers of the tangent / reverse chains that share an epilogue variant run as ONE launch in which every
+ *     workgroup loops over the layers for its own tiles (tangent 1-2 | 3 | 4-7, reverse 8 | 7-5 | 4 | 3-1: 15 launches -> 7; default 1;
+ *     results bit-identical) */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);

@@ -39,6 +39,9 @@ struct LayerArgsDW {
   int ablate;                          // probe runs only (results WRONG; tuning key 17): 4 = no partial stores
 };
 
+constexpr int DW_MAXSEG = 4;                      // layers one launch may run back to back (same epilogue variant; round 5)
+struct LayerArgsDWSeg { LayerArgsDW l[DW_MAXSEG]; int n; };
+
 constexpr int DW_XLDS = 1024;                     // bytes behind the ring: lin8's sdf weight row (EPI_BWD8)
 constexpr int DW_WG_UINT4 = 8 * 8 * 2 * 64;      // uint4 per workgroup partial (128 KiB)
 #ifndef DW_VALU_PER_MFMA
@@ -63,11 +66,26 @@ __device__ __forceinline__ void dw_dma4(unsigned long long sbase, unsigned voff,
                : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
 
+// A launch runs seg.n consecutive layers of one chain (same epilogue variant) back to back: every workgroup walks its OWN tiles layer
+// after layer -- layer l + 1 reads, tile by tile, what the same workgroup wrote in layer l (through the XCD's L2: the DMA fetches are
+// non-temporal, i.e. they bypass this CU's L1), so no workgroup waits for another and the launch boundaries between the layers (and the
+// ragged last round of each: 64 of 256 workgroups own a 17th tile at C2) disappear.  Between two layers: every wave drains its stores,
+// one workgroup barrier.
 template <int EPI, bool FULL>     // FULL: N = 256 output rows and 256 valid rows of the gradient's row operand (no row tests anywhere)
-__global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
+__global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDWSeg seg) {
   typedef WsCfg<EPI, 16> C;
   static_assert(C::NAUX == 2, "tangent / reverse epilogues only");
   constexpr bool TANK = (EPI == EPI_TAN || EPI == EPI_TAN_PF);      // gradient operand = aux1 (u_l); reverse: aux0 (h_l)
+  // (the per-layer arguments are read from the kernel-argument segment through a pointer: indexing the by-value struct with a run-time
+  // index would copy it to scratch)
+  const LayerArgsDW* tab = (const LayerArgsDW*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int nlayers = seg.n;
+  for (int li = 0; li < nlayers; ++li) {
+  if (li > 0) {                                   // layer li - 1's stores (all waves') before layer li's fetches; the ring is free again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const LayerArgsDW d = tab[li];
   const LayerArgsWS& a = d.w;
   extern __shared__ __attribute__((aligned(16))) unsigned char wslds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -342,6 +360,7 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDW d) {
       if (lane < 32) d.pbias[blockIdx.x * 256 + wr + 32 * i + lane] = t;
     }
   }
+  }      // layers of the segment
 }
 
 // ---------------------------------------------------------------------------------------------

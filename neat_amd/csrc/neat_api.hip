@@ -255,7 +255,9 @@ int g_chain_pp = 1;         // with key 16: the chain variables of the tangent /
                             // instead of one array per layer: since the weight gradients are contracted in the launch that holds them no later
                             // kernel reads them, and a line rewritten while it is still in the Infinity Cache never costs an HBM write (tuning key 24)
 int g_dw_nsub = 16;         // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
-template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) {
+int g_dw_segments = 1;      // with key 16: consecutive layers of a chain that share an epilogue variant run as ONE launch with a per-workgroup layer loop
+                            // (tangent 1-2 | 3 | 4-7, reverse 8 | 7-5 | 4 | 3-1: 15 launches -> 7; tuning key 25)
+template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW* d0, int n = 1) {
   static DevOnce attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_kernel_wsdw<EPI, FULL>),
@@ -263,14 +265,22 @@ template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  LayerArgsDW d = d0;
-  d.w.ntiles = d.w.ldp / WSP;
-  d.w.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 28);
-  d.ablate = g_dw_ablate;
-  if (FULL && (d.w.N != 256 || d.rowsA != 256)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((layer_kernel_wsdw<EPI, FULL>), dim3(dw_grid(d.w.ldp)), dim3(WST), (WsCfg<EPI, 16>::LDS + DW_XLDS), st, d);
+  if (n < 1 || n > DW_MAXSEG) return hipErrorInvalidValue;
+  LayerArgsDWSeg seg{};
+  seg.n = n;
+  for (int i = 0; i < n; ++i) {
+    LayerArgsDW& d = seg.l[i];
+    d = d0[i];
+    d.w.ntiles = d.w.ldp / WSP;
+    d.w.aux_nt = (g_ws_aux_nt & 3) | ((g_ws_aux_nt >> 1) & 28);
+    d.ablate = g_dw_ablate;
+    if (FULL && (d.w.N != 256 || d.rowsA != 256)) return hipErrorInvalidValue;
+    if (d.w.ldp != d0[0].w.ldp) return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL((layer_kernel_wsdw<EPI, FULL>), dim3(dw_grid(seg.l[0].w.ldp)), dim3(WST), (WsCfg<EPI, 16>::LDS + DW_XLDS), st, seg);
   return hipGetLastError();
 }
+template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW& d0) { return launch_layer_wsdw<EPI, FULL>(st, &d0, 1); }
 template <int EPI, int KS = 16, bool OUTF = false> hipError_t launch_layer_ws(hipStream_t st, const LayerArgsWS& a0) {
   static DevOnce attr_set;
   if (!attr_set) {
@@ -1065,6 +1075,18 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     // the layer (2 N 256 P) + the gradient (2 rowsA 256 P); bytes: input, two epilogue operands, outputs, the partial
     return prof_begin(c.st, 0, 2.0 * N * 256 * P + 2.0 * rowsA * 256 * P, 256 * P * 2.0 + N * P * 2.0 * 4 + (double)dwg * DW_WG_UINT4 * 16.0);
   };
+  LayerArgsDW pend[DW_MAXSEG];
+  int npend = 0, pend_variant = 0;
+  double pend_flops = 0.0, pend_bytes = 0.0;
+  auto flush_tan = [&]() -> hipError_t {
+    if (!npend) return hipSuccess;
+    ProfSlot* ps = prof_begin(c.st, 0, pend_flops, pend_bytes);
+    const hipError_t r = pend_variant == 1 ? launch_layer_wsdw<EPI_TAN_PF, false>(c.st, pend, npend) : launch_layer_wsdw<EPI_TAN, true>(c.st, pend, npend);
+    prof_end(c.st, ps);
+    dbg_sync(c.st, "tangent+dW layers", npend, 0, 0);
+    npend = 0; pend_flops = pend_bytes = 0.0;
+    return r;
+  };
   for (int l = 0; l < 8; ++l) {
     In a = l == 0 ? in(c.prec ? w.Ehbf : F(w.Eh), PE_ROWS) : in(w.vh[l], l == 4 ? (c.prec ? 224 : 217) : 256);
     In b = l == 4 ? (c.prec ? in(w.Ehbf4, 32) : in(F(w.Eh), PE_ROWS)) : NOIN;
@@ -1081,11 +1103,12 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       if (l == 3) s.padfill = u16p(w.Ehbf);
       d.auxA2 = nullptr; d.auxA_split = 1 << 30; d.rowsA = kO[l];
       dw_job(l, 0, d);
-      ProfSlot* ps = dw_prof(kO[l], kO[l]);
-      e = l == 3 ? launch_layer_wsdw<EPI_TAN_PF, false>(c.st, d) : launch_layer_wsdw<EPI_TAN, true>(c.st, d);
-      prof_end(c.st, ps);
-      dbg_sync(c.st, "tangent+dW layer", l, 0, 0);
-      if (e != hipSuccess) return e;
+      // consecutive layers with the same epilogue variant go out as ONE launch (layer loop per workgroup, kernels_dw.hpp): 1-2 | 3 | 4-7
+      const int variant = l == 3 ? 1 : 0;
+      if (npend && (variant != pend_variant || npend == DW_MAXSEG || !g_dw_segments)) { if ((e = flush_tan()) != hipSuccess) return e; }
+      pend[npend++] = d; pend_variant = variant; pend_flops += 2.0 * kO[l] * 256 * (double)c.P + 2.0 * kO[l] * 256 * (double)c.P;
+      pend_bytes += 256 * (double)c.P * 2.0 + kO[l] * (double)c.P * 2.0 * 4 + (double)dwg * DW_WG_UINT4 * 16.0;
+      if (l == 7 || !g_dw_segments) { if ((e = flush_tan()) != hipSuccess) return e; }
       continue;
     }
     if ((e = layer(c, L.fwd[l], EPI_TAN, a, b, nullptr, kO[l], w.vh[l + 1], w.m[l], 1 << 30, w.h[l + 1], w.u[l], 0, 0, 1 << 30,
@@ -1162,6 +1185,15 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
   };
   const bool inter = g_wgrad_interleave != 0 && !dw;
   if (inter && (e = wgrad_layer(8)) != hipSuccess) return e;
+  auto flush_rev = [&]() -> hipError_t {
+    if (!npend) return hipSuccess;
+    ProfSlot* ps = prof_begin(c.st, 0, pend_flops, pend_bytes);
+    const hipError_t r = pend_variant == 0 ? launch_layer_wsdw<EPI_BWD, true>(c.st, pend, npend) : launch_layer_wsdw<EPI_BWD, false>(c.st, pend, npend);
+    prof_end(c.st, ps);
+    dbg_sync(c.st, "reverse+dW layers", npend, 0, 0);
+    npend = 0; pend_flops = pend_bytes = 0.0;
+    return r;
+  };
   for (int l = 7; l >= 1; --l) {
     if (inter && (e = wgrad_layer(l)) != hipSuccess) return e;
     const int N = l == 4 ? 217 : kI[l];
@@ -1179,11 +1211,12 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
       // octet 27 (finite), so rows >= 217 of the product are finite garbage that the gather never writes -- no row mask needed
       d.rowsA = 256;
       dw_job(l, 1, d);
-      ProfSlot* ps = dw_prof(N, d.rowsA);
-      e = (N == 256 && d.rowsA == 256) ? launch_layer_wsdw<EPI_BWD, true>(c.st, d) : launch_layer_wsdw<EPI_BWD, false>(c.st, d);
-      prof_end(c.st, ps);
-      dbg_sync(c.st, "reverse+dW layer", l, 0, 0);
-      if (e != hipSuccess) return e;
+      // 7-5 | 4 (217 output rows: the row-tested variant) | 3-1 as one launch each
+      const int variant = (N == 256 && d.rowsA == 256) ? 0 : 1;
+      if (npend && (variant != pend_variant || npend == DW_MAXSEG || !g_dw_segments)) { if ((e = flush_rev()) != hipSuccess) return e; }
+      pend[npend++] = d; pend_variant = variant; pend_flops += 2.0 * N * 256 * (double)c.P + 2.0 * d.rowsA * 256 * (double)c.P;
+      pend_bytes += 256 * (double)c.P * 2.0 + N * (double)c.P * 2.0 * 4 + (double)dwg * DW_WG_UINT4 * 16.0;
+      if (l == 1 || !g_dw_segments) { if ((e = flush_rev()) != hipSuccess) return e; }
       continue;
     }
     if ((e = layer(c, L.tr[l], EPI_BWD, in(w.m[l], kO[l]), NOIN, nullptr, N, w.m[l - 1], Arr{}, 1 << 30, w.h[l], w.m[l - 1])) != hipSuccess) return e;
@@ -1644,6 +1677,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 22 && (value == 0 || value == 1)) { g_dw_lin8 = value; return 0; }
   if (key == 23 && value >= 16 && value <= DW_MAXGRID) { g_dw_grid = value; return 0; }
   if (key == 24 && (value == 0 || value == 1)) { g_chain_pp = value; return 0; }
+  if (key == 25 && (value == 0 || value == 1)) { g_dw_segments = value; return 0; }
   return -1;
 }
 

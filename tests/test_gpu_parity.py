@@ -1192,8 +1192,9 @@ def test_in_kernel_weight_gradients_agree_with_wgrad_launches(dev, R, S, half):
 @pytest.mark.parametrize("R,S", [(1024, 128), (600, 98)])
 def test_chain_variables_in_two_buffers_change_nothing(dev, R, S, half):
     """Tuning key 24 (round 5): the tangent / reverse launches with in-kernel weight gradients write their chain variables into two
-    alternating buffers instead of one array per layer (no later kernel reads them).  Same launches, same arithmetic: outputs and
-    EVERY gradient bit-identical to the one-array-per-layer run."""
+    alternating buffers instead of one array per layer (no later kernel reads them).  Tuning key 25: consecutive layers with the same
+    epilogue variant run as ONE launch in which every workgroup loops over the layers for its own tiles (15 launches -> 7).  Same
+    arithmetic in the same order per workgroup: outputs and EVERY gradient bit-identical to the one-launch-per-layer, one-array-per-layer run."""
     from neat_amd import _lib, rend_util
     m = build_model(dev, "rough", seed=8, train=True).set_precision(half)
     sc = synth.synth_scene(seed=8, n_rays=R)
@@ -1206,7 +1207,8 @@ def test_chain_variables_in_two_buffers_change_nothing(dev, R, S, half):
     cot_l = torch.randn(R, 2, 3, generator=gen).to(dev)
 
     def run(key):
-        _lib.check(_lib.lib().neat_set_tuning(24, key), "neat_set_tuning")
+        _lib.check(_lib.lib().neat_set_tuning(24, key & 1), "neat_set_tuning")
+        _lib.check(_lib.lib().neat_set_tuning(25, key >> 1), "neat_set_tuning")      # (round 5) several layers per launch
         m.zero_grad()
         torch.manual_seed(7)
         rgb, l3, *_ = m._render(c, d, z, False)
@@ -1216,14 +1218,16 @@ def test_chain_variables_in_two_buffers_change_nothing(dev, R, S, half):
     try:
         _lib.check(_lib.lib().neat_set_tuning(16, 2), "neat_set_tuning")
         r0, l0, g0 = run(0)
-        r1, l1, g1 = run(1)
+        others = [run(1), run(2), run(3)]          # two buffers / layer segments / both (the default)
     finally:
         _lib.lib().neat_set_tuning(16, 1)
         _lib.lib().neat_set_tuning(24, 1)
-    assert torch.equal(r0, r1) and torch.equal(l0, l1)
-    for k in g0:
-        assert torch.isfinite(g1[k]).all(), k
-        assert torch.equal(g0[k], g1[k]), k
+        _lib.lib().neat_set_tuning(25, 1)
+    for r1, l1, g1 in others:
+        assert torch.equal(r0, r1) and torch.equal(l0, l1)
+        for k in g0:
+            assert torch.isfinite(g1[k]).all(), k
+            assert torch.equal(g0[k], g1[k]), k
 
 
 @pytest.mark.parametrize("half", ["bf16", "fp16"])
