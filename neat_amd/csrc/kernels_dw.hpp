@@ -350,7 +350,14 @@ __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDWSeg seg) 
         const f32x2_t v = {dacc[j][8 * hf + 2 * e] * sc, dacc[j][8 * hf + 2 * e + 1] * sc};
         w4[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_t));
       }
-      dst[(j * 2 + hf) * 64] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+#ifndef NEAT_DW_NT_PART
+#define NEAT_DW_NT_PART 0
+#endif
+      if (NEAT_DW_NT_PART) {
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+        const v4u_t wv = {w4[0], w4[1], w4[2], w4[3]};
+        __builtin_nontemporal_store(wv, reinterpret_cast<v4u_t*>(dst + (j * 2 + hf) * 64));
+      } else dst[(j * 2 + hf) * 64] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
   if (lane == 0) d.pscale[blockIdx.x * 8 + wave] = __uint_as_float((ex - 14u) << 23);
   if (!TANK && BIAS) {

@@ -75,6 +75,18 @@ struct F6Lane {
 // everything is unrolled).
 // ---------------------------------------------------------------------------------------------------------------
 struct F6EpiState { float m0, m1, w0, w1; unsigned lo; };       // what travels from half unit A to half unit B of a value pair
+#ifndef NEAT_F6_NT_E
+#define NEAT_F6_NT_E 0         // the fp32 PE rows the primal chain saves
+#endif
+#ifndef NEAT_F6_NT
+#define NEAT_F6_NT 1           // the saved arrays (h_l, u_l: read again only by the backward pass) leave with non-temporal stores: they no longer
+                               // displace the weight fragments the rolling refills fetch from L2 (round 5: adjoint chain 300 -> 255 us at C2)
+#endif
+__device__ __forceinline__ void f6_store8(void* p, uint2 v) {
+  typedef unsigned long long u64_t;
+  if (NEAT_F6_NT) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v), reinterpret_cast<u64_t*>(p));
+  else *reinterpret_cast<uint2*>(p) = v;
+}
 
 // epilogue of one layer (compile-time description): activation, destination, row count, bias rows
 template <bool ACT_, bool SAVE_, int N_, int DST_, int BIASOFF_> struct F6EpiCfg {
@@ -135,7 +147,7 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
     const uint2 v = make_uint2(st.lo, pk);
     if (E::SPLIT > 0) *reinterpret_cast<uint2*>(L.quad[E::DST] + ((i * 4 + q) * BP + t * 32) * 16) = v;
     if (E::SAVE && (FULL || t < nt))
-      *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((unsigned)(i * 4 + q) * L.ldp16 + L.gquad) + t * 512) = v;
+      f6_store8(reinterpret_cast<char*>(hout) + ((unsigned)(i * 4 + q) * L.ldp16 + L.gquad) + t * 512, v);
     return;
   }
   if (h == 0) {
@@ -169,7 +181,7 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
   if (E::ACT && NEAT_F6_ABLATE != 5) *reinterpret_cast<uint2*>(L.quad[E::DST] + ((i * 4 + q) * BP + t * 32) * 16) = v;
   if (NEAT_F6_ABLATE == 5) asm volatile("" :: "v"(v.x), "v"(v.y));
   if (E::SAVE && NEAT_F6_ABLATE != 9 && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
-    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q) * L.ldp16) + t * 512) + (size_t)L.gquad) = v;
+    f6_store8(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q) * L.ldp16) + t * 512) + (size_t)L.gquad, v);
 }
 
 // MMA = false: drain stage (epilogue only).  KS k-steps of layer input region SRC (0 = XA, 1 = XB, 2 = PE), tile t; the epilogue
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
           xc[c] = ok ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_fm) + ((unsigned)c * ldp4 + pvo)) : 0.0f;
         auto put = [&](int j, float v) {
           pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
-          if (SAVE && ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo)) = v;
+          if (SAVE && ok) { if (NEAT_F6_NT_E) __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo))); else *reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo)) = v; }
         };
         if (fg == NG - 1) {
 #pragma unroll
@@ -621,7 +633,12 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
         if (!(FULL || t < nt)) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {      // kernarg base + one 32-bit per-lane offset (the arrays are < 4 GB) + immediate
-          const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512);
+#ifndef NEAT_ADJ_NT_LOAD
+#define NEAT_ADJ_NT_LOAD 1      // the saved h quads arrive with non-temporal loads (round 5: 284 -> 271 us at C2)
+#endif
+          typedef unsigned long long u64_t;
+          const u64_t* hp = reinterpret_cast<const u64_t*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512);
+          const uint2 v = NEAT_ADJ_NT_LOAD ? __builtin_bit_cast(uint2, __builtin_nontemporal_load(hp)) : *reinterpret_cast<const uint2*>(hp);
           dst[q].x = __uint_as_float(v.x); dst[q].y = __uint_as_float(v.y);
         }
       };
@@ -937,7 +954,7 @@ __global__ __launch_bounds__(PHT, 2) void sdf_fused_ph_kernel(FusedArgs a, int n
           xc[c] = ok ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_fm) + ((unsigned)c * ldp4 + pvo)) : 0.0f;
         auto put = [&](int j, float v) {
           pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
-          if (SAVE && ok) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo)) = v;
+          if (SAVE && ok) { if (NEAT_F6_NT_E) __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo))); else *reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo)) = v; }
         };
         if (fg == 3) {
 #pragma unroll

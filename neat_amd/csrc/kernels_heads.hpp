@@ -42,12 +42,18 @@ struct HC {
                               // 128 = no barriers inside the layers, 256 = only a workgroup's first batch loads its inputs (forward kernel)
 #endif
 
-#ifndef NEAT_HC_NT
-#define NEAT_HC_NT 0          // 1: the hidden arrays leave with non-temporal stores
+#ifndef NEAT_HC_NT_FWD
+#define NEAT_HC_NT_FWD 1      // the forward chain's hidden arrays (read again only by the backward pass's weight gradients) leave with non-temporal
+                              // stores: they no longer push the layers' weight fragments, which every batch re-reads, out of the XCD's L2 (round 5:
+                              // forward chains 113 -> 105 us)
 #endif
+#ifndef NEAT_HC_NT_BWD
+#define NEAT_HC_NT_BWD 0      // the backward chain's cotangent arrays (read by the weight-gradient launch right behind it)
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void hc_store8(void* p, uint2 v) {
   typedef unsigned long long u64_t;
-  if (NEAT_HC_NT) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v), reinterpret_cast<u64_t*>(p));
+  if (NT) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v), reinterpret_cast<u64_t*>(p));
   else *reinterpret_cast<uint2*>(p) = v;
 }
 #ifndef NEAT_HC_WIDE
@@ -61,10 +67,11 @@ __device__ __forceinline__ uint4 hc_octet(uint2 prev, uint2 cur) {
   const v2u_t s1 = __builtin_amdgcn_permlane32_swap(prev.y, cur.y, false, false);
   return make_uint4(s0.x, s1.x, s0.y, s1.y);
 }
+template <bool NT = false>
 __device__ __forceinline__ void hc_store16(void* p, uint4 v) {
   typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
   const v4u_t w = {v.x, v.y, v.z, v.w};
-  if (NEAT_HC_NT) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t*>(p));
+  if (NT) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t*>(p));
   else *reinterpret_cast<v4u_t*>(p) = w;
 }
 #ifndef NEAT_HC_TIMING
@@ -78,6 +85,17 @@ __device__ __forceinline__ void hc_store16(void* p, uint4 v) {
 
 __device__ __forceinline__ uint4 hc_ldg(const void* base, unsigned off) {
   return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(base) + off);
+}
+#ifndef NEAT_HC_NT_IN
+#define NEAT_HC_NT_IN 0       // the chains' input tiles (feature rows, small inputs, output cotangents) arrive with non-temporal loads
+#endif
+__device__ __forceinline__ uint4 hc_ldg_in(const void* base, unsigned off) {
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  if (NEAT_HC_NT_IN) {
+    const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(reinterpret_cast<const unsigned char*>(base) + off));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return hc_ldg(base, off);
 }
 
 // One stage: KS k-steps of `acc` over the fragment column `fr`, epi(e) called 16 / KS times per k-step for e = 0 .. 15.
@@ -238,11 +256,11 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int idx = tb + i * C::THREADS, oct = idx >> 7, pp = idx & 127;
-        if (pp < npts) reinterpret_cast<uint4*>(hclds + C::XA)[oct * BP + pp] = hc_ldg(a.feat, ((unsigned)oct * (unsigned)a.ldp + p0 + pp) * 16u);
+        if (pp < npts) reinterpret_cast<uint4*>(hclds + C::XA)[oct * BP + pp] = hc_ldg_in(a.feat, ((unsigned)oct * (unsigned)a.ldp + p0 + pp) * 16u);
       }
       const int so = tb >> 7, sp = tb & 127;       // 4 octet rows per pass
       for (int o = so; o * 8 < a.srows; o += 4)
-        if (sp < npts) reinterpret_cast<uint4*>(hclds + C::S)[o * BP + sp] = hc_ldg(a.smallbf, ((unsigned)o * (unsigned)a.ldp + p0 + sp) * 16u);
+        if (sp < npts) reinterpret_cast<uint4*>(hclds + C::S)[o * BP + sp] = hc_ldg_in(a.smallbf, ((unsigned)o * (unsigned)a.ldp + p0 + sp) * 16u);
     }
     __syncthreads();
     HC_STAMP(1);
@@ -279,10 +297,17 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
       if (!(NEAT_HC_ABLATE & 16)) *reinterpret_cast<uint2*>(plq + q * (BP * 16)) = vh;
       if (SAVE) {
         if (NEAT_HC_WIDE) {
-          if (q & 1) hc_store16(reinterpret_cast<char*>(phout) + (size_t)(q - 1) * ldp16 + pgw, hc_octet(vprev, vh));
+          if (q & 1) hc_store16<NEAT_HC_NT_FWD != 0>(reinterpret_cast<char*>(phout) + (size_t)(q - 1) * ldp16 + pgw, hc_octet(vprev, vh));
           else vprev = vh;
-        } else if (!(NEAT_HC_ABLATE & 4)) hc_store8(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
-        if (q == 3 && !(NEAT_HC_ABLATE & 8)) { *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pmout) + pmoff) = relu_mask_word(mbits); mbits = 0; }
+        } else if (!(NEAT_HC_ABLATE & 4)) hc_store8<NEAT_HC_NT_FWD != 0>(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
+#ifndef NEAT_HC_NT_MASK
+#define NEAT_HC_NT_MASK 0     // mask words: non-temporal stores (forward chain) and loads (backward chain)
+#endif
+        if (q == 3 && !(NEAT_HC_ABLATE & 8)) {
+          if (NEAT_HC_NT_MASK) __builtin_nontemporal_store(relu_mask_word(mbits), reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pmout) + pmoff));
+          else *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pmout) + pmoff) = relu_mask_word(mbits);
+          mbits = 0;
+        }
       }
     };
     auto set_pend = [&](int l, int dst, int t) {        // layer l (0..3) writes buffer dst and hid[l + 1] / mask[l + 1]
@@ -462,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
 #endif
     HC_STAMP(0);
     // ---- the output cotangent (one octet per point) -> S
-    if (tb < npts) reinterpret_cast<uint4*>(hclds + C::S)[tb] = hc_ldg(a.top, (p0 + (unsigned)tb) * 16u);
+    if (tb < npts) reinterpret_cast<uint4*>(hclds + C::S)[tb] = hc_ldg_in(a.top, (p0 + (unsigned)tb) * 16u);
     __syncthreads();
 
     f32x16 acc[2];
@@ -475,6 +500,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
     uint2 vprev = make_uint2(0u, 0u);   // wide stores (hc_octet): the even quad waits for its odd neighbour
     unsigned pgw = 0;
     auto ldmask = [&](int l, int t) -> unsigned {
+      if (NEAT_HC_NT_MASK) return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.mask[l]) + (mlane + (unsigned)t * 2048u)));
       return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.mask[l]) + (mlane + (unsigned)t * 2048u));
     };
     // masked epilogue: quad -> LDS buffer + ab array.  Per pair: rounding, then the pair's two mask bits (the sign bits of the mask
@@ -487,9 +513,9 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
       const uint2 vh = make_uint2(ph[0], ph[1]);
       *reinterpret_cast<uint2*>(plq + q * (BP * 16)) = vh;
       if (NEAT_HC_WIDE) {
-        if (q & 1) hc_store16(reinterpret_cast<char*>(phout) + (size_t)(q - 1) * ldp16 + pgw, hc_octet(vprev, vh));
+        if (q & 1) hc_store16<NEAT_HC_NT_BWD != 0>(reinterpret_cast<char*>(phout) + (size_t)(q - 1) * ldp16 + pgw, hc_octet(vprev, vh));
         else vprev = vh;
-      } else hc_store8(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
+      } else hc_store8<NEAT_HC_NT_BWD != 0>(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
     };
     // feature-cotangent epilogue: quad -> featc (the second head adds, in the first head's scale)
     auto epi_feat = [&](const f32x16& ap, int e) {
@@ -503,7 +529,10 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
       }
       ph[j >> 1] = pack2(rv.x, rv.y);
       if (j != 3) return;
-      *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.featc) + (size_t)q * ldp16 + pg) = make_uint2(ph[0], ph[1]);
+#ifndef NEAT_HC_NT_FEATC
+#define NEAT_HC_NT_FEATC 0
+#endif
+      hc_store8<NEAT_HC_NT_FEATC != 0>(reinterpret_cast<char*>(a.featc) + (size_t)q * ldp16 + pg, make_uint2(ph[0], ph[1]));
     };
     auto set_pend = [&](int l, int dst, int t) {        // the stage that produced the cotangent ab[l] (masked by mask[l + 1]) into buffer dst
       plq = quad[dst] + t * 512;

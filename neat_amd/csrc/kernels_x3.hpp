@@ -22,6 +22,22 @@
 
 namespace neat {
 
+#ifndef NEAT_X3_NT
+#define NEAT_X3_NT 1          // saved planes of the split-precision chains (read again only by later passes) leave with non-temporal stores, the
+                              // adjoint chain's saved-activation quads arrive with non-temporal loads: the weight fragments every batch
+                              // re-reads stay in the XCD's L2 (round 5; as NEAT_F6_NT / NEAT_ADJ_NT_LOAD in kernels_fused.hpp)
+#endif
+__device__ __forceinline__ void x3_store8(void* p, uint2 v) {
+  typedef unsigned long long u64_t;
+  if (NEAT_X3_NT) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v), reinterpret_cast<u64_t*>(p));
+  else *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ uint2 x3_load8(const void* p) {
+  typedef unsigned long long u64_t;
+  if (NEAT_X3_NT) return __builtin_bit_cast(uint2, __builtin_nontemporal_load(reinterpret_cast<const u64_t*>(p)));
+  return *reinterpret_cast<const uint2*>(p);
+}
+
 struct X3 {
   static constexpr int BP = X3_BATCH, THREADS = 512;
   static constexpr int XPL = 32 * BP * 16;              // one plane of an activation buffer [32 octets][BP][16 B]
@@ -285,8 +301,8 @@ __global__ __launch_bounds__(512, 2) void sdf_chain_x3_kernel(FusedArgs a, int n
       // (lin3, N = 217: the octet of rows 216..223 = [h216 | PE rows 0..6] is completed and stored by skip_fix below)
       if (save && !(N == 217 && q == 3 && wave == 6)) {
         const unsigned off = (unsigned)q * L.ldp16 + L.gquad + t * 512;
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + off) = vh;
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(lout) + off) = vl;
+        x3_store8(reinterpret_cast<char*>(hout) + off, vh);
+        x3_store8(reinterpret_cast<char*>(lout) + off, vl);
       }
     };
     auto none = [](int) {};
@@ -519,8 +535,8 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
       hqh[q] = make_uint2(off, off); hql[q] = make_uint2(off >> 8, off >> 9);
       return;
 #endif
-      hqh[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hs) + off);
-      hql[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(ls) + off);
+      hqh[q] = x3_load8(reinterpret_cast<const char*>(hs) + off);
+      hql[q] = x3_load8(reinterpret_cast<const char*>(ls) + off);
     };
     auto load_h = [&](const u16* hs, const u16* ls, int t) {
 #pragma unroll
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
           x3_split2(wq[q].z * d2, wq[q].w * d3, vh.y, vl.y);
           *reinterpret_cast<uint2*>(L.quad[0] + (q * BP + t * 32) * 16) = vh;
           *reinterpret_cast<uint2*>(L.quad[0] + LO + (q * BP + t * 32) * 16) = vl;
-          if (SAVE) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.u[7]) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+          if (SAVE) x3_store8(reinterpret_cast<char*>(a.u[7]) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512, vh);
         }
       }
     }
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_x3_kernel(AdjArgs a, int n
       *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
       *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
 #ifndef NEAT_X3_ADJ_NOSTORE   // probe (results are WRONG): what the adjoint chain costs without its u stores
-      if (SAVE && (MODE == 0 || wave < 7)) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(uout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+      if (SAVE && (MODE == 0 || wave < 7)) x3_store8(reinterpret_cast<char*>(uout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512, vh);
 #endif
     };
     auto none = [](int) {};
@@ -816,7 +832,13 @@ __global__ __launch_bounds__(512, 2) void head_chain_x3_kernel(HeadX3Args a, int
       const uint2 vh = make_uint2(ph[0], ph[1]), vl = make_uint2(pl[0], pl[1]);
       *reinterpret_cast<uint2*>(L.quad[DST] + (q * BP + t * 32) * 16) = vh;
       *reinterpret_cast<uint2*>(L.quad[DST] + LO + (q * BP + t * 32) * 16) = vl;
-      if (SAVE) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+#ifndef NEAT_X3_NT_HEADS
+#define NEAT_X3_NT_HEADS 0    // (the heads' hidden planes: measured +4 us per launch with non-temporal stores)
+#endif
+      if (SAVE) {
+        if (NEAT_X3_NT_HEADS) x3_store8(reinterpret_cast<char*>(hout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512, vh);
+        else *reinterpret_cast<uint2*>(reinterpret_cast<char*>(hout) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512) = vh;
+      }
     };
     auto none = [](int) {};
 #define HD_EPI(ACC_, T_, DST_, L_) [&](int e) { epi_elem(ACC_, e, T_, DST_, a.hid[L_], a.mask[L_]); }

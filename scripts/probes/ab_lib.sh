@@ -1,6 +1,8 @@
+# A/B of library builds through NEAT_HIP_LIB:  bash scripts/probes/ab_lib.sh [precision] -- the default build against every abl_libs/libneat_*.so
+P=${1:-bf16}
 for r in 1 2; do
-for lib in "" "$PWD/abl_libs/libneat_narrow.so"; do
-NEAT_HIP_LIB=$lib python bench.py --no-secondary --no-cpu-baseline --steps 40 2>/dev/null | grep '^{"metric"' | python -c "
+for lib in "" $PWD/abl_libs/libneat_*.so; do
+NEAT_HIP_LIB=$lib python bench.py --precision $P --no-secondary --no-cpu-baseline --steps 40 2>/dev/null | grep '^{"metric"' | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline']['all_kernels']
-print('lib', '$lib'[-14:] or 'wide(default)', 'ms', round(d['ms_per_step'],4), 'fused', round(k['sdf_fused_kernel']['avg_us'],1), 'adjoint', round(k['sdf_adjoint_kernel']['avg_us'],1))"
+print('%-14s' % ('$lib'.split('libneat_')[-1] or 'default'), 'ms', round(d['ms_per_step'],4), ' '.join('%s %.1f' % (n.split('_kernel')[0], v['avg_us']) for n, v in k.items()))"
 done; done
