@@ -71,21 +71,24 @@ __device__ __forceinline__ void dw_dma4(unsigned long long sbase, unsigned voff,
 // non-temporal, i.e. they bypass this CU's L1), so no workgroup waits for another and the launch boundaries between the layers (and the
 // ragged last round of each: 64 of 256 workgroups own a 17th tile at C2) disappear.  Between two layers: every wave drains its stores,
 // one workgroup barrier.
+// (Only the FULL variants carry the layer loop: the row-tested variants and lin8's are single launches anyway, and with the loop around them
+// their register allocation spilled 16-52 B more -- lin3's tangent launch 70 -> 96 us, lin4's reverse launch 63 -> 87 us.)
 template <int EPI, bool FULL>     // FULL: N = 256 output rows and 256 valid rows of the gradient's row operand (no row tests anywhere)
 __global__ __launch_bounds__(WST, 2) void layer_kernel_wsdw(LayerArgsDWSeg seg) {
+  constexpr bool SEG = FULL && EPI != EPI_BWD8;
   typedef WsCfg<EPI, 16> C;
   static_assert(C::NAUX == 2, "tangent / reverse epilogues only");
   constexpr bool TANK = (EPI == EPI_TAN || EPI == EPI_TAN_PF);      // gradient operand = aux1 (u_l); reverse: aux0 (h_l)
   // (the per-layer arguments are read from the kernel-argument segment through a pointer: indexing the by-value struct with a run-time
   // index would copy it to scratch)
   const LayerArgsDW* tab = (const LayerArgsDW*)__builtin_amdgcn_kernarg_segment_ptr();
-  const int nlayers = seg.n;
+  const int nlayers = SEG ? seg.n : 1;
   for (int li = 0; li < nlayers; ++li) {
-  if (li > 0) {                                   // layer li - 1's stores (all waves') before layer li's fetches; the ring is free again
+  if (SEG && li > 0) {                                   // layer li - 1's stores (all waves') before layer li's fetches; the ring is free again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  const LayerArgsDW d = tab[li];
+  const LayerArgsDW d = SEG ? tab[li] : seg.l[0];
   const LayerArgsWS& a = d.w;
   extern __shared__ __attribute__((aligned(16))) unsigned char wslds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;

@@ -75,6 +75,10 @@ struct F6Lane {
 // everything is unrolled).
 // ---------------------------------------------------------------------------------------------------------------
 struct F6EpiState { float m0, m1, w0, w1; unsigned lo; };       // what travels from half unit A to half unit B of a value pair
+#ifndef NEAT_ADJ_NT_FROWS
+#define NEAT_ADJ_NT_FROWS 0     // the adjoint chain's fp32 rows (PE cotangents e0 / es, read by sdf_finalize_kernel right behind it)
+#endif
+__device__ __forceinline__ void f6_storef(float* p, float v) { if (NEAT_ADJ_NT_FROWS) __builtin_nontemporal_store(v, p); else *p = v; }
 #ifndef NEAT_F6_NT_E
 #define NEAT_F6_NT_E 0         // the fp32 PE rows the primal chain saves
 #endif
@@ -139,8 +143,8 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
       const int n0 = 32 * (RT * wave + i) + 8 * q + 4 * hio + 2 * pr;
       const bool st_ok = FULL || t < nt;
       const unsigned col = L.fcol + t * 32, ld = L.ldp16 >> 4;
-      if (n0 >= E::SPLIT) { r0 = 0.0f; if (st_ok && n0 < E::N) L.frows[(unsigned)(n0 - E::SPLIT) * ld + col] = x0; }
-      if (n0 + 1 >= E::SPLIT) { r1 = 0.0f; if (st_ok && n0 + 1 < E::N) L.frows[(unsigned)(n0 + 1 - E::SPLIT) * ld + col] = x1; }
+      if (n0 >= E::SPLIT) { r0 = 0.0f; if (st_ok && n0 < E::N) f6_storef(L.frows + (unsigned)(n0 - E::SPLIT) * ld + col, x0); }
+      if (n0 + 1 >= E::SPLIT) { r1 = 0.0f; if (st_ok && n0 + 1 < E::N) f6_storef(L.frows + (unsigned)(n0 + 1 - E::SPLIT) * ld + col, x1); }
     }
     const unsigned pk = pack2(r0, r1);
     if (pr == 0) { st.lo = pk; return; }

@@ -265,7 +265,7 @@ template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (n < 1 || n > DW_MAXSEG) return hipErrorInvalidValue;
+  if (n < 1 || n > DW_MAXSEG || (n > 1 && !(FULL && EPI != EPI_BWD8))) return hipErrorInvalidValue;      // (only the FULL variants carry the layer loop)
   LayerArgsDWSeg seg{};
   seg.n = n;
   for (int i = 0; i < n; ++i) {
