@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
           else vprev = vh;
         } else if (!(NEAT_HC_ABLATE & 4)) hc_store8<NEAT_HC_NT_FWD != 0>(reinterpret_cast<char*>(phout) + (size_t)q * ldp16 + pg, vh);
 #ifndef NEAT_HC_NT_MASK
-#define NEAT_HC_NT_MASK 0     // mask words: non-temporal stores (forward chain) and loads (backward chain)
+#define NEAT_HC_NT_MASK 1     // mask words: non-temporal stores (forward chain) and loads (backward chain); round 5: -2..3 us per backward chain
 #endif
         if (q == 3 && !(NEAT_HC_ABLATE & 8)) {
           if (NEAT_HC_NT_MASK) __builtin_nontemporal_store(relu_mask_word(mbits), reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pmout) + pmoff));
