@@ -1520,10 +1520,13 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const unsigned w4[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
-          float t = 0.0f;
+          // one serial chain per row, fenced: the SLP vectoriser otherwise pairs the sums into v_pk_add_f32, and a packed fp32 op
+          // beside MFMAs costs far more than its issue slot (-6 us per hidden-layer launch, round 5)
+          float t = rsum[i];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t += bf_lo(w4[e]) + bf_hi(w4[e]);
-          rsum[i] += t;
+          for (int e = 0; e < 4; ++e) { t += bf_lo(w4[e]); t += bf_hi(w4[e]); }
+          asm volatile("" : "+v"(t));
+          rsum[i] = t;
         }
       }
 #pragma unroll

@@ -275,8 +275,8 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
     unsigned ph[2]; float keep = 0.0f; unsigned mbits = 0;
     uint2 vprev = make_uint2(0u, 0u);   // wide stores: the even quad waits for its odd neighbour
     unsigned pgw = 0;                   // ... and the lane's octet offset: lanes 32-63 one octet row further, no half-octet offset
-    // one call per accumulator element; the work is done per PAIR (odd e) on the packed ALU: bias (v_pk_add_f32), rounding
-    // (v_cvt_pk), ReLU and mask bit on the packed 16-bit pair
+    // one call per accumulator element; the work is done per PAIR (odd e): bias, rounding (v_cvt_pk), ReLU and mask bit on the
+    // packed 16-bit pair
     auto epi_elem = [&](const f32x16& ap, int e) {
       if (NEAT_HC_ABLATE & 64) {          // matrix side alone: the accumulators stay live through one add per element
         keep += ap[e];
@@ -288,7 +288,11 @@ __global__ __launch_bounds__(512, 2) void head_chain_kernel(HeadX3Args a, int np
       if ((j & 1) == 0) return;
       const v2f_t av = {ap[e - 1], ap[e]};
       const v2f_t bv = (j == 1) ? v2f_t{bqv.x, bqv.y} : v2f_t{bqv.z, bqv.w};
-      const v2f_t rv = pk_add_f32(av, bv);
+#ifndef NEAT_HC_PK_BIAS
+#define NEAT_HC_PK_BIAS 0     // 1: the bias add as one v_pk_add_f32 per pair (rounds 3-4).  A packed fp32 op beside MFMAs costs far more than its
+                              // issue slot (MI355X_MICROARCH.md): two v_add_f32 are 2-3.5 us per forward chain faster (round 5)
+#endif
+      const v2f_t rv = NEAT_HC_PK_BIAS ? pk_add_f32(av, bv) : v2f_t{av.x + bv.x, av.y + bv.y};
       const unsigned pr = pk_relu16(pack2(rv.x, rv.y));
       ph[j >> 1] = pr;
       if (SAVE && !(NEAT_HC_ABLATE & 8)) relu_mask_push(mbits, pr);
@@ -524,8 +528,7 @@ __global__ __launch_bounds__(512, 2) void head_bwd_chain_kernel(HeadBwdArgs a, i
       v2f_t rv = {ap[e - 1], ap[e]};
       if (HEAD == 1) {
         const unsigned wd = (j & 2) ? pf[q].y : pf[q].x;
-        const v2f_t old = {bf_lo(wd), bf_hi(wd)}, rr = {rho, rho};
-        rv = rv * rr + old;
+        rv = v2f_t{fmaf(rv.x, rho, bf_lo(wd)), fmaf(rv.y, rho, bf_hi(wd))};      // (two v_fma_f32, not one v_pk_fma_f32: see NEAT_HC_PK_BIAS)
       }
       ph[j >> 1] = pack2(rv.x, rv.y);
       if (j != 3) return;

@@ -11,16 +11,16 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I."
 C=$R/abl_libs
 [ -f $C/neat_api.o ] || /opt/rocm/bin/hipcc $F -c neat_api.hip -o $C/neat_api.o 2>/dev/null &
 [ -f $C/neat_api_f16.o ] || /opt/rocm/bin/hipcc $F -DNEAT_HALF=1 -c neat_api.hip -o $C/neat_api_f16.o 2>/dev/null &
-[ -f $C/neat_fused.o ] || /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -c neat_fused.hip -o $C/neat_fused.o 2>/dev/null &
-[ -f $C/neat_fused_f16.o ] || /opt/rocm/bin/hipcc $F -DNEAT_HALF=1 -mllvm -amdgpu-mfma-vgpr-form=1 -c neat_fused.hip -o $C/neat_fused_f16.o 2>/dev/null &
+[ -f $C/neat_fused.o ] || /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize -c neat_fused.hip -o $C/neat_fused.o 2>/dev/null &
+[ -f $C/neat_fused_f16.o ] || /opt/rocm/bin/hipcc $F -DNEAT_HALF=1 -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize -c neat_fused.hip -o $C/neat_fused_f16.o 2>/dev/null &
 wait
 api=$C/neat_api.o; fused=$C/neat_fused.o; fused16=$C/neat_fused_f16.o
 if [[ $name == x* ]]; then
   fused16=$C/neat_fused_f16_$name.o
-  /opt/rocm/bin/hipcc $F -DNEAT_HALF=1 -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c neat_fused.hip -o $fused16 2>/dev/null
+  /opt/rocm/bin/hipcc $F -DNEAT_HALF=1 -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize "$@" -c neat_fused.hip -o $fused16 2>/dev/null
 elif [[ $name == f* ]]; then
   fused=$C/neat_fused_$name.o
-  /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c neat_fused.hip -o $fused 2>/dev/null
+  /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize "$@" -c neat_fused.hip -o $fused 2>/dev/null
 else
   api=$C/neat_api_$name.o
   /opt/rocm/bin/hipcc $F "$@" -c neat_api.hip -o $api 2>/dev/null

@@ -1,7 +1,7 @@
 #!/bin/bash
 # spill / wait summary of the fused-chain kernels' ISA (neat_fused.hip):  bash scripts/probes/isa_fused.sh [extra -D flags]
 R=$(cd "$(dirname "$0")/../.." && pwd)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/neat_amd/csrc -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -S --cuda-device-only $R/neat_amd/csrc/neat_fused.hip -o /tmp/fused.s 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R/neat_amd/csrc -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize "$@" -S --cuda-device-only $R/neat_amd/csrc/neat_fused.hip -o /tmp/fused.s 2>/dev/null
 python - <<'PY'
 import re
 s = open('/tmp/fused.s').read()
