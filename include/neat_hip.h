@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 11 */
+int neat_abi_version(void);      /* 12 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -77,9 +77,11 @@ int neat_pack_weights(const neat_net_params* net, float* packed, int precision, 
 int neat_camera_rays(const float* uv, const float* pose, const float* K, int kstride, int R, float* dirs, float* origins /* [R,3] or NULL: the camera centre per ray */,
                      void* stream);
 /* a12: the eikonal points of a training step (neat_wfr_rend_a.py:515-527) as one array [2R + J, 3]:
- * [uniform [R,3] (drawn by the caller) | origins + z_eik dirs | extra [J,3] (the global junctions, J may be 0)]. */
+ * [uniform [R,3] (drawn by the caller) | origins + z_eik dirs | extra [J,3] (the global junctions, J may be 0)].
+ * z_eik [R] = the depth drawn per ray; NULL (ABI v12): picked here as z[r, idx[r]] from the ray's S depths z [R,S] with the drawn
+ * indices idx [R] (int64) -- the `torch.gather(z_vals, 1, idx)` of model/ray_sampler.py:276-277 without a launch of its own. */
 int neat_eik_points(const float* uniform, const float* origins, const float* dirs, const float* z_eik, const float* extra, int R, int J,
-                    float* out, void* stream);
+                    float* out, const float* z, int S, const long long* idx, void* stream);
 
 /* ---- a4+a5: SDF / implicit network (neat_wfr_rend_a.py:78-137) -----------------------------------
  * mode 0: values only  -> sdf[P] = get_sdf_vals(x)            (:131-137), nothing saved
@@ -107,13 +109,14 @@ int neat_heads_forward(const float* packed, const neat_net_params* net, const fl
                        float* rgb, float* lines, void* stream);
 
 /* ---- a5-a10 fused main pass: VolSDFNetwork.forward :392-422 (+ :530-536 normal_map in eval) -------
- * origins/dirs [R,3], z [R,S] sorted depths, beta = DEVICE pointer to one float holding
- * |density.beta| + beta_min (model/density.py:28-30) -- a pointer so that no host sync is needed.
+ * origins/dirs [R,3], z [R,S] sorted depths, beta = DEVICE pointer to one float (a pointer so that no host sync is needed); the
+ * density's beta is |*beta| + beta_min (model/density.py:28-30; ABI v12): pass the raw parameter density.beta and the module's
+ * beta_min, or -- as up to v11 -- the value of get_beta() and 0.
  * Outputs (row-major, NULL to skip where noted): points [R,S,3] (opt), weights [R,S] (opt),
  * sdf [R,S] (opt), rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], normal_map [R,3] (opt). */
 size_t neat_render_ws_floats(int R, int S, int E, int precision);
 int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                        const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                        const float* z, int R, int S, int precision, const float* beta, float beta_min, float radius, float scale, float* ws,
                         float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                         float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream);
 /* a12 folded in: `eik_points` [E,3] (may be NULL with E = 0) are E extra points appended to the R*S ray samples for
@@ -122,11 +125,13 @@ int neat_render_forward(const float* packed, const neat_net_params* net, const f
  *
  * Backward of neat_render_forward.  Cotangents d_rgb [R,3], d_lines3d [R,6], d_depth [R], d_xyz [R,3], d_eik_grad [E,3],
  * d_acc [R] = cotangent of the ray's opacity acc_map = sum_i w_i (the white_bkgd term of :411-413; ABI v11) (NULL = zero).  lines3d uses detached weights exactly as :410.  Writes all 19 layers' grads and the
- * per-ray partial derivative wrt beta, dbeta_ray [R] (sum it, times sign(density.beta)). */
+ * per-ray partial derivative wrt the density's beta, dbeta_ray [R].  dbeta (device pointer to one float, or NULL; ABI v12) receives
+ * the gradient of *beta itself: sgn(*beta) * sum_r dbeta_ray[r], summed in a fixed order by one more tiny launch (the `.sum()` and the
+ * backward of `.abs()` of density.py:29-30). */
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs,
-                         const float* z, int R, int S, int E, int precision, const float* beta,
+                         const float* z, int R, int S, int E, int precision, const float* beta, float beta_min,
                          const float* d_rgb, const float* d_lines3d, const float* d_depth, const float* d_xyz,
-                         const float* d_eik_grad, const float* d_acc, const neat_net_grads* grads, float* dbeta_ray, void* stream);
+                         const float* d_eik_grad, const float* d_acc, const neat_net_grads* grads, float* dbeta_ray, float* dbeta, void* stream);
 
 /* Forward-only variant for eval / inference callers (code/neat-final-parsing.py:203-218 drives `model(s)` in 2048-ray chunks under
  * model.eval(); training/volsdf_train.py:312-320 renders validation images the same way): same arguments and results as
@@ -134,7 +139,7 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
  * of the two heads ping-pong between two buffers): about a quarter of neat_render_ws_floats. */
 size_t neat_render_eval_ws_floats(int R, int S, int precision);
 int neat_render_forward_eval(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                             const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                             const float* z, int R, int S, int precision, const float* beta, float beta_min, float radius, float scale, float* ws,
                              float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                              float* xyz, float* normal_map, void* stream);
 
@@ -242,12 +247,17 @@ int neat_junction_gate(const long long* rows, const long long* cols, int K, cons
  * upstream gradient), pair_cost [K,J] = cdist_1(loc3, glo3) + 0.1 cdist_1(loc2c, glo2c);
  * neat_loss_pairs (ri, ci, n_match from neat_lsap over pair_cost) -> scal[2..5] = mean 3-D / calibrated 2-D / pixel 2-D pair
  * distance and the count of pairs with cost < 10, scal[6] = rgb + w_eik eik + w_line line_loss[0] + w_j3 j3d + w_j2 j2d;
- * d_glo3 [J,3], d_glo2c [J,2] = cotangents of the global junctions. */
+ * d_glo3 [J,3], d_glo2c [J,2] = cotangents of the global junctions.
+ * ABI v12: the cotangents can leave as gradients of the TOTAL loss scal[6], so that the backward pass has nothing left to multiply:
+ * d_gtheta carries eik_grad_scale (pass w_eik, or 1), d_glo3 / d_glo2c carry w_j3 / w_j2 when weighted_grads != 0; `total` (or NULL)
+ * receives scal[6] once more, in an allocation of its own (the differentiable output of the caller's autograd node). */
 int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E, const float* loc3, const float* loc2c, int K,
-                    const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost, void* stream);
+                    const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost,
+                    float eik_grad_scale, void* stream);
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
-                    float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, void* stream);
+                    float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, int weighted_grads,
+                    float* total, void* stream);
 /* global-junction MLP ffn(latents) (rend_a :303-313, :491): x [J,256] -> relu(W0 x + b0) -> relu(W1 . + b1) -> W2 . + b2 = y [J,3];
  * torch nn.Linear layouts (W [out,in]); h1, h2 [J,256] are saved for the backward; ws2 = 2 J 256 floats of scratch. */
 int neat_ffn_forward(const float* x, int J, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
@@ -257,6 +267,9 @@ int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, c
                       void* stream);
 /* inverse of one n x n matrix (n <= 4, row stride lda): pose.inverse() (rend_a :440), K.inverse() (loss_wfr.py:59) */
 int neat_inv_small(const float* A, int n, int lda, float* out, void* stream);
+/* what the junction block's projections read (rend_a :424-431, :440) in one launch (ABI v12): w2c [3,4] = the first three rows of
+ * pose^-1 (pose [4,4] cam-to-world, contiguous) and K3 [3,3] = the contiguous copy of the intrinsics' 3x3 block (row stride kstride) */
+int neat_camera_mats(const float* pose, const float* K, int kstride, float* w2c, float* K3, void* stream);
 int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream);
 int neat_project2d_backward(const float* K, const float* w2c, const float* X, int N, const float* d_uv, float* d_X, void* stream);
 int neat_line_loss(const float* pred, const float* gt, const float* weight, int R, float threshold, float* out2, float* per_line,
@@ -264,9 +277,10 @@ int neat_line_loss(const float* pred, const float* gt, const float* weight, int 
 /* Both line terms of VolSDFLoss.forward (loss_wfr.py:52-65) in one launch: pred_px / pred_calib [R,4] = the projected 3-D lines in
  * pixel and in calibrated coordinates, gt5 [R,5] = (x1, y1, x2, y2, weight), K [3,3].  out3 = (l2d pixel term, calibrated line
  * loss, #segments the pixel term accepts); the ground-truth end points are calibrated with K^-1 inside; d_pred_calib [R,4] =
- * d out3[1] / d pred_calib.  Same arithmetic as neat_line_loss + neat_inv_small + neat_project2d on the same inputs. */
+ * grad_scale * d out3[1] / d pred_calib (grad_scale, ABI v12: the line term's weight in the total loss, or 1).  Same arithmetic as
+ * neat_line_loss + neat_inv_small + neat_project2d on the same inputs. */
 int neat_line_losses(const float* pred_px, const float* pred_calib, const float* gt5, const float* K, int R, float threshold, float* out3,
-                     float* d_pred_calib, void* stream);
+                     float* d_pred_calib, float grad_scale, void* stream);
 
 /* ---- a16: Adam step over one flat fp32 parameter buffer = torch.optim.Adam(lr) as the reference trainer builds it
  * (training/volsdf_train.py:177; no weight decay, no amsgrad).  The parameters and both moments are flat [n]; the

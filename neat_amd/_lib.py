@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 11
+ABI_VERSION = 12
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "fp16x3": 4}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/probes/abl_build.sh)
@@ -26,7 +26,7 @@ _SIGNATURES = {
     "neat_abi_version": (ctypes.c_int, []),
     "neat_packed_floats": (ctypes.c_size_t, [ctypes.c_int]),
     "neat_pack_weights": (ctypes.c_int, [ctypes.POINTER(NetParams), c_fp, ctypes.c_int, c_fp]),
-    "neat_eik_points": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "neat_eik_points": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_camera_rays": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_sdf_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "neat_sdf_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -38,14 +38,15 @@ _SIGNATURES = {
                                           c_fp, c_fp, c_fp]),
     "neat_render_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "neat_render_forward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                           c_fp, ctypes.c_float, ctypes.c_float, c_fp,
+                                           c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp,
                                            c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_render_eval_ws_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "neat_render_forward_eval": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                c_fp, ctypes.c_float, ctypes.c_float, c_fp,
+                                                c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp,
                                                 c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_render_backward": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                            ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp]),
+                                            ctypes.c_int, c_fp, ctypes.c_float, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(NetGrads), c_fp, c_fp,
+                                            c_fp]),
     "neat_sampler_bound": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp,
                                           ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_sampler_resample": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_float,
@@ -75,14 +76,15 @@ _SIGNATURES = {
     "neat_junction_gate": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp,
                                           c_fp, c_fp, c_fp]),
     "neat_loss_terms": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
-                                       c_fp, c_fp, c_fp, c_fp, c_fp]),
+                                       c_fp, c_fp, c_fp, c_fp, ctypes.c_float, c_fp]),
     "neat_loss_pairs": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp,
-                                       c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp]),
+                                       c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_fp, c_fp]),
+    "neat_camera_mats": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_inv_small": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d_backward": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_line_loss": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, c_fp, c_fp]),
-    "neat_line_losses": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, c_fp]),
+    "neat_line_losses": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, ctypes.c_float, c_fp]),
     "neat_adam_step": (ctypes.c_int, [c_fp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int),
                                       ctypes.c_int, c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp]),
     "neat_lsap_ws_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

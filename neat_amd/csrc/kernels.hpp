@@ -936,6 +936,7 @@ struct CompositeArgs {
   const float* x_fm; const float* rgb_fm; const float* lin_fm; const float* g_fm;   // [3|3|6|3][ldp]
   int R, S, ldp; const float* beta_ptr;
   float* weights; float* rgb; float* lines3d; float* depth; float* xyz; float* normal_map;   // outputs (row-major)
+  float beta_min = 0.0f;      // the density's beta = |*beta_ptr| + beta_min (LaplaceDensity.get_beta, density.py:29-30)
 };
 
 __global__ __launch_bounds__(WG) void composite_fwd_kernel(CompositeArgs a) {
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(WG) void composite_fwd_kernel(CompositeArgs a) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.R) return;
   const float dn = sqrtf(a.dirs[r * 3] * a.dirs[r * 3] + a.dirs[r * 3 + 1] * a.dirs[r * 3 + 1] + a.dirs[r * 3 + 2] * a.dirs[r * 3 + 2]);
-  const float beta = *a.beta_ptr;
+  const float beta = fabsf(*a.beta_ptr) + a.beta_min;
   float carry = 0.0f;
   float acc[16];
 #pragma unroll
@@ -1010,6 +1011,7 @@ struct CompositeBwdArgs {
   const float* cot_slot_a = nullptr; // f16 build: the attraction head's backward chain runs in its own power-of-two scale (its cotangents,
                                      // line-loss weight 0.01 and detached weights, are orders of magnitude below the colour ones: in the
                                      // common scale they sit in f16's subnormal range); null = the common one
+  float beta_min = 0.0f;             // beta = |*beta_ptr| + beta_min, as in CompositeArgs
   int tail_from = 0;                 // > 0: the workgroups behind the rays' zero the columns [tail_from, ldp) of zrgb / dlin / dsdf_row and of the
                                      // octet copies (eikonal points, padding: no head cotangents) -- what zero_tail3_kernel did in a launch of its own
 };
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.R) return;
   const float dn = sqrtf(a.dirs[r * 3] * a.dirs[r * 3] + a.dirs[r * 3 + 1] * a.dirs[r * 3 + 1] + a.dirs[r * 3 + 2] * a.dirs[r * 3 + 2]);
-  const float beta = *a.beta_ptr;
+  const float beta = fabsf(*a.beta_ptr) + a.beta_min;
   float drgb[3] = {0.f, 0.f, 0.f}, dxyz[3] = {0.f, 0.f, 0.f}, dl[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float cs = cot_scale_of(a.cot_slot);
 #pragma unroll
@@ -1146,16 +1148,38 @@ __global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __
 // eikonal points of a training step (rend_a :515-527): [uniform draws in the bounding cube | one point per ray at its drawn depth
 // o + z d | optional extra points (the global junctions)] as one [2R + J, 3] array, one launch instead of addcmul + cat (+ cat)
 __global__ void eik_points_kernel(const float* __restrict__ uniform, const float* __restrict__ o, const float* __restrict__ d,
-                                  const float* __restrict__ z_eik, const float* __restrict__ extra, int R, int J, float* __restrict__ out) {
+                                  const float* __restrict__ z_eik, const float* __restrict__ extra, int R, int J, float* __restrict__ out,
+                                  const float* __restrict__ z, int S, const long long* __restrict__ idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = (2 * R + J) * 3;
   if (i >= n) return;
   const int p = i / 3, c = i - 3 * p;
   float v;
   if (p < R) v = uniform[i];
-  else if (p < 2 * R) { const int r = p - R; v = fmaf(z_eik[r], d[3 * r + c], o[3 * r + c]); }
+  else if (p < 2 * R) {
+    const int r = p - R;
+    const float ze = z_eik ? z_eik[r] : z[(size_t)r * S + idx[r]];     // the drawn depth, or the draw's index into the ray's depths
+    v = fmaf(ze, d[3 * r + c], o[3 * r + c]);
+  }
   else v = extra[i - 6 * R];
   out[i] = v;
+}
+
+// d loss / d beta_param = sgn(beta_param) * sum over the rays of composite_bwd_kernel's per-ray partials (fixed order: one workgroup,
+// strided per-thread sums, wave shuffles, waves in order) -- the `.sum()` and the backward of `.abs()` of density.py:29-30 in one launch
+__global__ __launch_bounds__(256) void beta_grad_kernel(const float* __restrict__ dbeta_ray, int R, const float* __restrict__ beta_ptr,
+                                                        float* __restrict__ out) {
+  __shared__ float s_w[4];
+  float acc = 0.0f;
+  for (int r = threadIdx.x; r < R; r += 256) acc += dbeta_ray[r];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b = *beta_ptr;
+    const float t = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+    out[0] = b > 0.0f ? t : (b < 0.0f ? -t : 0.0f);
+  }
 }
 
 }  // namespace neat

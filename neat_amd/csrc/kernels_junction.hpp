@@ -445,12 +445,13 @@ __device__ __forceinline__ void inv_small_body(const float* sA, float* __restric
 // Both line losses of VolSDFLoss.forward in one launch (loss_wfr.py:52-65): the gated pixel-space term on the (detached) 2-D lines,
 // the count of segments it accepts, the K^-1 calibration of the ground-truth end points (:59-63) and the differentiable calibrated
 // term whose weights are masked by the first term's gate.  gt5 [R,5] = (x1, y1, x2, y2, weight) as the dataset delivers it.
-//   out[0] = l2d (pixel term), out[1] = line loss (calibrated term), out[2] = #{per_line_px < thr};  d_pred_c [R,4] = d out[1] / d pred_c.
+//   out[0] = l2d (pixel term), out[1] = line loss (calibrated term), out[2] = #{per_line_px < thr};  d_pred_c [R,4] = grad_scale * d out[1] / d pred_c
+// (grad_scale = the line term's weight in the total loss: the backward pass then has nothing left to multiply).
 // Same arithmetic and summation order as line_loss_kernel / inv_small_kernel / project2d_kernel, which it replaces on this path
 // (eleven launches: two slices, compare, ones, cat, inverse, projection, mask product, two line losses, sum).
 __global__ __launch_bounds__(1024) void line_losses_kernel(const float* __restrict__ pred_u, const float* __restrict__ pred_c,
                                                            const float* __restrict__ gt5, const float* __restrict__ K, int R, float thr,
-                                                           float* __restrict__ out, float* __restrict__ d_pred_c) {
+                                                           float* __restrict__ out, float* __restrict__ d_pred_c, float grad_scale) {
   __shared__ float s_acc[4][16];
   __shared__ float s_kinv[9], s_k[9];
   __shared__ float s_inv;
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(1024) void line_losses_kernel(const float* __restri
     terms(r, lu, lc, w, sg);
     const float coef = (lc < thr) ? (w * (lu < thr ? 1.0f : 0.0f)) * inv * 0.25f : 0.0f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) d_pred_c[4 * r + c] = coef * sg[c];
+    for (int c = 0; c < 4; ++c) d_pred_c[4 * r + c] = (coef * sg[c]) * grad_scale;
   }
 }
 
@@ -535,6 +536,19 @@ __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, fl
   else if (n == 3) inv_small_body<3>(sA, out);
   else if (n == 2) inv_small_body<2>(sA, out);
   else out[0] = 1.0f / sA[0];
+}
+
+// world-to-camera [R | T] = the first three rows of pose^-1, and the contiguous 3x3 block of the intrinsics: what the junction block's
+// projections read (rend_a :424-431).  One launch instead of the inverse plus a strided copy.
+__global__ void camera_mats_kernel(const float* __restrict__ pose, const float* __restrict__ K, int kstride, float* __restrict__ w2c,
+                                   float* __restrict__ K3) {
+  __shared__ float sA[16], sInv[16];
+  if (threadIdx.x < 16) sA[threadIdx.x] = pose[threadIdx.x];
+  if (threadIdx.x < 9) K3[threadIdx.x] = K[(threadIdx.x / 3) * kstride + threadIdx.x % 3];
+  __syncthreads();
+  if (threadIdx.x == 0) inv_small_body<4>(sA, sInv);
+  __syncthreads();
+  if (threadIdx.x < 12) w2c[threadIdx.x] = sInv[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -918,6 +932,7 @@ struct LossTermsArgs {
   const float* glo3; const float* glo2c; int J;
   float* scal;                 // [0] rgb loss, [1] eikonal loss
   float* d_rgb; float* d_gtheta; float* pair_cost;
+  float eik_grad_scale;        // d_gtheta = eik_grad_scale * d scal[1] / d gtheta (the eikonal weight: gradients of the TOTAL loss, or 1)
 };
 
 __global__ __launch_bounds__(1024) void loss_terms_kernel(LossTermsArgs a) {
@@ -937,7 +952,7 @@ __global__ __launch_bounds__(1024) void loss_terms_kernel(LossTermsArgs a) {
     const float gx = a.gtheta[3 * i], gy = a.gtheta[3 * i + 1], gz = a.gtheta[3 * i + 2];
     const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
     acc += (nrm - 1.0f) * (nrm - 1.0f);
-    const float c = nrm > 0.0f ? 2.0f * (nrm - 1.0f) * inv_e / nrm : 0.0f;        // d/dg |g| = g/|g| (0 at the origin, as torch)
+    const float c = nrm > 0.0f ? (2.0f * (nrm - 1.0f) * inv_e / nrm) * a.eik_grad_scale : 0.0f;        // d/dg |g| = g/|g| (0 at the origin, as torch)
     a.d_gtheta[3 * i] = c * gx; a.d_gtheta[3 * i + 1] = c * gy; a.d_gtheta[3 * i + 2] = c * gz;
   }
   const float eik = block_sum(acc, s_red) * inv_e;
@@ -961,6 +976,8 @@ struct LossPairsArgs {
   float* scal;                 // [2] j3d, [3] j2d (calibrated), [4] j2d (pixels), [5] count of pairs with cost < 10
   float* d_glo3; float* d_glo2c;                                               // [J,3], [J,2], fully written
   const float* line_loss; float w_eik, w_line, w_j3, w_j2;                     // scal[6] = rgb + w_eik eik + w_line line + w_j3 j3d + w_j2 j2d
+  int weighted_grads;                                                           // 1: d_glo3 / d_glo2c carry w_j3 / w_j2 (gradients of scal[6])
+  float* total;                                                                 // scal[6] once more, in a tensor of its own (or null)
 };
 
 __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
@@ -971,6 +988,7 @@ __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
   __syncthreads();
   const int n = max(*a.n_match, 0);
   const float inv = 1.0f / (float)max(n, 1);
+  const float g3 = a.weighted_grads ? a.w_j3 : 1.0f, g2 = a.weighted_grads ? a.w_j2 : 1.0f;
   float s3 = 0.0f, s2 = 0.0f, spx = 0.0f, cnt = 0.0f;
   for (int q = tid; q < a.Kmax; q += nt) {
     const long long r = a.ri[q], c = a.ci[q];
@@ -979,13 +997,13 @@ __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
     for (int e = 0; e < 3; ++e) {
       const float d = a.loc3[3 * r + e] - a.glo3[3 * c + e];
       s3 += fabsf(d);
-      a.d_glo3[3 * c + e] = -(d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv;     // each global junction is matched at most once
+      a.d_glo3[3 * c + e] = (-(d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv) * g3;     // each global junction is matched at most once
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float d = a.loc2c[2 * r + e] - a.glo2c[2 * c + e];
       s2 += fabsf(d);
-      a.d_glo2c[2 * c + e] = -(d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv;
+      a.d_glo2c[2 * c + e] = (-(d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv) * g2;
       spx += fabsf(a.loc2[2 * r + e] - a.glo2[2 * c + e]);
     }
     if (a.pair_cost[r * a.J + c] < 10.0f) cnt += 1.0f;
@@ -993,7 +1011,9 @@ __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
   s3 = block_sum(s3, s_red); s2 = block_sum(s2, s_red); spx = block_sum(spx, s_red); cnt = block_sum(cnt, s_red);
   if (tid == 0) {
     a.scal[2] = s3 * inv; a.scal[3] = s2 * inv; a.scal[4] = spx * inv; a.scal[5] = cnt;
-    a.scal[6] = a.scal[0] + a.w_eik * a.scal[1] + a.w_line * a.line_loss[0] + a.w_j3 * (s3 * inv) + a.w_j2 * (s2 * inv);
+    const float tot = a.scal[0] + a.w_eik * a.scal[1] + a.w_line * a.line_loss[0] + a.w_j3 * (s3 * inv) + a.w_j2 * (s2 * inv);
+    a.scal[6] = tot;
+    if (a.total) a.total[0] = tot;
   }
 }
 

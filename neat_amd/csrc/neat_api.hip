@@ -1646,7 +1646,7 @@ NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated)
 
 extern "C" {
 
-int neat_abi_version(void) { return 11; }
+int neat_abi_version(void) { return 12; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
 #if !NEAT_HALF
@@ -1759,10 +1759,12 @@ int neat_camera_rays(const float* uv, const float* pose, const float* K, int kst
 }
 
 int neat_eik_points(const float* uniform, const float* origins, const float* dirs, const float* z_eik, const float* extra, int R, int J,
-                    float* out, void* stream) {
+                    float* out, const float* z, int S, const long long* idx, void* stream) {
   if (R <= 0 || J < 0) return R == 0 && J == 0 ? 0 : -1;
-  if (!uniform || !origins || !dirs || !z_eik || !out || (J > 0 && !extra)) return -1;
-  hipLaunchKernelGGL(eik_points_kernel, grid1((2 * R + J) * 3), dim3(256), 0, (hipStream_t)stream, uniform, origins, dirs, z_eik, extra, R, J, out);
+  if (!uniform || !origins || !dirs || !out || (J > 0 && !extra)) return -1;
+  if (!z_eik && (!z || !idx || S <= 0)) return -1;           // the depth per ray: given, or picked from the ray's S depths by idx
+  hipLaunchKernelGGL(eik_points_kernel, grid1((2 * R + J) * 3), dim3(256), 0, (hipStream_t)stream, uniform, origins, dirs, z_eik, extra, R, J, out,
+                     z, S, idx);
   return (int)hipGetLastError();
 }
 
@@ -1888,7 +1890,7 @@ size_t neat_render_ws_floats(int R, int S, int E, int precision) {
 }
 
 static int render_forward_impl(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                               const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                               const float* z, int R, int S, int precision, const float* beta, float beta_min, float radius, float scale, float* ws,
                                float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                                float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream, bool fwd_only) {
   const int x3 = take_x3(precision); (void)x3;
@@ -1913,18 +1915,18 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
   NEAT_CHECK(heads_forward(c, h, w.feat, w.featlo, !fwd_only, Pm));
   CompositeArgs ca;
   ca.z = z; ca.sdf = w.sdf; ca.dirs = dirs; ca.x_fm = w.x; ca.rgb_fm = h.rgb; ca.lin_fm = h.lin; ca.g_fm = w.g;
-  ca.R = R; ca.S = S; ca.ldp = c.ldp; ca.beta_ptr = beta;
+  ca.R = R; ca.S = S; ca.ldp = c.ldp; ca.beta_ptr = beta; ca.beta_min = beta_min;
   ca.weights = weights; ca.rgb = rgb; ca.lines3d = lines3d; ca.depth = depth; ca.xyz = xyz; ca.normal_map = normal_map;
   hipLaunchKernelGGL(composite_fwd_kernel, dim3((R + 3) / 4), dim3(WG), 0, c.st, ca);
   return (int)hipGetLastError();
 }
 
 int neat_render_forward(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                        const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                        const float* z, int R, int S, int precision, const float* beta, float beta_min, float radius, float scale, float* ws,
                         float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                         float* xyz, float* normal_map, const float* eik_points, int E, float* eik_grad, void* stream) {
-  NEAT_F16_FWD(neat_render_forward(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d, depth, xyz, normal_map, eik_points, E, eik_grad, stream))
-  return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d,
+  NEAT_F16_FWD(neat_render_forward(packed, net, origins, dirs, z, R, S, precision, beta, beta_min, radius, scale, ws, points, weights, sdf, rgb, lines3d, depth, xyz, normal_map, eik_points, E, eik_grad, stream))
+  return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, beta_min, radius, scale, ws, points, weights, sdf, rgb, lines3d,
                              depth, xyz, normal_map, eik_points, E, eik_grad, stream, false);
 }
 
@@ -1939,24 +1941,24 @@ size_t neat_render_eval_ws_floats(int R, int S, int precision) {
 }
 
 int neat_render_forward_eval(const float* packed, const neat_net_params* net, const float* origins, const float* dirs,
-                             const float* z, int R, int S, int precision, const float* beta, float radius, float scale, float* ws,
+                             const float* z, int R, int S, int precision, const float* beta, float beta_min, float radius, float scale, float* ws,
                              float* points, float* weights, float* sdf, float* rgb, float* lines3d, float* depth,
                              float* xyz, float* normal_map, void* stream) {
-  NEAT_F16_FWD(neat_render_forward_eval(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d, depth, xyz, normal_map, stream))
-  return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, radius, scale, ws, points, weights, sdf, rgb, lines3d,
+  NEAT_F16_FWD(neat_render_forward_eval(packed, net, origins, dirs, z, R, S, precision, beta, beta_min, radius, scale, ws, points, weights, sdf, rgb, lines3d, depth, xyz, normal_map, stream))
+  return render_forward_impl(packed, net, origins, dirs, z, R, S, precision, beta, beta_min, radius, scale, ws, points, weights, sdf, rgb, lines3d,
                              depth, xyz, normal_map, nullptr, 0, nullptr, stream, true);
 }
 
 int neat_render_backward(const float* packed, const neat_net_params* net, float* ws, const float* dirs, const float* z,
-                         int R, int S, int E, int precision, const float* beta, const float* d_rgb, const float* d_lines3d,
+                         int R, int S, int E, int precision, const float* beta, float beta_min, const float* d_rgb, const float* d_lines3d,
                          const float* d_depth, const float* d_xyz, const float* d_eik_grad, const float* d_acc,
-                         const neat_net_grads* grads, float* dbeta_ray, void* stream) {
-  NEAT_F16_FWD(neat_render_backward(packed, net, ws, dirs, z, R, S, E, precision, beta, d_rgb, d_lines3d, d_depth, d_xyz, d_eik_grad, d_acc, grads, dbeta_ray, stream))
+                         const neat_net_grads* grads, float* dbeta_ray, float* dbeta, void* stream) {
+  NEAT_F16_FWD(neat_render_backward(packed, net, ws, dirs, z, R, S, E, precision, beta, beta_min, d_rgb, d_lines3d, d_depth, d_xyz, d_eik_grad, d_acc, grads, dbeta_ray, dbeta, stream))
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
   if (hx3 == 2) return -1;
   if (R <= 0 || S <= 0) return 0;
-  if (!packed || !net || !ws || !grads || bad_prec(precision) || E < 0) return -1;
+  if (!packed || !net || !ws || !grads || bad_prec(precision) || E < 0 || (dbeta && (!dbeta_ray || !beta))) return -1;
   const int Pm = R * S, P = Pm + E;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   c.x3 = x3; c.hx3 = hx3;
@@ -1964,7 +1966,7 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   HeadWs h = head_ws(ws + w.total, c.ldp, precision);
   CompositeBwdArgs cb;
   cb.z = z; cb.sdf = w.sdf; cb.dirs = dirs; cb.mask = w.mask; cb.x_fm = w.x; cb.rgb_fm = h.rgb;
-  cb.R = R; cb.S = S; cb.ldp = c.ldp; cb.beta_ptr = beta;
+  cb.R = R; cb.S = S; cb.ldp = c.ldp; cb.beta_ptr = beta; cb.beta_min = beta_min;
   cb.d_rgb = d_rgb; cb.d_lines3d = d_lines3d; cb.d_depth = d_depth; cb.d_xyz = d_xyz; cb.d_acc = d_acc;
   cb.zrgb_fm = h.zrgb; cb.dlin_fm = h.dlin; cb.dsdf_row = w.abar8; cb.dbeta_ray = dbeta_ray;
   cb.zrgb_oct = reinterpret_cast<u16*>(h.topbf_r.p); cb.dlin_oct = reinterpret_cast<u16*>(h.topbf_a.p);      // (null in the fp32 build)
@@ -1979,6 +1981,7 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents: zeroed by extra workgroups of the same launch
   cb.tail_from = c.ldp > Pm ? Pm : 0;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4 + (c.ldp > Pm ? (c.ldp - Pm + WG - 1) / WG : 0)), dim3(WG), 0, c.st, cb);
+  if (dbeta) hipLaunchKernelGGL(beta_grad_kernel, dim3(1), dim3(256), 0, c.st, dbeta_ray, R, beta, dbeta);
   NEAT_CHECK(heads_backward(c, h, w, grads, slot, slot_a, Pm));
   const NormalCot nc{h.sc_r, h.sc_a, nullptr, Pm, d_eik_grad, slot, slot_a};
   NEAT_CHECK(sdf_backward_chains(c, w, grads, &nc));
@@ -2172,21 +2175,23 @@ int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, c
 }
 
 int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E, const float* loc3, const float* loc2c, int K,
-                    const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost, void* stream) {
+                    const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost,
+                    float eik_grad_scale, void* stream) {
   if (R <= 0 || !rgb || !rgb_gt || !scal || !d_rgb || E < 0 || K < 0 || J < 0) return -1;
   if ((E > 0 && (!gtheta || !d_gtheta)) || (K > 0 && J > 0 && (!loc3 || !loc2c || !glo3 || !glo2c || !pair_cost))) return -1;
-  LossTermsArgs a{rgb, rgb_gt, R, gtheta, E, loc3, loc2c, (J > 0 ? K : 0), glo3, glo2c, J, scal, d_rgb, d_gtheta, pair_cost};
+  LossTermsArgs a{rgb, rgb_gt, R, gtheta, E, loc3, loc2c, (J > 0 ? K : 0), glo3, glo2c, J, scal, d_rgb, d_gtheta, pair_cost, eik_grad_scale};
   hipLaunchKernelGGL(loss_terms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
-                    float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, void* stream) {
+                    float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, int weighted_grads,
+                    float* total, void* stream) {
   if (Kmax < 0 || J <= 0 || !ri || !ci || !n_match || !loc3 || !loc2c || !loc2 || !glo3 || !glo2c || !glo2 || !pair_cost || !scal ||
       !d_glo3 || !d_glo2c || !line_loss) return -1;
   LossPairsArgs a{ri, ci, n_match, Kmax, loc3, loc2c, loc2, glo3, glo2c, glo2, J, pair_cost, scal, d_glo3, d_glo2c, line_loss, w_eik, w_line,
-                  w_j3, w_j2};
+                  w_j3, w_j2, weighted_grads, total};
   hipLaunchKernelGGL(loss_pairs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -2222,6 +2227,12 @@ int neat_inv_small(const float* A, int n, int lda, float* out, void* stream) {
   return (int)hipGetLastError();
 }
 
+int neat_camera_mats(const float* pose, const float* K, int kstride, float* w2c, float* K3, void* stream) {
+  if (!pose || !K || !w2c || !K3 || kstride < 3) return -1;
+  hipLaunchKernelGGL(camera_mats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pose, K, kstride, w2c, K3);
+  return (int)hipGetLastError();
+}
+
 int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream) {
   if (N <= 0) return 0;
   if (!K || !w2c || !X || !uv) return -1;
@@ -2244,9 +2255,9 @@ int neat_line_loss(const float* pred, const float* gt, const float* weight, int 
 }
 
 int neat_line_losses(const float* pred_px, const float* pred_calib, const float* gt5, const float* K, int R, float threshold, float* out3,
-                     float* d_pred_calib, void* stream) {
+                     float* d_pred_calib, float grad_scale, void* stream) {
   if (R <= 0 || !pred_px || !pred_calib || !gt5 || !K || !out3 || !d_pred_calib) return -1;
-  hipLaunchKernelGGL(line_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred_px, pred_calib, gt5, K, R, threshold, out3, d_pred_calib);
+  hipLaunchKernelGGL(line_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred_px, pred_calib, gt5, K, R, threshold, out3, d_pred_calib, grad_scale);
   return (int)hipGetLastError();
 }
 

@@ -46,7 +46,7 @@ class VolSDFLoss(nn.Module):
         self.steps = 0
         self.nan_check = "deferred"      # "off": no host-visible flag at all (HIP-graph capture); the trainer polls `nan_flag`
         self.nan_flag = None
-        self.fused_tail = True           # CUDA + L1 rgb loss: the tail of forward() runs as two HIP launches (neat_loss_terms / neat_loss_pairs)
+        self.fused_tail = True           # CUDA + L1 rgb loss: forward() after the projections runs as three HIP launches + the matching (ops.loss_tail)
 
     def _defer_nan_check(self, line_loss):
         """The reference drops into pdb on a NaN line loss (loss_wfr.py:66-67).  Reading the flag here would drain the
@@ -85,7 +85,36 @@ class VolSDFLoss(nn.Module):
         self.steps += 1
         dev = model_outputs["rgb_values"].device
         gt5 = ground_truth["lines2d"][0].to(dev)
-        if dev.type == "cuda" and "labels" not in ground_truth and gt5.shape[-1] == 5:
+        padded = getattr(model_outputs, "padded", None)
+        if padded is not None:           # neat_amd model: matched junctions padded + mask, no data-dependent shape
+            loc3, loc2c, loc2, good = padded["j3d_local"], padded["j2d_local_calib"], padded["j2d_local"], model_outputs.good
+        else:                            # plain dict (e.g. the reference model's outputs): already compact
+            loc3, loc2c, loc2, good = (model_outputs["j3d_local"], model_outputs["j2d_local_calib"],
+                                       model_outputs["j2d_local"], None)
+        have_junctions = loc3.shape[0] > 0
+        fused_lines = dev.type == "cuda" and "labels" not in ground_truth and gt5.shape[-1] == 5
+        if (fused_lines and self.fused_tail and type(self.rgb_loss) is nn.L1Loss and self.rgb_loss.reduction == "mean"):
+            # everything after the projections -- both line terms with the K^-1 calibration of the ground truth between them, rgb,
+            # eikonal, the junction pair terms around the device matching, the weighted total -- in three launches + neat_lsap, one
+            # autograd node whose backward launches nothing (ops.LossTailFn)
+            from . import ops
+            gtheta = model_outputs["grad_theta"] if "grad_theta" in model_outputs else None
+            glo = (model_outputs["j3d_global"], model_outputs["j2d_global_calib"], model_outputs["j2d_global"].detach()) if have_junctions \
+                else (None, None, None)
+            loss, scal, line3 = ops.loss_tail(model_outputs["rgb_values"], gtheta, glo[0], glo[1], model_outputs["lines2d_calib"],
+                                              model_outputs["lines2d"].detach(), gt5, model_outputs["K"], ground_truth["rgb"].to(dev),
+                                              loc3 if have_junctions else None, loc2c if have_junctions else None,
+                                              loc2 if have_junctions else None, glo[2], good, self.eikonal_weight, self.line_weight,
+                                              self.junction_3d_weight, self.junction_2d_weight, 100.0)
+            line_loss = line3[1]
+            self._check_deferred()
+            self._defer_nan_check(line_loss)
+            out = {"rgb_loss": scal[0], "eikonal_loss": scal[1], "line_loss": line_loss, "l2d_loss": line3[0], "count": line3[2],
+                   "j3d_loss": scal[2], "j2d_loss": scal[3], "j2d_stat": scal[4], "jcount": scal[5], "loss": loss}
+            if "median" in model_outputs:
+                out["median"] = model_outputs["median"]
+            return out
+        if fused_lines:
             # both line terms, the K^-1 calibration of the ground truth between them and the count: one launch
             from . import ops
             l2d_uncalib, line_loss, count = ops.line_losses(model_outputs["lines2d"].reshape(-1, 4), model_outputs["lines2d_calib"].reshape(-1, 4),
@@ -112,28 +141,6 @@ class VolSDFLoss(nn.Module):
             count = close.sum()
         self._check_deferred()
         self._defer_nan_check(line_loss)
-        padded = getattr(model_outputs, "padded", None)
-        if padded is not None:           # neat_amd model: matched junctions padded + mask, no data-dependent shape
-            loc3, loc2c, loc2, good = padded["j3d_local"], padded["j2d_local_calib"], padded["j2d_local"], model_outputs.good
-        else:                            # plain dict (e.g. the reference model's outputs): already compact
-            loc3, loc2c, loc2, good = (model_outputs["j3d_local"], model_outputs["j2d_local_calib"],
-                                       model_outputs["j2d_local"], None)
-        have_junctions = loc3.shape[0] > 0
-        if self.fused_tail and dev.type == "cuda" and type(self.rgb_loss) is nn.L1Loss and self.rgb_loss.reduction == "mean":
-            # rgb + eikonal + junction pair terms + weighted total: two launches around the device matching (neat_loss_*)
-            from . import ops
-            gtheta = model_outputs["grad_theta"] if "grad_theta" in model_outputs else None
-            glo = (model_outputs["j3d_global"], model_outputs["j2d_global_calib"], model_outputs["j2d_global"]) if have_junctions \
-                else (None, None, None)
-            loss, scal = ops.loss_tail(model_outputs["rgb_values"], gtheta, glo[0], glo[1], line_loss, ground_truth["rgb"].to(dev),
-                                       loc3 if have_junctions else None, loc2c if have_junctions else None,
-                                       loc2 if have_junctions else None, glo[2], good, self.eikonal_weight, self.line_weight,
-                                       self.junction_3d_weight, self.junction_2d_weight)
-            out = {"rgb_loss": scal[0], "eikonal_loss": scal[1], "line_loss": line_loss, "l2d_loss": l2d_uncalib, "count": count,
-                   "j3d_loss": scal[2], "j2d_loss": scal[3], "j2d_stat": scal[4], "jcount": scal[5], "loss": loss}
-            if "median" in model_outputs:
-                out["median"] = model_outputs["median"]
-            return out
         rgb_loss = self.get_rgb_loss(model_outputs["rgb_values"], ground_truth["rgb"].to(dev))
         zero = torch.zeros((), device=dev)
         eikonal = self.get_eikonal_loss(model_outputs["grad_theta"]) if "grad_theta" in model_outputs else zero

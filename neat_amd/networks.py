@@ -368,9 +368,15 @@ class VolSDFNetwork(_HipModule):
         return 0.0 if self.white_bkgd else self.scene_bounding_sphere
 
     def _render(self, cam_loc, ray_dirs, z_vals, want_normal_map, eik_points=None, with_eik=False):
+        if z_vals.is_cuda and type(self.density) is LaplaceDensity:
+            # the raw parameter and beta_min: |beta| + beta_min (density.py:29-30) is formed inside the compositing kernels and its
+            # backward (sum over the rays, sign) inside neat_render_backward -- five elementwise launches less per step
+            beta, beta_min = self.density.beta, self.density.beta_min
+        else:
+            beta, beta_min = self.density.get_beta(), 0.0
         rgb, lines3d, depth, xyz, eik_grad, weights, sdf, points, nmap = ops.render_rays(
-            self.handle(), cam_loc, ray_dirs, z_vals, self.density.get_beta(), self._sphere(),
-            self.implicit_network.sphere_scale, want_normal_map, eik_points, self.bg_color if self.white_bkgd else None)
+            self.handle(), cam_loc, ray_dirs, z_vals, beta, self._sphere(),
+            self.implicit_network.sphere_scale, want_normal_map, eik_points, self.bg_color if self.white_bkgd else None, beta_min)
         if with_eik:
             return rgb, lines3d, depth, xyz, weights, sdf, points, nmap, eik_grad
         return rgb, lines3d, depth, xyz, weights, sdf, points, nmap
@@ -406,6 +412,8 @@ class VolSDFNetwork(_HipModule):
         if self.z_vals_override is not None:
             z = self.z_vals_override
             idx = self._cpu_random("eik_idx", lambda: torch.randint(z.shape[-1], (z.shape[0],)), z.device)
+            if z.is_cuda and self.training and not self.junction_eikonal:
+                return z, (z, idx)          # the eikonal-point launch picks z[r, idx[r]] itself (ops.eik_points)
             return z, z.gather(1, idx.unsqueeze(-1))
         return self.ray_sampler.get_z_vals(ray_dirs, cam_loc, self)
 
@@ -439,9 +447,12 @@ class VolSDFNetwork(_HipModule):
         points3d = xyz
         main = torch.cuda.current_stream() if xyz.is_cuda else None
         side = self._side_stream(xyz.device) if (main is not None and self.use_side_stream) else None
-        w2c = ops.inv_small(pose[0])[:3]                     # one launch, no host-side singularity check, no sync
+        if xyz.is_cuda and pose.shape[1:] == (4, 4) and intrinsics.dtype == torch.float32 and intrinsics.stride(-1) == 1:
+            w2c, K3 = ops.camera_mats(pose[0], intrinsics[0])     # [R | T] of pose^-1 and the contiguous 3x3 intrinsics: one launch, no sync
+        else:
+            w2c = ops.inv_small(pose[0])[:3]                 # one launch, no host-side singularity check, no sync
+            K3 = intrinsics[0, :3, :3]
         Rm, T = w2c[:, :3], w2c[:, 3:]
-        K3 = intrinsics[0, :3, :3]
         eye = _eye3(K3.device)
 
         def l3d_block():
@@ -617,6 +628,10 @@ class VolSDFNetwork(_HipModule):
         """Eikonal points: uniform in the bounding cube + one near-surface sample per ray (rend_a :515-527)."""
         r = self.scene_bounding_sphere
         eik = self._cpu_random("eik_uniform", lambda: torch.empty(n_rays, 3).uniform_(-r, r), ray_dirs.device)
+        if isinstance(z_eik, tuple):          # (depths [R,S], drawn index per ray): given depth samples (_z_vals)
+            if eik.is_cuda:
+                return ops.eik_points(eik, cam_loc, ray_dirs, None, junctions, z=z_eik[0], idx=z_eik[1])
+            z_eik = z_eik[0].gather(1, z_eik[1].unsqueeze(-1))
         if eik.is_cuda:
             return ops.eik_points(eik, cam_loc, ray_dirs, z_eik, junctions)       # [uniform | o + z d | junctions]: one launch
         eik = torch.cat([eik, torch.addcmul(cam_loc, z_eik, ray_dirs)], 0)

@@ -235,7 +235,7 @@ class RenderRaysFn(torch.autograd.Function):
     return its raw gradient (the eikonal term, :515-527).  Differentiable wrt all 57 network parameters and beta."""
 
     @staticmethod
-    def forward(ctx, handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, bg_color, *params):
+    def forward(ctx, handle, origins, dirs, z, beta, beta_min, radius, scale, want_normal_map, eik_points, bg_color, *params):
         lib = _lib.lib()
         ctx.set_materialize_grads(False)
         origins, dirs, z = (_f32c(t.detach()) for t in (origins, dirs, z))
@@ -256,13 +256,13 @@ class RenderRaysFn(torch.autograd.Function):
         xyz = torch.empty(R, 3, device=dev)
         nmap = torch.empty(R, 3, device=dev) if want_normal_map else None
         eik_grad = torch.empty(E, 3, device=dev)
-        _lib.check(lib.neat_render_forward(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, _p(beta_d),
+        _lib.check(lib.neat_render_forward(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, _p(beta_d), float(beta_min),
                                            float(radius), float(scale), _p(ws), _p(points), _p(weights), _p(sdf), _p(rgb),
                                            _p(lines3d), _p(depth), _p(xyz), _p(nmap), _p(eik) if E else None, E,
                                            _p(eik_grad) if E else None, _stream()), "neat_render_forward")
         ctx.handle, ctx.shape, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, (R, S, E), ws, packed, netp, prec
         ctx.keep = params          # (see SdfOutputsFn)
-        ctx.dirs, ctx.z, ctx.beta_d, ctx.beta_shape = dirs, z, beta_d, beta.shape
+        ctx.dirs, ctx.z, ctx.beta_d, ctx.beta_shape, ctx.beta_min = dirs, z, beta_d, beta.shape, float(beta_min)
         # white_bkgd (rend_a :411-413): what the weights leave of a ray is filled with the background colour; the backward pass sends
         # the cotangent of the opacity, -(d_rgb . bg), through the compositing kernel (d_acc)
         ctx.bg = None if bg_color is None else _f32c(bg_color.detach().reshape(3))
@@ -282,16 +282,18 @@ class RenderRaysFn(torch.autograd.Function):
         gr, views, _ = _grad_buffers(h, 0, _lib.NUM_LAYERS, dev)
         d_rgb, d_lines3d, d_depth, d_xyz, d_eik = (_f32c(t) for t in (d_rgb, d_lines3d, d_depth, d_xyz, d_eik))
         dbeta_ray = torch.empty(R, device=dev)
+        dbeta = torch.empty(1, device=dev)          # sgn(beta) * sum of the per-ray partials: one tiny launch inside neat_render_backward
         d_acc = None if ctx.bg is None or d_rgb is None else _f32c(-(d_rgb @ ctx.bg))
         _lib.check(lib.neat_render_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), _p(ctx.dirs), _p(ctx.z), R, S, E,
-                                            ctx.prec, _p(ctx.beta_d), _p(d_rgb), _p(d_lines3d), _p(d_depth), _p(d_xyz),
-                                            _p(d_eik) if E else None, _p(d_acc), ctypes.byref(gr), _p(dbeta_ray), _stream()),
+                                            ctx.prec, _p(ctx.beta_d), ctx.beta_min, _p(d_rgb), _p(d_lines3d), _p(d_depth), _p(d_xyz),
+                                            _p(d_eik) if E else None, _p(d_acc), ctypes.byref(gr), _p(dbeta_ray), _p(dbeta),
+                                            _stream()),
                    "neat_render_backward")
         ctx.ws = None
-        return (None, None, None, None, dbeta_ray.sum().reshape(ctx.beta_shape), None, None, None, None, None, *views)
+        return (None, None, None, None, dbeta.reshape(ctx.beta_shape), None, None, None, None, None, None, *views)
 
 
-def render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False):
+def render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False, beta_min=0.0):
     """Forward-only main pass (no autograd graph, no backward workspace): what eval / inference callers run
     (neat-final-parsing.py:203-218, 2048-ray chunks).  Same results as render_rays."""
     lib = _lib.lib()
@@ -306,7 +308,7 @@ def render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_
     rgb, lines3d = torch.empty(R, 3, device=dev), torch.empty(R, 2, 3, device=dev)
     depth, xyz = torch.empty(R, device=dev), torch.empty(R, 3, device=dev)
     nmap = torch.empty(R, 3, device=dev) if want_normal_map else None
-    _lib.check(lib.neat_render_forward_eval(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, _p(beta_d),
+    _lib.check(lib.neat_render_forward_eval(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, _p(beta_d), float(beta_min),
                                             float(radius), float(scale), _p(ws), _p(points), _p(weights), _p(sdf), _p(rgb),
                                             _p(lines3d), _p(depth), _p(xyz), _p(nmap), _stream()), "neat_render_forward_eval")
     if nmap is None:
@@ -314,16 +316,16 @@ def render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_
     return rgb, lines3d, depth, xyz, torch.empty(0, 3, device=dev), weights, sdf, points, nmap
 
 
-def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False, eik_points=None, bg_color=None):
+def render_rays(handle, origins, dirs, z, beta, radius, scale, want_normal_map=False, eik_points=None, bg_color=None, beta_min=0.0):
     """-> rgb [R,3], lines3d [R,2,3], depth [R], xyz [R,3], eik_grad [E,3], weights, sdf, points, normal_map"""
     if not handle.has_heads():
         raise RuntimeError("render_rays needs the SDF network and both heads attached to the NetHandle")
     if not torch.is_grad_enabled() and eik_points is None:
-        out = render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map)
+        out = render_rays_eval(handle, origins, dirs, z, beta, radius, scale, want_normal_map, beta_min)
         if bg_color is not None:           # white_bkgd (rend_a :411-413)
             out = (out[0] + (1.0 - out[5].sum(-1, keepdim=True)) * bg_color.reshape(1, 3),) + tuple(out[1:])
         return out
-    return RenderRaysFn.apply(handle, origins, dirs, z, beta, radius, scale, want_normal_map, eik_points, bg_color, *handle.tensors())
+    return RenderRaysFn.apply(handle, origins, dirs, z, beta, beta_min, radius, scale, want_normal_map, eik_points, bg_color, *handle.tensors())
 
 
 def camera_rays(uv, pose, intrinsics, with_origins=False):
@@ -344,14 +346,23 @@ def camera_rays(uv, pose, intrinsics, with_origins=False):
     return dirs, pose_c[:, :3, 3]
 
 
-def eik_points(uniform, origins, dirs, z_eik, extra=None):
-    """[uniform | origins + z_eik dirs | extra] -> [2R + J, 3] in one launch (no gradient: the inputs are draws and detached depths)."""
-    uniform, origins, dirs, z_eik = (_f32c(t.detach()) for t in (uniform, origins, dirs, z_eik.reshape(-1)))
+def eik_points(uniform, origins, dirs, z_eik, extra=None, z=None, idx=None):
+    """[uniform | origins + z_eik dirs | extra] -> [2R + J, 3] in one launch (no gradient: the inputs are draws and detached depths).
+    z_eik None: the depth of ray r is z[r, idx[r]] (the draw's index into the ray's depths; the gather happens inside the launch)."""
+    uniform, origins, dirs = (_f32c(t.detach()) for t in (uniform, origins, dirs))
     R = uniform.shape[0]
+    if z_eik is not None:
+        z_eik, zc, ic, S = _f32c(z_eik.detach().reshape(-1)), None, None, 0
+    else:
+        zc, ic = _f32c(z.detach()), idx.detach().reshape(-1).to(torch.int64).contiguous()
+        S = zc.shape[1]
+        if zc.shape[0] != R or ic.shape[0] != R:
+            raise RuntimeError("eik_points: z [R,S] and idx [R]")
     ex = _f32c(extra.detach()) if extra is not None and extra.shape[0] > 0 else None
     J = ex.shape[0] if ex is not None else 0
     out = torch.empty(2 * R + J, 3, device=uniform.device)
-    _lib.check(_lib.lib().neat_eik_points(_p(uniform), _p(origins), _p(dirs), _p(z_eik), _p(ex), R, J, _p(out), _stream()), "neat_eik_points")
+    _lib.check(_lib.lib().neat_eik_points(_p(uniform), _p(origins), _p(dirs), _p(z_eik), _p(ex), R, J, _p(out), _p(zc), S, _p(ic), _stream()),
+               "neat_eik_points")
     return out
 
 
@@ -523,10 +534,13 @@ class Project2DFn(torch.autograd.Function):
         _lib.check(lib.neat_project2d(_p(K3), _p(w2c), _p(Xc), Xc.shape[0], _p(uv), _stream()), "neat_project2d")
         ctx.save_for_backward(K3, w2c, Xc)
         ctx.shape = X.shape
+        ctx.set_materialize_grads(False)      # a projection nobody differentiates through costs no backward launch
         return uv.reshape(*X.shape[:-1], 2)
 
     @staticmethod
     def backward(ctx, d_uv):
+        if d_uv is None:
+            return None, None, None
         K3, w2c, Xc = ctx.saved_tensors
         d = _f32c(d_uv.reshape(-1, 2))
         dX = torch.empty_like(Xc)
@@ -580,7 +594,7 @@ class LineLossesFn(torch.autograd.Function):
             raise RuntimeError("line_losses: pred [R,4] x2, gt [R,5], K [3,3]")
         out3 = torch.empty(3, device=pc.device)
         d_pred = torch.empty(R, 4, device=pc.device)
-        _lib.check(_lib.lib().neat_line_losses(_p(pu), _p(pc), _p(g), _p(Kc), R, float(threshold), _p(out3), _p(d_pred), _stream()),
+        _lib.check(_lib.lib().neat_line_losses(_p(pu), _p(pc), _p(g), _p(Kc), R, float(threshold), _p(out3), _p(d_pred), 1.0, _stream()),
                    "neat_line_losses")
         ctx.save_for_backward(d_pred)
         ctx.set_materialize_grads(False)
@@ -665,80 +679,103 @@ def dbscan_means(points, eps):
     return flat[:3 * (n // 2)].view(n // 2, 3), valid.view(torch.bool), count      # the kernel writes 0 / 1: reinterpret, no copy
 
 
+_GRAD_ONE = {}
+
+
+def grad_one(device):
+    """The constant 1.0 to seed `loss.backward(gradient=...)` with (neat_amd.train): no `ones_like` launch per step, and LossTailFn
+    recognises it -- its flat gradient buffer already holds the gradients of the total loss, so nothing is multiplied."""
+    key = str(device)
+    t = _GRAD_ONE.get(key)
+    if t is None:
+        t = _GRAD_ONE[key] = torch.ones((), device=device)
+    return t
+
+
 class LossTailFn(torch.autograd.Function):
-    """rgb L1 + eikonal + junction pair terms of VolSDFLoss and the weighted total, in two launches around neat_lsap.
-    Differentiable inputs: rgb, grad_theta, the global junctions (3-D and calibrated 2-D) and the line loss."""
+    """VolSDFLoss.forward after the projections (loss_wfr.py:52-137) in three launches around neat_lsap: both line terms
+    (neat_line_losses), rgb L1 + eikonal + the junction pair cost (neat_loss_terms), the matched-pair terms and the weighted total
+    (neat_loss_pairs).  Differentiable inputs: rgb, grad_theta, the global junctions (3-D and calibrated 2-D) and the calibrated 2-D
+    lines.  Every gradient leaves its kernel as a gradient of the TOTAL loss (the loss weights are applied there) into one flat buffer:
+    backward is one multiply by the upstream gradient, or nothing at all when that is `grad_one`."""
 
     @staticmethod
-    def forward(ctx, rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2):
+    def forward(ctx, rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good,
+                w_eik, w_line, w_j3, w_j2, threshold):
         lib = _lib.lib()
         dev = rgb.device
         c = lambda t: None if t is None else _f32c(t.detach())
         rgb_c, gt_c, gth_c = c(rgb), c(rgb_gt.reshape(-1, 3)), c(gtheta)
         glo3_c, glo2c_c, glo2_c, loc3_c, loc2c_c, loc2_c = c(glo3), c(glo2c), c(glo2), c(loc3), c(loc2c), c(loc2)
+        pc, pu, g5, Kc = c(pred_calib.reshape(-1, 4)), c(pred_px.reshape(-1, 4)), c(gt5), c(Kmat)
         R, E = rgb_c.shape[0], 0 if gth_c is None else gth_c.shape[0]
+        L = pc.shape[0]
+        if pu.shape != (L, 4) or g5.shape != (L, 5) or Kc.numel() != 9:
+            raise RuntimeError("loss_tail: lines [L,4] x2, gt [L,5], K [3,3]")
         K = 0 if loc3_c is None else loc3_c.shape[0]
         J = 0 if glo3_c is None else glo3_c.shape[0]
-        # (with junction pairs the two launches write all seven scalars the caller reads: no fill launch)
-        scal = torch.empty(8, device=dev) if (K and J) else torch.zeros(8, device=dev)
-        # every gradient the two launches produce lives in ONE flat buffer, so that backward is two multiplies (per-element
-        # loss weight x upstream gradient, then x buffer) instead of one or two per tensor
         have_pairs = bool(K and J)
-        sizes = [R * 3, E * 3, J * 3 if have_pairs else 0, J * 2 if have_pairs else 0]
+        # (with junction pairs the launches write all seven scalars the caller reads: no fill launch)
+        scal = torch.empty(8, device=dev) if have_pairs else torch.zeros(8, device=dev)
+        line3 = torch.empty(3, device=dev)
+        sizes = [R * 3, E * 3, J * 3 if have_pairs else 0, J * 2 if have_pairs else 0, L * 4]
         flat = torch.empty(sum(sizes), device=dev)
-        d_rgb, d_gth, d_glo3, d_glo2c = flat.split(sizes)
+        d_rgb, d_gth, d_glo3, d_glo2c, d_pred = flat.split(sizes)
         d_gth = d_gth if E else None
-        pair_cost = torch.empty(K, J, device=dev) if K and J else None
+        pair_cost = torch.empty(K, J, device=dev) if have_pairs else None
+        _lib.check(lib.neat_line_losses(_p(pu), _p(pc), _p(g5), _p(Kc), L, float(threshold), _p(line3), _p(d_pred), w_line, _stream()),
+                   "neat_line_losses")
         _lib.check(lib.neat_loss_terms(_p(rgb_c), _p(gt_c), R, _p(gth_c), E, _p(loc3_c), _p(loc2c_c), K, _p(glo3_c), _p(glo2c_c), J,
-                                       _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), _stream()), "neat_loss_terms")
-        if K and J:
+                                       _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), w_eik, _stream()), "neat_loss_terms")
+        if have_pairs:
             ri, ci, n_match = linear_sum_assignment(pair_cost, good)
+            loss = torch.empty((), device=dev)
             _lib.check(lib.neat_loss_pairs(_p(ri), _p(ci), _p(n_match), ri.shape[0], _p(loc3_c), _p(loc2c_c), _p(loc2_c), _p(glo3_c),
                                            _p(glo2c_c), _p(glo2_c), J, _p(pair_cost), _p(scal), _p(d_glo3), _p(d_glo2c),
-                                           _p(_f32c(line_loss.detach().reshape(1))), w_eik, w_line, w_j3, w_j2, _stream()),
-                       "neat_loss_pairs")
-            loss = scal[6].clone()
+                                           _ip(line3, 1), w_eik, w_line, w_j3, w_j2, 1, _p(loss), _stream()), "neat_loss_pairs")
         else:
-            loss = scal[0] + w_eik * scal[1] + w_line * line_loss.detach()
-        ctx.save_for_backward(flat, _segment_weights(tuple(sizes) + (1,), (1.0, w_eik, w_j3, w_j2, w_line), dev))
+            loss = scal[0] + w_eik * scal[1] + w_line * line3[1]
+        ctx.save_for_backward(flat)
         ctx.sizes = sizes
         ctx.set_materialize_grads(False)
         ctx.shapes = (rgb.shape, None if gtheta is None else gtheta.shape, None if glo3 is None or not have_pairs else glo3.shape,
-                      None if glo2c is None or not have_pairs else glo2c.shape, line_loss.shape)
-        ctx.mark_non_differentiable(scal)
-        return loss, scal
+                      None if glo2c is None or not have_pairs else glo2c.shape, pred_calib.shape)
+        ctx.mark_non_differentiable(scal, line3)
+        return loss, scal, line3
 
     @staticmethod
-    def backward(ctx, g_loss, g_scal):
+    def backward(ctx, g_loss, g_scal, g_line3):
         if g_loss is None:
-            return (None,) * 15
-        flat, wvec = ctx.saved_tensors
-        scale = wvec * g_loss                        # [.. per-element loss weights .., w_line] x upstream gradient
-        g = (flat * scale[:-1]).split(ctx.sizes)
-        s_rgb, s_gth, s_glo3, s_glo2c, s_line = ctx.shapes
+            return (None,) * 19
+        (flat,) = ctx.saved_tensors
+        one = _GRAD_ONE.get(str(flat.device))
+        if one is None or g_loss.data_ptr() != one.data_ptr():
+            flat = flat * g_loss
+        g = flat.split(ctx.sizes)
+        s_rgb, s_gth, s_glo3, s_glo2c, s_pred = ctx.shapes
         return (g[0].view(s_rgb),
                 None if s_gth is None else g[1].view(s_gth),
                 None if s_glo3 is None else g[2].view(s_glo3),
                 None if s_glo2c is None else g[3].view(s_glo2c),
-                scale[-1:].view(s_line), None, None, None, None, None, None, None, None, None, None)
+                g[4].view(s_pred)) + (None,) * 14
 
 
-_SEG_WEIGHTS = {}
+def loss_tail(rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2,
+              threshold=100.0):
+    """-> (total loss, scal [8] = rgb, eikonal, j3d, j2d, j2d pixels, jcount, total, -, line3 [3] = l2d pixel term, line loss, count)."""
+    return LossTailFn.apply(rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good,
+                            float(w_eik), float(w_line), float(w_j3), float(w_j2), float(threshold))
 
 
-def _segment_weights(sizes, weights, device):
-    """Per-element loss weights of LossTailFn's flat gradient buffer (cached per shape / weights / device)."""
-    key = (sizes, weights, str(device))
-    w = _SEG_WEIGHTS.get(key)
-    if w is None:
-        w = torch.cat([torch.full((n,), float(v)) for n, v in zip(sizes, weights)]).to(device)
-        _SEG_WEIGHTS[key] = w
-    return w
-
-
-def loss_tail(rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2):
-    return LossTailFn.apply(rgb, gtheta, glo3, glo2c, line_loss, rgb_gt, loc3, loc2c, loc2, glo2, good,
-                            float(w_eik), float(w_line), float(w_j3), float(w_j2))
+def camera_mats(pose, intrinsics):
+    """pose [4,4] cam-to-world, intrinsics [>=3, >=3] -> (w2c [3,4] = the first three rows of pose^-1, K3 [3,3] contiguous): one launch
+    (rend_a :424-431, :440; no gradient)."""
+    pose, Kc = _f32c(pose.detach()), intrinsics.detach()
+    if Kc.dtype != torch.float32 or not Kc.is_cuda or Kc.stride(-1) != 1 or pose.shape != (4, 4):
+        raise RuntimeError("camera_mats: pose [4,4] and intrinsics with unit column stride, CUDA float32")
+    w2c, K3 = torch.empty(3, 4, device=pose.device), torch.empty(3, 3, device=pose.device)
+    _lib.check(_lib.lib().neat_camera_mats(_p(pose), _p(Kc), int(Kc.stride(-2)), _p(w2c), _p(K3), _stream()), "neat_camera_mats")
+    return w2c, K3
 
 
 def l3d_points(x, origins, dirs, normals):

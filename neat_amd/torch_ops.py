@@ -137,7 +137,7 @@ def render_rays(origins: Tensor, dirs: Tensor, z: Tensor, beta: Tensor, params: 
     nmap = torch.empty(R, 3, device=dev) if want_normal_map else None
     eik_grad = torch.empty(E, 3, device=dev)
     _lib.check(lib.neat_render_forward(ops._p(packed), ops.ctypes.byref(netp), ops._p(origins), ops._p(dirs), ops._p(z), R, S, prec,
-                                       ops._p(beta_d), float(radius), float(scale), ops._p(ws), ops._p(points), ops._p(weights), ops._p(sdf),
+                                       ops._p(beta_d), 0.0, float(radius), float(scale), ops._p(ws), ops._p(points), ops._p(weights), ops._p(sdf),
                                        ops._p(rgb), ops._p(lines3d), ops._p(depth), ops._p(xyz), ops._p(nmap), ops._p(eik), E,
                                        ops._p(eik_grad) if E else None, ops._stream()), "neat_render_forward")
     if nmap is None:
@@ -159,12 +159,12 @@ def render_rays_backward(ws: Tensor, dirs: Tensor, z: Tensor, beta: Tensor, para
     dirs, z = ops._f32c(dirs), ops._f32c(z)
     beta_d = ops._f32c(beta.reshape(1))
     d_rgb, d_lines3d, d_depth, d_xyz, d_eik = (ops._f32c(t) for t in (d_rgb, d_lines3d, d_depth, d_xyz, d_eik))
-    dbeta_ray = torch.empty(R, device=dev)
+    dbeta_ray, dbeta = torch.empty(R, device=dev), torch.empty(1, device=dev)
     _lib.check(lib.neat_render_backward(ops._p(packed), ops.ctypes.byref(netp), ops._p(ws), ops._p(dirs), ops._p(z), R, S, E, h.precision,
-                                        ops._p(beta_d), ops._p(d_rgb), ops._p(d_lines3d), ops._p(d_depth), ops._p(d_xyz),
-                                        ops._p(d_eik) if E else None, None, ops.ctypes.byref(gr), ops._p(dbeta_ray), ops._stream()),
+                                        ops._p(beta_d), 0.0, ops._p(d_rgb), ops._p(d_lines3d), ops._p(d_depth), ops._p(d_xyz),
+                                        ops._p(d_eik) if E else None, None, ops.ctypes.byref(gr), ops._p(dbeta_ray), ops._p(dbeta), ops._stream()),
                "neat_render_backward")
-    return [dbeta_ray.sum().reshape(beta.shape)] + [v.clone() for v in views]
+    return [dbeta.reshape(beta.shape)] + [v.clone() for v in views]
 
 
 def _render_setup(ctx, inputs, output):

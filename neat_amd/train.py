@@ -12,6 +12,16 @@ from .wireframe import WireframeGraph
 GT_KEYS = ("rgb", "lines2d")      # what VolSDFLoss reads from the ground truth (loss_wfr.py:92-110)
 
 
+def _backward(loss):
+    """loss.backward() seeded with a persistent 1.0 on the device: no `ones_like` launch per step, and the loss's own autograd node
+    (ops.LossTailFn) recognises the seed and multiplies nothing."""
+    if loss.is_cuda:
+        from . import ops
+        loss.backward(gradient=ops.grad_one(loss.device))
+    else:
+        loss.backward()
+
+
 class Trainer:
     def __init__(self, model_conf=None, loss_conf=None, lr=5.0e-4, decay_steps=200000, device="cuda:0", state_dict=None, parts=None):
         self.device = torch.device(device)
@@ -57,7 +67,7 @@ class Trainer:
         out = self.model(model_input)
         losses = self.loss(out, ground_truth)
         self.optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
+        _backward(losses["loss"])
         self.bucket.all_reduce_mean()
         self.optimizer.step()
         self.scheduler.step()
@@ -210,7 +220,7 @@ class Trainer:
         losses = self.loss(out, entry.static_gt)
         if zero:
             self.optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
+        _backward(losses["loss"])
         return out, losses
 
     def _finish_step(self, entry, on_collective=None):

@@ -1552,11 +1552,20 @@ def test_eik_points_and_ray_origins_kernels(dev, R, J):
     assert got.shape == (2 * R + J, 3)
     close(got, ref, tol=1e-6, what="eik points")
     assert torch.equal(got[:R], uni) and (J == 0 or torch.equal(got[2 * R:], extra))
+    # ABI v12: the depth of a ray picked inside the launch from its S depths by the drawn index (ray_sampler.py:276-277's gather)
+    S = 11
+    zs = (torch.rand(R, S, generator=gen) * 5).to(dev)
+    idx = torch.randint(S, (R,), generator=gen).to(dev)
+    picked = ops.eik_points(uni, o, d, None, extra, z=zs, idx=idx)
+    assert torch.equal(picked, ops.eik_points(uni, o, d, zs.gather(1, idx.unsqueeze(-1)), extra))
     sc = synth.synth_scene(seed=3, n_rays=R)
     uv, pose, K = (T(sc[k]).to(dev) for k in ("uv", "pose", "intrinsics"))
     dirs, cam, origins = ops.camera_rays(uv, pose, K, with_origins=True)
     dirs2, cam2 = rend_util.get_camera_params(uv, pose, K)
     assert torch.equal(dirs, dirs2) and torch.equal(origins, cam2.expand(R, 3))
+    # ABI v12: [R | T] of pose^-1 and the contiguous 3x3 intrinsics in one launch
+    w2c, K3 = ops.camera_mats(pose[0], K[0])
+    assert torch.equal(w2c, ops.inv_small(pose[0])[:3]) and torch.equal(K3, K[0, :3, :3]) and K3.is_contiguous()
 
 
 def test_hierarchical_sampler_on_device(dev, golden):
@@ -1940,6 +1949,17 @@ def test_fused_loss_tail_vs_torch_formulation(dev, use_median, R):
         assert (x is None) == (y is None)
         if x is not None:
             close(y, x, tol=1e-5, what="loss-tail gradient")
+    # the trainer's seed (ops.grad_one): LossTailFn hands out its flat buffer unmultiplied -- the same gradients; any other upstream
+    # gradient goes through one multiply
+    from neat_amd import ops
+    lf = VolSDFLoss(**synth.ABC_NEAT_A_LOSS_CONF)
+    lo = lf(out, gt)
+    g1 = torch.autograd.grad(lo["loss"], leaves, grad_outputs=ops.grad_one(dev), retain_graph=True, allow_unused=True)
+    g3 = torch.autograd.grad(lo["loss"], leaves, grad_outputs=torch.full((), 3.0, device=dev), retain_graph=True, allow_unused=True)
+    for x, y, w in zip(gb, g1, g3):
+        if x is not None:
+            assert torch.equal(x, y)
+            close(w, 3.0 * x, tol=1e-6, what="loss-tail gradient x 3")
 
 
 def test_junction_block_kernels_vs_torch(dev):
@@ -2119,3 +2139,34 @@ def test_copy_batch_device_and_pinned_sources(dev):
         assert float(buf[0]) == -7 and float(buf[-1]) == -7
     assert not ops.copy_batch_ok(torch.zeros(4, device=dev), torch.zeros(4))            # pageable host memory
     assert not ops.copy_batch_ok(torch.zeros(4, 4, device=dev).t(), torch.zeros(4, 4, device=dev))
+
+
+@pytest.mark.parametrize("raw", [0.07, -0.07])
+def test_density_beta_formed_inside_the_kernels(dev, raw):
+    """ABI v12: neat_render_forward / backward take the raw parameter density.beta and beta_min; |beta| + beta_min (density.py:29-30)
+    is formed in the compositing kernels and the backward returns d loss / d beta_param = sgn(beta_param) * sum of the per-ray partials
+    from one launch.  Same outputs and gradients as handing over get_beta() (beta_min = 0), for a negative parameter too."""
+    from neat_amd import networks, ops
+    torch.manual_seed(0)
+    m = networks.VolSDFNetwork(synth.ABC_NEAT_A_MODEL_CONF)
+    m.load_state_dict({k: T(v) for k, v in synth.synth_state_dict(5, "rough").items()})
+    m.to(dev).train()
+    with torch.no_grad():
+        m.density.beta.fill_(raw)
+    R, S = 64, 16
+    sc = synth.synth_scene(seed=5, n_rays=R)
+    o = T(sc["pose"])[0, :3, 3].to(dev).expand(R, 3).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=torch.Generator().manual_seed(1)), dim=-1).to(dev)
+    z = T(synth.synth_z_vals(5, R, S)).to(dev)
+    res = []
+    for mode in ("effective", "raw"):
+        m.zero_grad(set_to_none=True)
+        beta, bmin = (m.density.get_beta(), 0.0) if mode == "effective" else (m.density.beta, m.density.beta_min)
+        out = ops.render_rays(m.handle(), o, d, z, beta, 3.0, 20.0, False, None, None, bmin)
+        (out[0].sum() + out[2].sum() + 0.1 * out[1].sum()).backward()
+        res.append(([t.detach().clone() for t in out[:4]], m.density.beta.grad.clone(), m.implicit_network.lin8.bias.grad.clone()))
+    (oa, ba, la), (ob, bb, lb) = res
+    for x, y in zip(oa, ob):
+        assert torch.equal(x, y)
+    assert torch.equal(la, lb)
+    assert float(ba) != 0.0 and abs(float(ba) - float(bb)) <= 2e-6 * abs(float(ba)), (float(ba), float(bb))      # (two summation orders)
