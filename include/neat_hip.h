@@ -180,6 +180,11 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
  * open[k]) and int32 cont[max_rounds] (the resample launch of round k writes 1 = "refined, go on" or 2 = "final samples drawn").
  * A launch of round k > 0 does nothing unless cont[k-1] == 1, so the rounds after the final one cost only their launch.
  *  neat_sdf_values_gated     : neat_sdf_forward(mode 0) that returns at once unless *gate == gate_value (gate = &cont[k-1], 1).
+ *  neat_sdf_values_rays      : the same for the points o + z d of R rays x S depths (sdf [R S]): the round's `cam_loc + samples * dirs`
+ *                              (:146) is formed by the launch that lays the points out for the SDF kernels (ABI v12).
+ *  neat_sampler_init         : what precedes the first round (:131-143) in one launch (ABI v12): beta0[0] = |*beta| + beta_min
+ *                              (density.py:29-30), beta_ray[r] = sqrt(beta_c sum_i (z[r,i+1] - z[r,i])^2) with beta_c = 1 / (4 log(1 + eps)),
+ *                              and the nctl control words of the rounds zeroed.
  *  neat_sampler_bound_dev    : neat_sampler_bound with `open` = &open[k] and the same gate.
  *  neat_sampler_resample_dev : decides refine = *open && round + 1 < max_rounds on the device.  refine: N_refine samples at u_refine
  *                              (shared by the rays), merged grid and order, as neat_sampler_resample(refine=1).  Otherwise the N_final
@@ -191,6 +196,11 @@ int neat_sampler_finish(const float* samples, int N, const float* z, int n, cons
  *                              neat_sampler_finish.  `pick` [n_extra] receives the indices. */
 int neat_sdf_values_gated(const float* packed, const neat_net_params* net, const float* x, int P, int precision, float radius,
                           float scale, float* ws, float* sdf, const int* gate, int gate_value, void* stream);
+int neat_sdf_values_rays(const float* packed, const neat_net_params* net, const float* origins, const float* dirs, const float* z, int R,
+                         int S, int precision, float radius, float scale, float* ws, float* sdf, const int* gate, int gate_value,
+                         void* stream);
+int neat_sampler_init(const float* z, int R, int n, const float* beta, float beta_min, float beta_c, float* beta0, float* beta_ray,
+                      int* ctl, int nctl, void* stream);
 int neat_sampler_bound_dev(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
                            const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out,
                            int* open, const int* gate, int gate_value, void* stream);

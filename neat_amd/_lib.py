@@ -57,6 +57,10 @@ _SIGNATURES = {
     "neat_uniform_depths": (ctypes.c_int, [c_fp, ctypes.c_float, c_fp, ctypes.c_float, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "neat_sdf_values_gated": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                              ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
+    "neat_sdf_values_rays": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
+    "neat_sampler_init": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int,
+                                         c_fp]),
     "neat_sampler_bound_dev": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp,
                                               ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
     "neat_sampler_resample_dev": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_float,

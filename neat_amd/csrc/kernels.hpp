@@ -615,7 +615,7 @@ __global__ void points_from_rays_kernel(const float* __restrict__ o, const float
     const int r = p / S;
     const float zz = z[p];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) xv[c] = o[r * 3 + c] + zz * d[r * 3 + c];
+    for (int c = 0; c < 3; ++c) xv[c] = __fadd_rn(o[r * 3 + c], __fmul_rn(zz, d[r * 3 + c]));      // torch's `cam_loc + z * dirs` (rend_a :395-396): product rounded, then the sum -- no fma
     if (pts_rm) { pts_rm[p * 3 + 0] = xv[0]; pts_rm[p * 3 + 1] = xv[1]; pts_rm[p * 3 + 2] = xv[2]; }
   }
 #pragma unroll

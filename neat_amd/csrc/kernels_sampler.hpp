@@ -291,6 +291,25 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
   }
 }
 
+// What Algorithm 1 computes before its first round (ray_sampler.py:131-143), one wavefront per ray: beta0 = |beta_param| + beta_min
+// (density.py:29-30; written once), the ray's initial beta = sqrt(beta_c * sum_i (z[i+1] - z[i])^2) with beta_c = 1 / (4 log(1 + eps))
+// (Lemma 2), and the control words of the device-decided rounds zeroed -- nine elementwise / reduction launches otherwise.
+__global__ __launch_bounds__(256) void sampler_init_kernel(const float* __restrict__ z, int R, int n, const float* __restrict__ beta_ptr,
+                                                           float beta_min, float beta_c, float* __restrict__ beta0,
+                                                           float* __restrict__ beta_out, int* __restrict__ ctl, int nctl) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < nctl; i += 256) ctl[i] = 0;
+    if (threadIdx.x == 0) beta0[0] = fabsf(*beta_ptr) + beta_min;
+  }
+  if (r >= R) return;
+  const float* zr = z + (size_t)r * n;
+  float acc = 0.0f;
+  for (int j = lane; j + 1 < n; j += 64) { const float g = zr[j + 1] - zr[j]; acc += g * g; }
+  acc = wave_sum(acc);
+  if (lane == 0) beta_out[r] = sqrtf(beta_c * acc);
+}
+
 // Which samples of the final grid join the output (ray_sampler.py:263-268), decided on the device from the grid size n:
 //   eval : torch.linspace(0, n - 1, n_extra).long()            (the reference's formula, fp32, symmetric around the middle)
 //   train: a uniformly random n_extra-subset without replacement (the reference: torch.randperm(n)[:n_extra]) = the n_extra smallest

@@ -1638,7 +1638,7 @@ NEAT_TWIN(neat_set_tuning) NEAT_TWIN(neat_prof_enable) NEAT_TWIN(neat_prof_colle
 NEAT_TWIN(neat_packed_floats) NEAT_TWIN(neat_pack_weights) NEAT_TWIN(neat_sdf_ws_floats) NEAT_TWIN(neat_sdf_forward)
 NEAT_TWIN(neat_sdf_backward) NEAT_TWIN(neat_heads_ws_floats) NEAT_TWIN(neat_heads_forward) NEAT_TWIN(neat_render_ws_floats)
 NEAT_TWIN(neat_render_forward) NEAT_TWIN(neat_render_backward) NEAT_TWIN(neat_render_eval_ws_floats)
-NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated)
+NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated) NEAT_TWIN(neat_sdf_values_rays)
 #define NEAT_F16_FWD(call) if (precision == 3) { precision = BF16; return f16_##call; } if (precision == HX3 || precision == HX3_FASTVALUES) return f16_##call;
 #else
 #define NEAT_F16_FWD(call)
@@ -1775,19 +1775,21 @@ size_t neat_sdf_ws_floats(int P, int mode, int precision) {
   return bad_prec(precision) ? 0 : sdf_ws(nullptr, round_ldp(P, precision), mode, precision, hx3 == 1).total;
 }
 
-int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
-                     float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad,
-                     void* stream) {
-  NEAT_F16_FWD(neat_sdf_forward(packed, net, x, P, mode, precision, radius, scale, ws, out257, sdf, feat, grad, stream))
+// x [P,3] row-major, or (x == null) the points o + z d of R rays x S depths (P = R S)
+struct RayPoints { const float* origins; const float* dirs; const float* z; int R, S; };
+static int sdf_forward_impl(const float* packed, const neat_net_params* net, const float* x, const RayPoints* rp, int P, int mode, int precision,
+                            float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad, void* stream) {
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
   if (hx3 == 2 && mode != 0) return -1;      // NEAT_F16X3 fast values: values-mode calls only
   if (P <= 0) return 0;
-  if (!packed || !net || !x || !ws || bad_prec(precision)) return -1;
+  if (!packed || !net || (!x && !rp) || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   c.x3 = x3; c.hx3 = hx3;
   SdfWs w = sdf_ws(ws, c.ldp, mode, precision, hx3);
-  hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
+  if (x) hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
+  else hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, rp->origins, rp->dirs, rp->z, rp->R, rp->S, c.ldp, w.x,
+                          (float*)nullptr, (const float*)nullptr, 0);
   if (mode == 0 && precision) {
     NEAT_CHECK(sdf_primal(c, w, false, radius, scale, sdf));      // fused: PE -> 9 layers -> clamp, one launch
     return (int)hipGetLastError();
@@ -1805,6 +1807,27 @@ int neat_sdf_forward(const float* packed, const neat_net_params* net, const floa
                      w.sdf, w.g, w.mask, sdf, grad, P, (float*)nullptr);
   export_out8(c, w, out257, feat);
   return (int)hipGetLastError();
+}
+
+int neat_sdf_forward(const float* packed, const neat_net_params* net, const float* x, int P, int mode, int precision,
+                     float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad,
+                     void* stream) {
+  NEAT_F16_FWD(neat_sdf_forward(packed, net, x, P, mode, precision, radius, scale, ws, out257, sdf, feat, grad, stream))
+  if (P > 0 && !x) return -1;
+  return sdf_forward_impl(packed, net, x, nullptr, P, mode, precision, radius, scale, ws, out257, sdf, feat, grad, stream);
+}
+
+int neat_sdf_values_rays(const float* packed, const neat_net_params* net, const float* origins, const float* dirs, const float* z, int R,
+                         int S, int precision, float radius, float scale, float* ws, float* sdf, const int* gate, int gate_value,
+                         void* stream) {
+  NEAT_F16_FWD(neat_sdf_values_rays(packed, net, origins, dirs, z, R, S, precision, radius, scale, ws, sdf, gate, gate_value, stream))
+  if (R <= 0 || S <= 0) return 0;
+  if (!packed || !net || !origins || !dirs || !z || !ws || !sdf || bad_prec(precision)) return -1;
+  const RayPoints rp{origins, dirs, z, R, S};
+  g_gate = gate; g_gate_value = gate_value;
+  const int rc = sdf_forward_impl(packed, net, nullptr, &rp, R * S, 0, precision, radius, scale, ws, nullptr, sdf, nullptr, nullptr, stream);
+  g_gate = nullptr;
+  return rc;
 }
 
 int neat_sdf_values_gated(const float* packed, const neat_net_params* net, const float* x, int P, int precision, float radius,
@@ -2034,6 +2057,14 @@ int neat_uniform_depths(const float* near_r, float near_s, const float* far_r, f
   if (R <= 0 || N <= 0) return 0;
   if (!t || !z) return -1;
   hipLaunchKernelGGL(uniform_depths_kernel, dim3((R * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, near_r, near_s, far_r, far_s, t, rnd, R, N, z);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_init(const float* z, int R, int n, const float* beta, float beta_min, float beta_c, float* beta0, float* beta_ray,
+                      int* ctl, int nctl, void* stream) {
+  if (R <= 0 || n < 2 || n > SMAX || !z || !beta || !beta0 || !beta_ray || nctl < 0 || (nctl > 0 && !ctl)) return -1;
+  hipLaunchKernelGGL(sampler_init_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, R, n, beta, beta_min, beta_c, beta0, beta_ray,
+                     ctl, nctl);
   return (int)hipGetLastError();
 }
 

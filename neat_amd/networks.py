@@ -145,6 +145,11 @@ class ImplicitNetwork(_HipModule):
             return self._outputs(x, self.sdf_bounding_sphere)[1]
         return ops.sdf_values(self.handle(), x, self.sdf_bounding_sphere, self.sphere_scale, gate=gate, fast=fast)
 
+    def get_sdf_vals_rays(self, cam_loc, ray_dirs, z, gate=None, fast=False):
+        """get_sdf_vals(cam_loc + z * ray_dirs) for R rays x S depths without autograd (what a sampler round asks for,
+        ray_sampler.py:146-151): the points never exist as a row-major tensor."""
+        return ops.sdf_values_rays(self.handle(), cam_loc, ray_dirs, z, self.sdf_bounding_sphere, self.sphere_scale, gate=gate, fast=fast)
+
 
 class _Head(_HipModule):
     first_layer = None

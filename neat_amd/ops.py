@@ -215,6 +215,36 @@ def sdf_values(handle, x, radius, scale, gate=None, fast=False):
     return sdf
 
 
+def sdf_values_rays(handle, origins, dirs, z, radius, scale, gate=None, fast=False):
+    """sdf_values at the points origins + z dirs of R rays x S depths -> [R S, 1]; the points are formed by the launch that lays them
+    out for the SDF kernels (no addcmul, no layout change: two launches less per sampler round)."""
+    lib = _lib.lib()
+    origins, dirs, z = (_f32c(t.detach()) for t in (origins, dirs, z))
+    R, S = z.shape
+    sdf = torch.empty(R * S, 1, device=z.device)
+    if R * S == 0:
+        return sdf
+    packed, netp = handle.packed()
+    prec = 5 if (fast and handle.precision == 4) else handle.precision
+    ws = torch.empty(lib.neat_sdf_ws_floats(R * S, 0, prec), device=z.device, dtype=torch.float32)
+    gptr, gval = (None, 0) if gate is None else (ctypes.c_void_p(gate[0].data_ptr() + 4 * gate[1]), int(gate[2]))
+    _lib.check(lib.neat_sdf_values_rays(_p(packed), ctypes.byref(netp), _p(origins), _p(dirs), _p(z), R, S, prec, float(radius), float(scale),
+                                        _p(ws), _p(sdf), gptr, gval, _stream()), "neat_sdf_values_rays")
+    return sdf
+
+
+def sampler_init(z, beta_param, beta_min, beta_c, nctl):
+    """What Algorithm 1 computes before its first round (ray_sampler.py:131-143) in one launch -> (beta0 [1] = |beta_param| + beta_min,
+    per-ray beta [R] = sqrt(beta_c sum gap^2), ctl int32 [nctl] zeroed)."""
+    z = _f32c(z.detach())
+    R, n = z.shape
+    dev = z.device
+    beta0, beta, ctl = torch.empty(1, device=dev), torch.empty(R, device=dev), torch.empty(nctl, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().neat_sampler_init(_p(z), R, n, _p(_f32c(beta_param.detach().reshape(1))), float(beta_min), float(beta_c), _p(beta0),
+                                            _p(beta), _p(ctl), nctl, _stream()), "neat_sampler_init")
+    return beta0, beta, ctl
+
+
 def heads_forward(handle, points, normals, view_dirs, feats):
     """rgb [P,3] and line endpoints [P,2,3] of the two heads on given inputs (forward only)."""
     lib = _lib.lib()

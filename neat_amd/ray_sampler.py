@@ -67,6 +67,18 @@ def _draw(model, name, fn, dev):
     return hook(name, fn, dev) if hook is not None else fn().to(dev)
 
 
+_UNIT_GRIDS = {}
+
+
+def _unit_grid(n, device):
+    """torch.linspace(0, 1, n) on the device, made once per (n, device): the refine rounds' u (ray_sampler.py:226) is a constant."""
+    key = (int(n), str(device))
+    g = _UNIT_GRIDS.get(key)
+    if g is None:
+        g = _UNIT_GRIDS[key] = torch.linspace(0.0, 1.0, n, device=device)
+    return g
+
+
 def _fast(model):
     """Keyword for get_sdf_vals: the model's opt-in to one-product f16 SDF queries in the sampler (conf key
     model.hip_sampler_fast_values, fp16x3 only).  A reference-shaped model object without the attribute gets none."""
@@ -205,20 +217,30 @@ class ErrorBoundSampler(RaySampler):
         from . import ops
         dev, R = ray_dirs.device, ray_dirs.shape[0]
         K, Ne, N = self.max_total_iters, self.N_samples_eval, self.N_samples
-        beta0 = model.density.get_beta().detach()
         z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
-        gap = z[:, 1:] - z[:, :-1]
-        beta = torch.sqrt(self._beta_c * (gap ** 2.0).sum(-1))
-        ctl = torch.zeros(2 * K + 1, dtype=torch.int32, device=dev)
-        u_refine = torch.linspace(0.0, 1.0, Ne, device=dev)
-        u_final = _draw(model, "sampler_u", lambda: torch.rand(R, N), dev) if model.training else torch.linspace(0.0, 1.0, N, device=dev)
+        density = getattr(model, "density", None)
+        if type(density).__name__ == "LaplaceDensity" and hasattr(density, "beta_min"):
+            # beta0 = |beta| + beta_min, the rays' initial beta (Lemma 2) and the zeroed control words: one launch (neat_sampler_init)
+            beta0, beta, ctl = ops.sampler_init(z, density.beta, density.beta_min, self._beta_c, 2 * K + 1)
+        else:
+            beta0 = model.density.get_beta().detach()
+            gap = z[:, 1:] - z[:, :-1]
+            beta = torch.sqrt(self._beta_c * (gap ** 2.0).sum(-1))
+            ctl = torch.zeros(2 * K + 1, dtype=torch.int32, device=dev)
+        u_refine = _unit_grid(Ne, dev)
+        u_final = _draw(model, "sampler_u", lambda: torch.rand(R, N), dev) if model.training else _unit_grid(N, dev)
         samples, z_final = torch.empty(R, N, device=dev), torch.empty(R, Ne * K, device=dev)
         fresh, order, sdf = z, None, None
+        on_rays = getattr(model.implicit_network, "get_sdf_vals_rays", None)
         cam, dirs = cam_loc.unsqueeze(1), ray_dirs.unsqueeze(1)
         for k in range(K):
-            pts = torch.addcmul(cam, fresh.unsqueeze(2), dirs).reshape(-1, 3)
+            gate = (ctl, K + k - 1, 1) if k > 0 else None
             with torch.no_grad():
-                new_sdf = model.implicit_network.get_sdf_vals(pts, gate=(ctl, K + k - 1, 1) if k > 0 else None, **_fast(model)).reshape(R, -1)
+                if on_rays is not None:
+                    new_sdf = on_rays(cam_loc, ray_dirs, fresh, gate=gate, **_fast(model)).reshape(R, -1)
+                else:
+                    pts = torch.addcmul(cam, fresh.unsqueeze(2), dirs).reshape(-1, 3)
+                    new_sdf = model.implicit_network.get_sdf_vals(pts, gate=gate, **_fast(model)).reshape(R, -1)
             sdf, beta, fresh, z_next, order_next = ops.sampler_round_dev(z, sdf, new_sdf, order, beta, beta0, self.eps, self.beta_iters,
                                                                          self.add_tiny, u_refine, u_final, samples, z_final, ctl, k, K)
             z, order = z_next, order_next
@@ -256,17 +278,25 @@ class ErrorBoundSampler(RaySampler):
         if ray_dirs.is_cuda and (self.sync_free or self._eval_on_device(model)):
             return self.get_z_vals_device(ray_dirs, cam_loc, model)
         dev, R = ray_dirs.device, ray_dirs.shape[0]
-        beta0 = model.density.get_beta().detach()
         z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
         fresh, order, sdf = z, None, None
-        gap = z[:, 1:] - z[:, :-1]
-        beta = torch.sqrt(self._beta_c * (gap ** 2.0).sum(-1))
+        density = getattr(model, "density", None)
+        on_rays = getattr(model.implicit_network, "get_sdf_vals_rays", None) if ray_dirs.is_cuda else None
+        if ray_dirs.is_cuda and type(density).__name__ == "LaplaceDensity" and hasattr(density, "beta_min"):
+            beta0, beta, _ = ops.sampler_init(z, density.beta, density.beta_min, self._beta_c, 0)      # (as get_z_vals_device: same bits)
+        else:
+            beta0 = model.density.get_beta().detach()
+            gap = z[:, 1:] - z[:, :-1]
+            beta = torch.sqrt(self._beta_c * (gap ** 2.0).sum(-1))
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         rounds, open_ = 0, True
         while open_ and rounds < self.max_total_iters:
-            pts = (cam_loc.unsqueeze(1) + fresh.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
             with torch.no_grad():
-                new_sdf = model.implicit_network.get_sdf_vals(pts, **_fast(model)).reshape(R, -1)
+                if on_rays is not None:
+                    new_sdf = on_rays(cam_loc, ray_dirs, fresh, **_fast(model)).reshape(R, -1)
+                else:
+                    pts = (cam_loc.unsqueeze(1) + fresh.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+                    new_sdf = model.implicit_network.get_sdf_vals(pts, **_fast(model)).reshape(R, -1)
             flag.zero_()
             sdf, beta = ops.sampler_bound(z, sdf, new_sdf, order, beta, beta0, self.eps, self.beta_iters, flag)
             rounds += 1
