@@ -699,7 +699,8 @@ __global__ void adjoint_seed_kernel(const float* __restrict__ v8, const float* _
 // hin (main pass; small_r == null: off): the heads' small inputs of the same point in the same launch (what head_inputs_kernel,
 // below, does in a launch of its own for the stand-alone heads entry): render [p(3), PE4(view)(27), normal(3)], attraction
 // [p(3), view(3), normal(3)], fp32 rows + octet-major 16-bit copies
-struct HeadInArgs { const float* dirs; int P, S; float* small_r; float* small_a; u16* bf_r; u16* bf_a; };
+struct HeadInArgs { const float* dirs; int P, S; float* small_r; float* small_a; u16* bf_r; u16* bf_a;
+                    int skip_fp32 = 0; };     // 1: only the 16-bit copies are read (bf16 / f16 builds: every consumer takes the octets)
 template <bool FAST>
 __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float* __restrict__ out8,
                                     const float* __restrict__ e0, const float* __restrict__ es, int P, int ldp,
@@ -765,10 +766,12 @@ __global__ void sdf_finalize_kernel(const float* __restrict__ x_fm, const float*
       vr[30 + c] = gc;
       va[c] = xc; va[3 + c] = dc; va[6 + c] = gc;
     }
+    if (!hin.skip_fp32) {
 #pragma unroll
-    for (int i = 0; i < 33; ++i) hin.small_r[(size_t)i * ldp + p] = vr[i];
+      for (int i = 0; i < 33; ++i) hin.small_r[(size_t)i * ldp + p] = vr[i];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) hin.small_a[(size_t)i * ldp + p] = va[i];
+      for (int i = 0; i < 9; ++i) hin.small_a[(size_t)i * ldp + p] = va[i];
+    }
     if (hin.bf_r) {
 #pragma unroll
       for (int o = 0; o < 5; ++o)

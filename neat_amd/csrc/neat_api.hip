@@ -1932,7 +1932,8 @@ static int render_forward_impl(const float* packed, const neat_net_params* net, 
   NEAT_CHECK(sdf_adjoint(c, w, !fwd_only));
   // normals + sphere clamp, and in the same launch the heads' small inputs (the heads run over every column of the tile grid; only
   // the first R*S columns are consumed)
-  const HeadInArgs hin{dirs, Pm, S, h.small_r, h.small_a, reinterpret_cast<u16*>(h.smallbf_r.p), reinterpret_cast<u16*>(h.smallbf_a.p)};
+  HeadInArgs hin{dirs, Pm, S, h.small_r, h.small_a, reinterpret_cast<u16*>(h.smallbf_r.p), reinterpret_cast<u16*>(h.smallbf_a.p)};
+  hin.skip_fp32 = (oct_operands(c) && !c.hx3) ? 1 : 0;      // (the split-precision head chains read the fp32 rows; nothing else does in a 16-bit build)
   FINALIZE_LAUNCH_H(c, hin, w.x, w.sdfraw, w.e0, w.es, P, c.ldp, radius, scale,
                     w.sdf, w.g, w.mask, sdf, (float*)nullptr, Pm, eik_grad);
   NEAT_CHECK(heads_forward(c, h, w.feat, w.featlo, !fwd_only, Pm));
