@@ -547,6 +547,9 @@ def main():
                         # PMC bytes against the library's own algorithmic bytes of the same launches: wasted re-reads show as > 1, a stale
                         # traffic.json as a jump (scripts/check_traffic.py fails the profile refresh beyond +-10 %)
                         "traffic_vs_algorithmic_bytes": (traffic / k["bytes_per_launch"]) if traffic else None,
+                        # the committed PMC figure no longer describes the launches of THIS run when it leaves the library's live byte
+                        # accounting by more than 15 % (a kernel changed and profiles/traffic.json was not regenerated)
+                        "traffic_stale": (abs(traffic / k["bytes_per_launch"] - 1.0) > 0.15) if traffic else None,
                         "avg_launch_us": k["avg_us"], "launches": k["launches"], "flop_per_launch": k["flop_per_launch"],
                         "flop_per_byte": k["flop_per_byte"],
                         "hbm": {"achieved_gbytes_per_s": k["gbytes_per_s"], "peak_gbytes_per_s": PEAK_HBM_GBS,
