@@ -5,7 +5,7 @@
 #include <vector>
 template <int NR, int NW>
 __global__ __launch_bounds__(256) void stream_kernel(const uint4* const* in, uint4* const* out, size_t n) {
-  const uint4* ip[NR]; uint4* op[NW];
+  const uint4* ip[NR]; uint4* op[NW ? NW : 1];
 #pragma unroll
   for (int i = 0; i < NR; ++i) ip[i] = in[i];
 #pragma unroll
@@ -16,14 +16,15 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* const* in, uin
     for (int r = 0; r < NR; ++r) { const uint4 v = ip[r][i]; acc.x ^= v.x; acc.y += v.y; acc.z ^= v.z; acc.w += v.w; }
 #pragma unroll
     for (int w = 0; w < NW; ++w) { acc.x += w; op[w][i] = acc; }
+    if (NW == 0 && acc.x == 0x12345679u && acc.y == 0x9abcdef1u) out[0][0] = acc;      // read-only variants: keep the loads alive
   }
 }
 template <int NR, int NW>
 void run(const std::vector<uint4*>& bufs, size_t n, int grid) {
   const uint4** din; uint4** dout;
-  hipMalloc(&din, NR * sizeof(void*)); hipMalloc(&dout, NW * sizeof(void*));
+  hipMalloc(&din, NR * sizeof(void*)); hipMalloc(&dout, (NW ? NW : 1) * sizeof(void*));
   hipMemcpy(din, bufs.data(), NR * sizeof(void*), hipMemcpyHostToDevice);
-  hipMemcpy(dout, bufs.data() + NR, NW * sizeof(void*), hipMemcpyHostToDevice);
+  hipMemcpy(dout, bufs.data() + NR, (NW ? NW : 1) * sizeof(void*), hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((stream_kernel<NR, NW>), dim3(grid), dim3(256), 0, 0, din, dout, n);
   hipEventRecord(e0, 0);
@@ -41,6 +42,8 @@ int main() {
   for (auto& b : bufs) { hipMalloc(&b, n * 16); hipMemset(b, 1, n * 16); }
   for (int grid : {256 * 4, 256 * 8, 256 * 16, 256 * 32}) {
     run<1, 1>(bufs, n, grid); run<2, 1>(bufs, n, grid); run<3, 1>(bufs, n, grid); run<3, 2>(bufs, n, grid); run<2, 2>(bufs, n, grid);
+    // read-only mixes (round 5): what the weight-gradient launches, the gather of the in-kernel partials, the row dots and the finish launches are
+    run<2, 0>(bufs, n, grid); run<4, 0>(bufs, n, grid); run<7, 0>(bufs, n, grid);
   }
   return 0;
 }
