@@ -359,7 +359,9 @@ int neat_volume_weights(const float* z, const float* sdf, int R, int S, const fl
  *     buffers each instead of one array per layer (default 1; results bit-identical, fewer HBM write-backs)
  *  25 with key 16: consecutive layers of the tangent / reverse chains that share an epilogue variant run as ONE launch in which every
  *     workgroup loops over the layers for its own tiles (tangent 1-2 | 3 | 4-7, reverse 8 | 7-5 | 4 | 3-1: 15 launches -> 7; default 1;
- *     results bit-identical) */
+ *     results bit-identical)
+ *  28 the two 256 x 256 layers of the global-junction MLP (neat_ffn_forward / neat_ffn_backward's data path) on the fp32 matrix pipe
+ *     (v_mfma_f32_32x32x2_f32: exact fp32 products, fixed summation order) instead of the vector-ALU kernel (default 1) */
 int neat_set_tuning(int key, int value);
 int neat_prof_enable(int on);
 int neat_prof_collect(int cls, double* total_ms, double* total_flops, int* launches, double* total_bytes);

@@ -706,6 +706,55 @@ __global__ __launch_bounds__(256) void ffn_dense_kernel(const float* __restrict_
   }
 }
 
+// The two 256 x 256 layers of the junction MLP on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, 64 flop per cycle
+// and SIMD instead of the vector ALU's 64 per CU-quarter with its LDS operand reads):  y[j][o] = epi( sum_i x[j][i] Wm(o, i) ), I = O = 256,
+// Wm(o, i) = TRANS ? W[i * 256 + o] : W[o * 256 + i];  epi as ffn_dense_kernel.  Workgroup = one 32 (outputs) x 32 (rows) tile, its four
+// waves split the 256 inputs (64 each: 32 MFMAs), the four partial tiles meet in LDS and are summed in wave order (deterministic).
+// k-order inside a chunk of 8 inputs: MFMA step s takes inputs (8c + s, 8c + 4 + s) -- lane half kh holds inputs 8c + 4 kh .. + 3 of its
+// row as one float4, for both operands alike.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void ffn_mfma_kernel(const float* __restrict__ x, int J, const float* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gate, int relu, float* __restrict__ y) {
+  __shared__ float part[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, kh = lane >> 5;
+  const int j0 = blockIdx.x * 32, o0 = blockIdx.y * 32, k0 = 64 * wave;
+  const int jrow = min(j0 + m, J - 1);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float4 av[8], bv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int i = k0 + 8 * c + 4 * kh;
+    bv[c] = *reinterpret_cast<const float4*>(x + (size_t)jrow * FFN_H + i);
+    if (!TRANS) av[c] = *reinterpret_cast<const float4*>(W + (size_t)(o0 + m) * FFN_H + i);
+    else av[c] = make_float4(W[(size_t)i * FFN_H + o0 + m], W[(size_t)(i + 1) * FFN_H + o0 + m], W[(size_t)(i + 2) * FFN_H + o0 + m],
+                             W[(size_t)(i + 3) * FFN_H + o0 + m]);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+  }
+  // accumulator layout: column (row j) = lane & 31, output row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * kh][m] = acc[r];
+  __syncthreads();
+  const int oo = tid & 31;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int jj = (tid >> 5) + 8 * q, j = j0 + jj, o = o0 + oo;
+    if (j >= J) continue;
+    float v = bias ? bias[o] : 0.0f;
+    v += part[0][oo][jj]; v += part[1][oo][jj]; v += part[2][oo][jj]; v += part[3][oo][jj];
+    if (relu) v = fmaxf(v, 0.0f);
+    if (gate && !(gate[(size_t)j * FFN_H + o] > 0.0f)) v = 0.0f;
+    y[(size_t)j * FFN_H + o] = v;
+  }
+}
+
 // blockIdx.y: 0: dW0 = d_a1^T x, db0 ; 1: dW1 = d_a2^T h1, db1 ; 2 (rows 0..2): dW2 = dy^T h2, db2.  blockIdx.x = FFN_RN output rows.
 // 1024 threads = 16 wavefronts: wavefront g sums ITS sixteenth of the J rows (a lane = four columns of the block's output rows: one 16-byte load
 // per row of the input, eight rows in flight), the sixteen partial sums are combined in group order (deterministic).  One thread per

@@ -255,6 +255,8 @@ int g_chain_pp = 1;         // with key 16: the chain variables of the tangent /
                             // instead of one array per layer: since the weight gradients are contracted in the launch that holds them no later
                             // kernel reads them, and a line rewritten while it is still in the Infinity Cache never costs an HBM write (tuning key 24)
 int g_dw_nsub = 16;         // sub-ranges of workgroup partials summed by dw_gather_kernel (= fp32 splits per layer seen by the finish; tuning key 18)
+int g_ffn_mfma = 1;         // the 256 x 256 layers of the global-junction MLP (forward and data backward) on the fp32 matrix pipe (ffn_mfma_kernel) instead
+                            // of the vector-ALU kernel (tuning key 28)
 int g_dw_segments = 1;      // with key 16: consecutive layers of a chain that share an epilogue variant run as ONE launch with a per-workgroup layer loop
                             // (tangent 1-2 | 3 | 4-7, reverse 8 | 7-5 | 4 | 3-1: 15 launches -> 7; tuning key 25)
 template <int EPI, bool FULL> hipError_t launch_layer_wsdw(hipStream_t st, const LayerArgsDW* d0, int n = 1) {
@@ -1678,6 +1680,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 23 && value >= 16 && value <= DW_MAXGRID) { g_dw_grid = value; return 0; }
   if (key == 24 && (value == 0 || value == 1)) { g_chain_pp = value; return 0; }
   if (key == 25 && (value == 0 || value == 1)) { g_dw_segments = value; return 0; }
+  if (key == 28 && (value == 0 || value == 1)) { g_ffn_mfma = value; return 0; }
   return -1;
 }
 
@@ -2179,8 +2182,14 @@ int neat_ffn_forward(const float* x, int J, const float* W0, const float* b0, co
   // few rows (the 64 latents of the ABC scenes): one launch per layer, each spread over rows x 32-output blocks
   const dim3 gh((J + FFN_RB - 1) / FFN_RB, FFN_H / 32), g3((J + FFN_RB - 1) / FFN_RB, 1);
   const float* nogate = nullptr; float* noy2 = nullptr;
-  hipLaunchKernelGGL(ffn_dense_kernel<false>, gh, dim3(256), 0, st, x, J, FFN_H, FFN_H, W0, b0, nogate, 1, h1, noy2);
-  hipLaunchKernelGGL(ffn_dense_kernel<false>, gh, dim3(256), 0, st, (const float*)h1, J, FFN_H, FFN_H, W1, b1, nogate, 1, h2, noy2);
+  if (g_ffn_mfma) {      // the two 256 x 256 layers on the fp32 matrix pipe (tuning key 28)
+    const dim3 gm((J + 31) / 32, FFN_H / 32);
+    hipLaunchKernelGGL(ffn_mfma_kernel<false>, gm, dim3(256), 0, st, x, J, W0, b0, nogate, 1, h1);
+    hipLaunchKernelGGL(ffn_mfma_kernel<false>, gm, dim3(256), 0, st, (const float*)h1, J, W1, b1, nogate, 1, h2);
+  } else {
+    hipLaunchKernelGGL(ffn_dense_kernel<false>, gh, dim3(256), 0, st, x, J, FFN_H, FFN_H, W0, b0, nogate, 1, h1, noy2);
+    hipLaunchKernelGGL(ffn_dense_kernel<false>, gh, dim3(256), 0, st, (const float*)h1, J, FFN_H, FFN_H, W1, b1, nogate, 1, h2, noy2);
+  }
   hipLaunchKernelGGL(ffn_dense_kernel<false>, g3, dim3(256), 0, st, (const float*)h2, J, FFN_H, 3, W2, b2, nogate, 0, y, noy2);
   return (int)hipGetLastError();
 }
@@ -2198,8 +2207,14 @@ int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, c
     const dim3 gh((J + FFN_RB - 1) / FFN_RB, FFN_H / 32);
     const float* nobias = nullptr; const float* nogate = nullptr; float* noy2 = nullptr;
     hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, dy, J, 3, FFN_H, W2, nobias, h2, 0, d_a2, noy2);
-    hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a2, J, FFN_H, FFN_H, W1, nobias, h1, 0, d_a1, noy2);
-    hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a1, J, FFN_H, FFN_H, W0, nobias, nogate, 0, dx, noy2);
+    if (g_ffn_mfma) {
+      const dim3 gm((J + 31) / 32, FFN_H / 32);
+      hipLaunchKernelGGL(ffn_mfma_kernel<true>, gm, dim3(256), 0, st, (const float*)d_a2, J, W1, nobias, h1, 0, d_a1);
+      hipLaunchKernelGGL(ffn_mfma_kernel<true>, gm, dim3(256), 0, st, (const float*)d_a1, J, W0, nobias, nogate, 0, dx);
+    } else {
+      hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a2, J, FFN_H, FFN_H, W1, nobias, h1, 0, d_a1, noy2);
+      hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a1, J, FFN_H, FFN_H, W0, nobias, nogate, 0, dx, noy2);
+    }
   }
   hipLaunchKernelGGL(ffn_backward_weights_kernel, dim3(FFN_H / FFN_RN, 3), dim3(64 * FFN_JG), 0, (hipStream_t)stream, x, h1, h2, d_a1, d_a2, dy, J, dW0, db0,
                      dW1, db1, dW2, db2);
