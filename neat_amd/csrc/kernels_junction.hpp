@@ -822,6 +822,78 @@ __global__ __launch_bounds__(64 * FFN_JG) void ffn_backward_weights_kernel(const
   if (k == 0) db[n0 + r] = b;
 }
 
+// The same three weight gradients on the fp32 matrix pipe: dW[o][i] = sum_j d[j][o] in[j][i].  grid (8 input tiles, 8 output tiles, 3 layers;
+// the 3-row layer uses output tile 0 only); a workgroup = one 32 x 32 tile of dW, its eight waves split the J rows (contiguous ranges, rows 2t / 2t + 1
+// per MFMA), partial tiles and the bias partial sums meet in LDS and are added in wave order (deterministic).
+constexpr int FFN_WNW = 8;          // waves of ffn_wgrad_mfma_kernel (each takes 1 / FFN_WNW of the rows)
+__global__ __launch_bounds__(64 * FFN_WNW) void ffn_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ h1, const float* __restrict__ h2,
+    const float* __restrict__ d_a1, const float* __restrict__ d_a2, const float* __restrict__ dy, int J, float* __restrict__ dW0,
+    float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2) {
+  __shared__ float part[FFN_WNW][32][33];
+  __shared__ float bpart[FFN_WNW][32];
+  const int which = blockIdx.z;
+  const int N = which == 2 ? 3 : FFN_H;
+  const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  if (o0 >= N) return;
+  const float* d = which == 0 ? d_a1 : (which == 1 ? d_a2 : dy);
+  const float* in = which == 0 ? x : (which == 1 ? h1 : h2);
+  const int ldd = which == 2 ? 3 : FFN_H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, kh = lane >> 5;
+  const bool okA = o0 + m < N;
+  const int per = ((J + FFN_WNW - 1) / FFN_WNW + 1) & ~1;                 // rows per wave (even)
+  const int jb = min(J, wave * per), je = min(J, jb + per);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float bs = 0.0f;
+  const float* dp = d + (okA ? o0 + m : 0);
+  const float* ip = in + i0 + m;
+  int j = jb;
+  for (; j + 16 <= je; j += 16) {                        // eight MFMAs per trip, their sixteen operand loads in flight together
+    float av[8], bv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int jj = j + 2 * t + kh;
+      av[t] = okA ? dp[(size_t)jj * ldd] : 0.0f;
+      bv[t] = ip[(size_t)jj * FFN_H];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+      bs += av[t];
+    }
+  }
+  for (; j < je; j += 2) {
+    const int jj = j + kh;
+    const bool okj = jj < je;
+    const float a = (okA && okj) ? dp[(size_t)jj * ldd] : 0.0f;
+    const float b = okj ? ip[(size_t)jj * FFN_H] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    bs += a;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * kh][m] = acc[r];
+  bs += __shfl_xor(bs, 32);
+  if (kh == 0) bpart[wave][m] = bs;
+  __syncthreads();
+  float* dW = which == 0 ? dW0 : (which == 1 ? dW1 : dW2);
+  float* db = which == 0 ? db0 : (which == 1 ? db1 : db2);
+  const int ii = tid & 31;
+  for (int oo = tid >> 5; oo < 32; oo += 2 * FFN_WNW) {
+    if (o0 + oo >= N) continue;
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < FFN_WNW; ++w) v += part[w][oo][ii];
+    dW[(size_t)(o0 + oo) * FFN_H + i0 + ii] = v;
+  }
+  if (blockIdx.x == 0 && tid < 32 && o0 + tid < N) {
+    float b = 0.0f;
+#pragma unroll
+    for (int w = 0; w < FFN_WNW; ++w) b += bpart[w][tid];
+    db[o0 + tid] = b;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // DBSCAN(eps, min_samples = 2) of n 3-D points and the cluster means, on the device: the junction candidates of the
 // DTU / BlendedMVS confs (VolSDFNetwork.cluster_dbscan, rend_a :328-339, sklearn on the host in the reference).  With

@@ -2216,6 +2216,10 @@ int neat_ffn_backward(const float* x, int J, const float* W0, const float* W1, c
       hipLaunchKernelGGL(ffn_dense_kernel<true>, gh, dim3(256), 0, st, (const float*)d_a1, J, FFN_H, FFN_H, W0, nobias, nogate, 0, dx, noy2);
     }
   }
+  if (g_ffn_mfma)
+    hipLaunchKernelGGL(ffn_wgrad_mfma_kernel, dim3(FFN_H / 32, FFN_H / 32, 3), dim3(64 * FFN_WNW), 0, (hipStream_t)stream, x, h1, h2, d_a1, d_a2, dy, J, dW0, db0,
+                       dW1, db1, dW2, db2);
+  else
   hipLaunchKernelGGL(ffn_backward_weights_kernel, dim3(FFN_H / FFN_RN, 3), dim3(64 * FFN_JG), 0, (hipStream_t)stream, x, h1, h2, d_a1, d_a2, dy, J, dW0, db0,
                      dW1, db1, dW2, db2);
   return (int)hipGetLastError();
