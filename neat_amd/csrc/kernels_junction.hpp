@@ -241,7 +241,10 @@ __global__ __launch_bounds__(LSAP_WG) void lsap_kernel(LsapArgs a) {
 // multi-tensor kernels over 65 tensors.  Arithmetic in torch's order:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g g ; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------
-constexpr int ADAM_MAXSEG = 96, ADAM_PASSES = 4;
+#ifndef NEAT_ADAM_PASSES
+#define NEAT_ADAM_PASSES 1      // float4 passes per thread: 1 = four times the workgroups, one short chain each (14.8 -> 10.4 us at the 1.2 M parameters; 2: 12.6, 4: 14.8)
+#endif
+constexpr int ADAM_MAXSEG = 96, ADAM_PASSES = NEAT_ADAM_PASSES;
 struct AdamSegs {                 // gradient of segment s covers [off[s], off[s+1]); per-segment bias corrections (torch counts steps per tensor)
   const float* g[ADAM_MAXSEG]; long long off[ADAM_MAXSEG + 1]; float lr_over_bc1[ADAM_MAXSEG], inv_sqrt_bc2[ADAM_MAXSEG]; int nseg;
 };
