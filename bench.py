@@ -206,6 +206,64 @@ def secondary_legs(dev, sd, headline_precision, steps, note):
                workload="train step with the conf-default ErrorBoundSampler, its SDF queries in one-product f16 (hip_sampler_fast_values)")
     legs[f"sampler_step_{parity}_fast_values"] = leg
     del tr
+    # ---- north_star's own sub-metric: "the 8-layer x 256-wide SDF MLP at >= 40 % MFMA peak" = the values-mode fused SDF forward (PE ->
+    # lin0..lin8 -> sphere clamp, nothing saved), the launch a sampler round makes for its 1024 x 128 new depths -- five per real step.
+    # HIP events of the library around THAT kernel (class 2), 20 launches; flops = the library's algorithmic count for the launch: lin0..lin7
+    # in full + the ONE row of lin8 a query needs (459 264 MAC = 0.9185 MFLOP per point; SURVEY 8(d)'s 1.0491 MFLOP includes the 256
+    # feature rows of lin8, which only the main pass computes).
+    from neat_amd import _lib, ops
+    lib = _lib.lib()
+    for prec in dict.fromkeys((headline_precision, parity)):
+        tr = Trainer(device=dev, state_dict=sd)
+        tr.model.set_precision(prec).eval()
+        net = tr.model.implicit_network
+        pts, NL = R_RAYS * S_SAMPLES, 20
+        with torch.no_grad():
+            dirs, cam = tr.model._rays(inp)
+            zq = torch.tensor(synth.synth_z_vals(42, R_RAYS, S_SAMPLES)).to(dev)
+            handle = net.handle()
+            ws, ldp = ops.sdf_query_workspace(handle, pts, dev)
+            # the query points, laid out once by the sampler's prologue launch (as in a real step); then NL launches of the values kernel
+            # alone, captured in one HIP graph and replayed between two events: kernel time + the ~1.5 us a graph node costs.  (HIP
+            # events around EAGER launches of this kernel read 25-30 us high: 171-179 us against 146 in the graph and in the tracer.)
+            ops.sampler_init_rays(zq, tr.model.density.beta, tr.model.density.beta_min, 1.0, 1, cam.contiguous(), dirs.contiguous(), ws, ldp, None, 0, 0, 0)
+            run = lambda: ops.sdf_values_laid_out(handle, ws, pts, net.sdf_bounding_sphere, net.sphere_scale)
+            for _ in range(3):
+                run()
+            lib.neat_prof_enable(1)                  # (one eager launch: the library's algorithmic flop count of this launch)
+            run()
+            torch.cuda.synchronize()
+            ms, fl, n, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+            _lib.check(lib.neat_prof_collect(2, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n), ctypes.byref(by)), "neat_prof_collect")
+            lib.neat_prof_enable(0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(NL):
+                    run()
+            for _ in range(3):
+                g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / (5 * NL)
+        flop_pt = fl.value / max(n.value, 1) / pts
+        tf = flop_pt * pts / (us * 1e-6) / 1e12
+        note(f"secondary leg sdf_mlp_forward_{prec}: {us:.1f} us per {pts} points")
+        legs[f"sdf_mlp_forward_{prec}"] = {
+            "us_per_launch": us, "points": pts, "launches": 5 * NL, "value": pts / (us * 1e-6), "unit": "SDF-MLP evaluations/s",
+            "tflops": tf, "peak_tflops": PEAK_TFLOPS[prec], "frac": tf / PEAK_TFLOPS[prec], "flop_per_point": flop_pt, "precision": prec,
+            "frac_at_full_forward_flops": 1.0491e6 * pts / (us * 1e-6) / 1e12 / PEAK_TFLOPS[prec],
+            "products_per_mac": 3 if prec == "fp16x3" else 1,
+            "workload": "values-mode fused SDF forward (PE-6 -> 8 x 256 softplus MLP -> sdf, sphere clamp) on 1024 rays x 128 depths = one sampler round's query; "
+                        f"{NL} launches captured in one HIP graph, replayed 5x between two events; frac = the launch's algorithmic flops (lin0..lin7 + the one row of "
+                        "lin8 a query needs: 0.918 MFLOP per point, 1 product per MAC) / dense 16-bit MFMA peak; frac_at_full_forward_flops prices the same "
+                        "time with SURVEY 8(d)'s 1.0491 MFLOP (incl. lin8's 256 feature rows, which this launch does not compute)"
+                        + (" -- the 3-product f16 build issues 3 MFMAs per algorithmic MAC" if prec == "fp16x3" else "")}
+        del tr, g
     # ---- the other BASELINE configs under the same clock; single GPU, HIP-graph replay, synthetic rays
     sd_dtu = {k: torch.tensor(v) for k, v in synth.synth_state_dict(42, "rough", num_junctions=1024).items()}
     for label, rays, precs, what, parity_note in (
@@ -537,13 +595,37 @@ def main():
                     traffic = tj.get("sdf_adjoint_x3_kernel", {}).get("hbm_bytes_per_launch")
                 if traffic is not None:
                     traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run)"
-            # the hot path is bounded by the MFMA roof (fused, it moves ~5 B per ray-sample against 9.1 MFLOP), so the
-            # dominant kernel class is priced in algorithmic flop/s against the dense MFMA peak of the dtype.  The HBM side is
-            # kept as evidence: algorithmic bytes of the launches as they are today, and the PMC traffic per launch.
+            # Which roof the dominant class sits on is decided by ITS byte mix, not by SURVEY 8(d)'s hope for a fused path (~5 B per
+            # ray-sample): below the ridge (peak flop/s / peak B/s = 312 flop/B for bf16) a launch cannot reach the MFMA roof however
+            # well it issues, and `achieved` / `peak` / `frac` are then the HBM figures.  Both fractions are always carried
+            # (`frac_mfma`, `frac_hbm`), plus the whole step's fraction of the MFMA peak and the counter-derived MFMA utilisation.
             steps_prof = n_prof if graphed else args.steps
             step_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in kernels.values()) / max(steps_prof, 1)
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": k["tflops"], "peak": peak, "unit": "TFLOP/s",
-                        "frac": k["tflops"] / peak, "traffic": traffic, "traffic_source": traffic_source,
+            ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+            frac_mfma, frac_hbm = k["tflops"] / peak, k["gbytes_per_s"] / PEAK_HBM_GBS
+            for v in kernels.values():
+                v["bound"] = "hbm" if v["flop_per_byte"] < ridge else "mfma"
+                v["frac_mfma"], v["frac_hbm"] = v["tflops"] / peak, v["gbytes_per_s"] / PEAK_HBM_GBS
+            # MFMA utilisation from the SQ counters (SQ_VALU_MFMA_BUSY_CYCLES / (launch time x 2.4 GHz x 1024 SIMDs)): like `traffic` a
+            # committed figure of the same command (scripts/pmc_sq.sh -> scripts/make_mfma_util.py -> profiles/mfma_util.json)
+            mfma_util, upath = None, os.path.join(ROOT, "profiles", "mfma_util.json")
+            if os.path.exists(upath):
+                uj = json.load(open(upath)).get(args.precision, {}).get("classes", {})
+                mfma_util = {c: round(v["mfma_util"], 4) for c, v in uj.items()} or None
+            hbm_bound = k["bound"] == "hbm"
+            roofline = {"bound": k["bound"], "kernel": dom,
+                        "achieved": k["gbytes_per_s"] if hbm_bound else k["tflops"], "peak": PEAK_HBM_GBS if hbm_bound else peak,
+                        "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": frac_hbm if hbm_bound else frac_mfma,
+                        "frac_mfma": frac_mfma, "frac_hbm": frac_hbm, "achieved_tflops": k["tflops"], "achieved_gbytes_per_s": k["gbytes_per_s"],
+                        "ridge_flop_per_byte": ridge,
+                        "bound_note": ("the dominant class runs at %.0f flop/B against a ridge of %.0f: HBM-bound by its byte mix (chain variables "
+                                       "stream through HBM once per layer); the guide's achievable HBM rate is ~6.3 of the 8 TB/s spec"
+                                       % (k["flop_per_byte"], ridge)) if hbm_bound else "above the ridge: priced against the dense MFMA peak",
+                        "step_frac_of_mfma_peak": rays * S_SAMPLES * args.steps / elapsed * FLOP_PER_RAY_SAMPLE / 1e12 / peak,
+                        "mfma_util_from_counters": mfma_util,
+                        "mfma_util_source": "profiles/mfma_util.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES pass of this command, committed; "
+                                            "busy cycles / (launch duration x 2.4 GHz x 1024 SIMDs), not measured in this run)" if mfma_util else None,
+                        "traffic": traffic, "traffic_source": traffic_source,
                         # PMC bytes against the library's own algorithmic bytes of the same launches: wasted re-reads show as > 1, a stale
                         # traffic.json as a jump (scripts/check_traffic.py fails the profile refresh beyond +-10 %)
                         "traffic_vs_algorithmic_bytes": (traffic / k["bytes_per_launch"]) if traffic else None,

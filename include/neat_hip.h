@@ -37,7 +37,7 @@ typedef struct neat_net_grads {
   float* db[NEAT_NUM_LAYERS];
 } neat_net_grads;
 
-int neat_abi_version(void);      /* 12 */
+int neat_abi_version(void);      /* 13 */
 
 /* `precision` selects the build of the GEMM-class kernels:
  *   NEAT_F32  (0): exact-f32 MFMA, fp32 activations  -- parity build (outputs within 1e-4 of the reference)
@@ -211,6 +211,40 @@ int neat_sampler_resample_dev(const float* z, const float* sdf, int n, int R, co
 int neat_sampler_finish_dev(const float* samples, int N, const float* z_final, int ld_final, const int* n_final, const float* keys,
                             int n_extra, int* pick, float near, float far, int R, const int* eik_idx, float* z_vals, float* z_eik,
                             void* stream);
+
+/* ---- a3, one launch per round (ABI v13; replaces bound_dev + resample_dev + the layout launch of neat_sdf_values_rays per round) ------
+ * The same arithmetic as the entry points above, reference model/ray_sampler.py:145-254 per round.  Control words
+ * ctl = int32 open[max_rounds] | ran[max_rounds] | n_final (zeroed by neat_sampler_init_rays): round k ORs 1 into open[k] when a ray's
+ * beta is still above beta0 (the batch-global test of :200); a launch of round k > 0 (this one and the round's SDF query, gate =
+ * &open[k-1], gate_value 1) does nothing unless open[k-1] is set.  Because the test cannot be read inside the launch that produces it,
+ * a round prepares both outcomes: every ray refines (rounds before the last), and the rays whose own beta has reached beta0 -- all
+ * rays in the last round -- also draw the final samples, copy the grid to z_final and write n_final; the last round that ran wins.
+ *  neat_sdf_ldp             : point stride of the SDF kernels' feature-major layout for P points (the first 3 rows of a
+ *                             neat_sdf_ws_floats workspace are x [3][ldp]).
+ *  neat_sdf_values_laid_out : neat_sdf_values_gated on points that already sit in the workspace's x rows.
+ *  neat_sampler_init_rays   : neat_sampler_init + (x_fm != NULL) the first round's query points cam_loc + z dirs (:146) into x_fm,
+ *                             + (keys != NULL) for every possible final grid size n_step (c + 1), c < n_cand, the n_extra smallest
+ *                             of its first n keys in key order -> pick_all [n_cand][n_extra] (the training-mode randperm(n)[:n_extra]
+ *                             of :264-265 as neat_sampler_finish_dev draws it, computed beside the prologue instead of behind the rounds).
+ *  neat_sampler_round       : merge + d* + bisection (as neat_sampler_bound), then refine: N_refine samples at u_refine, merged grid
+ *                             z_merged / order_out [R, n + N_refine], and the NEXT round's query points into x_fm [3][ldp] (the
+ *                             workspace of the next neat_sdf_values_laid_out; NULL: not wanted); final: N_final samples at u_final.
+ *  neat_sampler_finish_picked : neat_sampler_finish with the grid size read from *n_final and the picks from
+ *                             pick_all[n / n_step - 1] (pick_all == NULL: linspace(0, n - 1, n_extra).long(), eval mode :266). */
+int neat_sdf_ldp(int P, int precision);
+int neat_sdf_values_laid_out(const float* packed, const neat_net_params* net, int P, int precision, float radius, float scale, float* ws,
+                             float* sdf, const int* gate, int gate_value, void* stream);
+int neat_sampler_init_rays(const float* z, int R, int n, const float* beta, float beta_min, float beta_c, float* beta0, float* beta_ray,
+                           int* ctl, int nctl, const float* origins, const float* dirs, float* x_fm, int ldp, const float* keys, int n_step,
+                           int n_cand, int n_extra, int* pick_all, void* stream);
+int neat_sampler_round(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
+                       const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out, int* ctl, int round,
+                       int max_rounds, float add_tiny, const float* u_refine, int N_refine, float* samples_refine, float* z_merged,
+                       int* order_out, const float* origins, const float* dirs, float* x_fm, int ldp, const float* u_final,
+                       int u_final_stride, int N_final, float* samples_final, float* z_final, int ld_final, void* stream);
+int neat_sampler_finish_picked(const float* samples, int N, const float* z_final, int ld_final, const int* n_final, const int* pick_all,
+                               int n_step, int n_extra, float near, float far, int R, const int* eik_idx, float* z_vals, float* z_eik,
+                               void* stream);
 
 /* ---- 8f-1 (next row): dataset attraction field, replacement for the un-vendored hawp.base._C.encodels ------------
  * (datasets/blender_hawp_dataset.py:96, scene_hawp_dataset.py:95).  lines [N,4] = (x1,y1,x2,y2) in pixels;

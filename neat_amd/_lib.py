@@ -6,7 +6,7 @@ import ctypes
 import os
 
 NUM_LAYERS = 19
-ABI_VERSION = 12
+ABI_VERSION = 13
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "fp16x3": 4}
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEAT_HIP_LIB") or os.path.join(_HERE, "csrc", "libneat_hip.so")      # NEAT_HIP_LIB: a probe build (scripts/probes/abl_build.sh)
@@ -69,6 +69,11 @@ _SIGNATURES = {
                                                  c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "neat_sampler_finish_dev": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
+    "neat_sdf_ldp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "neat_sdf_values_laid_out": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
+    "neat_sampler_init_rays": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "neat_sampler_round": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp]),
+    "neat_sampler_finish_picked": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_encode_lines": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_gather_batch": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int,
                                          c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),

@@ -600,6 +600,10 @@ __global__ __launch_bounds__(WG) void rowscale_kernel(RowScaleArgs a) {
 // small per-point kernels (feature-major outputs)
 // ---------------------------------------------------------------------------------------------
 // x = o + z d for p = r*S + i ; also writes row-major points if requested
+// A value the compiler may not fuse into an fma with its consumer.  (HIP's __fmul_rn / __fadd_rn are plain operators under the default
+// -ffp-contract=fast and DO get contracted: the round-5 form of the two kernels below compiled to v_fmac_f32 / v_pk_fma_f32.)
+__device__ __forceinline__ float rounded(float x) { asm volatile("" : "+v"(x)); return x; }
+
 __global__ void points_from_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                         const float* __restrict__ z, int R, int S, int ldp,
                                         float* __restrict__ x_fm, float* __restrict__ pts_rm,
@@ -615,7 +619,7 @@ __global__ void points_from_rays_kernel(const float* __restrict__ o, const float
     const int r = p / S;
     const float zz = z[p];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) xv[c] = __fadd_rn(o[r * 3 + c], __fmul_rn(zz, d[r * 3 + c]));      // torch's `cam_loc + z * dirs` (rend_a :395-396): product rounded, then the sum -- no fma
+    for (int c = 0; c < 3; ++c) xv[c] = o[r * 3 + c] + rounded(zz * d[r * 3 + c]);      // torch's `cam_loc + z * dirs` (rend_a :395-396): product rounded, then the sum -- no fma
     if (pts_rm) { pts_rm[p * 3 + 0] = xv[0]; pts_rm[p * 3 + 1] = xv[1]; pts_rm[p * 3 + 2] = xv[2]; }
   }
 #pragma unroll
@@ -1162,7 +1166,7 @@ __global__ void eik_points_kernel(const float* __restrict__ uniform, const float
   else if (p < 2 * R) {
     const int r = p - R;
     const float ze = z_eik ? z_eik[r] : z[(size_t)r * S + idx[r]];     // the drawn depth, or the draw's index into the ray's depths
-    v = fmaf(ze, d[3 * r + c], o[3 * r + c]);
+    v = o[3 * r + c] + rounded(ze * d[3 * r + c]);      // `cam_loc + z_samples_eik * ray_dirs` (rend_a :519-520): product rounded, then the sum, like the main pass's points
   }
   else v = extra[i - 6 * R];
   out[i] = v;

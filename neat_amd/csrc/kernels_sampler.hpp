@@ -76,60 +76,89 @@ __device__ __forceinline__ float interval_bound(float a, float d0, float d1) {
 // wave per ray scanning 64-interval chunks took 105 us per launch at n = 640 (1024 rays = one wave per SIMD, everything exposed
 // latency); lane-blocked with unrolled chains 76 us; four waves per ray ... see DESIGN.md.
 constexpr int BOUND_T = 256;
-struct BoundScratch { double e[BOUND_T / 64], s[BOUND_T / 64]; float mx[BOUND_T / 64]; };
+constexpr int BOUND_NB = 1;       // betas evaluated per pass of the bisection
+struct BoundScratch { double e[BOUND_NB][BOUND_T / 64], s[BOUND_NB][BOUND_T / 64]; float mx[BOUND_NB][BOUND_T / 64]; };
 
-template <int PER>
-__device__ __forceinline__ float error_bound_t(const float* sdf, const float* dist, const float* dstar, int m, float beta, int tid,
-                                               BoundScratch* sc) {
+// NB betas per pass.  Round 6 measured NB = 3 (the midpoint and both candidates for the next one: five passes instead of the bisection's
+// ten dependent evaluations, same bits): sampler_bound_kernel 20-26 -> 27-33 us -- the launch is bound by its VALU instructions (16
+// waves per compute unit keep the pipes busy), not by the dependent chain, so three times the arithmetic per pass costs more than the
+// halved pass count saves.  NB = 1 is what runs.
+template <int PER, int NB>
+__device__ __forceinline__ void error_bound_t(const float* sdf, const float* dist, const float* dstar, int m, const float (&beta)[NB], int tid,
+                                              BoundScratch* sc, float (&out)[NB]) {
   const int lane = tid & 63, wave = tid >> 6;
   const int j0 = tid * PER;
   // The bisection only compares this bound with eps, so its terms use the hardware exp2 / reciprocal forms (each within ~2 ulp of
   // the library functions, 1 or 2 instructions instead of 15 .. 40): the kernel is VALU-bound -- 11 evaluations x n intervals x
   // 1024 rays -- and the exact expf / expm1f / IEEE-division sequences were 5/6 of its instructions.  The pdf the samples are
-  // drawn from (sampler_resample_kernel) keeps the exact functions.
-  const float inv_b = 1.0f / beta, inv_q = 1.0f / (4.0f * beta * beta);
-  float e[PER], sv[PER];
-  double te = 0.0, ts = 0.0;
+  // drawn from (resample_cdf_t) keeps the exact functions.
+  float e[NB][PER], sv[NB][PER];
+  double te[NB], ts[NB], ie[NB], is[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { te[b] = 0.0; ts[b] = 0.0; }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const bool ok = j0 + k < m;
     const int j = min(j0 + k, m - 1);
-    const float d = dist[j], sd = sdf[j];
+    const float d = dist[j], sd = sdf[j], ds = dstar[j];
     const float sg = (sd > 0.0f) ? 0.5f : ((sd < 0.0f) ? -0.5f : 0.0f);
-    e[k] = ok ? d * inv_b * (0.5f + sg * (__expf(-fabsf(sd) * inv_b) - 1.0f)) : 0.0f;      // d * laplace_sigma(sd, beta)
-    sv[k] = ok ? __expf(-dstar[j] * inv_b) * (d * d) * inv_q : 0.0f;
-    te += (double)e[k];
-    ts += (double)sv[k];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float inv_b = 1.0f / beta[b], inv_q = 1.0f / (4.0f * beta[b] * beta[b]);
+      e[b][k] = ok ? d * inv_b * (0.5f + sg * (__expf(-fabsf(sd) * inv_b) - 1.0f)) : 0.0f;      // d * laplace_sigma(sd, beta)
+      sv[b][k] = ok ? __expf(-ds * inv_b) * (d * d) * inv_q : 0.0f;
+      te[b] += (double)e[b][k];
+      ts[b] += (double)sv[b][k];
+    }
   }
-  const double ie = wave_incl_scan_d(te, lane), is = wave_incl_scan_d(ts, lane);
-  if (lane == 63) { sc->e[wave] = ie; sc->s[wave] = is; }
-  __syncthreads();
-  double re = ie - te, rs = is - ts;                       // exclusive offsets of this thread
 #pragma unroll
-  for (int w = 0; w < BOUND_T / 64; ++w)
-    if (w < wave) { re += sc->e[w]; rs += sc->s[w]; }
-  float best = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    rs += (double)sv[k];
-    const float b = (fminf(__expf((float)rs), 1.0e6f) - 1.0f) * __expf(-(float)re);
-    if (j0 + k < m) best = fmaxf(best, b);
-    re += (double)e[k];
+  for (int b = 0; b < NB; ++b) {
+    ie[b] = wave_incl_scan_d(te[b], lane); is[b] = wave_incl_scan_d(ts[b], lane);
+    if (lane == 63) { sc->e[b][wave] = ie[b]; sc->s[b][wave] = is[b]; }
   }
-  best = wave_max(best);
-  if (lane == 0) sc->mx[wave] = best;
+  __syncthreads();
+  float best[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    double re = ie[b] - te[b], rs = is[b] - ts[b];                       // exclusive offsets of this thread
+#pragma unroll
+    for (int w = 0; w < BOUND_T / 64; ++w)
+      if (w < wave) { re += sc->e[b][w]; rs += sc->s[b][w]; }
+    float bb = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      rs += (double)sv[b][k];
+      const float v = (fminf(__expf((float)rs), 1.0e6f) - 1.0f) * __expf(-(float)re);
+      if (j0 + k < m) bb = fmaxf(bb, v);
+      re += (double)e[b][k];
+    }
+    bb = wave_max(bb);
+    if (lane == 0) sc->mx[b][wave] = bb;
+    best[b] = bb;
+  }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < BOUND_T / 64; ++w) best = fmaxf(best, sc->mx[w]);
-  return best;                                             // (the next evaluation's first barrier orders the reuse of *sc)
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int w = 0; w < BOUND_T / 64; ++w) best[b] = fmaxf(best[b], sc->mx[b][w]);
+    out[b] = best[b];                                      // (the next evaluation's first barrier orders the reuse of *sc)
+  }
 }
 
-__device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int tid, BoundScratch* sc) {
+template <int NB>
+__device__ __forceinline__ void error_bound(const float* sdf, const float* dist, const float* dstar, int m, const float (&beta)[NB], int tid,
+                                            BoundScratch* sc, float (&out)[NB]) {
   switch (((m + BOUND_T - 1) / BOUND_T) | 1) {      // n = 128 k samples (the reference's grids): PER = 1 (n <= 256) or 3; SMAX = 1024 -> 5
-    case 1: return error_bound_t<1>(sdf, dist, dstar, m, beta, tid, sc);
-    case 3: return error_bound_t<3>(sdf, dist, dstar, m, beta, tid, sc);
-    default: return error_bound_t<5>(sdf, dist, dstar, m, beta, tid, sc);
+    case 1: error_bound_t<1, NB>(sdf, dist, dstar, m, beta, tid, sc, out); break;
+    case 3: error_bound_t<3, NB>(sdf, dist, dstar, m, beta, tid, sc, out); break;
+    default: error_bound_t<5, NB>(sdf, dist, dstar, m, beta, tid, sc, out); break;
   }
+}
+__device__ __forceinline__ float error_bound(const float* sdf, const float* dist, const float* dstar, int m, float beta, int tid, BoundScratch* sc) {
+  const float b1[1] = {beta};
+  float o1[1];
+  error_bound<1>(sdf, dist, dstar, m, b1, tid, sc, o1);
+  return o1[0];
 }
 
 struct SamplerBoundArgs {
@@ -141,41 +170,58 @@ struct SamplerBoundArgs {
   const int* gate; int gate_value;              // device-decided rounds (sync-free sampler): run only if *gate == gate_value (null: always)
 };
 
+// The ray's merged sdf values (:152-157), interval lengths and d* into LDS; `sdf_out` keeps the merged row for the next round.
+__device__ __forceinline__ void bound_load(const float* __restrict__ z, int n, int r, const float* __restrict__ sdf_old,
+                                           const float* __restrict__ sdf_new, const int* __restrict__ order, int n_old,
+                                           float* __restrict__ sdf_out, float* ssdf, float* sdist, float* sdstar, float* sz, int tid) {
+  for (int j = tid; j < n; j += BOUND_T) {
+    float v;
+    if (order) {
+      const int o = order[(size_t)r * n + j];
+      v = o < n_old ? sdf_old[(size_t)r * n_old + o] : sdf_new[(size_t)r * (n - n_old) + (o - n_old)];
+    } else {
+      v = sdf_new[(size_t)r * n + j];
+    }
+    ssdf[j] = v;
+    sdf_out[(size_t)r * n + j] = v;
+    if (sz) sz[j] = z[(size_t)r * n + j];
+  }
+  __syncthreads();
+  const int m = n - 1;
+  for (int j = tid; j < m; j += BOUND_T) {
+    const float d = z[(size_t)r * n + j + 1] - z[(size_t)r * n + j];
+    sdist[j] = d;
+    sdstar[j] = interval_bound(d, ssdf[j], ssdf[j + 1]);
+  }
+  __syncthreads();
+}
+
+// Per-ray bisection of beta on [beta0, beta_in] (:177-185); every thread of the workgroup holds the same lo / hi.
+__device__ __forceinline__ float bisect_beta(const float* ssdf, const float* sdist, const float* sdstar, int m, float beta0, float hi,
+                                             float eps, int iters, int tid, BoundScratch* sc) {
+  if (error_bound(ssdf, sdist, sdstar, m, beta0, tid, sc) <= eps) hi = beta0;      // (:177-178)
+  float lo = beta0;
+  // hi == lo (a ray whose bound already holds at beta0): every further midpoint is (beta0 + beta0) / 2 = beta0 exactly and passes the
+  // test again -- the reference's ten iterations change nothing, so they are skipped (round 6; same bits)
+  if (hi == lo) return hi;
+  int it = 0;
+  for (; it < iters; ++it) {
+    const float mid = (lo + hi) / 2.0f;
+    const float err = error_bound(ssdf, sdist, sdstar, m, mid, tid, sc);
+    if (err <= eps) hi = mid;
+    if (err > eps) lo = mid;
+  }
+  return hi;
+}
+
 __global__ __launch_bounds__(BOUND_T) void sampler_bound_kernel(SamplerBoundArgs a) {
   __shared__ float ssdf[SMAX], sdist[SMAX], sdstar[SMAX];
   __shared__ BoundScratch sc;
   if (a.gate && *a.gate != a.gate_value) return;
   const int r = blockIdx.x, tid = threadIdx.x, n = a.n;
-  const float* z = a.z + (size_t)r * n;
-  for (int j = tid; j < n; j += BOUND_T) {
-    float v;
-    if (a.order) {
-      const int o = a.order[(size_t)r * n + j];
-      v = o < a.n_old ? a.sdf_old[(size_t)r * a.n_old + o] : a.sdf_new[(size_t)r * (n - a.n_old) + (o - a.n_old)];
-    } else {
-      v = a.sdf_new[(size_t)r * n + j];
-    }
-    ssdf[j] = v;
-    a.sdf_out[(size_t)r * n + j] = v;
-  }
-  __syncthreads();
-  const int m = n - 1;
-  for (int j = tid; j < m; j += BOUND_T) {
-    const float d = z[j + 1] - z[j];
-    sdist[j] = d;
-    sdstar[j] = interval_bound(d, ssdf[j], ssdf[j + 1]);
-  }
-  __syncthreads();
+  bound_load(a.z, n, r, a.sdf_old, a.sdf_new, a.order, a.n_old, a.sdf_out, ssdf, sdist, sdstar, nullptr, tid);
   const float beta0 = *a.beta0;
-  float hi = a.beta_in[r];
-  if (error_bound(ssdf, sdist, sdstar, m, beta0, tid, &sc) <= a.eps) hi = beta0;      // (:177-178)
-  float lo = beta0;
-  for (int it = 0; it < a.iters; ++it) {                                                // bisection (:179-185); every thread holds the same lo / hi
-    const float mid = (lo + hi) / 2.0f;
-    const float err = error_bound(ssdf, sdist, sdstar, m, mid, tid, &sc);
-    if (err <= a.eps) hi = mid;
-    if (err > a.eps) lo = mid;
-  }
+  const float hi = bisect_beta(ssdf, sdist, sdstar, n - 1, beta0, a.beta_in[r], a.eps, a.iters, tid, &sc);
   if (tid == 0) {
     a.beta_out[r] = hi;
     if (hi > beta0) atomicOr(a.flag, 1);
@@ -199,10 +245,131 @@ struct SamplerResampleArgs {
   float* z_final; int ld_final; int* n_final;
 };
 
-__global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArgs a) {
+// ---- resampling of one ray by a workgroup of BOUND_T threads (round 6; before: one wavefront per ray, 64-interval chunks) -----------
+// Thread t owns the PER consecutive intervals [t PER, (t + 1) PER): fp64 partial sums, a DPP wave scan and the totals of the lower
+// waves give its prefix (as error_bound_t).  The reference's cumsums run on torch-CPU in double and round every knot once; so do these,
+// in another summation order (exact to ~1e-16 before the one rounding).
+struct ResampleScratch { double a[BOUND_T / 64], b[BOUND_T / 64]; };
+
+__device__ __forceinline__ double block_excl_offset(double incl, double own, int lane, int wave, double* tot, double* total) {
+  if (lane == 63) tot[wave] = incl;
+  __syncthreads();
+  double off = incl - own, all = 0.0;
+#pragma unroll
+  for (int w = 0; w < BOUND_T / 64; ++w) { if (w < wave) off += tot[w]; all += tot[w]; }
+  if (total) *total = all;
+  return off;
+}
+
+// pdf over the n-1 intervals (error-bound opacity :205-211 if refine, rendering weights + 1e-5 :220-222 otherwise) -> normalised ->
+// cdf[0..n-1] in scdf (cdf[0] = 0).  sz / ssdf: the ray's grid and sdf values in LDS.
+template <int PER>
+__device__ __forceinline__ void resample_cdf_t(const float* sz, const float* ssdf, float* scdf, int n, float beta, bool refine,
+                                               float add_tiny, int tid, ResampleScratch* sc) {
+  const int lane = tid & 63, wave = tid >> 6, m = n - 1, j0 = tid * PER;
+  float e[PER], sv[PER], pdf[PER];
+  double te = 0.0, ts = 0.0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int j = j0 + k;
+    e[k] = 0.0f; sv[k] = 0.0f;
+    if (j < n) {
+      const float d = (j < m) ? sz[j + 1] - sz[j] : 1e10f;
+      e[k] = d * laplace_sigma(ssdf[j], beta);
+      if (refine && j < m) sv[k] = expf(-interval_bound(d, ssdf[j], ssdf[j + 1]) / beta) * (d * d) / (4.0f * beta * beta);
+    }
+    te += (double)e[k];
+    ts += (double)sv[k];
+  }
+  const double ie = wave_incl_scan_d(te, lane), is = wave_incl_scan_d(ts, lane);
+  if (lane == 63) { sc->a[wave] = ie; sc->b[wave] = is; }
+  __syncthreads();
+  double re = ie - te, rs = is - ts;
+#pragma unroll
+  for (int w = 0; w < BOUND_T / 64; ++w)
+    if (w < wave) { re += sc->a[w]; rs += sc->b[w]; }
+  double tp = 0.0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int j = j0 + k;
+    const float T = expf(-(float)re);                  // exclusive prefix: never contains the 1e10 tail interval
+    rs += (double)sv[k];
+    float pv = 0.0f;
+    if (j < m) pv = refine ? (fminf(expf((float)rs), 1.0e6f) - 1.0f) * T + add_tiny : (1.0f - expf(-e[k])) * T + 1e-5f;
+    pdf[k] = pv;
+    tp += (double)pv;
+    re += (double)e[k];
+  }
+  __syncthreads();                                      // (sc->a / b are reused)
+  double sum;
+  const double ip = wave_incl_scan_d(tp, lane);
+  block_excl_offset(ip, tp, lane, wave, sc->a, &sum);
+  // normalise (pdf / sum in fp32, like `pdf / torch.sum(pdf)`), inclusive cumsum in fp64, each knot rounded once
+  const float sumf = (float)sum;
+  double tq = 0.0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { pdf[k] = (j0 + k < m) ? pdf[k] / sumf : 0.0f; tq += (double)pdf[k]; }
+  const double iq = wave_incl_scan_d(tq, lane);
+  double run = block_excl_offset(iq, tq, lane, wave, sc->b, nullptr);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    run += (double)pdf[k];
+    if (j0 + k < m) scdf[j0 + k + 1] = (float)run;
+  }
+  if (tid == 0) scdf[0] = 0.0f;
+  __syncthreads();
+}
+
+__device__ __forceinline__ void resample_cdf(const float* sz, const float* ssdf, float* scdf, int n, float beta, bool refine, float add_tiny,
+                                             int tid, ResampleScratch* sc) {
+  switch (((n + BOUND_T - 1) / BOUND_T) | 1) {
+    case 1: resample_cdf_t<1>(sz, ssdf, scdf, n, beta, refine, add_tiny, tid, sc); break;
+    case 3: resample_cdf_t<3>(sz, ssdf, scdf, n, beta, refine, add_tiny, tid, sc); break;
+    default: resample_cdf_t<5>(sz, ssdf, scdf, n, beta, refine, add_tiny, tid, sc); break;
+  }
+}
+
+// inverse CDF (:237-249): searchsorted(right) + lerp with the 1e-5 denominator guard; N samples at u -> ssmp (LDS) and `samples`
+__device__ __forceinline__ void resample_draw(const float* sz, const float* scdf, int n, const float* __restrict__ u, int N,
+                                              float* ssmp, float* __restrict__ samples, int tid) {
+  for (int k = tid; k < N; k += BOUND_T) {
+    const float uv = u[k];
+    int lo = 0, hi = n;                          // first index with cdf[idx] > u
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (scdf[mid] > uv) hi = mid; else lo = mid + 1; }
+    const int below = max(lo - 1, 0), above = min(lo, n - 1);
+    float den = scdf[above] - scdf[below];
+    if (den < 1e-5f) den = 1.0f;
+    const float t = (uv - scdf[below]) / den;
+    const float smp = sz[below] + t * (sz[above] - sz[below]);
+    if (ssmp) ssmp[k] = smp;
+    samples[k] = smp;
+  }
+}
+
+// sorted union of z (sorted) and the new samples (sorted: u is increasing): rank by binary search, old first on ties (:254)
+__device__ __forceinline__ void resample_merge(const float* sz, const float* ssmp, int n, int N, float* __restrict__ z_merged,
+                                               int* __restrict__ order, int tid) {
+  for (int j = tid; j < n; j += BOUND_T) {
+    const float v = sz[j];
+    int lo = 0, hi = N;                          // #samples < v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ssmp[mid] < v) lo = mid + 1; else hi = mid; }
+    z_merged[j + lo] = v;
+    order[j + lo] = j;
+  }
+  for (int k = tid; k < N; k += BOUND_T) {
+    const float v = ssmp[k];
+    int lo = 0, hi = n;                          // #z <= v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sz[mid] <= v) lo = mid + 1; else hi = mid; }
+    z_merged[k + lo] = v;
+    order[k + lo] = n + k;
+  }
+}
+
+__global__ __launch_bounds__(BOUND_T) void sampler_resample_kernel(SamplerResampleArgs a) {
   __shared__ float sz[SMAX], scdf[SMAX], ssmp[SMAX];
   __shared__ float ssdf[SMAX];
-  const int r = blockIdx.x, lane = threadIdx.x, n = a.n, m = n - 1;
+  __shared__ ResampleScratch sc;
+  const int r = blockIdx.x, tid = threadIdx.x, n = a.n;
   bool refine = a.refine != 0;
   const float* uptr = a.u; int ustride = a.u_stride, N = a.N;
   float* samples = a.samples;
@@ -212,102 +379,154 @@ __global__ __launch_bounds__(64) void sampler_resample_kernel(SamplerResampleArg
     if (!refine) { uptr = a.u_final; ustride = a.u_final_stride; N = a.N_final; samples = a.samples_final; }
   }
   const float beta = a.beta[r];
-  for (int j = lane; j < n; j += 64) { sz[j] = a.z[(size_t)r * n + j]; ssdf[j] = a.sdf[(size_t)r * n + j]; }
+  for (int j = tid; j < n; j += BOUND_T) { sz[j] = a.z[(size_t)r * n + j]; ssdf[j] = a.sdf[(size_t)r * n + j]; }
   __syncthreads();
   if (a.cont && !refine) {                        // the grid of the final round is what the tail of Algorithm 1 picks its extra samples from
-    for (int j = lane; j < n; j += 64) a.z_final[(size_t)r * a.ld_final + j] = sz[j];
-    if (r == 0 && lane == 0) { *a.n_final = n; }
+    for (int j = tid; j < n; j += BOUND_T) a.z_final[(size_t)r * a.ld_final + j] = sz[j];
+    if (r == 0 && tid == 0) { *a.n_final = n; }
   }
-  if (a.cont && lane == 0) a.cont[a.round] = refine ? 1 : 2;      // (every ray writes the same value; read by later launches only)
-  // pdf over the n-1 intervals -> scdf[1..n-1] (unnormalised), total in `sum`
-  double carryE = 0.0, carryS = 0.0, sum = 0.0;
-  for (int c0 = 0; c0 < n; c0 += 64) {
-    const int j = c0 + lane;
-    const bool ok = j < n;
-    float e = 0.0f, s = 0.0f;
-    if (ok) {
-      const float d = (j < m) ? sz[j + 1] - sz[j] : 1e10f;
-      e = d * laplace_sigma(ssdf[j], beta);
-      if (j < m) s = expf(-interval_bound(d, ssdf[j], ssdf[j + 1]) / beta) * (d * d) / (4.0f * beta * beta);
-    }
-    const double inclE = wave_incl_scan_d((double)e, lane), inclS = wave_incl_scan_d((double)s, lane);
-    double exclE = __shfl_up(inclE, 1);
-    if (lane == 0) exclE = 0.0;
-    const float T = expf(-(float)(carryE + exclE));
-    float pdf = 0.0f;
-    if (j < m) {
-      if (refine) pdf = (fminf(expf((float)(carryS + inclS)), 1.0e6f) - 1.0f) * T + a.add_tiny;      // (:205-211)
-      else pdf = (1.0f - expf(-e)) * T + 1e-5f;                                                  // (:220-222)
-      scdf[j + 1] = pdf;
-    }
-    sum += wave_sum_d((double)pdf);
-    carryE += __shfl(inclE, 63);
-    carryS += __shfl(inclS, 63);
-  }
-  __syncthreads();
-  // normalise (pdf / sum in fp32, like `pdf / torch.sum(pdf)`), then inclusive cumsum in fp64, each knot rounded once
-  // -> cdf[0..n-1] with cdf[0] = 0
-  const float sumf = (float)sum;
-  double carry = 0.0;
-  for (int c0 = 0; c0 < m; c0 += 64) {
-    const int j = c0 + lane;
-    const float p = (j < m) ? scdf[j + 1] / sumf : 0.0f;
-    const double incl = wave_incl_scan_d((double)p, lane);
-    if (j < m) scdf[j + 1] = (float)(carry + incl);
-    carry += __shfl(incl, 63);
-  }
-  if (lane == 0) scdf[0] = 0.0f;
-  __syncthreads();
-  // inverse CDF (:237-249): searchsorted(right) + lerp with the 1e-5 denominator guard
-  for (int k = lane; k < N; k += 64) {
-    const float u = uptr[(size_t)r * ustride + k];
-    int lo = 0, hi = n;                          // first index with cdf[idx] > u
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (scdf[mid] > u) hi = mid; else lo = mid + 1; }
-    const int below = max(lo - 1, 0), above = min(lo, n - 1);
-    float den = scdf[above] - scdf[below];
-    if (den < 1e-5f) den = 1.0f;
-    const float t = (u - scdf[below]) / den;
-    const float smp = sz[below] + t * (sz[above] - sz[below]);
-    ssmp[k] = smp;
-    samples[(size_t)r * N + k] = smp;
-  }
+  if (a.cont && tid == 0) a.cont[a.round] = refine ? 1 : 2;      // (every ray writes the same value; read by later launches only)
+  resample_cdf(sz, ssdf, scdf, n, beta, refine, a.add_tiny, tid, &sc);
+  resample_draw(sz, scdf, n, uptr + (size_t)r * ustride, N, ssmp, samples + (size_t)r * N, tid);
   if (!refine) return;
   __syncthreads();
-  // sorted union of z (sorted) and the new samples (sorted: u is increasing): rank by binary search, old first on ties
   const int tot = n + N;
-  for (int j = lane; j < n; j += 64) {
-    const float v = sz[j];
-    int lo = 0, hi = N;                          // #samples < v
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ssmp[mid] < v) lo = mid + 1; else hi = mid; }
-    a.z_merged[(size_t)r * tot + j + lo] = v;
-    a.order[(size_t)r * tot + j + lo] = j;
+  resample_merge(sz, ssmp, n, N, a.z_merged + (size_t)r * tot, a.order + (size_t)r * tot, tid);
+}
+
+// ---- one round of Algorithm 1 as ONE launch (round 6; device-decided rounds) ------------------------------------------------------
+// bound (merge, d*, bisection) -> refine resampling + merge + the NEXT round's query points in the SDF kernels' layout -> the final
+// resampling.  The batch-global test of ray_sampler.py:200 cannot be read inside the launch that produces it, so both outcomes are
+// prepared: every ray of a round before the last refines (used iff some ray sets open[round]); the final samples are drawn by the
+// rays that can still be part of a final round -- all rays in the last round, otherwise those whose own beta has reached beta0 (a
+// round is final only if every ray's has).  A launch of round k > 0 runs iff open[k-1] was set; cont[k] <- 1 marks a round that ran.
+struct SamplerRoundArgs {
+  const float* z; int n, R;                   // [R,n] sorted grid of this round
+  const float* sdf_old; const float* sdf_new; const int* order; int n_old;
+  const float* beta_in; const float* beta0; float eps; int iters;
+  float* sdf_out; float* beta_out;            // merged sdf [R,n], beta [R]
+  int* ctl; int round, max_rounds;            // open[max_rounds] | cont[max_rounds] | n_final
+  float add_tiny; const float* u_refine; int N_refine;
+  float* samples_refine; float* z_merged; int* order_out;      // [R,N_refine], [R,n+N_refine] x2
+  const float* origins; const float* dirs; float* x_fm; int ldp;   // next query: x_fm[c][r N_refine + k] = o + smp d (feature-major, stride ldp)
+  const float* u_final; int u_final_stride, N_final; float* samples_final; float* z_final; int ld_final;
+  int ablate;                                 // probes only (tuning key 30; results WRONG): 1 = no bisection, 2 = no refine path, 4 = no final path
+};
+
+__global__ __launch_bounds__(BOUND_T) void sampler_round_kernel(SamplerRoundArgs a) {
+  __shared__ float ssdf[SMAX], sdist[SMAX], sdstar[SMAX], sz[SMAX], scdf[SMAX], ssmp[SMAX];
+  __shared__ BoundScratch bsc;
+  __shared__ ResampleScratch rsc;
+  const int K = a.max_rounds;
+  if (a.round > 0 && a.ctl[a.round - 1] == 0) return;          // the previous round closed the sampler
+  const int r = blockIdx.x, tid = threadIdx.x, n = a.n;
+  bound_load(a.z, n, r, a.sdf_old, a.sdf_new, a.order, a.n_old, a.sdf_out, ssdf, sdist, sdstar, sz, tid);
+  const float beta0 = *a.beta0;
+  const float beta = (a.ablate & 1) ? a.beta_in[r] : bisect_beta(ssdf, sdist, sdstar, n - 1, beta0, a.beta_in[r], a.eps, a.iters, tid, &bsc);
+  const bool open = beta > beta0, last = a.round + 1 >= K;
+  if (tid == 0) {
+    a.beta_out[r] = beta;
+    if (open) atomicOr(a.ctl + a.round, 1);
+    a.ctl[K + a.round] = 1;
   }
-  for (int k = lane; k < N; k += 64) {
-    const float v = ssmp[k];
-    int lo = 0, hi = n;                          // #z <= v
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sz[mid] <= v) lo = mid + 1; else hi = mid; }
-    a.z_merged[(size_t)r * tot + k + lo] = v;
-    a.order[(size_t)r * tot + k + lo] = n + k;
+  if (!last && !(a.ablate & 2)) {
+    const int N = a.N_refine, tot = n + N;
+    resample_cdf(sz, ssdf, scdf, n, beta, true, a.add_tiny, tid, &rsc);
+    resample_draw(sz, scdf, n, a.u_refine, N, ssmp, a.samples_refine + (size_t)r * N, tid);
+    __syncthreads();
+    resample_merge(sz, ssmp, n, N, a.z_merged + (size_t)r * tot, a.order_out + (size_t)r * tot, tid);
+    if (a.x_fm) {
+      const float o0 = a.origins[3 * r], o1 = a.origins[3 * r + 1], o2 = a.origins[3 * r + 2];
+      const float d0 = a.dirs[3 * r], d1 = a.dirs[3 * r + 1], d2 = a.dirs[3 * r + 2];
+      for (int k = tid; k < N; k += BOUND_T) {
+        const float zz = ssmp[k];
+        const size_t p = (size_t)r * N + k;
+        a.x_fm[p] = o0 + rounded(zz * d0);                      // `cam_loc + samples * dirs` (:146): product rounded, then the sum
+        a.x_fm[(size_t)a.ldp + p] = o1 + rounded(zz * d1);
+        a.x_fm[2 * (size_t)a.ldp + p] = o2 + rounded(zz * d2);
+      }
+      if (r == a.R - 1)                                         // the layout's padding columns
+        for (int p = a.R * N + tid; p < a.ldp; p += BOUND_T) { a.x_fm[p] = 0.f; a.x_fm[(size_t)a.ldp + p] = 0.f; a.x_fm[2 * (size_t)a.ldp + p] = 0.f; }
+    }
+  }
+  if ((last || !open) && !(a.ablate & 4)) {
+    __syncthreads();
+    for (int j = tid; j < n; j += BOUND_T) a.z_final[(size_t)r * a.ld_final + j] = sz[j];
+    if (tid == 0) a.ctl[2 * K] = n;                             // (every ray that writes, writes this round's n; the last round to run wins)
+    resample_cdf(sz, ssdf, scdf, n, beta, false, a.add_tiny, tid, &rsc);
+    resample_draw(sz, scdf, n, a.u_final + (size_t)r * a.u_final_stride, a.N_final, nullptr, a.samples_final + (size_t)r * a.N_final, tid);
   }
 }
 
 // What Algorithm 1 computes before its first round (ray_sampler.py:131-143), one wavefront per ray: beta0 = |beta_param| + beta_min
 // (density.py:29-30; written once), the ray's initial beta = sqrt(beta_c * sum_i (z[i+1] - z[i])^2) with beta_c = 1 / (4 log(1 + eps))
 // (Lemma 2), and the control words of the device-decided rounds zeroed -- nine elementwise / reduction launches otherwise.
-__global__ __launch_bounds__(256) void sampler_init_kernel(const float* __restrict__ z, int R, int n, const float* __restrict__ beta_ptr,
-                                                           float beta_min, float beta_c, float* __restrict__ beta0,
-                                                           float* __restrict__ beta_out, int* __restrict__ ctl, int nctl) {
+// Round 6 adds two optional jobs to the same launch: (i) the FIRST round's query points o + z d in the SDF kernels' layout (x_fm
+// [3][ldp], as sampler_round_kernel writes the later rounds'), (ii) in extra workgroups, the training-mode picks of every possible final
+// grid size (sampler_pick_block) -- off the critical path instead of one 16 us launch behind the last round.
+struct SamplerInitArgs {
+  const float* z; int R, n; const float* beta_ptr; float beta_min, beta_c; float* beta0; float* beta_out; int* ctl; int nctl;
+  const float* origins; const float* dirs; float* x_fm; int ldp;      // (i): null = not wanted
+  const float* keys; int n_step, n_cand, n_extra; int* pick_all;       // (ii): pick_all [n_cand][n_extra] for grids of n_step (c + 1) depths
+  int init_blocks, pick_parts;
+};
+
+// The n_extra smallest of the first n keys, in key order (equal keys: the lower index first).  One key per thread; a candidate's keys
+// are spread over ceil(n / 256) workgroups (`part` = which 256 keys this workgroup ranks): on ONE compute unit the 8 compares per four
+// keys x n / 4 broadcast reads x n threads were 16 us (sampler_pick_kernel) resp. 25 us (256 threads, 3 keys each).
+__device__ __forceinline__ void sampler_pick_block(const float* __restrict__ keys, int n, int n_extra, int* __restrict__ pick, float* sk, int part) {
+  const int tid = threadIdx.x;
+  if (part * 256 >= n) return;
+  for (int i = tid; i < SMAX; i += 256) sk[i] = i < n ? keys[i] : INFINITY;      // padding never ranks below a key
+  __syncthreads();
+  const float4* sk4 = (const float4*)sk;
+  const int n4 = (n + 3) >> 2, i = part * 256 + tid;
+  if (i >= n) return;
+  const float x = sk[i];
+  int lt = 0, le = 0;
+#pragma unroll 4
+  for (int j = 0; j < n4; ++j) {                // (one broadcast ds_read_b128 per four keys)
+    const float4 k = sk4[j];
+    lt += (k.x < x) + (k.y < x) + (k.z < x) + (k.w < x);
+    le += (k.x <= x) + (k.y <= x) + (k.z <= x) + (k.w <= x);
+  }
+  int rank = lt;
+  if (le - lt > 1)                               // equal keys (24-bit uniforms: about 1 call in 80 has a pair)
+    for (int j = 0; j < i; ++j) rank += sk[j] == x;
+  if (rank < n_extra) pick[rank] = i;
+}
+
+__global__ __launch_bounds__(256) void sampler_init_kernel(SamplerInitArgs a) {
+  __shared__ __attribute__((aligned(16))) float sk[SMAX];
+  if ((int)blockIdx.x >= a.init_blocks) {          // pick role: pick_parts workgroups per candidate final grid
+    const int b = blockIdx.x - a.init_blocks, c = b / a.pick_parts;
+    sampler_pick_block(a.keys, min(a.n_step * (c + 1), SMAX), a.n_extra, a.pick_all + (size_t)c * a.n_extra, sk, b - c * a.pick_parts);
+    return;
+  }
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < nctl; i += 256) ctl[i] = 0;
-    if (threadIdx.x == 0) beta0[0] = fabsf(*beta_ptr) + beta_min;
+    for (int i = threadIdx.x; i < a.nctl; i += 256) a.ctl[i] = 0;
+    if (threadIdx.x == 0) a.beta0[0] = fabsf(*a.beta_ptr) + a.beta_min;
   }
-  if (r >= R) return;
-  const float* zr = z + (size_t)r * n;
+  if (a.x_fm && blockIdx.x == 0)                   // the layout's padding columns
+    for (int p = a.R * a.n + threadIdx.x; p < a.ldp; p += 256) { a.x_fm[p] = 0.f; a.x_fm[(size_t)a.ldp + p] = 0.f; a.x_fm[2 * (size_t)a.ldp + p] = 0.f; }
+  if (r >= a.R) return;
+  const float* zr = a.z + (size_t)r * a.n;
   float acc = 0.0f;
-  for (int j = lane; j + 1 < n; j += 64) { const float g = zr[j + 1] - zr[j]; acc += g * g; }
+  for (int j = lane; j + 1 < a.n; j += 64) { const float g = zr[j + 1] - zr[j]; acc += g * g; }
   acc = wave_sum(acc);
-  if (lane == 0) beta_out[r] = sqrtf(beta_c * acc);
+  if (lane == 0) a.beta_out[r] = sqrtf(a.beta_c * acc);
+  if (a.x_fm) {
+    const float o0 = a.origins[3 * r], o1 = a.origins[3 * r + 1], o2 = a.origins[3 * r + 2];
+    const float d0 = a.dirs[3 * r], d1 = a.dirs[3 * r + 1], d2 = a.dirs[3 * r + 2];
+    for (int j = lane; j < a.n; j += 64) {
+      const float zz = zr[j];
+      const size_t p = (size_t)r * a.n + j;
+      a.x_fm[p] = o0 + rounded(zz * d0);
+      a.x_fm[(size_t)a.ldp + p] = o1 + rounded(zz * d1);
+      a.x_fm[2 * (size_t)a.ldp + p] = o2 + rounded(zz * d2);
+    }
+  }
 }
 
 // Which samples of the final grid join the output (ray_sampler.py:263-268), decided on the device from the grid size n:
@@ -406,7 +625,6 @@ __global__ __launch_bounds__(64) void sample_pdf_kernel(SamplePdfArgs a) {
 // the caller), every operation is rounded separately like the reference's chain of elementwise torch ops (no fma contraction):
 //   z0 = near (1 - t) + far t;   training: mid = 0.5 (z0[j+1] + z0[j]), upper = [mid | z0[N-1]], lower = [z0[0] | mid],
 //   z = lower + (upper - lower) rand.      near / far: per ray (pointer) or one value for all rays.
-__device__ __forceinline__ float rounded(float x) { asm volatile("" : "+v"(x)); return x; }      // a product the compiler may not fuse into an fma
 __global__ void uniform_depths_kernel(const float* __restrict__ near_r, float near_s, const float* __restrict__ far_r, float far_s,
                                       const float* __restrict__ t, const float* __restrict__ rnd, int R, int N, float* __restrict__ z) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,18 +650,37 @@ struct SamplerFinishArgs {
   const int* eik_idx;                 // [R] index into the output row (:275-276)
   float* z_vals; float* z_eik;        // [R, N+2+n_extra] sorted, [R]
   int ld_z;                           // row stride of the grid (= n in the host-decided mode)
+  // round 6, device-decided rounds: the grid size is *n_final; pick = pick_all[n / n_step - 1] (sampler_init_kernel's pick role), or --
+  // pick == null, eval -- torch.linspace(0, n - 1, n_extra).long() evaluated here (the reference's formula, fp32, symmetric around the
+  // middle)
+  const int* n_final = nullptr; int n_step = 0;
 };
 
 __global__ __launch_bounds__(64) void sampler_finish_kernel(SamplerFinishArgs a) {
   __shared__ float v[SMAX];
   const int r = blockIdx.x, lane = threadIdx.x;
   const int M = a.N + 2 + a.n_extra;
+  const int* pick = a.pick;
+  int n = 0;
+  if (a.n_final) {
+    n = *a.n_final;
+    if (pick) pick += (size_t)(n / a.n_step - 1) * a.n_extra;
+  }
   for (int k = lane; k < M; k += 64) {
     float x;
     if (k < a.N) x = a.samples[(size_t)r * a.N + k];
     else if (k == a.N) x = a.near;
     else if (k == a.N + 1) x = a.far;
-    else x = a.z[(size_t)r * a.ld_z + a.pick[k - a.N - 2]];
+    else {
+      const int j = k - a.N - 2;
+      int idx;
+      if (pick) idx = pick[j];
+      else {
+        const float start = 0.0f, end = (float)(n - 1), step = (end - start) / (float)(a.n_extra - 1);
+        idx = (int)(j < a.n_extra / 2 ? start + step * (float)j : end - step * (float)(a.n_extra - 1 - j));
+      }
+      x = a.z[(size_t)r * a.ld_z + idx];
+    }
     v[k] = x;
   }
   __syncthreads();

@@ -237,6 +237,7 @@ inline int dw_grid(int ldp) {
 int g_ws_aux_nt = 15;       // non-temporal accesses (tuning key 11): bit 0 / 1 = fetch of aux0 / aux1 of the streaming layer kernels, bit 2 =
                             // weight-gradient operands, bit 3 = `in` of the layer kernels, bit 4 = store of out1 (m_l)
 int g_ws_wide_store = 1;    // streaming layer kernels: 16-byte output stores (tuning key 12)
+int g_sampler_ablate = 0;
 const int* g_gate = nullptr; int g_gate_value = 0;      // set around one neat_sdf_forward call by neat_sdf_values_gated
 int g_fused_interleave = 0; // fused primal chain: batches interleaved over the workgroups (tuning key 10)
 int g_ws_interleave = 1;    // 1: tiles interleaved over the workgroups instead of one contiguous range each
@@ -1640,7 +1641,7 @@ NEAT_TWIN(neat_set_tuning) NEAT_TWIN(neat_prof_enable) NEAT_TWIN(neat_prof_colle
 NEAT_TWIN(neat_packed_floats) NEAT_TWIN(neat_pack_weights) NEAT_TWIN(neat_sdf_ws_floats) NEAT_TWIN(neat_sdf_forward)
 NEAT_TWIN(neat_sdf_backward) NEAT_TWIN(neat_heads_ws_floats) NEAT_TWIN(neat_heads_forward) NEAT_TWIN(neat_render_ws_floats)
 NEAT_TWIN(neat_render_forward) NEAT_TWIN(neat_render_backward) NEAT_TWIN(neat_render_eval_ws_floats)
-NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated) NEAT_TWIN(neat_sdf_values_rays)
+NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated) NEAT_TWIN(neat_sdf_values_rays) NEAT_TWIN(neat_sdf_values_laid_out)
 #define NEAT_F16_FWD(call) if (precision == 3) { precision = BF16; return f16_##call; } if (precision == HX3 || precision == HX3_FASTVALUES) return f16_##call;
 #else
 #define NEAT_F16_FWD(call)
@@ -1648,7 +1649,7 @@ NEAT_TWIN(neat_render_forward_eval) NEAT_TWIN(neat_sdf_values_gated) NEAT_TWIN(n
 
 extern "C" {
 
-int neat_abi_version(void) { return 12; }
+int neat_abi_version(void) { return 13; }
 
 int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point tile (2 -> 64 points, 4 -> 128 points) */
 #if !NEAT_HALF
@@ -1681,6 +1682,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 24 && (value == 0 || value == 1)) { g_chain_pp = value; return 0; }
   if (key == 25 && (value == 0 || value == 1)) { g_dw_segments = value; return 0; }
   if (key == 28 && (value == 0 || value == 1)) { g_ffn_mfma = value; return 0; }
+  if (key == 30 && value >= 0 && value <= 7) { g_sampler_ablate = value; return 0; }      /* probes: sampler_round_kernel without its bisection (1) / refine (2) / final (4) part */
   return -1;
 }
 
@@ -1781,16 +1783,18 @@ size_t neat_sdf_ws_floats(int P, int mode, int precision) {
 // x [P,3] row-major, or (x == null) the points o + z d of R rays x S depths (P = R S)
 struct RayPoints { const float* origins; const float* dirs; const float* z; int R, S; };
 static int sdf_forward_impl(const float* packed, const neat_net_params* net, const float* x, const RayPoints* rp, int P, int mode, int precision,
-                            float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad, void* stream) {
+                            float radius, float scale, float* ws, float* out257, float* sdf, float* feat, float* grad, void* stream,
+                            bool laid_out = false) {
   const int x3 = take_x3(precision); (void)x3;
   const int hx3 = take_hx3(precision); (void)hx3;
   if (hx3 == 2 && mode != 0) return -1;      // NEAT_F16X3 fast values: values-mode calls only
   if (P <= 0) return 0;
-  if (!packed || !net || (!x && !rp) || !ws || bad_prec(precision)) return -1;
+  if (!packed || !net || (!x && !rp && !laid_out) || !ws || bad_prec(precision)) return -1;
   Ctx c{(hipStream_t)stream, packed, net, P, round_ldp(P, precision), precision};
   c.x3 = x3; c.hx3 = hx3;
   SdfWs w = sdf_ws(ws, c.ldp, mode, precision, hx3);
-  if (x) hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
+  if (laid_out) {}      // the caller (sampler_init_kernel / sampler_round_kernel) wrote w.x = the first 3 rows of the workspace
+  else if (x) hipLaunchKernelGGL(rm_to_fm_kernel, grid1(c.ldp), dim3(256), 0, c.st, x, P, 3, c.ldp, w.x);
   else hipLaunchKernelGGL(points_from_rays_kernel, grid1(c.ldp), dim3(256), 0, c.st, rp->origins, rp->dirs, rp->z, rp->R, rp->S, c.ldp, w.x,
                           (float*)nullptr, (const float*)nullptr, 0);
   if (mode == 0 && precision) {
@@ -1829,6 +1833,19 @@ int neat_sdf_values_rays(const float* packed, const neat_net_params* net, const 
   const RayPoints rp{origins, dirs, z, R, S};
   g_gate = gate; g_gate_value = gate_value;
   const int rc = sdf_forward_impl(packed, net, nullptr, &rp, R * S, 0, precision, radius, scale, ws, nullptr, sdf, nullptr, nullptr, stream);
+  g_gate = nullptr;
+  return rc;
+}
+
+int neat_sdf_ldp(int P, int precision) { return P <= 0 ? 0 : round_ldp(P, precision); }
+
+int neat_sdf_values_laid_out(const float* packed, const neat_net_params* net, int P, int precision, float radius, float scale, float* ws,
+                             float* sdf, const int* gate, int gate_value, void* stream) {
+  NEAT_F16_FWD(neat_sdf_values_laid_out(packed, net, P, precision, radius, scale, ws, sdf, gate, gate_value, stream))
+  if (P <= 0) return 0;
+  if (!packed || !net || !ws || !sdf || bad_prec(precision)) return -1;
+  g_gate = gate; g_gate_value = gate_value;
+  const int rc = sdf_forward_impl(packed, net, nullptr, nullptr, P, 0, precision, radius, scale, ws, nullptr, sdf, nullptr, nullptr, stream, true);
   g_gate = nullptr;
   return rc;
 }
@@ -2034,7 +2051,7 @@ int neat_sampler_resample(const float* z, const float* sdf, int n, int R, const 
   SamplerResampleArgs a{};
   a.z = z; a.sdf = sdf; a.n = n; a.R = R; a.beta = beta; a.refine = refine; a.add_tiny = add_tiny; a.u = u; a.u_stride = u_stride; a.N = N;
   a.samples = samples; a.z_merged = z_merged; a.order = order;
-  hipLaunchKernelGGL(sampler_resample_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sampler_resample_kernel, dim3(R), dim3(BOUND_T), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -2066,9 +2083,50 @@ int neat_uniform_depths(const float* near_r, float near_s, const float* far_r, f
 
 int neat_sampler_init(const float* z, int R, int n, const float* beta, float beta_min, float beta_c, float* beta0, float* beta_ray,
                       int* ctl, int nctl, void* stream) {
+  return neat_sampler_init_rays(z, R, n, beta, beta_min, beta_c, beta0, beta_ray, ctl, nctl, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0,
+                                nullptr, stream);
+}
+
+int neat_sampler_init_rays(const float* z, int R, int n, const float* beta, float beta_min, float beta_c, float* beta0, float* beta_ray,
+                           int* ctl, int nctl, const float* origins, const float* dirs, float* x_fm, int ldp, const float* keys, int n_step,
+                           int n_cand, int n_extra, int* pick_all, void* stream) {
   if (R <= 0 || n < 2 || n > SMAX || !z || !beta || !beta0 || !beta_ray || nctl < 0 || (nctl > 0 && !ctl)) return -1;
-  hipLaunchKernelGGL(sampler_init_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, R, n, beta, beta_min, beta_c, beta0, beta_ray,
-                     ctl, nctl);
+  if (x_fm && (!origins || !dirs || (long long)ldp < (long long)R * n)) return -1;
+  const bool picks = keys != nullptr;
+  if (picks && (!pick_all || n_step < 1 || n_cand < 1 || n_extra < 2 || n_extra > n_step || n_step * n_cand > SMAX)) return -1;
+  SamplerInitArgs a{z, R, n, beta, beta_min, beta_c, beta0, beta_ray, ctl, nctl, origins, dirs, x_fm, ldp, keys, n_step, n_cand, n_extra, pick_all,
+                    (R + 3) / 4, picks ? (n_step * n_cand + 255) / 256 : 0};
+  hipLaunchKernelGGL(sampler_init_kernel, dim3(a.init_blocks + n_cand * a.pick_parts), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_round(const float* z, int n, int R, const float* sdf_old, const float* sdf_new, const int* order, int n_old,
+                       const float* beta_in, const float* beta0, float eps, int iters, float* sdf_out, float* beta_out, int* ctl, int round,
+                       int max_rounds, float add_tiny, const float* u_refine, int N_refine, float* samples_refine, float* z_merged,
+                       int* order_out, const float* origins, const float* dirs, float* x_fm, int ldp, const float* u_final,
+                       int u_final_stride, int N_final, float* samples_final, float* z_final, int ld_final, void* stream) {
+  if (R <= 0) return 0;
+  const bool last = round + 1 >= max_rounds;
+  if (n < 2 || n > SMAX || !z || !sdf_new || (order && !sdf_old) || !beta_in || !beta0 || !sdf_out || !beta_out || !ctl || round < 0 ||
+      round >= max_rounds || N_final < 1 || N_final > SMAX || !u_final || !samples_final || !z_final || ld_final < n) return -1;
+  if (!last && (N_refine < 1 || n + N_refine > SMAX || !u_refine || !samples_refine || !z_merged || !order_out ||
+                (x_fm && (!origins || !dirs || (long long)ldp < (long long)R * N_refine)))) return -1;
+  SamplerRoundArgs a{z, n, R, sdf_old, sdf_new, order, n_old, beta_in, beta0, eps, iters, sdf_out, beta_out, ctl, round, max_rounds, add_tiny,
+                     u_refine, N_refine, samples_refine, z_merged, order_out, origins, dirs, x_fm, ldp, u_final, u_final_stride, N_final,
+                     samples_final, z_final, ld_final, g_sampler_ablate};
+  hipLaunchKernelGGL(sampler_round_kernel, dim3(R), dim3(BOUND_T), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int neat_sampler_finish_picked(const float* samples, int N, const float* z_final, int ld_final, const int* n_final, const int* pick_all,
+                               int n_step, int n_extra, float near, float far, int R, const int* eik_idx, float* z_vals, float* z_eik,
+                               void* stream) {
+  if (R <= 0) return 0;
+  if (N + 2 + n_extra > SMAX || ld_final > SMAX || !samples || !z_final || !n_final || n_extra == 1 || n_extra < 0 || n_step < 1 || !eik_idx ||
+      !z_vals || !z_eik) return -1;
+  SamplerFinishArgs a{samples, N, z_final, 0, pick_all, n_extra, near, far, R, eik_idx, z_vals, z_eik, ld_final};
+  a.n_final = n_final; a.n_step = n_step;
+  hipLaunchKernelGGL(sampler_finish_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -2096,7 +2154,7 @@ int neat_sampler_resample_dev(const float* z, const float* sdf, int n, int R, co
   a.open = open; a.cont = cont; a.round = round; a.max_rounds = max_rounds;
   a.u_final = u_final; a.u_final_stride = u_final_stride; a.N_final = N_final; a.samples_final = samples_final;
   a.z_final = z_final; a.ld_final = ld_final; a.n_final = n_final;
-  hipLaunchKernelGGL(sampler_resample_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sampler_resample_kernel, dim3(R), dim3(BOUND_T), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -522,6 +522,83 @@ def sampler_round_dev(z, sdf_old, sdf_new, order, beta_in, beta0, eps, iters, ad
     return sdf_out, beta_out, fresh, zm, order_out
 
 
+def sdf_query_workspace(handle, P, device, fast=False):
+    """Workspace of the values-mode SDF kernels for P points + the point stride of its x rows (the first 3 rows, feature-major): the
+    sampler's launches write a round's query points there themselves (neat_sampler_init_rays / neat_sampler_round)."""
+    lib = _lib.lib()
+    prec = 5 if (fast and handle.precision == 4) else handle.precision
+    ws = torch.empty(lib.neat_sdf_ws_floats(P, 0, prec), device=device, dtype=torch.float32)
+    return ws, int(lib.neat_sdf_ldp(P, prec))
+
+
+def sdf_values_laid_out(handle, ws, P, radius, scale, gate=None, fast=False):
+    """sdf_values on the P points already laid out in `ws` (sdf_query_workspace) -> [P, 1]."""
+    lib = _lib.lib()
+    sdf = torch.empty(P, 1, device=ws.device)
+    packed, netp = handle.packed()
+    prec = 5 if (fast and handle.precision == 4) else handle.precision
+    gptr, gval = (None, 0) if gate is None else (ctypes.c_void_p(gate[0].data_ptr() + 4 * gate[1]), int(gate[2]))
+    _lib.check(lib.neat_sdf_values_laid_out(_p(packed), ctypes.byref(netp), P, prec, float(radius), float(scale), _p(ws), _p(sdf), gptr, gval,
+                                            _stream()), "neat_sdf_values_laid_out")
+    return sdf
+
+
+def sampler_init_rays(z, beta_param, beta_min, beta_c, nctl, origins, dirs, x_fm, ldp, keys, n_step, n_cand, n_extra):
+    """sampler_init + the first round's query points into x_fm [3, ldp] + (keys given) the training-mode picks of every possible final
+    grid size -> (beta0, beta, ctl, pick_all [n_cand, n_extra] or None)."""
+    z = _f32c(z.detach())
+    R, n = z.shape
+    dev = z.device
+    beta0, beta, ctl = torch.empty(1, device=dev), torch.empty(R, device=dev), torch.empty(nctl, dtype=torch.int32, device=dev)
+    pick_all = torch.empty(n_cand, n_extra, dtype=torch.int32, device=dev) if keys is not None else None
+    _lib.check(_lib.lib().neat_sampler_init_rays(_p(z), R, n, _p(_f32c(beta_param.detach().reshape(1))), float(beta_min), float(beta_c),
+                                                 _p(beta0), _p(beta), _p(ctl), nctl, _p(_f32c(origins.detach())), _p(_f32c(dirs.detach())),
+                                                 _p(x_fm), int(ldp), _p(_f32c(keys)) if keys is not None else None, int(n_step), int(n_cand),
+                                                 int(n_extra), _p(pick_all), _stream()), "neat_sampler_init_rays")
+    return beta0, beta, ctl, pick_all
+
+
+def sampler_round(z, sdf_old, sdf_new, order, beta_in, beta0, eps, iters, add_tiny, u_refine, u_final, samples_final, z_final, ctl, rnd,
+                  max_rounds, origins, dirs, x_fm, ldp):
+    """Round `rnd` of Algorithm 1 as ONE launch (neat_sampler_round): bound + refine resampling + the next round's query points into
+    x_fm + (converged rays / last round) the final samples.  -> (merged sdf [R,n], beta [R], refine samples [R,Ne], merged grid
+    [R,n+Ne], order) -- the last three None in the last round."""
+    lib = _lib.lib()
+    z, sdf_new = _f32c(z), _f32c(sdf_new)
+    R, n = z.shape
+    n_old = 0
+    if order is not None:
+        sdf_old, n_old = _f32c(sdf_old), sdf_old.shape[1]
+    dev = z.device
+    sdf_out, beta_out = torch.empty(R, n, device=dev), torch.empty(R, device=dev)
+    Ne, N = u_refine.shape[-1], u_final.shape[-1]
+    last = rnd + 1 >= max_rounds
+    fresh = zm = order_out = None
+    if not last:
+        fresh, zm = torch.empty(R, Ne, device=dev), torch.empty(R, n + Ne, device=dev)
+        order_out = torch.empty(R, n + Ne, device=dev, dtype=torch.int32)
+    _lib.check(lib.neat_sampler_round(_p(z), n, R, _p(sdf_old) if order is not None else None, _p(sdf_new), _p(order), n_old,
+                                      _p(_f32c(beta_in)), _p(_f32c(beta0.reshape(1))), float(eps), int(iters), _p(sdf_out), _p(beta_out),
+                                      _p(ctl), int(rnd), int(max_rounds), float(add_tiny), _p(u_refine), Ne, _p(fresh), _p(zm), _p(order_out),
+                                      _p(origins), _p(dirs), _p(x_fm) if not last else None, int(ldp), _p(u_final),
+                                      N if u_final.dim() == 2 else 0, N, _p(samples_final), _p(z_final), z_final.shape[1], _stream()),
+               "neat_sampler_round")
+    return sdf_out, beta_out, fresh, zm, order_out
+
+
+def sampler_finish_picked(samples_final, z_final, ctl, max_rounds, pick_all, n_step, n_extra, near, far, eik_idx):
+    """-> z_vals [R, N+2+n_extra] sorted, z_eik [R,1]; the grid size comes from the control words, the picks from pick_all (training) or
+    from the reference's linspace formula (pick_all None, eval)."""
+    lib = _lib.lib()
+    R, N = samples_final.shape
+    dev = samples_final.device
+    out, zeik = torch.empty(R, N + 2 + n_extra, device=dev), torch.empty(R, 1, device=dev)
+    _lib.check(lib.neat_sampler_finish_picked(_p(samples_final), N, _p(z_final), z_final.shape[1], _ip(ctl, 2 * max_rounds), _p(pick_all),
+                                              int(n_step), int(n_extra), float(near), float(far), R, _p(eik_idx), _p(out), _p(zeik), _stream()),
+               "neat_sampler_finish_picked")
+    return out, zeik
+
+
 def sampler_finish_dev(samples_final, z_final, ctl, max_rounds, keys, n_extra, near, far, eik_idx):
     """-> z_vals [R, N+2+n_extra] sorted, z_eik [R,1], pick [n_extra] (device-chosen grid indices)."""
     lib = _lib.lib()
@@ -710,16 +787,38 @@ def dbscan_means(points, eps):
 
 
 _GRAD_ONE = {}
+_UNIT_SEED = [False]      # True only while neat_amd.train._backward runs `loss.backward(gradient=grad_one(...))`
 
 
 def grad_one(device):
-    """The constant 1.0 to seed `loss.backward(gradient=...)` with (neat_amd.train): no `ones_like` launch per step, and LossTailFn
-    recognises it -- its flat gradient buffer already holds the gradients of the total loss, so nothing is multiplied."""
+    """The constant 1.0 to seed `loss.backward(gradient=...)` with (neat_amd.train._backward): no `ones_like` launch per step.  It is
+    private to that call: created OUTSIDE any stream capture (a tensor first made inside an aborted capture would stay cached with its
+    fill never executed), never handed to user code, value fixed."""
     key = str(device)
     t = _GRAD_ONE.get(key)
     if t is None:
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.ones((), device=device)      # not cached: the capture's private pool owns it (Trainer.capture() makes the real one first)
         t = _GRAD_ONE[key] = torch.ones((), device=device)
     return t
+
+
+class unit_seed:
+    """`with unit_seed(device) as one: loss.backward(gradient=one)`: tells LossTailFn that the upstream gradient of this backward IS the
+    constant 1 -- its flat buffer already holds the gradients of the total loss, so nothing is multiplied.  The fast path is taken on
+    this flag (and the seed's identity), never on a pointer comparison alone: any other caller's gradient, or a mutated tensor, goes
+    through the multiply."""
+
+    def __init__(self, device):
+        self.one = grad_one(device)
+
+    def __enter__(self):
+        self.prev, _UNIT_SEED[0] = _UNIT_SEED[0], True
+        return self.one
+
+    def __exit__(self, *exc):
+        _UNIT_SEED[0] = self.prev
+        return False
 
 
 class LossTailFn(torch.autograd.Function):
@@ -727,7 +826,8 @@ class LossTailFn(torch.autograd.Function):
     (neat_line_losses), rgb L1 + eikonal + the junction pair cost (neat_loss_terms), the matched-pair terms and the weighted total
     (neat_loss_pairs).  Differentiable inputs: rgb, grad_theta, the global junctions (3-D and calibrated 2-D) and the calibrated 2-D
     lines.  Every gradient leaves its kernel as a gradient of the TOTAL loss (the loss weights are applied there) into one flat buffer:
-    backward is one multiply by the upstream gradient, or nothing at all when that is `grad_one`."""
+    backward is one multiply by the upstream gradient, or nothing at all inside `unit_seed` (the trainer's backward, which never
+    retains the graph: the returned gradients are then views of the saved buffer)."""
 
     @staticmethod
     def forward(ctx, rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good,
@@ -779,8 +879,8 @@ class LossTailFn(torch.autograd.Function):
             return (None,) * 19
         (flat,) = ctx.saved_tensors
         one = _GRAD_ONE.get(str(flat.device))
-        if one is None or g_loss.data_ptr() != one.data_ptr():
-            flat = flat * g_loss
+        if not (_UNIT_SEED[0] and one is not None and g_loss.data_ptr() == one.data_ptr()):
+            flat = flat * g_loss          # a fresh tensor: the views below never alias the saved buffer (retain_graph callers)
         g = flat.split(ctx.sizes)
         s_rgb, s_gth, s_glo3, s_glo2c, s_pred = ctx.shapes
         return (g[0].view(s_rgb),

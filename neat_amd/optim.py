@@ -44,7 +44,12 @@ class FlatAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, flat_grad=None):
         """flat_grad: ALL gradients live in this flat fp32 buffer, laid out like the parameters (dp.FlatGradBucket.flat after the
-        all-reduce): the pointer table is built once per buffer, no per-parameter host work in the step."""
+        all-reduce): the pointer table is built once per buffer, no per-parameter host work in the step.
+        Semantics of this (data-parallel) form = DistributedDataParallel's: EVERY parameter steps, a parameter that had no gradient on
+        any rank steps with the zeros the bucket packed for it (its moments decay).  That is deliberate -- which parameters have a
+        gradient is a property of one rank's batch (e.g. no matched junction on this view), and ranks that skipped different
+        parameters would drift apart; the pointer-table form below keeps torch.optim.Adam's single-process rule (no gradient: no
+        step, no step count)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():

@@ -9,6 +9,7 @@ Random draws are made on the CPU generator in the reference's order
 so a seeded run consumes the RNG stream exactly as the reference does.
 """
 import math
+import os
 
 import torch
 
@@ -184,6 +185,7 @@ class ErrorBoundSampler(RaySampler):
         self._beta_c = float(1.0 / (4.0 * torch.log(torch.tensor(self.eps + 1.0))))
         self.sync_free = False        # True: get_z_vals_device (control flow on the device, HIP-graph capturable)
         self._ctl = None              # device control words of the last sync-free call
+        self._pick_all = self._pick_direct = None
 
     # ----- pieces of Algorithm 1 --------------------------------------------------------------
     @staticmethod
@@ -213,7 +215,55 @@ class ErrorBoundSampler(RaySampler):
         Same arithmetic as get_z_vals.  Differences, all in the random draws: the final u [R, N] is drawn before the rounds instead of
         in the last one (same position in the CPU stream: the refine rounds draw nothing), and the training-mode
         `randperm(n)[:N_extra]` -- whose n is only known on the device -- becomes "the N_extra smallest of n uniform keys", the same
-        distribution from a different stretch of the stream.  Eval mode draws nothing here and is bit-identical to get_z_vals."""
+        distribution from a different stretch of the stream.  Eval mode draws nothing here and is bit-identical to get_z_vals.
+        Round 6: with the HIP SDF network a round is TWO launches -- the fused SDF query and neat_sampler_round (bound + resampling + the
+        next round's query points, written straight into the query's workspace) -- instead of four (`_get_z_vals_device_unfused`,
+        kept for model objects without the HIP entry points); the training-mode picks are computed beside the prologue."""
+        from . import ops
+        net = getattr(model, "implicit_network", None)
+        density = getattr(model, "density", None)
+        if not (hasattr(net, "get_sdf_vals_rays") and hasattr(net, "handle") and type(density).__name__ == "LaplaceDensity"
+                and hasattr(density, "beta_min") and os.environ.get("NEAT_SAMPLER_UNFUSED") != "1"):
+            return self._get_z_vals_device_unfused(ray_dirs, cam_loc, model)
+        dev, R = ray_dirs.device, ray_dirs.shape[0]
+        K, Ne, N = self.max_total_iters, self.N_samples_eval, self.N_samples
+        z = self.uniform_sampler.get_z_vals(ray_dirs, cam_loc, model)
+        u_refine = _unit_grid(Ne, dev)
+        u_final = _draw(model, "sampler_u", lambda: torch.rand(R, N), dev) if model.training else _unit_grid(N, dev)
+        n_extra = max(self.N_samples_extra, 0)
+        keys = _draw(model, "sampler_keys", lambda: torch.rand(Ne * K), dev) if (n_extra and model.training) else None
+        handle, fast = net.handle(), bool(getattr(model, "sampler_fast_values", False))
+        ws, ldp = ops.sdf_query_workspace(handle, R * Ne, dev, fast)      # one workspace for all rounds: every query has R * Ne points
+        o, d = cam_loc.detach().float().contiguous(), ray_dirs.detach().float().contiguous()
+        beta0, beta, ctl, pick_all = ops.sampler_init_rays(z, density.beta, density.beta_min, self._beta_c, 2 * K + 1, o, d, ws, ldp,
+                                                           keys, Ne, K, n_extra)
+        samples, z_final = torch.empty(R, N, device=dev), torch.empty(R, Ne * K, device=dev)
+        order, sdf = None, None
+        for k in range(K):
+            gate = (ctl, k - 1, 1) if k > 0 else None                     # open[k-1]: the previous round left a ray above beta0
+            new_sdf = ops.sdf_values_laid_out(handle, ws, R * Ne, net.sdf_bounding_sphere, net.sphere_scale, gate=gate, fast=fast).reshape(R, Ne)
+            sdf, beta, _, z_next, order_next = ops.sampler_round(z, sdf, new_sdf, order, beta, beta0, self.eps, self.beta_iters, self.add_tiny,
+                                                                 u_refine, u_final, samples, z_final, ctl, k, K, o, d, ws, ldp)
+            z, order = z_next, order_next
+        self._ctl, self._pick_all, self._pick_direct = ctl, pick_all, None
+        self.last_rounds = None                              # read lazily: rounds_taken()
+        n_out = N + 2 + n_extra
+        eik_idx = _draw(model, "sampler_eik_idx", lambda: torch.randint(n_out, (R,)).to(torch.int32), dev)
+        return ops.sampler_finish_picked(samples, z_final, ctl, K, pick_all, Ne, n_extra, self.near, self.far, eik_idx)
+
+    @property
+    def last_pick(self):
+        """Grid indices the last device-decided call took as its extra samples (one device read; tests)."""
+        if getattr(self, "_pick_direct", None) is not None:
+            return self._pick_direct
+        K, Ne = self.max_total_iters, self.N_samples_eval
+        n = int(self._ctl[2 * K].item())
+        if self._pick_all is None:
+            return torch.linspace(0, n - 1, self.N_samples_extra).long()
+        return self._pick_all[n // Ne - 1]
+
+    def _get_z_vals_device_unfused(self, ray_dirs, cam_loc, model):
+        """The round-2..5 form of get_z_vals_device: per round the SDF query, neat_sampler_bound_dev and neat_sampler_resample_dev."""
         from . import ops
         dev, R = ray_dirs.device, ray_dirs.shape[0]
         K, Ne, N = self.max_total_iters, self.N_samples_eval, self.N_samples
@@ -250,7 +300,8 @@ class ErrorBoundSampler(RaySampler):
         keys = _draw(model, "sampler_keys", lambda: torch.rand(Ne * K), dev) if (n_extra and model.training) else None
         n_out = N + 2 + n_extra
         eik_idx = _draw(model, "sampler_eik_idx", lambda: torch.randint(n_out, (R,)).to(torch.int32), dev)
-        z_vals, z_eik, self.last_pick = ops.sampler_finish_dev(samples, z_final, ctl, K, keys, n_extra, self.near, self.far, eik_idx)
+        self._pick_all = None
+        z_vals, z_eik, self._pick_direct = ops.sampler_finish_dev(samples, z_final, ctl, K, keys, n_extra, self.near, self.far, eik_idx)
         return z_vals, z_eik
 
     @staticmethod

@@ -14,10 +14,11 @@ GT_KEYS = ("rgb", "lines2d")      # what VolSDFLoss reads from the ground truth 
 
 def _backward(loss):
     """loss.backward() seeded with a persistent 1.0 on the device: no `ones_like` launch per step, and the loss's own autograd node
-    (ops.LossTailFn) recognises the seed and multiplies nothing."""
+    (ops.LossTailFn) is told through ops.unit_seed that the seed is the constant 1 and multiplies nothing."""
     if loss.is_cuda:
         from . import ops
-        loss.backward(gradient=ops.grad_one(loss.device))
+        with ops.unit_seed(loss.device) as one:
+            loss.backward(gradient=one)
     else:
         loss.backward()
 
@@ -172,6 +173,12 @@ class Trainer:
                 self._capture_fault()
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
+            # process-global device tensors the captured step reads must exist (and be filled) BEFORE the capture: with warmup = 0 no
+            # eager backward has run yet, and a tensor first created inside the capture has its fill recorded, not executed, in storage
+            # of the graph's private pool -- after an aborted capture it would stay cached with garbage in it
+            ops.grad_one(self.device)
+            if self.bucket.active():
+                self.bucket._ensure()
             graph = torch.cuda.CUDAGraph()
             # thread_local: a NCCL/RCCL watchdog thread may touch the runtime while this thread captures
             with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
@@ -270,11 +277,15 @@ class Trainer:
 
     def check_nan(self):
         """Graph mode keeps the line-loss NaN flag on the device (loss.nan_check == "off"); this reads it (one sync)."""
-        flag = self._last.nan_flag if self._last is not None else self.loss.nan_flag
+        deferred = None
         if self._last is None and hasattr(self.loss, "_check_deferred"):
-            self.loss._check_deferred()                     # eager steps publish through the loss's own deferred flag
+            try:
+                self.loss._check_deferred()                 # eager steps publish through the loss's own deferred flag
+            except FloatingPointError as exc:               # ... which raises on THIS rank: held until the ranks have agreed below
+                deferred = exc
+        flag = self._last.nan_flag if self._last is not None else self.loss.nan_flag      # (read after the deferred check has run)
         # (graph mode keeps the line loss itself as the flag -- testing it on the device every step would be one more launch)
-        bad = flag is not None and bool((torch.isnan(flag).any() if flag.is_floating_point() else flag.any()).item())
+        bad = deferred is not None or (flag is not None and bool((torch.isnan(flag).any() if flag.is_floating_point() else flag.any()).item()))
         # data parallel: the flag belongs to THIS rank's batch.  The ranks agree before anyone raises -- a rank that stopped alone would
         # leave the others blocked in the next gradient all-reduce until the watchdog tears the job down.  (Every rank calls this at
         # the same iterations: the runner's log interval and checkpoint epochs.)
@@ -283,7 +294,7 @@ class Trainer:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             bad = bool(t.item() > 0.0)
         if bad:
-            raise FloatingPointError("line loss is NaN on at least one rank (the reference drops into pdb here, loss_wfr.py:66-67)")
+            raise FloatingPointError("line loss is NaN on at least one rank (the reference drops into pdb here, loss_wfr.py:66-67)") from deferred
 
     def _load_batch(self, entry, model_input, ground_truth, collect=None):
         """Every tensor of the fresh batch is copied into the captured tensors, in ONE multi-tensor launch (a few KB per step).  No
