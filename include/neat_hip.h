@@ -298,6 +298,11 @@ int neat_junction_gate(const long long* rows, const long long* cols, int K, cons
 int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E, const float* loc3, const float* loc2c, int K,
                     const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost,
                     float eik_grad_scale, void* stream);
+/* ABI v13: neat_line_losses and neat_loss_terms (independent of each other) as the two workgroups of one launch; same arithmetic. */
+int neat_loss_lines_terms(const float* pred_px, const float* pred_calib, const float* gt5, const float* Kmat, int L, float threshold, float* out3,
+                          float* d_pred_calib, float grad_scale, const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E,
+                          const float* loc3, const float* loc2c, int K, const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb,
+                          float* d_gtheta, float* pair_cost, float eik_grad_scale, void* stream);
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
                     float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, int weighted_grads,
@@ -316,6 +321,14 @@ int neat_inv_small(const float* A, int n, int lda, float* out, void* stream);
 int neat_camera_mats(const float* pose, const float* K, int kstride, float* w2c, float* K3, void* stream);
 int neat_project2d(const float* K, const float* w2c, const float* X, int N, float* uv, void* stream);
 int neat_project2d_backward(const float* K, const float* w2c, const float* X, int N, const float* d_uv, float* d_X, void* stream);
+/* ABI v13: the junction block's camera-only work and its double projections as single launches.
+ *  neat_camera_setup   : neat_camera_rays for `uv` (dirs, origins) and -- uv2 != NULL -- for `uv2` (dirs2; rend_a :444), plus
+ *                        neat_camera_mats (w2c [3,4], K3 [3,3]); same arithmetic as the three launches.
+ *  neat_project2d_pair : neat_project2d of the same points with K (-> uv) and with K2 (-> uv2): rend_a :436-441 (lines2d / lines2d_calib),
+ *                        :469-471 (junction candidates), :493-496 (global junctions) project with the intrinsics and with the identity. */
+int neat_camera_setup(const float* uv, const float* uv2, const float* pose, const float* K, int kstride, int R, float* dirs, float* origins,
+                      float* dirs2, float* w2c, float* K3, void* stream);
+int neat_project2d_pair(const float* K, const float* K2, const float* w2c, const float* X, int N, float* uv, float* uv2, void* stream);
 int neat_line_loss(const float* pred, const float* gt, const float* weight, int R, float threshold, float* out2, float* per_line,
                    float* d_pred, void* stream);
 /* Both line terms of VolSDFLoss.forward (loss_wfr.py:52-65) in one launch: pred_px / pred_calib [R,4] = the projected 3-D lines in

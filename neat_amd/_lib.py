@@ -70,6 +70,11 @@ _SIGNATURES = {
     "neat_sampler_finish_dev": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_sdf_ldp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "neat_loss_lines_terms": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, ctypes.c_float,
+                                             c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
+                                             c_fp, c_fp, c_fp, c_fp, ctypes.c_float, c_fp]),
+    "neat_camera_setup": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "neat_project2d_pair": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_sdf_values_laid_out": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
     "neat_sampler_init_rays": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "neat_sampler_round": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp]),

@@ -1130,10 +1130,8 @@ __global__ __launch_bounds__(WG) void composite_bwd_kernel(CompositeBwdArgs a) {
 }
 
 // pixel -> ray (rend_util.py:55-81,95-108)
-__global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ Kin,
-                                   int kstride, int R, float* __restrict__ dirs, float* __restrict__ origins) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
+__device__ __forceinline__ void camera_ray(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ Kin,
+                                           int kstride, int r, float* __restrict__ dirs, float* __restrict__ origins) {
   const float fx = Kin[0], sk = Kin[1], cx = Kin[2], fy = Kin[kstride + 1], cy = Kin[kstride + 2];
   const float u = uv[r * 2], v = uv[r * 2 + 1];
   const float xl = (u - cx + cy * sk / fy - sk * v / fy) / fx;
@@ -1150,6 +1148,12 @@ __global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __
 #pragma unroll
     for (int c = 0; c < 3; ++c) origins[r * 3 + c] = pose[c * 4 + 3];
   }
+}
+__global__ void camera_rays_kernel(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ Kin,
+                                   int kstride, int R, float* __restrict__ dirs, float* __restrict__ origins) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  camera_ray(uv, pose, Kin, kstride, r, dirs, origins);
 }
 
 // eikonal points of a training step (rend_a :515-527): [uniform draws in the bounding cube | one point per ray at its drawn depth
@@ -1174,8 +1178,8 @@ __global__ void eik_points_kernel(const float* __restrict__ uniform, const float
 
 // d loss / d beta_param = sgn(beta_param) * sum over the rays of composite_bwd_kernel's per-ray partials (fixed order: one workgroup,
 // strided per-thread sums, wave shuffles, waves in order) -- the `.sum()` and the backward of `.abs()` of density.py:29-30 in one launch
-__global__ __launch_bounds__(256) void beta_grad_kernel(const float* __restrict__ dbeta_ray, int R, const float* __restrict__ beta_ptr,
-                                                        float* __restrict__ out) {
+__device__ __forceinline__ void beta_grad_body(const float* __restrict__ dbeta_ray, int R, const float* __restrict__ beta_ptr,
+                                               float* __restrict__ out) {
   __shared__ float s_w[4];
   float acc = 0.0f;
   for (int r = threadIdx.x; r < R; r += 256) acc += dbeta_ray[r];
@@ -1187,6 +1191,10 @@ __global__ __launch_bounds__(256) void beta_grad_kernel(const float* __restrict_
     const float t = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
     out[0] = b > 0.0f ? t : (b < 0.0f ? -t : 0.0f);
   }
+}
+__global__ __launch_bounds__(256) void beta_grad_kernel(const float* __restrict__ dbeta_ray, int R, const float* __restrict__ beta_ptr,
+                                                        float* __restrict__ out) {
+  beta_grad_body(dbeta_ray, R, beta_ptr, out);
 }
 
 }  // namespace neat

@@ -1278,8 +1278,12 @@ struct BwdPrologueArgs {
   const float* x_fm; const float* E;          // points, their PE rows [39][ldp] (saved by the forward pass)
   float* gh; float* Eh;                       // fp32 feature-major outputs [3][ldp], [39][ldp]
   u16* Ebf; u16* Ebf4; u16* Ehbf; u16* Ehbf4; // octet-major copies: rows 0..38 (5 octets) / rows 7..38 (4 octets)
+  // round 6: one more workgroup (the last) sums the per-ray partials of d loss / d beta (beta_grad_body; null: not wanted) -- they were
+  // written by composite_bwd_kernel, several launches earlier; one launch less per step
+  const float* dbeta_ray; int R; const float* beta_ptr; float* dbeta;
 };
-__global__ void bwd_prologue_kernel(BwdPrologueArgs a) {
+__global__ __launch_bounds__(256) void bwd_prologue_kernel(BwdPrologueArgs a) {
+  if (a.dbeta && blockIdx.x == gridDim.x - 1) { beta_grad_body(a.dbeta_ray, a.R, a.beta_ptr, a.dbeta); return; }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.ldp) return;
   const size_t ldp = (size_t)a.ldp;

@@ -337,6 +337,21 @@ __global__ void project2d_kernel(const float* __restrict__ K, const float* __res
   uv[2 * i] = cam[0] / w; uv[2 * i + 1] = cam[1] / w;
 }
 
+// The same point set through two intrinsics in one launch (round 6): the junction block projects the line end points, the junction
+// candidates and the global junctions once with K (pixels) and once with the identity (calibrated coordinates), rend_a :436-441,
+// :469-471, :493-496.  Same arithmetic as two project2d_kernel launches.
+__global__ void project2d_pair_kernel(const float* __restrict__ K, const float* __restrict__ K2, const float* __restrict__ w2c,
+                                      const float* __restrict__ X, int N, float* __restrict__ uv, float* __restrict__ uv2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float x[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+  float cam[3], w;
+  project_point(K, w2c, x, cam, w);
+  uv[2 * i] = cam[0] / w; uv[2 * i + 1] = cam[1] / w;
+  project_point(K2, w2c, x, cam, w);
+  uv2[2 * i] = cam[0] / w; uv2[2 * i + 1] = cam[1] / w;
+}
+
 // d_X = R^T K^T d_cam with d_cam = (d_u / w, d_v / w, -(d_u u + d_v v) / w)
 __global__ void project2d_bwd_kernel(const float* __restrict__ K, const float* __restrict__ w2c, const float* __restrict__ X, int N,
                                      const float* __restrict__ d_uv, float* __restrict__ d_X) {
@@ -452,9 +467,9 @@ __device__ __forceinline__ void inv_small_body(const float* sA, float* __restric
 // (grad_scale = the line term's weight in the total loss: the backward pass then has nothing left to multiply).
 // Same arithmetic and summation order as line_loss_kernel / inv_small_kernel / project2d_kernel, which it replaces on this path
 // (eleven launches: two slices, compare, ones, cat, inverse, projection, mask product, two line losses, sum).
-__global__ __launch_bounds__(1024) void line_losses_kernel(const float* __restrict__ pred_u, const float* __restrict__ pred_c,
-                                                           const float* __restrict__ gt5, const float* __restrict__ K, int R, float thr,
-                                                           float* __restrict__ out, float* __restrict__ d_pred_c, float grad_scale) {
+__device__ __forceinline__ void line_losses_body(const float* __restrict__ pred_u, const float* __restrict__ pred_c,
+                                                 const float* __restrict__ gt5, const float* __restrict__ K, int R, float thr,
+                                                 float* __restrict__ out, float* __restrict__ d_pred_c, float grad_scale) {
   __shared__ float s_acc[4][16];
   __shared__ float s_kinv[9], s_k[9];
   __shared__ float s_inv;
@@ -530,6 +545,12 @@ __global__ __launch_bounds__(1024) void line_losses_kernel(const float* __restri
   }
 }
 
+__global__ __launch_bounds__(1024) void line_losses_kernel(const float* __restrict__ pred_u, const float* __restrict__ pred_c,
+                                                           const float* __restrict__ gt5, const float* __restrict__ K, int R, float thr,
+                                                           float* __restrict__ out, float* __restrict__ d_pred_c, float grad_scale) {
+  line_losses_body(pred_u, pred_c, gt5, K, R, thr, out, d_pred_c, grad_scale);
+}
+
 __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, float* __restrict__ out) {
   __shared__ float sA[16];
   if (threadIdx.x < n * n) sA[threadIdx.x] = A[(threadIdx.x / n) * lda + threadIdx.x % n];      // one parallel fetch, not 16 dependent ones
@@ -546,6 +567,28 @@ __global__ void inv_small_kernel(const float* __restrict__ A, int n, int lda, fl
 __global__ void camera_mats_kernel(const float* __restrict__ pose, const float* __restrict__ K, int kstride, float* __restrict__ w2c,
                                    float* __restrict__ K3) {
   __shared__ float sA[16], sInv[16];
+  if (threadIdx.x < 16) sA[threadIdx.x] = pose[threadIdx.x];
+  if (threadIdx.x < 9) K3[threadIdx.x] = K[(threadIdx.x / 3) * kstride + threadIdx.x % 3];
+  __syncthreads();
+  if (threadIdx.x == 0) inv_small_body<4>(sA, sInv);
+  __syncthreads();
+  if (threadIdx.x < 12) w2c[threadIdx.x] = sInv[threadIdx.x];
+}
+
+// Everything a forward derives from the camera alone, in one launch (round 6; before: camera_rays_kernel twice and camera_mats_kernel):
+// the rays through `uv` with their origins (rend_a :382-396), the rays through `uv_proj` (:444), [R | T] of pose^-1 and the contiguous
+// intrinsics (:424-431).  Same arithmetic as the launches it replaces.
+__global__ __launch_bounds__(256) void camera_setup_kernel(const float* __restrict__ uv, const float* __restrict__ uv2, const float* __restrict__ pose,
+                                                           const float* __restrict__ K, int kstride, int R, float* __restrict__ dirs,
+                                                           float* __restrict__ origins, float* __restrict__ dirs2, float* __restrict__ w2c,
+                                                           float* __restrict__ K3) {
+  __shared__ float sA[16], sInv[16];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < R) {
+    camera_ray(uv, pose, K, kstride, r, dirs, origins);
+    if (uv2) camera_ray(uv2, pose, K, kstride, r, dirs2, nullptr);
+  }
+  if (blockIdx.x != 0) return;
   if (threadIdx.x < 16) sA[threadIdx.x] = pose[threadIdx.x];
   if (threadIdx.x < 9) K3[threadIdx.x] = K[(threadIdx.x / 3) * kstride + threadIdx.x % 3];
   __syncthreads();
@@ -1059,7 +1102,7 @@ struct LossTermsArgs {
   float eik_grad_scale;        // d_gtheta = eik_grad_scale * d scal[1] / d gtheta (the eikonal weight: gradients of the TOTAL loss, or 1)
 };
 
-__global__ __launch_bounds__(1024) void loss_terms_kernel(LossTermsArgs a) {
+__device__ __forceinline__ void loss_terms_body(const LossTermsArgs& a) {
   __shared__ float s_red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
   float acc = 0.0f;
@@ -1090,6 +1133,16 @@ __global__ __launch_bounds__(1024) void loss_terms_kernel(LossTermsArgs a) {
     for (int c = 0; c < 2; ++c) c2 += fabsf(a.loc2c[2 * k + c] - a.glo2c[2 * j + c]);
     a.pair_cost[idx] = c3 + 0.1f * c2;
   }
+}
+
+__global__ __launch_bounds__(1024) void loss_terms_kernel(LossTermsArgs a) { loss_terms_body(a); }
+
+// Both independent halves of the loss after the projections in ONE launch (round 6): workgroup 0 = the two line terms
+// (line_losses_body), workgroup 1 = rgb + eikonal + the junction pair cost (loss_terms_body).  Same arithmetic as the two launches.
+struct LineLossesArgs { const float* pred_u; const float* pred_c; const float* gt5; const float* K; int R; float thr; float* out; float* d_pred_c; float grad_scale; };
+__global__ __launch_bounds__(1024) void loss_lines_terms_kernel(LineLossesArgs l, LossTermsArgs t) {
+  if (blockIdx.x == 0) line_losses_body(l.pred_u, l.pred_c, l.gt5, l.K, l.R, l.thr, l.out, l.d_pred_c, l.grad_scale);
+  else loss_terms_body(t);
 }
 
 struct LossPairsArgs {

@@ -1028,7 +1028,8 @@ hipError_t wgrad(const Ctx& c, const SdfWs& w, int layer_id, const WPair* pairs_
 
 // double backward + backward: w.gh (cotangent of normals, masked) and w.abar8 (cotangent of lin8 output) are set
 // nc: the cotangent of the normals still has to be formed (its arguments); null = w.gh is set
-struct NormalCot { const float* sc_r; const float* sc_a; const float* extra_rm; int P_main; const float* d_tail_rm; const float* slot; const float* slot_a; };
+struct NormalCot { const float* sc_r; const float* sc_a; const float* extra_rm; int P_main; const float* d_tail_rm; const float* slot; const float* slot_a;
+                   const float* dbeta_ray = nullptr; int R = 0; const float* beta_ptr = nullptr; float* dbeta = nullptr; };
 hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grads* gr, const NormalCot* nc = nullptr) {
   const PackLayout& L = c.L();
   hipError_t e;
@@ -1040,7 +1041,8 @@ hipError_t sdf_backward_chains(const Ctx& c, const SdfWs& w, const neat_net_grad
     a.x_fm = w.x; a.E = w.E; a.gh = w.gh; a.Eh = w.Eh;
     a.Ebf = reinterpret_cast<u16*>(w.Ebf.p); a.Ebf4 = reinterpret_cast<u16*>(w.Ebf4.p);
     a.Ehbf = reinterpret_cast<u16*>(w.Ehbf.p); a.Ehbf4 = reinterpret_cast<u16*>(w.Ehbf4.p);
-    hipLaunchKernelGGL(bwd_prologue_kernel, grid1(c.ldp), dim3(256), 0, c.st, a);
+    a.dbeta_ray = nc->dbeta_ray; a.R = nc->R; a.beta_ptr = nc->beta_ptr; a.dbeta = nc->dbeta;
+    hipLaunchKernelGGL(bwd_prologue_kernel, dim3(grid1(c.ldp).x + (a.dbeta ? 1 : 0)), dim3(256), 0, c.st, a);
   } else {
     if (nc) hipLaunchKernelGGL(normal_cotangent_kernel, grid1(c.ldp), dim3(256), 0, c.st, nc->sc_r, nc->sc_a, nc->extra_rm, w.mask, c.P, c.ldp,
                                w.gh, nc->P_main, nc->d_tail_rm, nc->slot, nc->slot_a);
@@ -2025,9 +2027,11 @@ int neat_render_backward(const float* packed, const neat_net_params* net, float*
   // columns beyond the ray samples (eikonal points, padding) carry zero head cotangents: zeroed by extra workgroups of the same launch
   cb.tail_from = c.ldp > Pm ? Pm : 0;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4 + (c.ldp > Pm ? (c.ldp - Pm + WG - 1) / WG : 0)), dim3(WG), 0, c.st, cb);
-  if (dbeta) hipLaunchKernelGGL(beta_grad_kernel, dim3(1), dim3(256), 0, c.st, dbeta_ray, R, beta, dbeta);
+  // d loss / d beta: the per-ray partials are summed by one more workgroup of bwd_prologue_kernel (16-bit builds; fp32: a launch of its own)
+  if (dbeta && !c.prec) hipLaunchKernelGGL(beta_grad_kernel, dim3(1), dim3(256), 0, c.st, dbeta_ray, R, beta, dbeta);
   NEAT_CHECK(heads_backward(c, h, w, grads, slot, slot_a, Pm));
-  const NormalCot nc{h.sc_r, h.sc_a, nullptr, Pm, d_eik_grad, slot, slot_a};
+  NormalCot nc{h.sc_r, h.sc_a, nullptr, Pm, d_eik_grad, slot, slot_a};
+  if (dbeta && c.prec) { nc.dbeta_ray = dbeta_ray; nc.R = R; nc.beta_ptr = beta; nc.dbeta = dbeta; }
   NEAT_CHECK(sdf_backward_chains(c, w, grads, &nc));
   if (slot_a) { grad_unscale(c, grads, 0, L_ATTR, slot); grad_unscale(c, grads, L_ATTR, NLAYERS - L_ATTR, slot_a); }
   else grad_unscale(c, grads, 0, NLAYERS, slot);
@@ -2293,6 +2297,19 @@ int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* g
   return (int)hipGetLastError();
 }
 
+int neat_loss_lines_terms(const float* pred_px, const float* pred_calib, const float* gt5, const float* Kmat, int L, float threshold, float* out3,
+                          float* d_pred_calib, float grad_scale, const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E,
+                          const float* loc3, const float* loc2c, int K, const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb,
+                          float* d_gtheta, float* pair_cost, float eik_grad_scale, void* stream) {
+  if (L <= 0 || !pred_px || !pred_calib || !gt5 || !Kmat || !out3 || !d_pred_calib) return -1;
+  if (R <= 0 || !rgb || !rgb_gt || !scal || !d_rgb || E < 0 || K < 0 || J < 0) return -1;
+  if ((E > 0 && (!gtheta || !d_gtheta)) || (K > 0 && J > 0 && (!loc3 || !loc2c || !glo3 || !glo2c || !pair_cost))) return -1;
+  LineLossesArgs l{pred_px, pred_calib, gt5, Kmat, L, threshold, out3, d_pred_calib, grad_scale};
+  LossTermsArgs a{rgb, rgb_gt, R, gtheta, E, loc3, loc2c, (J > 0 ? K : 0), glo3, glo2c, J, scal, d_rgb, d_gtheta, pair_cost, eik_grad_scale};
+  hipLaunchKernelGGL(loss_lines_terms_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, l, a);
+  return (int)hipGetLastError();
+}
+
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
                     float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, int weighted_grads,
@@ -2346,6 +2363,20 @@ int neat_project2d(const float* K, const float* w2c, const float* X, int N, floa
   if (N <= 0) return 0;
   if (!K || !w2c || !X || !uv) return -1;
   hipLaunchKernelGGL(project2d_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, w2c, X, N, uv);
+  return (int)hipGetLastError();
+}
+
+int neat_project2d_pair(const float* K, const float* K2, const float* w2c, const float* X, int N, float* uv, float* uv2, void* stream) {
+  if (N <= 0) return 0;
+  if (!K || !K2 || !w2c || !X || !uv || !uv2) return -1;
+  hipLaunchKernelGGL(project2d_pair_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, K2, w2c, X, N, uv, uv2);
+  return (int)hipGetLastError();
+}
+
+int neat_camera_setup(const float* uv, const float* uv2, const float* pose, const float* K, int kstride, int R, float* dirs, float* origins,
+                      float* dirs2, float* w2c, float* K3, void* stream) {
+  if (R <= 0 || !uv || !pose || !K || !dirs || !origins || (uv2 && !dirs2) || !w2c || !K3 || kstride < 3) return -1;
+  hipLaunchKernelGGL(camera_setup_kernel, grid1(R), dim3(256), 0, (hipStream_t)stream, uv, uv2, pose, K, kstride, R, dirs, origins, dirs2, w2c, K3);
   return (int)hipGetLastError();
 }
 

@@ -439,7 +439,15 @@ class VolSDFNetwork(_HipModule):
 
     def forward(self, input):
         intrinsics, uv, pose = input["intrinsics"], input["uv"], input["pose"]
-        ray_dirs, cam_loc = self._rays(input)
+        # camera-only work of the whole forward in one launch: rays through uv and through uv_proj, [R | T] of pose^-1, the contiguous
+        # intrinsics (round 6; before: camera_rays twice + camera_mats)
+        setup = None
+        if (uv.is_cuda and pose.shape == (1, 4, 4) and intrinsics.dtype == torch.float32 and intrinsics.stride(-1) == 1
+                and intrinsics.shape[0] == 1 and "uv_proj" in input and input["uv_proj"].shape == uv.shape):
+            setup = ops.camera_setup(uv, input["uv_proj"], pose, intrinsics)
+            ray_dirs, cam_loc = setup[0], setup[1]
+        else:
+            ray_dirs, cam_loc = self._rays(input)
         n_rays = ray_dirs.shape[0]
         z_vals, z_eik = self._z_vals(ray_dirs, cam_loc)
         grad_theta = None
@@ -461,7 +469,9 @@ class VolSDFNetwork(_HipModule):
         points3d = xyz
         main = torch.cuda.current_stream() if xyz.is_cuda else None
         side = self._side_stream(xyz.device) if (main is not None and self.use_side_stream) else None
-        if xyz.is_cuda and pose.shape[1:] == (4, 4) and intrinsics.dtype == torch.float32 and intrinsics.stride(-1) == 1:
+        if setup is not None:
+            w2c, K3 = setup[3], setup[4]
+        elif xyz.is_cuda and pose.shape[1:] == (4, 4) and intrinsics.dtype == torch.float32 and intrinsics.stride(-1) == 1:
             w2c, K3 = ops.camera_mats(pose[0], intrinsics[0])     # [R | T] of pose^-1 and the contiguous 3x3 intrinsics: one launch, no sync
         else:
             w2c = ops.inv_small(pose[0])[:3]                 # one launch, no host-side singularity check, no sync
@@ -470,8 +480,13 @@ class VolSDFNetwork(_HipModule):
         eye = _eye3(K3.device)
 
         def l3d_block():
-            p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
-            l_dirs, l_orig = self._rays(input, "uv_proj")
+            if points3d.is_cuda:          # get_outputs(points3d) (rend_a :441-443) without the row-major copies of lin8's output (one
+                # launch): the junction block reads the sdf and the normal only; both keep their graph to the parameters
+                net = self.implicit_network
+                p3_sdf, p3_grad = ops.sdf_point_normals(net.handle(), points3d, net.sdf_bounding_sphere, net.sphere_scale)
+            else:
+                p3_sdf, _, p3_grad = self.implicit_network.get_outputs(points3d)
+            l_dirs, l_orig = (setup[2], cam_loc) if setup is not None else self._rays(input, "uv_proj")
             if points3d.is_cuda:          # plane intersection per ray: one launch
                 l3d = ops.l3d_points(points3d, l_orig, l_dirs, p3_grad)
             else:
@@ -519,11 +534,18 @@ class VolSDFNetwork(_HipModule):
             K3c, w2c3 = K3.contiguous(), w2c.contiguous()
             K3 = K3c           # the loss inverts output["K"]: hand it the contiguous copy
             proj = lambda Kc, X: ops.project2d(Kc, w2c3, X)
+            # the same points with K (pixels) and with the identity (calibrated): one launch for both (round 6)
+            proj_pair = lambda X: ops.project2d_pair(K3c, eye, w2c3, X)
         else:
             K3c = K3
             proj = lambda Kc, X: self.project2D(Kc, Rm, T, X)
-        lines2d = proj(K3c, lines3d.detach())
-        lines2d_calib = proj(eye, lines3d)
+            proj_pair = lambda X: (proj(K3c, X), proj(eye, X))
+        if xyz.is_cuda:
+            lines2d, lines2d_calib = proj_pair(lines3d)
+            lines2d = lines2d.detach()      # (rend_a :436: the pixel projection is taken of lines3d.detach())
+        else:
+            lines2d = proj(K3c, lines3d.detach())
+            lines2d_calib = proj(eye, lines3d)
         if self.training:
             cand_valid = None
             if self.dbscan_enabled:
@@ -540,8 +562,7 @@ class VolSDFNetwork(_HipModule):
             else:
                 cand3d = lines3d.detach().reshape(-1, 3)
             if self.dbscan_enabled or self.use_l3d:
-                cand2d = proj(K3c, cand3d)
-                cand2d_calib = proj(eye, cand3d)
+                cand2d, cand2d_calib = proj_pair(cand3d)
             else:      # the candidates ARE the line end points: their projections were just computed (same arithmetic, same values)
                 cand2d = lines2d.reshape(-1, 2)
                 cand2d_calib = lines2d_calib.detach().reshape(-1, 2)
@@ -586,8 +607,7 @@ class VolSDFNetwork(_HipModule):
             # padded + mask (what neat_amd.loss reads) and the compact tensors are built only if somebody asks for them
             output = JunctionOutputs(output, good, {"j2d_local": j2_pad, "j3d_local": j3_pad, "j2d_local_calib": j2c_pad})
             output["j3d_global"] = j3d_global
-            output["j2d_global"] = proj(K3c, j3d_global)
-            output["j2d_global_calib"] = proj(eye, j3d_global)
+            output["j2d_global"], output["j2d_global_calib"] = proj_pair(j3d_global)
         if side_b is not None:
             main.wait_stream(side_b)            # join: get_outputs(points3d) / l3d ran next to the matching above
         elif side is not None and not self.training:

@@ -853,10 +853,10 @@ class LossTailFn(torch.autograd.Function):
         d_rgb, d_gth, d_glo3, d_glo2c, d_pred = flat.split(sizes)
         d_gth = d_gth if E else None
         pair_cost = torch.empty(K, J, device=dev) if have_pairs else None
-        _lib.check(lib.neat_line_losses(_p(pu), _p(pc), _p(g5), _p(Kc), L, float(threshold), _p(line3), _p(d_pred), w_line, _stream()),
-                   "neat_line_losses")
-        _lib.check(lib.neat_loss_terms(_p(rgb_c), _p(gt_c), R, _p(gth_c), E, _p(loc3_c), _p(loc2c_c), K, _p(glo3_c), _p(glo2c_c), J,
-                                       _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), w_eik, _stream()), "neat_loss_terms")
+        # both line terms | rgb + eikonal + the junction pair cost: independent of each other, the two workgroups of ONE launch
+        _lib.check(lib.neat_loss_lines_terms(_p(pu), _p(pc), _p(g5), _p(Kc), L, float(threshold), _p(line3), _p(d_pred), w_line,
+                                             _p(rgb_c), _p(gt_c), R, _p(gth_c), E, _p(loc3_c), _p(loc2c_c), K, _p(glo3_c), _p(glo2c_c), J,
+                                             _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), w_eik, _stream()), "neat_loss_lines_terms")
         if have_pairs:
             ri, ci, n_match = linear_sum_assignment(pair_cost, good)
             loss = torch.empty((), device=dev)
@@ -895,6 +895,100 @@ def loss_tail(rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, 
     """-> (total loss, scal [8] = rgb, eikonal, j3d, j2d, j2d pixels, jcount, total, -, line3 [3] = l2d pixel term, line loss, count)."""
     return LossTailFn.apply(rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good,
                             float(w_eik), float(w_line), float(w_j3), float(w_j2), float(threshold))
+
+
+def camera_setup(uv, uv_proj, pose, intrinsics):
+    """Everything the forward derives from the camera alone in ONE launch (neat_camera_setup): rays through uv [1,R,2] (dirs [R,3],
+    origins [R,3]), rays through uv_proj (dirs [R,3]; None: not wanted), w2c [3,4] = [R | T] of pose^-1 and the contiguous K3 [3,3].
+    Same values as camera_rays x 2 + camera_mats."""
+    uv_c, pose_c, Kc = _f32c(uv.detach()), _f32c(pose.detach()), intrinsics.detach()
+    if pose_c.shape != (1, 4, 4) or Kc.dtype != torch.float32 or not Kc.is_cuda or Kc.stride(-1) != 1 or Kc.shape[0] != 1:
+        raise RuntimeError("camera_setup: one 4x4 pose, intrinsics with unit column stride, CUDA float32")
+    R, dev = uv_c.shape[1], uv_c.device
+    up = _f32c(uv_proj.detach()) if uv_proj is not None else None
+    if up is not None and up.shape != uv_c.shape:
+        raise RuntimeError("camera_setup: uv_proj must have uv's shape")
+    dirs, origins = torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev)
+    dirs2 = torch.empty(R, 3, device=dev) if up is not None else None
+    w2c, K3 = torch.empty(3, 4, device=dev), torch.empty(3, 3, device=dev)
+    _lib.check(_lib.lib().neat_camera_setup(_p(uv_c), _p(up), _p(pose_c), _p(Kc), int(Kc.stride(-2)), R, _p(dirs), _p(origins), _p(dirs2),
+                                            _p(w2c), _p(K3), _stream()), "neat_camera_setup")
+    return dirs, origins, dirs2, w2c, K3
+
+
+class Project2DPairFn(torch.autograd.Function):
+    """VolSDFNetwork.project2D of the same points with two intrinsics (pixels / calibrated) as one launch; backward: one launch per
+    output that received a gradient (gradient w.r.t. the points only)."""
+
+    @staticmethod
+    def forward(ctx, K3, K3b, w2c, X):
+        lib = _lib.lib()
+        K3, K3b, w2c = _f32c(K3.detach()), _f32c(K3b.detach()), _f32c(w2c.detach())
+        Xc = _f32c(X.detach().reshape(-1, 3))
+        uv, uv2 = torch.empty(Xc.shape[0], 2, device=Xc.device), torch.empty(Xc.shape[0], 2, device=Xc.device)
+        _lib.check(lib.neat_project2d_pair(_p(K3), _p(K3b), _p(w2c), _p(Xc), Xc.shape[0], _p(uv), _p(uv2), _stream()), "neat_project2d_pair")
+        ctx.save_for_backward(K3, K3b, w2c, Xc)
+        ctx.shape = X.shape
+        ctx.set_materialize_grads(False)
+        return uv.reshape(*X.shape[:-1], 2), uv2.reshape(*X.shape[:-1], 2)
+
+    @staticmethod
+    def backward(ctx, d_uv, d_uv2):
+        if d_uv is None and d_uv2 is None:
+            return None, None, None, None
+        K3, K3b, w2c, Xc = ctx.saved_tensors
+        total = None
+        for Kx, d in ((K3, d_uv), (K3b, d_uv2)):
+            if d is None:
+                continue
+            dX = torch.empty_like(Xc)
+            _lib.check(_lib.lib().neat_project2d_backward(_p(Kx), _p(w2c), _p(Xc), Xc.shape[0], _p(_f32c(d.reshape(-1, 2))), _p(dX), _stream()),
+                       "neat_project2d_backward")
+            total = dX if total is None else total + dX
+        return None, None, None, total.reshape(ctx.shape)
+
+
+def project2d_pair(K3, K3b, w2c, X):
+    """-> (project2d(K3, w2c, X), project2d(K3b, w2c, X)) from one launch."""
+    return Project2DPairFn.apply(K3, K3b, w2c, X)
+
+
+class SdfNormalsFn(torch.autograd.Function):
+    """ImplicitNetwork.get_outputs without the feature rows: (clamped sdf [P,1], d sdf / dx [P,3]), differentiable wrt the 27 SDF parameters
+    like SdfOutputsFn -- minus the two row-major copies of lin8's output (one launch) that the junction block never reads (rend_a :441-443)."""
+
+    @staticmethod
+    def forward(ctx, handle, x, radius, scale, *params):
+        lib = _lib.lib()
+        ctx.set_materialize_grads(False)
+        x = _f32c(x.detach())
+        P = x.shape[0]
+        packed, netp = handle.packed()
+        prec = handle.precision
+        ws = torch.empty(lib.neat_sdf_ws_floats(P, 1, prec), device=x.device, dtype=torch.float32)
+        sdf, grad = torch.empty(P, 1, device=x.device), torch.empty(P, 3, device=x.device)
+        _lib.check(lib.neat_sdf_forward(_p(packed), ctypes.byref(netp), _p(x), P, 1, prec, float(radius), float(scale), _p(ws),
+                                        None, _p(sdf), None, _p(grad), _stream()), "neat_sdf_forward(normals)")
+        ctx.handle, ctx.P, ctx.ws, ctx.packed, ctx.netp, ctx.prec = handle, P, ws, packed, netp, prec
+        ctx.keep = params
+        return sdf, grad
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_grad):
+        lib = _lib.lib()
+        gr, views, _ = _grad_buffers(ctx.handle, 0, N_SDF, ctx.ws.device)
+        d_sdf, d_grad = _f32c(d_sdf), _f32c(d_grad)
+        _lib.check(lib.neat_sdf_backward(_p(ctx.packed), ctypes.byref(ctx.netp), _p(ctx.ws), ctx.P, ctx.prec, None, _p(d_sdf), None, _p(d_grad),
+                                         ctypes.byref(gr), _stream()), "neat_sdf_backward")
+        ctx.ws = None
+        return (None, None, None, None, *views)
+
+
+def sdf_point_normals(handle, x, radius, scale):
+    """-> (clamped sdf [P,1], d sdf / dx [P,3]): get_outputs as the junction block uses it."""
+    if x.shape[0] == 0:
+        return x.new_zeros(0, 1), x.new_zeros(0, 3)
+    return SdfNormalsFn.apply(handle, x, radius, scale, *handle.tensors(0, N_SDF))
 
 
 def camera_mats(pose, intrinsics):
