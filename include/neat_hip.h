@@ -298,15 +298,20 @@ int neat_junction_gate(const long long* rows, const long long* cols, int K, cons
 int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E, const float* loc3, const float* loc2c, int K,
                     const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb, float* d_gtheta, float* pair_cost,
                     float eik_grad_scale, void* stream);
-/* ABI v13: neat_line_losses and neat_loss_terms (independent of each other) as the two workgroups of one launch; same arithmetic. */
+/* ABI v13: neat_line_losses and neat_loss_terms (independent of each other) as the two workgroups of one launch; same arithmetic.
+ * d_lines3d != NULL: pred_calib = neat_project2d(identity, w2c, lines3d [L,2,3]) (rend_a :441); the gradient of the line term is carried
+ * through that projection here (d_lines3d [L,2,3], neat_project2d_backward's arithmetic).  Likewise neat_loss_pairs with w2c != NULL:
+ * glo2c = neat_project2d(identity, w2c, glo3) (:496) and d_glo3 receives d_glo2c's share -- the projections' backward launches and the
+ * accumulation of the global junctions' two gradients disappear from the step. */
 int neat_loss_lines_terms(const float* pred_px, const float* pred_calib, const float* gt5, const float* Kmat, int L, float threshold, float* out3,
                           float* d_pred_calib, float grad_scale, const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E,
                           const float* loc3, const float* loc2c, int K, const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb,
-                          float* d_gtheta, float* pair_cost, float eik_grad_scale, void* stream);
+                          float* d_gtheta, float* pair_cost, float eik_grad_scale, const float* w2c, const float* lines3d, float* d_lines3d,
+                          void* stream);
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
                     float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, int weighted_grads,
-                    float* total, void* stream);
+                    float* total, const float* w2c, void* stream);
 /* global-junction MLP ffn(latents) (rend_a :303-313, :491): x [J,256] -> relu(W0 x + b0) -> relu(W1 . + b1) -> W2 . + b2 = y [J,3];
  * torch nn.Linear layouts (W [out,in]); h1, h2 [J,256] are saved for the backward; ws2 = 2 J 256 floats of scratch. */
 int neat_ffn_forward(const float* x, int J, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,

@@ -72,7 +72,7 @@ _SIGNATURES = {
     "neat_sdf_ldp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "neat_loss_lines_terms": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, ctypes.c_float,
                                              c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
-                                             c_fp, c_fp, c_fp, c_fp, ctypes.c_float, c_fp]),
+                                             c_fp, c_fp, c_fp, c_fp, ctypes.c_float, c_fp, c_fp, c_fp, c_fp]),
     "neat_camera_setup": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "neat_project2d_pair": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_sdf_values_laid_out": (ctypes.c_int, [c_fp, ctypes.POINTER(NetParams), ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
@@ -92,7 +92,7 @@ _SIGNATURES = {
     "neat_loss_terms": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
                                        c_fp, c_fp, c_fp, c_fp, ctypes.c_float, c_fp]),
     "neat_loss_pairs": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp,
-                                       c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_fp, c_fp]),
+                                       c_fp, c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_camera_mats": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "neat_inv_small": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "neat_project2d": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),

@@ -353,20 +353,33 @@ __global__ void project2d_pair_kernel(const float* __restrict__ K, const float* 
 }
 
 // d_X = R^T K^T d_cam with d_cam = (d_u / w, d_v / w, -(d_u u + d_v v) / w)
-__global__ void project2d_bwd_kernel(const float* __restrict__ K, const float* __restrict__ w2c, const float* __restrict__ X, int N,
-                                     const float* __restrict__ d_uv, float* __restrict__ d_X) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const float x[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+__device__ __forceinline__ void project_bwd_point(const float* K, const float* w2c, const float x[3], float du, float dv, float dX[3]) {
   float cam[3], w;
   project_point(K, w2c, x, cam, w);
-  const float du = d_uv[2 * i], dv = d_uv[2 * i + 1];
   const float dcam[3] = {du / w, dv / w, -(du * (cam[0] / w) + dv * (cam[1] / w)) / w};
   float dc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) dc[j] = K[j] * dcam[0] + K[3 + j] * dcam[1] + K[6 + j] * dcam[2];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) d_X[3 * i + j] = w2c[j] * dc[0] + w2c[4 + j] * dc[1] + w2c[8 + j] * dc[2];
+  for (int j = 0; j < 3; ++j) dX[j] = w2c[j] * dc[0] + w2c[4 + j] * dc[1] + w2c[8 + j] * dc[2];
+}
+__global__ void project2d_bwd_kernel(const float* __restrict__ K, const float* __restrict__ w2c, const float* __restrict__ X, int N,
+                                     const float* __restrict__ d_uv, float* __restrict__ d_X) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float x[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+  float dX[3];
+  project_bwd_point(K, w2c, x, d_uv[2 * i], d_uv[2 * i + 1], dX);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) d_X[3 * i + j] = dX[j];
+}
+// The identity intrinsics of the calibrated projections (rend_a :441, :496), for the backward passes folded into the loss kernels: the
+// products with its 1.0 / 0.0 entries are the ones project2d_bwd_kernel forms with the identity TENSOR, so the results are the same bits.
+__device__ __forceinline__ void project_bwd_calib(const float* w2c, const float x[3], float du, float dv, float dX[3]) {
+  float I3[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(I3[k]));      // opaque: no algebraic shortcut (0 * inf, -0) the tensor form would not take
+  project_bwd_point(I3, w2c, x, du, dv, dX);
 }
 
 // Endpoint-order-invariant L1 between 2-D segments, gated (model/networks/loss_wfr.py:34-45), one workgroup:
@@ -467,9 +480,13 @@ __device__ __forceinline__ void inv_small_body(const float* sA, float* __restric
 // (grad_scale = the line term's weight in the total loss: the backward pass then has nothing left to multiply).
 // Same arithmetic and summation order as line_loss_kernel / inv_small_kernel / project2d_kernel, which it replaces on this path
 // (eleven launches: two slices, compare, ones, cat, inverse, projection, mask product, two line losses, sum).
+// w2c / X3 / d_X3 (round 6; null: not wanted): the calibrated predictions are project2d(I, w2c, X3) of the 3-D line end points X3 [R,2,3]
+// (rend_a :441); their gradient is carried on to d_X3 = d loss / d X3 here (the arithmetic of project2d_bwd_kernel) -- one launch less.
 __device__ __forceinline__ void line_losses_body(const float* __restrict__ pred_u, const float* __restrict__ pred_c,
                                                  const float* __restrict__ gt5, const float* __restrict__ K, int R, float thr,
-                                                 float* __restrict__ out, float* __restrict__ d_pred_c, float grad_scale) {
+                                                 float* __restrict__ out, float* __restrict__ d_pred_c, float grad_scale,
+                                                 const float* __restrict__ w2c = nullptr, const float* __restrict__ X3 = nullptr,
+                                                 float* __restrict__ d_X3 = nullptr) {
   __shared__ float s_acc[4][16];
   __shared__ float s_kinv[9], s_k[9];
   __shared__ float s_inv;
@@ -540,8 +557,19 @@ __device__ __forceinline__ void line_losses_body(const float* __restrict__ pred_
     float lu, lc, w, sg[4];
     terms(r, lu, lc, w, sg);
     const float coef = (lc < thr) ? (w * (lu < thr ? 1.0f : 0.0f)) * inv * 0.25f : 0.0f;
+    float dp[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) d_pred_c[4 * r + c] = (coef * sg[c]) * grad_scale;
+    for (int c = 0; c < 4; ++c) { dp[c] = (coef * sg[c]) * grad_scale; d_pred_c[4 * r + c] = dp[c]; }
+    if (d_X3) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float x[3] = {X3[6 * r + 3 * e], X3[6 * r + 3 * e + 1], X3[6 * r + 3 * e + 2]};
+        float dX[3];
+        project_bwd_calib(w2c, x, dp[2 * e], dp[2 * e + 1], dX);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) d_X3[6 * r + 3 * e + j] = dX[j];
+      }
+    }
   }
 }
 
@@ -1139,9 +1167,10 @@ __global__ __launch_bounds__(1024) void loss_terms_kernel(LossTermsArgs a) { los
 
 // Both independent halves of the loss after the projections in ONE launch (round 6): workgroup 0 = the two line terms
 // (line_losses_body), workgroup 1 = rgb + eikonal + the junction pair cost (loss_terms_body).  Same arithmetic as the two launches.
-struct LineLossesArgs { const float* pred_u; const float* pred_c; const float* gt5; const float* K; int R; float thr; float* out; float* d_pred_c; float grad_scale; };
+struct LineLossesArgs { const float* pred_u; const float* pred_c; const float* gt5; const float* K; int R; float thr; float* out; float* d_pred_c; float grad_scale;
+                        const float* w2c; const float* X3; float* d_X3; };
 __global__ __launch_bounds__(1024) void loss_lines_terms_kernel(LineLossesArgs l, LossTermsArgs t) {
-  if (blockIdx.x == 0) line_losses_body(l.pred_u, l.pred_c, l.gt5, l.K, l.R, l.thr, l.out, l.d_pred_c, l.grad_scale);
+  if (blockIdx.x == 0) line_losses_body(l.pred_u, l.pred_c, l.gt5, l.K, l.R, l.thr, l.out, l.d_pred_c, l.grad_scale, l.w2c, l.X3, l.d_X3);
   else loss_terms_body(t);
 }
 
@@ -1155,6 +1184,7 @@ struct LossPairsArgs {
   const float* line_loss; float w_eik, w_line, w_j3, w_j2;                     // scal[6] = rgb + w_eik eik + w_line line + w_j3 j3d + w_j2 j2d
   int weighted_grads;                                                           // 1: d_glo3 / d_glo2c carry w_j3 / w_j2 (gradients of scal[6])
   float* total;                                                                 // scal[6] once more, in a tensor of its own (or null)
+  const float* w2c;            // round 6 (null: not wanted): glo2c = project2d(I, w2c, glo3) (rend_a :496) -- d_glo2c is carried on into d_glo3 here
 };
 
 __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
@@ -1186,6 +1216,15 @@ __global__ __launch_bounds__(1024) void loss_pairs_kernel(LossPairsArgs a) {
     if (a.pair_cost[r * a.J + c] < 10.0f) cnt += 1.0f;
   }
   s3 = block_sum(s3, s_red); s2 = block_sum(s2, s_red); spx = block_sum(spx, s_red); cnt = block_sum(cnt, s_red);
+  if (a.w2c) {                 // (block_sum's barriers order the writes above): d_glo3 += (d glo2c / d glo3)^T d_glo2c, project2d_bwd_kernel's arithmetic
+    for (int j = tid; j < a.J; j += nt) {
+      const float x[3] = {a.glo3[3 * j], a.glo3[3 * j + 1], a.glo3[3 * j + 2]};
+      float dX[3];
+      project_bwd_calib(a.w2c, x, a.d_glo2c[2 * j], a.d_glo2c[2 * j + 1], dX);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) a.d_glo3[3 * j + e] += dX[e];
+    }
+  }
   if (tid == 0) {
     a.scal[2] = s3 * inv; a.scal[3] = s2 * inv; a.scal[4] = spx * inv; a.scal[5] = cnt;
     const float tot = a.scal[0] + a.w_eik * a.scal[1] + a.w_line * a.line_loss[0] + a.w_j3 * (s3 * inv) + a.w_j2 * (s2 * inv);

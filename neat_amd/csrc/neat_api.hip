@@ -2300,11 +2300,13 @@ int neat_loss_terms(const float* rgb, const float* rgb_gt, int R, const float* g
 int neat_loss_lines_terms(const float* pred_px, const float* pred_calib, const float* gt5, const float* Kmat, int L, float threshold, float* out3,
                           float* d_pred_calib, float grad_scale, const float* rgb, const float* rgb_gt, int R, const float* gtheta, int E,
                           const float* loc3, const float* loc2c, int K, const float* glo3, const float* glo2c, int J, float* scal, float* d_rgb,
-                          float* d_gtheta, float* pair_cost, float eik_grad_scale, void* stream) {
+                          float* d_gtheta, float* pair_cost, float eik_grad_scale, const float* w2c, const float* lines3d, float* d_lines3d,
+                          void* stream) {
   if (L <= 0 || !pred_px || !pred_calib || !gt5 || !Kmat || !out3 || !d_pred_calib) return -1;
+  if (d_lines3d && (!w2c || !lines3d)) return -1;
   if (R <= 0 || !rgb || !rgb_gt || !scal || !d_rgb || E < 0 || K < 0 || J < 0) return -1;
   if ((E > 0 && (!gtheta || !d_gtheta)) || (K > 0 && J > 0 && (!loc3 || !loc2c || !glo3 || !glo2c || !pair_cost))) return -1;
-  LineLossesArgs l{pred_px, pred_calib, gt5, Kmat, L, threshold, out3, d_pred_calib, grad_scale};
+  LineLossesArgs l{pred_px, pred_calib, gt5, Kmat, L, threshold, out3, d_pred_calib, grad_scale, w2c, lines3d, d_lines3d};
   LossTermsArgs a{rgb, rgb_gt, R, gtheta, E, loc3, loc2c, (J > 0 ? K : 0), glo3, glo2c, J, scal, d_rgb, d_gtheta, pair_cost, eik_grad_scale};
   hipLaunchKernelGGL(loss_lines_terms_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, l, a);
   return (int)hipGetLastError();
@@ -2313,11 +2315,11 @@ int neat_loss_lines_terms(const float* pred_px, const float* pred_calib, const f
 int neat_loss_pairs(const long long* ri, const long long* ci, const int* n_match, int Kmax, const float* loc3, const float* loc2c,
                     const float* loc2, const float* glo3, const float* glo2c, const float* glo2, int J, const float* pair_cost, float* scal,
                     float* d_glo3, float* d_glo2c, const float* line_loss, float w_eik, float w_line, float w_j3, float w_j2, int weighted_grads,
-                    float* total, void* stream) {
+                    float* total, const float* w2c, void* stream) {
   if (Kmax < 0 || J <= 0 || !ri || !ci || !n_match || !loc3 || !loc2c || !loc2 || !glo3 || !glo2c || !glo2 || !pair_cost || !scal ||
       !d_glo3 || !d_glo2c || !line_loss) return -1;
   LossPairsArgs a{ri, ci, n_match, Kmax, loc3, loc2c, loc2, glo3, glo2c, glo2, J, pair_cost, scal, d_glo3, d_glo2c, line_loss, w_eik, w_line,
-                  w_j3, w_j2, weighted_grads, total};
+                  w_j3, w_j2, weighted_grads, total, w2c};
   hipLaunchKernelGGL(loss_pairs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

@@ -101,11 +101,17 @@ class VolSDFLoss(nn.Module):
             gtheta = model_outputs["grad_theta"] if "grad_theta" in model_outputs else None
             glo = (model_outputs["j3d_global"], model_outputs["j2d_global_calib"], model_outputs["j2d_global"].detach()) if have_junctions \
                 else (None, None, None)
+            # the model's calibrated projections (lines2d_calib, j2d_global_calib) as (points, w2c): the loss kernels then carry their
+            # gradients through the projections themselves (ops.LossTailFn) -- only for the very tensors the model made that way
+            cp = getattr(model_outputs, "calib_proj", None)
+            fold = (cp is not None and cp.get("lines2d_calib") is model_outputs["lines2d_calib"] and cp.get("lines3d") is model_outputs["lines3d"]
+                    and (not have_junctions or (cp.get("j2d_global_calib") is glo[1] and cp.get("j3d_global") is glo[0])))
             loss, scal, line3 = ops.loss_tail(model_outputs["rgb_values"], gtheta, glo[0], glo[1], model_outputs["lines2d_calib"],
                                               model_outputs["lines2d"].detach(), gt5, model_outputs["K"], ground_truth["rgb"].to(dev),
                                               loc3 if have_junctions else None, loc2c if have_junctions else None,
                                               loc2 if have_junctions else None, glo[2], good, self.eikonal_weight, self.line_weight,
-                                              self.junction_3d_weight, self.junction_2d_weight, 100.0)
+                                              self.junction_3d_weight, self.junction_2d_weight, 100.0,
+                                              cp["lines3d"] if fold else None, cp["w2c"] if fold else None)
             line_loss = line3[1]
             self._check_deferred()
             self._defer_nan_check(line_loss)

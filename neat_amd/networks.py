@@ -287,6 +287,10 @@ class JunctionOutputs(dict):
     def __init__(self, base, good, padded):
         super().__init__(base)
         self.good, self.padded = good, padded
+        # (set by VolSDFNetwork.forward on CUDA) how the calibrated projections were made: {"w2c", "lines3d", "lines2d_calib",
+        # "j3d_global", "j2d_global_calib"} with lines2d_calib = project2D(I, w2c, lines3d) etc.; neat_amd.loss folds their backward
+        # passes into its own kernels when it is handed exactly these tensors
+        self.calib_proj = None
 
     def __missing__(self, key):
         if key in self.padded:
@@ -608,6 +612,9 @@ class VolSDFNetwork(_HipModule):
             output = JunctionOutputs(output, good, {"j2d_local": j2_pad, "j3d_local": j3_pad, "j2d_local_calib": j2c_pad})
             output["j3d_global"] = j3d_global
             output["j2d_global"], output["j2d_global_calib"] = proj_pair(j3d_global)
+            if xyz.is_cuda:
+                output.calib_proj = {"w2c": w2c3, "lines3d": lines3d, "lines2d_calib": lines2d_calib, "j3d_global": j3d_global,
+                                     "j2d_global_calib": output["j2d_global_calib"]}
         if side_b is not None:
             main.wait_stream(side_b)            # join: get_outputs(points3d) / l3d ran next to the matching above
         elif side is not None and not self.training:

@@ -831,7 +831,10 @@ class LossTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good,
-                w_eik, w_line, w_j3, w_j2, threshold):
+                w_eik, w_line, w_j3, w_j2, threshold, lines3d=None, w2c=None):
+        # lines3d / w2c given (the model's own outputs, networks.JunctionOutputs.calib_proj): pred_calib = project2d(I, w2c, lines3d) and
+        # glo2c = project2d(I, w2c, glo3); the kernels then carry their gradients through those projections themselves and the node's
+        # differentiable inputs are lines3d and glo3 -- no projection backward launch, no accumulation of glo3's two gradients
         lib = _lib.lib()
         dev = rgb.device
         c = lambda t: None if t is None else _f32c(t.detach())
@@ -848,53 +851,59 @@ class LossTailFn(torch.autograd.Function):
         # (with junction pairs the launches write all seven scalars the caller reads: no fill launch)
         scal = torch.empty(8, device=dev) if have_pairs else torch.zeros(8, device=dev)
         line3 = torch.empty(3, device=dev)
-        sizes = [R * 3, E * 3, J * 3 if have_pairs else 0, J * 2 if have_pairs else 0, L * 4]
+        fold = lines3d is not None and w2c is not None
+        x3_c, w2c_c = (_f32c(lines3d.detach().reshape(-1, 6)), _f32c(w2c.detach())) if fold else (None, None)
+        if fold and (x3_c.shape[0] != L or w2c_c.shape != (3, 4)):
+            raise RuntimeError("loss_tail: lines3d [L,2,3] and w2c [3,4]")
+        sizes = [R * 3, E * 3, J * 3 if have_pairs else 0, J * 2 if have_pairs else 0, L * 4, L * 6 if fold else 0]
         flat = torch.empty(sum(sizes), device=dev)
-        d_rgb, d_gth, d_glo3, d_glo2c, d_pred = flat.split(sizes)
+        d_rgb, d_gth, d_glo3, d_glo2c, d_pred, d_x3 = flat.split(sizes)
         d_gth = d_gth if E else None
         pair_cost = torch.empty(K, J, device=dev) if have_pairs else None
         # both line terms | rgb + eikonal + the junction pair cost: independent of each other, the two workgroups of ONE launch
         _lib.check(lib.neat_loss_lines_terms(_p(pu), _p(pc), _p(g5), _p(Kc), L, float(threshold), _p(line3), _p(d_pred), w_line,
                                              _p(rgb_c), _p(gt_c), R, _p(gth_c), E, _p(loc3_c), _p(loc2c_c), K, _p(glo3_c), _p(glo2c_c), J,
-                                             _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), w_eik, _stream()), "neat_loss_lines_terms")
+                                             _p(scal), _p(d_rgb), _p(d_gth), _p(pair_cost), w_eik, _p(w2c_c), _p(x3_c), _p(d_x3) if fold else None,
+                                             _stream()), "neat_loss_lines_terms")
         if have_pairs:
             ri, ci, n_match = linear_sum_assignment(pair_cost, good)
             loss = torch.empty((), device=dev)
             _lib.check(lib.neat_loss_pairs(_p(ri), _p(ci), _p(n_match), ri.shape[0], _p(loc3_c), _p(loc2c_c), _p(loc2_c), _p(glo3_c),
                                            _p(glo2c_c), _p(glo2_c), J, _p(pair_cost), _p(scal), _p(d_glo3), _p(d_glo2c),
-                                           _ip(line3, 1), w_eik, w_line, w_j3, w_j2, 1, _p(loss), _stream()), "neat_loss_pairs")
+                                           _ip(line3, 1), w_eik, w_line, w_j3, w_j2, 1, _p(loss), _p(w2c_c), _stream()), "neat_loss_pairs")
         else:
             loss = scal[0] + w_eik * scal[1] + w_line * line3[1]
         ctx.save_for_backward(flat)
         ctx.sizes = sizes
         ctx.set_materialize_grads(False)
         ctx.shapes = (rgb.shape, None if gtheta is None else gtheta.shape, None if glo3 is None or not have_pairs else glo3.shape,
-                      None if glo2c is None or not have_pairs else glo2c.shape, pred_calib.shape)
+                      None if glo2c is None or not have_pairs or fold else glo2c.shape, None if fold else pred_calib.shape,
+                      lines3d.shape if fold else None)
         ctx.mark_non_differentiable(scal, line3)
         return loss, scal, line3
 
     @staticmethod
     def backward(ctx, g_loss, g_scal, g_line3):
         if g_loss is None:
-            return (None,) * 19
+            return (None,) * 21
         (flat,) = ctx.saved_tensors
         one = _GRAD_ONE.get(str(flat.device))
         if not (_UNIT_SEED[0] and one is not None and g_loss.data_ptr() == one.data_ptr()):
             flat = flat * g_loss          # a fresh tensor: the views below never alias the saved buffer (retain_graph callers)
         g = flat.split(ctx.sizes)
-        s_rgb, s_gth, s_glo3, s_glo2c, s_pred = ctx.shapes
+        s_rgb, s_gth, s_glo3, s_glo2c, s_pred, s_x3 = ctx.shapes
         return (g[0].view(s_rgb),
                 None if s_gth is None else g[1].view(s_gth),
                 None if s_glo3 is None else g[2].view(s_glo3),
                 None if s_glo2c is None else g[3].view(s_glo2c),
-                g[4].view(s_pred)) + (None,) * 14
+                None if s_pred is None else g[4].view(s_pred)) + (None,) * 14 + (None if s_x3 is None else g[5].view(s_x3), None)
 
 
 def loss_tail(rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good, w_eik, w_line, w_j3, w_j2,
-              threshold=100.0):
+              threshold=100.0, lines3d=None, w2c=None):
     """-> (total loss, scal [8] = rgb, eikonal, j3d, j2d, j2d pixels, jcount, total, -, line3 [3] = l2d pixel term, line loss, count)."""
     return LossTailFn.apply(rgb, gtheta, glo3, glo2c, pred_calib, pred_px, gt5, Kmat, rgb_gt, loc3, loc2c, loc2, glo2, good,
-                            float(w_eik), float(w_line), float(w_j3), float(w_j2), float(threshold))
+                            float(w_eik), float(w_line), float(w_j3), float(w_j2), float(threshold), lines3d, w2c)
 
 
 def camera_setup(uv, uv_proj, pose, intrinsics):
