@@ -537,7 +537,9 @@ def main():
         host_ms = 1e3 * host_s / 9.0
         barrier()
         dist_info = {"backend": dist.get_backend(), "world": world, "ranks": world, "host_ms_per_step": host_ms,
-                     "step_sequence": ("graph replay (ends with the gradient pack) -> all-reduce -> Adam on the flat buffer, one stream"
+                     "step_sequence": (("ONE graph launch: forward + loss + backward + gradient pack + all-reduce + Adam on the flat buffer"
+                                        if getattr(tr._last, "adam_has", None) is not None else
+                                        "graph replay (ends with the gradient pack) -> all-reduce -> Adam on the flat buffer, one stream")
                                        if graphed and getattr(tr._last, "packed", False) else "eager step + pack + all-reduce + Adam"),
                      "ms_per_step_by_rank": [1e3 * float(t.item()) / args.steps for t in every],
                      "allreduce_ms": float(ar.item()), "allreduce_bytes": int(flat.numel() * 4),
@@ -654,7 +656,8 @@ def main():
                                    ((" + RCCL grad all-reduce" if dist.get_backend() == "nccl" else " + gloo grad all-reduce (functional check)") if dist.is_initialized() else ""),
                        "rays_per_gpu": rays, "samples_per_ray": S_SAMPLES, "global_rays": world * rays,
                        "parallelism": f"dp{world}", "weights": "synthetic 'rough' (seed 42)",
-                       "launch": "hip graph replay (forward+loss+backward) + eager all-reduce/Adam" if graphed else "eager" + graph_note,
+                       "launch": (("hip graph replay, the whole step one launch (forward + loss + backward" + (" + gradient pack + all-reduce" if getattr(tr._last, "packed", False) else "") + " + Adam)")
+                                  if getattr(tr._last, "adam_has", None) is not None else "hip graph replay (forward+loss+backward) + eager all-reduce/Adam") if graphed else "eager" + graph_note,
                        "dist_backend": (dist.get_backend() if dist.is_initialized() else None)},
             "rays_per_s": world * rays * args.steps / elapsed,
             "step_tflops": value * FLOP_PER_RAY_SAMPLE / 1e12,

@@ -351,6 +351,10 @@ int neat_line_losses(const float* pred_px, const float* pred_calib, const float*
  * that segment has taken including this one (torch counts steps per tensor) -- host arrays, nseg <= 96. */
 int neat_adam_step(float* params, const float* const* grads, const long long* seg_offsets, const int* seg_steps, int nseg,
                    float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, void* stream);
+/* ABI v13: neat_adam_step with its step-dependent numbers in DEVICE memory -- coef [2 nseg] = (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t))
+ * per segment -- so that the launch can be captured in the step's HIP graph and replayed; grads[s] == NULL: segment untouched. */
+int neat_adam_step_coef(float* params, const float* const* grads, const long long* seg_offsets, int nseg, float* exp_avg, float* exp_avg_sq,
+                        const float* coef, float beta1, float beta2, float eps, void* stream);
 
 /* ---- 8f-2 (next row): device-side rectangular assignment = scipy.optimize.linear_sum_assignment as called at
  * model/networks/neat_wfr_rend_a.py:473 and model/networks/loss_wfr.py:108 (same algorithm, float64 duals, same tie

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "neat_sampler_finish_dev": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_float,
                                                ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "neat_sdf_ldp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "neat_adam_step_coef": (ctypes.c_int, [c_fp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, c_fp, c_fp,
+                                           c_fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_fp]),
     "neat_loss_lines_terms": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp, ctypes.c_float,
                                              c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, ctypes.c_int,
                                              c_fp, c_fp, c_fp, c_fp, ctypes.c_float, c_fp, c_fp, c_fp, c_fp]),

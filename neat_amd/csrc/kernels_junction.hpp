@@ -250,8 +250,11 @@ struct AdamSegs {                 // gradient of segment s covers [off[s], off[s
 };
 
 constexpr int ADAM_SEGS_KERNARG_OFFSET = 8;     // adam_flat_kernel(float* p, AdamSegs segs, ...): segs follows the first pointer
+// coef (round 6; null: the kernel-argument table's values): device array [2 nseg] = (lr / bias_correction1, 1 / sqrt(bias_correction2))
+// per segment -- the step-dependent numbers of a launch that is CAPTURED in the step's HIP graph; the host refreshes the array
+// before every replay (same double-precision formulas, neat_amd/optim.py)
 __global__ void adam_flat_kernel(float* __restrict__ p, AdamSegs segs, float* __restrict__ m, float* __restrict__ v,
-                                 long long n, float beta1, float beta2, float eps) {
+                                 long long n, float beta1, float beta2, float eps, const float* __restrict__ coef) {
   __shared__ long long s_off[ADAM_MAXSEG + 1];
   __shared__ const float* s_g[ADAM_MAXSEG];
   __shared__ float s_a1[ADAM_MAXSEG], s_a2[ADAM_MAXSEG];
@@ -262,7 +265,7 @@ __global__ void adam_flat_kernel(float* __restrict__ p, AdamSegs segs, float* __
   const karg_segs tab = (karg_segs)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + ADAM_SEGS_KERNARG_OFFSET);
   for (int t = threadIdx.x; t <= segs.nseg; t += blockDim.x) {
     s_off[t] = tab->off[t];
-    if (t < segs.nseg) { s_g[t] = tab->g[t]; s_a1[t] = tab->lr_over_bc1[t]; s_a2[t] = tab->inv_sqrt_bc2[t]; }
+    if (t < segs.nseg) { s_g[t] = tab->g[t]; s_a1[t] = coef ? coef[2 * t] : tab->lr_over_bc1[t]; s_a2[t] = coef ? coef[2 * t + 1] : tab->inv_sqrt_bc2[t]; }
   }
   __syncthreads();
   // ADAM_PASSES coalesced float4 passes per thread (the segment table above is built once per 4 * ADAM_PASSES * blockDim

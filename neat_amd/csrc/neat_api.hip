@@ -2228,7 +2228,24 @@ int neat_adam_step(float* params, const float* const* grads, const long long* se
   const long long per_block = 1024LL * ADAM_PASSES;    // ADAM_PASSES float4 passes of 256 threads
   const long long blocks = (n + per_block - 1) / per_block;
   hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
-                     exp_avg_sq, n, beta1, beta2, eps);
+                     exp_avg_sq, n, beta1, beta2, eps, (const float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int neat_adam_step_coef(float* params, const float* const* grads, const long long* seg_offsets, int nseg, float* exp_avg, float* exp_avg_sq,
+                        const float* coef, float beta1, float beta2, float eps, void* stream) {
+  if (nseg <= 0) return 0;
+  if (!params || !grads || !seg_offsets || !exp_avg || !exp_avg_sq || !coef || nseg > ADAM_MAXSEG) return -1;
+  AdamSegs segs{};
+  for (int s = 0; s < nseg; ++s) { segs.g[s] = grads[s]; segs.off[s] = seg_offsets[s]; }
+  segs.off[nseg] = seg_offsets[nseg];
+  segs.nseg = nseg;
+  const long long n = seg_offsets[nseg];
+  if (n <= 0) return 0;
+  const long long per_block = 1024LL * ADAM_PASSES;
+  const long long blocks = (n + per_block - 1) / per_block;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, segs, exp_avg,
+                     exp_avg_sq, n, beta1, beta2, eps, coef);
   return (int)hipGetLastError();
 }
 

@@ -33,6 +33,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(self.numel, device=dev)
         self.exp_avg_sq = torch.zeros(self.numel, device=dev)
         self._steps = (ctypes.c_int * len(sizes))()
+        # step-dependent numbers of a CAPTURED launch (capture_step): (lr / bias_correction1, 1 / sqrt(bias_correction2)) per tensor, in
+        # device memory; refreshed by the trainer before every replay with next_coef()
+        self.coef = torch.zeros(2 * len(sizes), device=dev)
         for i, p in enumerate(self._params):
             off, n = self._offsets[i], sizes[i]
             view = self.flat_param[off:off + n].view(p.shape)
@@ -89,6 +92,63 @@ class FlatAdam(torch.optim.Optimizer):
         torch._C._increment_version(self._params)
         self._steps_dirty = True                   # state[p]["step"] is refreshed when somebody reads it (state_dict), not 65 tensors per step
         return loss
+
+    @torch.no_grad()
+    def capture_step(self, flat_grad=None):
+        """The Adam launch as a node of the step's HIP graph (call INSIDE the capture): gradients through a pointer table -- the
+        parameters' .grad tensors as they are now (the graph's own static tensors), or one flat buffer -- and the step-dependent
+        numbers from `self.coef` (device).  Returns `has`: which parameters the captured launch updates; the caller refreshes
+        `self.coef` with next_coef(has) before every replay.  Nothing is stepped by this call (a capture does not execute)."""
+        group = self.param_groups[0]
+        self._realias()
+        tab = (ctypes.c_void_p * len(self._params))()
+        has = []
+        for i, p in enumerate(self._params):
+            if flat_grad is not None:
+                tab[i] = flat_grad.data_ptr() + 4 * self._offsets[i]
+                has.append(True)
+            else:
+                g = p.grad
+                ok = g is not None and g.dtype == torch.float32 and g.is_contiguous()
+                if g is not None and not ok:
+                    raise RuntimeError("FlatAdam.capture_step: contiguous float32 gradients only")
+                if ok:
+                    tab[i] = g.data_ptr()
+                has.append(ok)
+        b1, b2 = group["betas"]
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().neat_adam_step_coef(P(self.flat_param), tab, self._offsets, len(self._params), P(self.exp_avg), P(self.exp_avg_sq),
+                                                  P(self.coef), float(b1), float(b2), float(group["eps"]),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "neat_adam_step_coef")
+        return has
+
+    def next_coef(self, has):
+        """Counts one step for the parameters of `has` and returns the captured launch's numbers for it as a CPU float32 tensor
+        [2 n] (the arithmetic of neat_adam_step: double precision, rounded once)."""
+        import math
+        group = self.param_groups[0]
+        # (neat_adam_step receives lr and the betas as C floats and widens them: the same float32-rounded values here, so that a
+        # replayed step and an eager one update the parameters to the same bits)
+        f32 = lambda x: ctypes.c_float(float(x)).value
+        b1, b2 = (f32(b) for b in group["betas"])
+        lr = f32(group["lr"])
+        out = torch.zeros(2 * len(self._params), dtype=torch.float32)
+        cache = {}
+        for i, h in enumerate(has):
+            if not h:
+                continue
+            self._steps[i] += 1
+            t = self._steps[i]
+            c = cache.get(t)
+            if c is None:
+                c = cache[t] = (lr / (1.0 - math.pow(b1, t)), 1.0 / math.sqrt(1.0 - math.pow(b2, t)))
+            out[2 * i], out[2 * i + 1] = c
+        self._steps_dirty = True
+        return out
+
+    def after_replay(self):
+        """The parameters changed behind autograd's back (a replayed graph): bump their version counters."""
+        torch._C._increment_version(self._params)
 
     def _sync_steps(self):
         if getattr(self, "_steps_dirty", False):

@@ -1,5 +1,7 @@
 """One training step of the hot path as the reference trainer runs it (code/training/volsdf_train.py:361-374,408):
 forward -> loss -> zero_grad/backward -> [gradient all-reduce] -> Adam step -> per-iteration ExponentialLR."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -49,6 +51,10 @@ class Trainer:
         self._visits, self._uncapturable, self._last = {}, set(), None
         self._capture_fault = None
         self.replays = self.eager_steps = 0
+        # round 6: what a captured step holds besides forward + loss + backward: the Adam launch (graph_tail) and, in a data-parallel
+        # run, the gradient all-reduce in front of it (graph_collective; off: all-reduce and Adam stay eager behind the replay)
+        self.graph_tail = os.environ.get("NEAT_GRAPH_TAIL", "1") != "0"
+        self.graph_collective = os.environ.get("NEAT_GRAPH_COLLECTIVE", "1") != "0"
 
     def step(self, model_input, ground_truth):
         if self._graphs or self.auto_capture:
@@ -190,7 +196,20 @@ class Trainer:
                 entry.packed = self.bucket.active() and self.device.type == "cuda" and hasattr(self.optimizer, "flat_param")
                 if entry.packed:
                     self.bucket.pack()
+                # round 6: the tail of the step inside the graph too -- [the gradient all-reduce on RCCL, when `graph_collective`] and
+                # the Adam launch (its step-dependent numbers live in device memory, refreshed with the step's other host-made
+                # inputs): a replayed step is then ONE graph launch, nothing is enqueued behind it
+                # (gloo's device all-reduce synchronises the stream: not capturable, the tail then stays eager as in round 5)
+                coll_ok = self.graph_collective and dist.is_initialized() and dist.get_backend(self.bucket.group) == "nccl"
+                tail = self.graph_tail and hasattr(self.optimizer, "capture_step") and (not entry.packed or coll_ok)
+                if tail:
+                    if entry.packed:
+                        self.bucket.reduce_packed(repoint=False)
+                    entry.adam_has = self.optimizer.capture_step(flat_grad=self.bucket.flat if entry.packed else None)
             entry.graph = graph
+            if entry.adam_has is not None:      # one more host-made input of every replay, staged like the CPU draws
+                opt, has = self.optimizer, entry.adam_has
+                entry.randoms["adam_coef"] = {"draw": lambda: opt.next_coef(has), "dev": opt.coef, "order": 1 << 30}
             entry.static_grads = [(p, p.grad) for p in self.model.parameters()]
             entry.nan_flag = self.loss.nan_flag
             ok = True
@@ -208,6 +227,9 @@ class Trainer:
         if ok:
             self._graphs[key] = entry
             self._load_batch(entry, model_input, ground_truth)      # (same values; loads the multi-tensor copy kernel outside any timed step)
+            if entry.adam_has is not None:                  # this replay's Adam numbers (the draws were refilled before the capture)
+                slot = entry.randoms["adam_coef"]
+                slot["dev"].copy_(slot["draw"]())
             self._finish_step(entry)                        # the capture pass itself does not execute: replay it once
             self.replays += 1
             self._last = entry
@@ -215,6 +237,15 @@ class Trainer:
             self._last = None                               # check_nan() reads the loss's own flag again, not the previous layout's
             self.loss.nan_flag = None                       # ... and that flag must not be a tensor of the aborted capture (never executed)
                                                             # or a stale warm-up value: the eager steps below publish their own
+        if not ok and entry.packed and self.graph_tail and self.graph_collective and dist.is_initialized() and dist.get_backend(self.bucket.group) == "nccl":
+            # the collective may be what the runtime refused to capture: once more with all-reduce and Adam eager behind the replay
+            self.graph_collective = False
+            self._uncapturable.discard(key)
+            first_error = self.capture_error
+            ok = self.capture(model_input, ground_truth, warmup=0)
+            if ok:
+                self.capture_error = RuntimeError(f"captured without the collective (with it: {first_error!r})")
+                return True
         if not ok and warmup > 0:
             self.optimizer.zero_grad(set_to_none=True)      # (whatever a half-finished attempt left in .grad)
             for _ in range(warmup + 1 - finished):          # the steps the successful path would have taken
@@ -231,6 +262,16 @@ class Trainer:
         return out, losses
 
     def _finish_step(self, entry, on_collective=None):
+        if entry is not None and entry.adam_has is not None:
+            for p, g in entry.static_grads:                 # (kept pointing at this graph's tensors for whoever reads .grad afterwards)
+                if p.grad is not g:
+                    p.grad = g
+            entry.graph.replay()                            # forward + loss + backward [+ pack + all-reduce] + Adam: one launch
+            if on_collective is not None and entry.packed:
+                on_collective()
+            self.optimizer.after_replay()
+            self.scheduler.step()
+            return
         if entry is not None and entry.packed:
             entry.graph.replay()                            # ... ends with the pack of its own gradient tensors into bucket.flat
             self.bucket.reduce_packed()
@@ -349,6 +390,7 @@ class _Captured:
     """One captured batch layout: the graph, its static input tensors, its outputs and the gradient tensors it writes."""
     graph = static_in = static_gt = static_z = outputs = static_grads = randoms = nan_flag = None
     packed = False          # the graph ends with the pack of its gradients into the data-parallel bucket (dp.FlatGradBucket.pack)
+    adam_has = None         # round 6: the graph also holds [the all-reduce and] the Adam launch; which parameters that launch steps
 
 
 def synthetic_batch(seed, n_rays, device, view=0):

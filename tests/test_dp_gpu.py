@@ -69,6 +69,10 @@ def test_bench_line_with_the_collective_agrees_with_the_plain_line():
     assert len(forced["dist"]["ms_per_step_by_rank"]) == 1 and forced["dist"]["allreduce_bytes"] == 4 * 1219274
     assert 0.0 < forced["dist"]["allreduce_ms"] < 1.0, forced["dist"]
     assert abs(forced["value"] / plain["value"] - 1.0) <= 0.03, (forced["value"], plain["value"], forced["dist"])
+    # round 6: the replayed step of BOTH runs is one graph launch -- Adam inside, and with a process group the gradient pack and the RCCL
+    # all-reduce in front of it; the host then needs a fraction of the GPU's time per step
+    assert "one launch" in plain["config"]["launch"] and "all-reduce + Adam" in forced["config"]["launch"], (plain["config"]["launch"], forced["config"]["launch"])
+    assert "ONE graph launch" in forced["dist"]["step_sequence"] and forced["dist"]["host_ms_per_step"] < 0.5 * forced["ms_per_step"], forced["dist"]
 
 
 @pytest.mark.gpu
@@ -91,6 +95,6 @@ def test_c4_workload_line_with_the_collective():
     assert line["config"]["workload"].startswith("C4") and "secondary" not in line
     d = line["dist"]
     assert d["backend"] == "nccl" and d["ranks"] == 1 and d["allreduce_bytes"] == 4 * (1219274 + 960 * 256)
-    assert "gradient pack" in d["step_sequence"], d
+    assert "gradient pack" in d["step_sequence"] and "ONE graph launch" in d["step_sequence"], d
     assert 0.0 < d["host_ms_per_step"] < line["ms_per_step"], (d["host_ms_per_step"], line["ms_per_step"])
     assert line["value"] > 2.0e7, line["value"]

@@ -2048,6 +2048,34 @@ def test_fused_loss_tail_vs_torch_formulation(dev, use_median, R):
             close(w, 3.0 * x, tol=1e-6, what="loss-tail gradient x 3")
 
 
+def test_graph_tail_equals_eager_tail(dev, monkeypatch):
+    """Round 6: the captured step holds the Adam launch too (FlatAdam.capture_step: gradients through the graph's own
+    tensors, the step-dependent numbers in device memory, refreshed before every replay) -- a replayed step is ONE graph launch.
+    Against the round-5 form (graph, then the eager Adam launch): the same parameters and optimizer state, bit for bit, over
+    several steps with a decaying learning rate."""
+    from neat_amd.train import Trainer, synthetic_batch
+    res = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("NEAT_GRAPH_TAIL", tail)
+        torch.manual_seed(7)
+        tr = Trainer(device=dev, state_dict={k: T(v) for k, v in synth.synth_state_dict(11, "rough").items()}, decay_steps=50)
+        tr.model.set_precision("bf16")
+        tr.model.z_vals_override = T(synth.synth_z_vals(2, 96, 40)).to(dev)
+        _, inp, gt = synthetic_batch(2, 96, dev)
+        assert tr.capture(inp, gt, warmup=1), tr.capture_error
+        assert (tr._last.adam_has is not None) == (tail == "1")
+        for _ in range(5):
+            tr.step(inp, gt)
+        torch.cuda.synchronize()
+        st = tr.optimizer.state_dict()["state"]
+        res.append((torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).clone(),
+                    [float(st[i]["step"]) for i in sorted(st)], torch.cat([st[i]["exp_avg_sq"].reshape(-1) for i in sorted(st)]).clone(),
+                    tr.optimizer.param_groups[0]["lr"]))
+    (pa, sa, va, la), (pb, sb, vb, lb) = res
+    assert sa == sb and set(sa) == {7.0} and la == lb
+    assert torch.equal(pa, pb) and torch.equal(va, vb)
+
+
 def test_junction_block_kernels_vs_torch(dev):
     """neat_l3d / neat_junction_cost / neat_junction_gate against the torch formulations they replace."""
     from neat_amd import ops
