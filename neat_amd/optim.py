@@ -126,25 +126,26 @@ class FlatAdam(torch.optim.Optimizer):
         """Counts one step for the parameters of `has` and returns the captured launch's numbers for it as a CPU float32 tensor
         [2 n] (the arithmetic of neat_adam_step: double precision, rounded once)."""
         import math
+        import numpy as np
         group = self.param_groups[0]
         # (neat_adam_step receives lr and the betas as C floats and widens them: the same float32-rounded values here, so that a
         # replayed step and an eager one update the parameters to the same bits)
         f32 = lambda x: ctypes.c_float(float(x)).value
         b1, b2 = (f32(b) for b in group["betas"])
         lr = f32(group["lr"])
-        out = torch.zeros(2 * len(self._params), dtype=torch.float32)
-        cache = {}
-        for i, h in enumerate(has):
-            if not h:
-                continue
-            self._steps[i] += 1
-            t = self._steps[i]
-            c = cache.get(t)
-            if c is None:
-                c = cache[t] = (lr / (1.0 - math.pow(b1, t)), 1.0 / math.sqrt(1.0 - math.pow(b2, t)))
-            out[2 * i], out[2 * i + 1] = c
+        steps = np.ctypeslib.as_array(self._steps)               # (a view: the increments land in the ctypes array)
+        mask = getattr(has, "_mask", None)
+        if mask is None:
+            mask = np.asarray(has, dtype=bool)
+        steps[mask] += 1
+        out = np.zeros((len(self._params), 2), dtype=np.float32)
+        for t in np.unique(steps[mask]):                          # one value in a normal run: every parameter has taken every step
+            t = int(t)
+            sel = mask & (steps == t)
+            out[sel, 0] = lr / (1.0 - math.pow(b1, t))
+            out[sel, 1] = 1.0 / math.sqrt(1.0 - math.pow(b2, t))
         self._steps_dirty = True
-        return out
+        return torch.from_numpy(out.reshape(-1))
 
     def after_replay(self):
         """The parameters changed behind autograd's back (a replayed graph): bump their version counters."""
