@@ -93,17 +93,22 @@ __device__ __forceinline__ void f6_store8(void* p, uint2 v) {
 }
 
 // epilogue of one layer (compile-time description): activation, destination, row count, bias rows
-template <bool ACT_, bool SAVE_, int N_, int DST_, int BIASOFF_> struct F6EpiCfg {
-  static constexpr bool ACT = ACT_, SAVE = SAVE_, NONE = false, REV = false;
+// UDOM (round 6, values mode): the activations stay in the softplus's own scale -- h' = max(u, 0) + log2(1 + 2^-|u|) with u = 100 log2(e) x,
+// i.e. h' = (100 / ln 2) h.  The next layer's pre-activation in that scale is then simply acc' + b' (the inputs are already multiplied by
+// 100 log2 e), so the epilogue needs neither the fma's scale nor the output multiply: two vector instructions less per value pair of a
+// kernel whose vector pipe is the longer one.  The PE rows enter scaled the same way, the sdf sum is divided once per point.  Nothing is
+// saved in values mode, so no other kernel sees the scale.
+template <bool ACT_, bool SAVE_, int N_, int DST_, int BIASOFF_, bool UDOM_ = false> struct F6EpiCfg {
+  static constexpr bool ACT = ACT_, SAVE = SAVE_, NONE = false, REV = false, UDOM = UDOM_;
   static constexpr int N = N_, DST = DST_, BIASOFF = BIASOFF_, SPLIT = 1 << 30;
 };
-struct F6NoEpi { static constexpr bool ACT = false, SAVE = false, NONE = true, REV = false; static constexpr int N = 256, DST = 0, BIASOFF = 0, SPLIT = 1 << 30; };
+struct F6NoEpi { static constexpr bool ACT = false, SAVE = false, NONE = true, REV = false, UDOM = false; static constexpr int N = 256, DST = 0, BIASOFF = 0, SPLIT = 1 << 30; };
 // adjoint chain (fused EPI_REV): value = acc * phi'(h), phi'(a) = 1 - exp(-100 h), h = the saved post-activation of the layer below,
 // which travels in the `bq` argument as raw bf16 quads (bq[g].x / .y = the two pairs of quad g).  Rows >= SPLIT leave as fp32 rows
 // (row - SPLIT) of F6Lane::frows without the phi' factor and are zero on chip and in the bf16 array: the PE cotangent of the skip
 // layer (SPLIT = 217) and the whole output of the last layer (SPLIT = 0, N = 39).
 template <bool SAVE_, int N_, int DST_, int SPLIT_> struct F6RevCfg {
-  static constexpr bool ACT = false, SAVE = SAVE_, NONE = false, REV = true;
+  static constexpr bool ACT = false, SAVE = SAVE_, NONE = false, REV = true, UDOM = false;
   static constexpr int N = N_, DST = DST_, BIASOFF = 0, SPLIT = SPLIT_;
 };
 
@@ -156,7 +161,7 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
   }
   if (h == 0) {
     if (E::ACT && NEAT_F6_ABLATE != 1) {
-      const float u0 = NEAT_F6_ABLATE == 6 ? x0 : fmaf(x0, SOFTPLUS_C, b0), u1 = NEAT_F6_ABLATE == 6 ? x1 : fmaf(x1, SOFTPLUS_C, b1);
+      const float u0 = NEAT_F6_ABLATE == 6 ? x0 : (E::UDOM ? x0 + b0 : fmaf(x0, SOFTPLUS_C, b0)), u1 = NEAT_F6_ABLATE == 6 ? x1 : (E::UDOM ? x1 + b1 : fmaf(x1, SOFTPLUS_C, b1));
       st.w0 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u0));
       st.w1 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u1));
       st.m0 = fmaxf(u0, 0.0f); st.m1 = fmaxf(u1, 0.0f);
@@ -167,8 +172,9 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
   }
   float r0 = st.m0, r1 = st.m1;
   if (E::ACT && NEAT_F6_ABLATE != 1) {
-    r0 = (st.m0 + __builtin_amdgcn_logf(st.w0)) * (NEAT_F6_ABLATE == 6 ? 1.0f : 0.0069314718055994531f);
-    r1 = (st.m1 + __builtin_amdgcn_logf(st.w1)) * (NEAT_F6_ABLATE == 6 ? 1.0f : 0.0069314718055994531f);
+    r0 = st.m0 + __builtin_amdgcn_logf(st.w0);
+    r1 = st.m1 + __builtin_amdgcn_logf(st.w1);
+    if (!E::UDOM && NEAT_F6_ABLATE != 6) { r0 *= 0.0069314718055994531f; r1 *= 0.0069314718055994531f; }
   }
   const unsigned pk = pack2(r0, r1);
   if (pr == 0) { st.lo = pk; return; }
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
         for (int c = 0; c < 3; ++c)
           xc[c] = ok ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_fm) + ((unsigned)c * ldp4 + pvo)) : 0.0f;
         auto put = [&](int j, float v) {
-          pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(v);
+          pe16[((j >> 3) * BP + p) * 8 + (j & 7)] = f2bf(VALUES ? v * SOFTPLUS_C : v);      // (values mode: the softplus's scale, F6EpiCfg UDOM)
           if (SAVE && ok) { if (NEAT_F6_NT_E) __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo))); else *reinterpret_cast<float*>(reinterpret_cast<char*>(a.E) + ((unsigned)j * ldp4 + pvo)) = v; }
         };
         if (fg == NG - 1) {
@@ -388,14 +394,14 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       }
       __syncthreads();
 
-      typedef F6EpiCfg<true, SAVE, 256, 0, 0 * 256> E0;      // lin0 -> XA
-      typedef F6EpiCfg<true, SAVE, 256, 1, 1 * 256> E1;      // lin1 -> XB
-      typedef F6EpiCfg<true, SAVE, 256, 0, 2 * 256> E2;
-      typedef F6EpiCfg<true, SAVE, 217, 1, 3 * 256> E3;      // lin3 -> XB rows 0..216 (+ PE rows 0..6 in the last octet)
-      typedef F6EpiCfg<true, SAVE, 256, 0, 4 * 256> E4;
-      typedef F6EpiCfg<true, SAVE, 256, 1, 5 * 256> E5;
-      typedef F6EpiCfg<true, SAVE, 256, 0, 6 * 256> E6;
-      typedef F6EpiCfg<true, SAVE, 256, 1, 7 * 256> E7;
+      typedef F6EpiCfg<true, SAVE, 256, 0, 0 * 256, VALUES> E0;      // lin0 -> XA
+      typedef F6EpiCfg<true, SAVE, 256, 1, 1 * 256, VALUES> E1;      // lin1 -> XB
+      typedef F6EpiCfg<true, SAVE, 256, 0, 2 * 256, VALUES> E2;
+      typedef F6EpiCfg<true, SAVE, 217, 1, 3 * 256, VALUES> E3;      // lin3 -> XB rows 0..216 (+ PE rows 0..6 in the last octet)
+      typedef F6EpiCfg<true, SAVE, 256, 0, 4 * 256, VALUES> E4;
+      typedef F6EpiCfg<true, SAVE, 256, 1, 5 * 256, VALUES> E5;
+      typedef F6EpiCfg<true, SAVE, 256, 0, 6 * 256, VALUES> E6;
+      typedef F6EpiCfg<true, SAVE, 256, 1, 7 * 256, VALUES> E7;
       typedef F6EpiCfg<false, true, 256, 0, 8 * 256> E8;     // lin8 feature rows -> HBM only
       f32x16 acc[2][RT];
       float4 bq[4 * RT];
@@ -545,8 +551,15 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
     else chain(std::true_type{});
     if (tid < nt * 32) {
       float sv = biasl[8 * 256 + (VALUES ? 0 : 256)];
+      if (VALUES) {            // h8 arrived in the softplus's scale: the row sum back to the sdf's
+        float t = 0.0f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) sv += red[w * BP + tid];
+        for (int w = 0; w < NW; ++w) t += red[w * BP + tid];
+        sv += t * (1.0f / SOFTPLUS_C);
+      } else {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sv += red[w * BP + tid];
+      }
       const int p = p0 + tid;
       if (VALUES) {
         if (a.radius > 0.0f) {
