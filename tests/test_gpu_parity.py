@@ -948,7 +948,7 @@ def test_full_size_train_step_vs_oracle(dev, cfg, precision):
 # ----------------------------------------------------------------------------------------------------------------
 # bf16 build (BASELINE config 2: "bf16").  bf16 has an 8-bit mantissa, so it cannot meet the 1e-4 fp32 tolerance --
 # that is what the fp32 build above is for.  Here the bar is bf16-grade agreement with the SAME oracle on the same
-# inputs.  Measured on MI355X (scripts/bf16_error_table.py; fp32 build in brackets), max error relative to the tensor's scale:
+# inputs.  Measured on MI355X (tests/tools/bf16_error_table.py; fp32 build in brackets), max error relative to the tensor's scale:
 # rgb 2.5e-4 (2e-7), lines3d 1.7e-3 (2e-6), depth / xyz 1.8e-3 (2e-6), sdf 3e-3 (5e-5), eikonal normals 1.9e-2 (8e-6), loss 1e-3
 # (2e-7); per gradient tensor, relative L2 error  |g - g_ref|_2 / |g_ref|_2  at most 8.4e-2 (1.1e-5), worst on the heads' input
 # layers, which read the normals (a nine-layer bf16 adjoint chain).  The test bounds are those numbers with ~1.5x head room:
@@ -959,7 +959,7 @@ BF16_GRAD_REL_L2 = 0.12
 
 
 # the two 16-bit builds against the oracle: (outputs, sdf, normals, loss, per-tensor gradient rel-L2).  Measured at these sizes
-# (scripts/bf16_error_table.py): bf16 2e-3 / 3e-3 / 1.9e-2 / 1e-3 / 8.4e-2;  f16 (3 more mantissa bits) 2.3e-4 / 5.5e-4 / 2.5e-3 /
+# (tests/tools/bf16_error_table.py): bf16 2e-3 / 3e-3 / 1.9e-2 / 1e-3 / 8.4e-2;  f16 (3 more mantissa bits) 2.3e-4 / 5.5e-4 / 2.5e-3 /
 # 2.6e-5 / 3.5e-2 -- the gradient figure is the worst THIN tensor (a head bias, lin8.bias), where ReLU units whose sign flips under
 # 16-bit rounding of their pre-activation carry the error; it does not scale with the mantissa like the outputs do.
 HALF_BOUNDS = {"bf16": (5e-3, 1e-2, 3e-2, 5e-3, None), "fp16": (6e-4, 2e-3, 6e-3, 2e-4, 0.06)}

@@ -6,7 +6,7 @@ weight gradient of the heads -- and whose activations are rounded at storage.  E
 Prints, per scheme, the output errors (relative to each tensor's scale; bar 1e-4) and the worst gradient error (max-abs over
 max; bar 2e-3) against the plain fp32 oracle on the same inputs.
 
-    python scripts/precision_emul.py [R S]
+    python tests/tools/precision_emul.py [R S]
 """
 import math
 import sys

@@ -4,7 +4,7 @@ than 2e-4)?  The oracle's Algorithm 1 is run with an SDF network whose matmuls e
 planes, fp32 accumulation, activations kept as hi + lo between layers like kernels_x3.hpp):
     x3 : hi*hi + lo*hi + hi*lo (what runs today)      a2 : (hi + lo) activations x hi weights      w2 : hi activations x (hi + lo) weights
     x1 : hi*hi (= hip_sampler_fast_values)
-    python scripts/sampler_products_emul.py
+    python tests/tools/sampler_products_emul.py
 """
 import os, sys
 import numpy as np
