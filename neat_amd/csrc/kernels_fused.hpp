@@ -281,6 +281,11 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
   constexpr int BP = C::BP, F6T = C::THREADS, NW = C::NW;
   static_assert(NT == 4 && (RT == 1 || RT == 2), "the PE phase maps threads to (point of a 128-point batch, frequency group)");
   if (a.gate && *a.gate != a.gate_value) return;
+#ifndef NEAT_F6_PRIO
+#define NEAT_F6_PRIO 0      // probe: static priority for one half of the workgroup's waves (MI355X_MICROARCH.md, pairing item 4: the second-dispatched half)
+#endif
+  if (NEAT_F6_PRIO == 1 && threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
+  if (NEAT_F6_PRIO == 2 && threadIdx.x < 256) __builtin_amdgcn_s_setprio(1);
   extern __shared__ __attribute__((aligned(16))) unsigned char f6lds[];
   float* biasl = reinterpret_cast<float*>(f6lds + C::BIAS);     // [l][256]; lin8 in packed row order
   float* red = reinterpret_cast<float*>(f6lds + C::RED);        // [waves][BP]: partial sums of the sdf row
@@ -596,6 +601,8 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
   constexpr int BP = C::BP, F6T = C::THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char f6lds[];
   float* seedw = reinterpret_cast<float*>(f6lds + C::BIAS);      // [256]: w8[k] * rs8
+  if (NEAT_F6_PRIO == 1 && threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
+  if (NEAT_F6_PRIO == 2 && threadIdx.x < 256) __builtin_amdgcn_s_setprio(1);
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int k = tid; k < 256; k += F6T) seedw[k] = a.w8[k] * a.rs8[0];

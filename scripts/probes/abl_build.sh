@@ -4,7 +4,7 @@
 # chains' unit (the split-precision chains of kernels_x3.hpp run there); otherwise neat_api.hip (primary).  The other units are
 # compiled once without flags and cached in abl_libs/ (delete abl_libs/*.o after editing sources).
 set -e
-R=$(cd "$(dirname "$0")/.." && pwd); name=$1; shift
+R=$(cd "$(dirname "$0")/../.." && pwd); name=$1; shift
 mkdir -p $R/abl_libs; cd $R/neat_amd/csrc
 [ -f f16_symbols.h ] || bash build.sh > /dev/null 2>&1
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I."
