@@ -1449,6 +1449,12 @@ __global__ __launch_bounds__(W3T, 2) void wgrad_kernel_h3(WgradArgsH3 a) {
       const bool second = opB[hq] && oct >= a.splitB;
       const uint4* seg = reinterpret_cast<const uint4*>(second ? base2 : base) + (size_t)(second ? oct - a.splitB : oct) * a.ldp;
       const int g = min(C::QPW * wave + hq, C::QA + C::QB - 1);
+#ifndef NEAT_W3_SKIP_SURPLUS
+#define NEAT_W3_SKIP_SURPLUS 1      // round 6: the waves whose DMA slots lie beyond the stage's quads (NCB = 5: waves 6, 7; NCB = 1: waves 5..7) issue
+#endif                              // nothing instead of re-reading the last quad -- their counted waits are then trivially met.  Same-box A/B, three
+                                    // passes: <5> 49.7-50.8 -> 47.9-48.5 us, <1> 40.0-40.3 -> 38.2-38.7 us.  (Compile-time for NCB = 4, which has no
+                                    // surplus: a runtime test there cost its launch 2-3 us.)
+      if constexpr (NEAT_W3_SKIP_SURPLUS && 8 * C::QPW > C::QA + C::QB) { if (C::QPW * wave + hq >= C::QA + C::QB) continue; }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int p = pbeg + st * pstep + 16 * i + dl_pt;
