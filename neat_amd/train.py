@@ -53,8 +53,13 @@ class Trainer:
         self.replays = self.eager_steps = 0
         # round 6: what a captured step holds besides forward + loss + backward: the Adam launch (graph_tail) and, in a data-parallel
         # run, the gradient all-reduce in front of it (graph_collective; off: all-reduce and Adam stay eager behind the replay)
+        # graph_collective defaults to the case that could be verified on hardware: the one-rank RCCL group (NEAT_FORCE_DIST=1; same
+        # trajectory as without a group, tests/test_dp_gpu.py).  With more than one rank the collective stays eager behind the replay unless
+        # NEAT_GRAPH_COLLECTIVE=1 asks for it: no multi-GPU box was available to try a captured multi-rank all-reduce, and a hang cannot
+        # be caught the way a refused capture can.
         self.graph_tail = os.environ.get("NEAT_GRAPH_TAIL", "1") != "0"
-        self.graph_collective = os.environ.get("NEAT_GRAPH_COLLECTIVE", "1") != "0"
+        gc = os.environ.get("NEAT_GRAPH_COLLECTIVE")
+        self.graph_collective = (gc == "1") if gc is not None else not (dist.is_initialized() and dist.get_world_size() > 1)
 
     def step(self, model_input, ground_truth):
         if self._graphs or self.auto_capture:
