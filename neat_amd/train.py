@@ -59,7 +59,7 @@ class Trainer:
         # be caught the way a refused capture can.
         self.graph_tail = os.environ.get("NEAT_GRAPH_TAIL", "1") != "0"
         gc = os.environ.get("NEAT_GRAPH_COLLECTIVE")
-        self.graph_collective = (gc == "1") if gc is not None else not (dist.is_initialized() and dist.get_world_size() > 1)
+        self.graph_collective = None if gc is None else gc == "1"      # None: decided when a step is captured (_collective_in_graph)
 
     def step(self, model_input, ground_truth):
         if self._graphs or self.auto_capture:
@@ -205,7 +205,7 @@ class Trainer:
                 # the Adam launch (its step-dependent numbers live in device memory, refreshed with the step's other host-made
                 # inputs): a replayed step is then ONE graph launch, nothing is enqueued behind it
                 # (gloo's device all-reduce synchronises the stream: not capturable, the tail then stays eager as in round 5)
-                coll_ok = self.graph_collective and dist.is_initialized() and dist.get_backend(self.bucket.group) == "nccl"
+                coll_ok = self._collective_in_graph()
                 tail = self.graph_tail and hasattr(self.optimizer, "capture_step") and (not entry.packed or coll_ok)
                 if tail:
                     if entry.packed:
@@ -242,7 +242,7 @@ class Trainer:
             self._last = None                               # check_nan() reads the loss's own flag again, not the previous layout's
             self.loss.nan_flag = None                       # ... and that flag must not be a tensor of the aborted capture (never executed)
                                                             # or a stale warm-up value: the eager steps below publish their own
-        if not ok and entry.packed and self.graph_tail and self.graph_collective and dist.is_initialized() and dist.get_backend(self.bucket.group) == "nccl":
+        if not ok and entry.packed and self.graph_tail and self._collective_in_graph():
             # the collective may be what the runtime refused to capture: once more with all-reduce and Adam eager behind the replay
             self.graph_collective = False
             self._uncapturable.discard(key)
@@ -257,6 +257,15 @@ class Trainer:
                 self.step_eager(model_input, ground_truth)
                 self.eager_steps += 1
         return ok
+
+    def _collective_in_graph(self):
+        """May the gradient all-reduce be captured with the step?  Only on RCCL (gloo synchronises the stream); by default only for the
+        one-rank group, the case verified on hardware (see __init__)."""
+        if not (dist.is_initialized() and dist.get_backend(self.bucket.group) == "nccl"):
+            return False
+        if self.graph_collective is None:
+            return dist.get_world_size(self.bucket.group) == 1
+        return bool(self.graph_collective)
 
     def _fwd_bwd(self, entry, zero=True):
         out = self.model(entry.static_in)
