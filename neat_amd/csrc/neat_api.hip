@@ -223,15 +223,28 @@ int g_fused_nt = 0;         // its batch: 4 = 128 points, 2 = 64 points, 0 = whi
 int g_layer_ws = 1;         // hidden 256x256 bf16 layers: 1 = weight-stationary streaming kernel, 0 = layer_kernel_h
 int g_ws_grid = 256;        // persistent workgroups of layer_kernel_ws (one per CU)
 constexpr int DW_MAXGRID = 256;     // workgroup partials the workspace holds per (layer, pair)
-int g_dw_grid = DW_MAXGRID;  // workgroups (= partials per set) of the launches that contract weight gradients on chip (tuning key 23)
+int g_dw_grid = DW_MAXGRID;  // workgroups (= partials per set) of the launches that contract weight gradients on chip (tuning key 23); 0 = balanced (dw_grid)
 inline int dw_slots(int ldp) {          // workgroup partials the workspace holds per (layer, pair): what dw_grid() can reach at this size
   const int nt = ldp / WSP;
   return nt < DW_MAXGRID ? (nt > 0 ? nt : 1) : DW_MAXGRID;
 }
 inline int dw_grid(int ldp) {
   int g = g_ws_grid < DW_MAXGRID ? g_ws_grid : DW_MAXGRID;
-  g = g < g_dw_grid ? g : g_dw_grid;
   const int nt = ldp / WSP;
+  if (g_dw_grid > 0) g = g < g_dw_grid ? g : g_dw_grid;
+  else if (nt > g) {
+    // key 23 = 0 (round 6, measured, NOT the default): the persistent workgroups walk ceil(nt / g) tiles, so 4160 tiles over 256 workgroups cost
+    // 17 rounds for 16.25 of work; this takes the grid in [208, 256] (multiples of 8) that leaves the fewest idle tile slots -- 208 at C2 (20 tiles
+    // each) and at C4's rank shape (10 each), with 19 % fewer partials for the gather.  Same-box A/B, two passes, 256 vs balanced: C2 2.721 / 2.709
+    // vs 2.726 / 2.718 ms, C4 rank 1.764 / 1.774 vs 1.761 / 1.760, real step 3.350 / 3.378 vs 3.403 / 3.350, C3 4.954 / 4.995 vs 5.015 / 5.005:
+    // what the balance wins the 48 idle compute units lose in bandwidth.  (160 workgroups: +4 % on C2, 128: +12 %.)
+    int best = g, waste = ((nt + g - 1) / g) * g - nt;
+    for (int c = g - 8; c >= 208; c -= 8) {
+      const int w = ((nt + c - 1) / c) * c - nt;
+      if (w < waste) { waste = w; best = c; }
+    }
+    g = best;
+  }
   return nt < g ? nt : g;
 }
 int g_ws_aux_nt = 15;       // non-temporal accesses (tuning key 11): bit 0 / 1 = fetch of aux0 / aux1 of the streaming layer kernels, bit 2 =
@@ -1680,7 +1693,7 @@ int neat_set_tuning(int key, int value) {          /* 0: bf16 layer-kernel point
   if (key == 20 && (value == 0 || value == 1)) { g_head_l4_batched = value; return 0; }
   if (key == 21 && value >= 0 && value <= 4) { g_wgrad_narrow = value; return 0; }
   if (key == 22 && (value == 0 || value == 1)) { g_dw_lin8 = value; return 0; }
-  if (key == 23 && value >= 16 && value <= DW_MAXGRID) { g_dw_grid = value; return 0; }
+  if (key == 23 && (value == 0 || (value >= 16 && value <= DW_MAXGRID))) { g_dw_grid = value; return 0; }
   if (key == 24 && (value == 0 || value == 1)) { g_chain_pp = value; return 0; }
   if (key == 25 && (value == 0 || value == 1)) { g_dw_segments = value; return 0; }
   if (key == 28 && (value == 0 || value == 1)) { g_ffn_mfma = value; return 0; }
