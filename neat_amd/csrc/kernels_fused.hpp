@@ -118,6 +118,15 @@ template <class E, int RT> __device__ __forceinline__ void f6_load_bias(const F6
   for (int g = 0; g < 4 * RT; ++g) bq[g] = *reinterpret_cast<const float4*>(L.bias + (E::BIASOFF + (g >> 2) * 32 + 8 * (g & 3)) * 4);
 }
 
+// the same rows in accumulator order (row tile i, quad q, element j -> c0[i][4 q + j]): operand C of a layer's first MFMA (f6_stage CINIT)
+template <class E, int RT> __device__ __forceinline__ void f6_load_bias16(const F6Lane& L, f32x16 (&c0)[RT]) {
+#pragma unroll
+  for (int g = 0; g < 4 * RT; ++g) {
+    const float4 b = *reinterpret_cast<const float4*>(L.bias + (E::BIASOFF + (g >> 2) * 32 + 8 * (g & 3)) * 4);
+    c0[g >> 2][4 * (g & 3) + 0] = b.x; c0[g >> 2][4 * (g & 3) + 1] = b.y; c0[g >> 2][4 * (g & 3) + 2] = b.z; c0[g >> 2][4 * (g & 3) + 3] = b.w;
+  }
+}
+
 // half unit h (0 = A: bias, exp2, max; 1 = B: log2, scale, pack, store) of value pair e (0..15): quad g = e >> 1 = (row tile
 // i = g >> 2, quad q = g & 3), pair e & 1 of the quad; t = point tile the accumulators `ae` belong to
 template <int NT, int RT, bool FULL, class E>
@@ -161,10 +170,13 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
   }
   if (h == 0) {
     if (E::ACT && NEAT_F6_ABLATE != 1) {
-      const float u0 = NEAT_F6_ABLATE == 6 ? x0 : (E::UDOM ? x0 + b0 : fmaf(x0, SOFTPLUS_C, b0)), u1 = NEAT_F6_ABLATE == 6 ? x1 : (E::UDOM ? x1 + b1 : fmaf(x1, SOFTPLUS_C, b1));
+      const float u0 = NEAT_F6_ABLATE == 6 ? x0 : (E::UDOM ? x0 : fmaf(x0, SOFTPLUS_C, b0)), u1 = NEAT_F6_ABLATE == 6 ? x1 : (E::UDOM ? x1 : fmaf(x1, SOFTPLUS_C, b1));      // (UDOM: the bias came in through the accumulator, f6_stage CINIT)
       st.w0 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u0));
       st.w1 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u1));
-      st.m0 = fmaxf(u0, 0.0f); st.m1 = fmaxf(u1, 0.0f);
+      // (UDOM: u is a raw MFMA result; fmaxf -- and the median of (u, 0, inf), which is folded into it -- would first canonicalise it: one
+      // v_max_f32 u, u, u per value, exactly the instruction the bias in the accumulator saved)
+      if (E::UDOM) { asm("v_max_f32 %0, 0, %1" : "=v"(st.m0) : "v"(u0)); asm("v_max_f32 %0, 0, %1" : "=v"(st.m1) : "v"(u1)); }
+      else { st.m0 = fmaxf(u0, 0.0f); st.m1 = fmaxf(u1, 0.0f); }
     } else {
       st.m0 = x0 + b0; st.m1 = x1 + b1;
     }
@@ -202,10 +214,13 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
 // WROLL (adjoint chain): this is the layer's last tile -- slot ks of the weight registers is dead after its MFMA and is refilled right
 // there with the NEXT layer's slot ks (wnx = that layer's per-lane fragment address), so one set of 16 fragment registers serves
 // the whole chain instead of two (the request is a full stage, >= 1000 cycles, ahead of its first use; the weights sit in L2).
-template <int NT, int RT, bool FULL, bool MMA, int KS, int SRC, class E, int ROFF, bool BAR, bool WROLL = false>
+// CINIT (values mode, F6EpiCfg UDOM): the accumulators start from c0 = the layer's bias rows of this lane instead of zero (operand C of the
+// first k-step's MFMA), so the epilogue has no bias add left.
+template <int NT, int RT, bool FULL, bool MMA, int KS, int SRC, class E, int ROFF, bool BAR, bool WROLL = false, bool CINIT = false>
 __device__ __forceinline__ void f6_stage(const F6Lane& L, std::conditional_t<WROLL, uint4, const uint4> (&wc)[RT][16], int t, f32x16 (&am)[RT],
                                          const f32x16 (&ae)[RT], const float4 (&bq)[4 * RT], int te, int nt, u16* hout, int wave, int hi,
-                                         uint4 (&ring)[NEAT_F6_RING], const unsigned char* nfr, const unsigned char* wnx = nullptr) {
+                                         uint4 (&ring)[NEAT_F6_RING], const unsigned char* nfr, const unsigned char* wnx = nullptr,
+                                         const f32x16* c0 = nullptr) {
   typedef F6Cfg<NT, RT> C;
   constexpr int STEP = 2 * C::BP * 16;                 // bytes between k-steps of a fragment column
   constexpr int HU = 16 * RT;                          // epilogue half units of a tile: 8 RT value pairs x {A, B}
@@ -242,7 +257,7 @@ __device__ __forceinline__ void f6_stage(const F6Lane& L, std::conditional_t<WRO
       // between runs at ~75 cycles per MFMA instead of 32); they are summed after the last k-step
       f32x16& dst = (NEAT_F6_SPLITK && RT == 1 && (ks & 1)) ? odd : am[i];
       if (NEAT_F6_ABLATE != 2)
-        dst = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wc[i][ks]), *reinterpret_cast<const bf16x8*>(&cur), ks >= (NEAT_F6_SPLITK && RT == 1 ? 2 : 1) ? dst : zero, 0, 0, 0);
+        dst = NEAT_MFMA16(*reinterpret_cast<const bf16x8*>(&wc[i][ks]), *reinterpret_cast<const bf16x8*>(&cur), ks >= (NEAT_F6_SPLITK && RT == 1 ? 2 : 1) ? dst : ((CINIT && ks == 0) ? c0[i] : zero), 0, 0, 0);
       else if (ks == 0) { am[i] = zero; am[i][0] = __uint_as_float(cur.x ^ wc[i][ks].x); }
       if constexpr (WROLL) wc[i][ks] = *reinterpret_cast<const uint4*>(wnx + ks * 1024);
       if (NEAT_F6_GROUP == 1) {
@@ -410,6 +425,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       typedef F6EpiCfg<false, true, 256, 0, 8 * 256> E8;     // lin8 feature rows -> HBM only
       f32x16 acc[2][RT];
       float4 bq[4 * RT];
+      f32x16 c0[RT];                 // values mode: the bias rows of the layer whose MFMAs run, as their first operand C
       uint4 ring[NEAT_F6_RING];
       constexpr int RD = NEAT_F6_RING;
 #define F6_KSUM(S_) ((S_) < 4 ? 4 * (S_) : ((S_) < 33 ? 16 * (S_) - 48 : 16 * (S_) - 64))      /* k-steps before stage S_ (stage 32 = drain) */
@@ -428,10 +444,11 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       // stage of a layer prefetches fragments of the next layer's input NSRC_ (3 = none).  A barrier ends every second stage
       // (a tile written in stage w is read in stage w + 3) and every stage where ALLBAR_ says so.
 #define F6_STAGE(S_, T_, KS_, SRC_, WC_, E_, H_, TE_, NFR_, BAR_)                                                                   \
-      f6_stage<NT, RT, FULL, true, KS_, SRC_, E_, F6_KSUM(S_) % RD, BAR_>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], bq, TE_, nt, H_, wave, hi, ring, NFR_);
+      f6_stage<NT, RT, FULL, true, KS_, SRC_, E_, F6_KSUM(S_) % RD, BAR_, false, VALUES>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], bq, TE_, nt, H_, wave, hi, ring, NFR_, nullptr, c0);
 #define F6_LAYER(S0_, KS_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, NSRC_, ALLBAR_, PRE_)                                              \
-      { PRE_(0) F6_STAGE((S0_) + 0, 0, KS_, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512, (ALLBAR_ || ((S0_) + 0) % 2 == 1))  \
-        f6_load_bias<ECUR_, RT>(L, bq);                                                                                          \
+      { if (VALUES) f6_load_bias16<ECUR_, RT>(L, c0);                                                                            \
+        PRE_(0) F6_STAGE((S0_) + 0, 0, KS_, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512, (ALLBAR_ || ((S0_) + 0) % 2 == 1))  \
+        if (!VALUES) f6_load_bias<ECUR_, RT>(L, bq);                                                                                          \
         PRE_(1) F6_STAGE((S0_) + 1, 1, KS_, SRC_, WC_, ECUR_, HCUR_, 0, L.frag[SRC_] + 2 * 512, (ALLBAR_ || ((S0_) + 1) % 2 == 1))  \
         PRE_(2) F6_STAGE((S0_) + 2, 2, KS_, SRC_, WC_, ECUR_, HCUR_, 1, L.frag[SRC_] + 3 * 512, (ALLBAR_ || ((S0_) + 2) % 2 == 1))  \
         PRE_(3) F6_STAGE((S0_) + 3, 3, KS_, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 3 ? L.frag[(NSRC_) < 3 ? (NSRC_) : 0] : nullptr), (ALLBAR_ || ((S0_) + 3) % 2 == 1)) }
@@ -443,8 +460,9 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
         _Pragma("unroll") for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[SRC_] + j * 2 * BP * 16);
 #define F6_LAYER1(KS_, SRC_, WC_, ECUR_, HCUR_)                                                                                     \
         { F6_RING0(SRC_)                                                                                                            \
-          f6_stage<NT, RT, true, true, KS_, SRC_, F6NoEpi, 0, false>(L, WC_, 0, acc[0], acc[1], bq, 0, 1, nullptr, wave, hi, ring, nullptr); \
-          f6_load_bias<ECUR_, RT>(L, bq);                                                                                           \
+          if (VALUES) f6_load_bias16<ECUR_, RT>(L, c0);                                                                             \
+          f6_stage<NT, RT, true, true, KS_, SRC_, F6NoEpi, 0, false, false, VALUES>(L, WC_, 0, acc[0], acc[1], bq, 0, 1, nullptr, wave, hi, ring, nullptr, nullptr, c0); \
+          if (!VALUES) f6_load_bias<ECUR_, RT>(L, bq);                                                                                           \
           f6_stage<NT, RT, true, false, 16, 0, ECUR_, 0, true>(L, WC_, 0, acc[1], acc[0], bq, 0, 1, HCUR_, wave, hi, ring, nullptr); }
         F6_LAYER1(4, 2, wB, E0, a.h[1])
         load_w(wB, a.Wp[2], 16, 256);
