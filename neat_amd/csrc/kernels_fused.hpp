@@ -168,25 +168,25 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
       f6_store8(reinterpret_cast<char*>(hout) + ((unsigned)(i * 4 + q) * L.ldp16 + L.gquad) + t * 512, v);
     return;
   }
+  // The bias is already in the accumulator (f6_stage CINIT): x = W in + b.  Softplus with beta = 100 (rend_a :94):
+  //   standard scale:  h = max(x, 0) + (ln 2 / 100) log2(1 + 2^(-|x| 100 log2 e))     -- max, mul, exp2, 1 +, log2, fma
+  //   UDOM (x is u = 100 log2 e * pre-activation):  h' = max(u, 0) + log2(1 + 2^-|u|)  -- max, exp2, 1 +, log2, +
+  // The maximum is inline asm: fmaxf on a raw MFMA result is preceded by a canonicalising v_max_f32 x, x, x (and the median of (x, 0, inf)
+  // is folded into the same pair), one instruction per value more.
   if (h == 0) {
     if (E::ACT && NEAT_F6_ABLATE != 1) {
-      const float u0 = NEAT_F6_ABLATE == 6 ? x0 : (E::UDOM ? x0 : fmaf(x0, SOFTPLUS_C, b0)), u1 = NEAT_F6_ABLATE == 6 ? x1 : (E::UDOM ? x1 : fmaf(x1, SOFTPLUS_C, b1));      // (UDOM: the bias came in through the accumulator, f6_stage CINIT)
-      st.w0 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u0));
-      st.w1 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(u1));
-      // (UDOM: u is a raw MFMA result; fmaxf -- and the median of (u, 0, inf), which is folded into it -- would first canonicalise it: one
-      // v_max_f32 u, u, u per value, exactly the instruction the bias in the accumulator saved)
-      if (E::UDOM) { asm("v_max_f32 %0, 0, %1" : "=v"(st.m0) : "v"(u0)); asm("v_max_f32 %0, 0, %1" : "=v"(st.m1) : "v"(u1)); }
-      else { st.m0 = fmaxf(u0, 0.0f); st.m1 = fmaxf(u1, 0.0f); }
+      st.w0 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(E::UDOM || NEAT_F6_ABLATE == 6 ? x0 : x0 * SOFTPLUS_C));
+      st.w1 = 1.0f + __builtin_amdgcn_exp2f(-fabsf(E::UDOM || NEAT_F6_ABLATE == 6 ? x1 : x1 * SOFTPLUS_C));
+      asm("v_max_f32 %0, 0, %1" : "=v"(st.m0) : "v"(x0)); asm("v_max_f32 %0, 0, %1" : "=v"(st.m1) : "v"(x1));
     } else {
-      st.m0 = x0 + b0; st.m1 = x1 + b1;
+      st.m0 = x0; st.m1 = x1;
     }
     return;
   }
   float r0 = st.m0, r1 = st.m1;
   if (E::ACT && NEAT_F6_ABLATE != 1) {
-    r0 = st.m0 + __builtin_amdgcn_logf(st.w0);
-    r1 = st.m1 + __builtin_amdgcn_logf(st.w1);
-    if (!E::UDOM && NEAT_F6_ABLATE != 6) { r0 *= 0.0069314718055994531f; r1 *= 0.0069314718055994531f; }
+    if (E::UDOM || NEAT_F6_ABLATE == 6) { r0 = st.m0 + __builtin_amdgcn_logf(st.w0); r1 = st.m1 + __builtin_amdgcn_logf(st.w1); }
+    else { r0 = fmaf(__builtin_amdgcn_logf(st.w0), 0.0069314718055994531f, st.m0); r1 = fmaf(__builtin_amdgcn_logf(st.w1), 0.0069314718055994531f, st.m1); }
   }
   const unsigned pk = pack2(r0, r1);
   if (pr == 0) { st.lo = pk; return; }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
     float v = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (l == k && n < (k == 3 ? 217 : 256)) v = a.bias[k][n];
-    biasl[idx] = v * SOFTPLUS_C;             // hidden layers: pre-scaled for the softplus epilogue
+    biasl[idx] = VALUES ? v * SOFTPLUS_C : v;      // hidden layers (values mode: in the softplus's scale, F6EpiCfg UDOM); operand C of the layer's first MFMAs
   }
   for (int n = tid; n < 257; n += F6T) {
     int bi = n + a.bias8_rot; if (bi >= a.bias8_n) bi -= a.bias8_n;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       typedef F6EpiCfg<false, true, 256, 0, 8 * 256> E8;     // lin8 feature rows -> HBM only
       f32x16 acc[2][RT];
       float4 bq[4 * RT];
-      f32x16 c0[RT];                 // values mode: the bias rows of the layer whose MFMAs run, as their first operand C
+      f32x16 c0[RT];                 // the bias rows of the layer whose MFMAs run, as their first operand C
       uint4 ring[NEAT_F6_RING];
       constexpr int RD = NEAT_F6_RING;
 #define F6_KSUM(S_) ((S_) < 4 ? 4 * (S_) : ((S_) < 33 ? 16 * (S_) - 48 : 16 * (S_) - 64))      /* k-steps before stage S_ (stage 32 = drain) */
@@ -444,11 +444,11 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
       // stage of a layer prefetches fragments of the next layer's input NSRC_ (3 = none).  A barrier ends every second stage
       // (a tile written in stage w is read in stage w + 3) and every stage where ALLBAR_ says so.
 #define F6_STAGE(S_, T_, KS_, SRC_, WC_, E_, H_, TE_, NFR_, BAR_)                                                                   \
-      f6_stage<NT, RT, FULL, true, KS_, SRC_, E_, F6_KSUM(S_) % RD, BAR_, false, VALUES>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], bq, TE_, nt, H_, wave, hi, ring, NFR_, nullptr, c0);
+      f6_stage<NT, RT, FULL, true, KS_, SRC_, E_, F6_KSUM(S_) % RD, BAR_, false, true>(L, WC_, T_, acc[(S_) & 1], acc[((S_) + 1) & 1], bq, TE_, nt, H_, wave, hi, ring, NFR_, nullptr, c0);
 #define F6_LAYER(S0_, KS_, SRC_, WC_, EPREV_, ECUR_, HPREV_, HCUR_, NSRC_, ALLBAR_, PRE_)                                              \
-      { if (VALUES) f6_load_bias16<ECUR_, RT>(L, c0);                                                                            \
+      { f6_load_bias16<ECUR_, RT>(L, c0);                                                                                        \
         PRE_(0) F6_STAGE((S0_) + 0, 0, KS_, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512, (ALLBAR_ || ((S0_) + 0) % 2 == 1))  \
-        if (!VALUES) f6_load_bias<ECUR_, RT>(L, bq);                                                                                          \
+                                                                                                \
         PRE_(1) F6_STAGE((S0_) + 1, 1, KS_, SRC_, WC_, ECUR_, HCUR_, 0, L.frag[SRC_] + 2 * 512, (ALLBAR_ || ((S0_) + 1) % 2 == 1))  \
         PRE_(2) F6_STAGE((S0_) + 2, 2, KS_, SRC_, WC_, ECUR_, HCUR_, 1, L.frag[SRC_] + 3 * 512, (ALLBAR_ || ((S0_) + 2) % 2 == 1))  \
         PRE_(3) F6_STAGE((S0_) + 3, 3, KS_, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 3 ? L.frag[(NSRC_) < 3 ? (NSRC_) : 0] : nullptr), (ALLBAR_ || ((S0_) + 3) % 2 == 1)) }
@@ -460,9 +460,9 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
         _Pragma("unroll") for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[SRC_] + j * 2 * BP * 16);
 #define F6_LAYER1(KS_, SRC_, WC_, ECUR_, HCUR_)                                                                                     \
         { F6_RING0(SRC_)                                                                                                            \
-          if (VALUES) f6_load_bias16<ECUR_, RT>(L, c0);                                                                             \
-          f6_stage<NT, RT, true, true, KS_, SRC_, F6NoEpi, 0, false, false, VALUES>(L, WC_, 0, acc[0], acc[1], bq, 0, 1, nullptr, wave, hi, ring, nullptr, nullptr, c0); \
-          if (!VALUES) f6_load_bias<ECUR_, RT>(L, bq);                                                                                           \
+          f6_load_bias16<ECUR_, RT>(L, c0);                                                                                         \
+          f6_stage<NT, RT, true, true, KS_, SRC_, F6NoEpi, 0, false, false, true>(L, WC_, 0, acc[0], acc[1], bq, 0, 1, nullptr, wave, hi, ring, nullptr, nullptr, c0); \
+                                                                                                   \
           f6_stage<NT, RT, true, false, 16, 0, ECUR_, 0, true>(L, WC_, 0, acc[1], acc[0], bq, 0, 1, HCUR_, wave, hi, ring, nullptr); }
         F6_LAYER1(4, 2, wB, E0, a.h[1])
         load_w(wB, a.Wp[2], 16, 256);
