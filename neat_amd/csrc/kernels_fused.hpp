@@ -28,6 +28,19 @@ namespace neat {
 #ifndef NEAT_F6_ABLATE
 #define NEAT_F6_ABLATE 0
 #endif
+#ifndef NEAT_ADJ_ABLATE
+#define NEAT_ADJ_ABLATE 0   // probe builds of the adjoint chain only (results WRONG): 1 = no stores of u, 2 = no loads of the saved h quads
+#endif
+#ifndef NEAT_ADJ_NT_LOAD
+#define NEAT_ADJ_NT_LOAD 1      // adjoint chain: the saved h quads arrive with non-temporal loads (round 5: 284 -> 271 us at C2)
+#endif
+#ifndef NEAT_F6_WIDE
+#define NEAT_F6_WIDE 1         // primal chain (save mode): the hidden activations leave as 16-byte stores (as NEAT_ADJ_WIDE)
+#endif
+#ifndef NEAT_ADJ_WIDE
+#define NEAT_ADJ_WIDE 1       // adjoint chain: the saved h quads arrive and the u quads leave as 16-byte accesses (whole octets: lanes 0-31 the octet of
+                              // quad 2j, lanes 32-63 the octet of quad 2j+1, halves exchanged with v_permlane32_swap) instead of 8-byte ones
+#endif
 #ifndef NEAT_F6_SPLITK
 #define NEAT_F6_SPLITK 0    // RT = 1: k-steps alternate between two accumulator chains (measured neutral)
 #endif
@@ -61,6 +74,7 @@ struct F6Lane {
   const unsigned char* bias;      // bias float4 reads: BIAS + (64 wave + 4 hi) * 4
   const unsigned char* pe0;       // PE octet 0 of this lane's point: PE + (lane & 31) * 16        (+ t * 512)
   unsigned gquad;                 // HBM quad store:   ((8 wave) * ldp + p0 + (lane & 31)) * 16 + 8 hi      (per batch)
+  unsigned goct;                  // adjoint chain, 16-byte accesses: ((4 wave + hi) * ldp + p0 + (lane & 31)) * 16 -- lanes 32-63 one octet row further, whole octets
   unsigned ldp16;                 // ldp * 16
   float* frows;                   // adjoint chain: fp32 feature-major rows [.][ldp] for the rows >= SPLIT of the current layer
   unsigned fcol;                  // p0 + (lane & 31)                                                             (per batch)
@@ -74,7 +88,7 @@ struct F6Lane {
 // epilogue, so there is no bubble between layers.  Accumulators ping-pong between two register sets (static indices:
 // everything is unrolled).
 // ---------------------------------------------------------------------------------------------------------------
-struct F6EpiState { float m0, m1, w0, w1; unsigned lo; };       // what travels from half unit A to half unit B of a value pair
+struct F6EpiState { float m0, m1, w0, w1; unsigned lo; uint2 vprev; unsigned hs[4]; };       // what travels from half unit A to half unit B of a value pair (vprev: adjoint chain, the even quad of a 16-byte store)
 #ifndef NEAT_ADJ_NT_FROWS
 #define NEAT_ADJ_NT_FROWS 0     // the adjoint chain's fp32 rows (PE cotangents e0 / es, read by sdf_finalize_kernel right behind it)
 #endif
@@ -86,6 +100,19 @@ __device__ __forceinline__ void f6_storef(float* p, float v) { if (NEAT_ADJ_NT_F
 #define NEAT_F6_NT 1           // the saved arrays (h_l, u_l: read again only by the backward pass) leave with non-temporal stores: they no longer
                                // displace the weight fragments the rolling refills fetch from L2 (round 5: adjoint chain 300 -> 255 us at C2)
 #endif
+// quads 2j (prev) and 2j+1 (cur) of this lane -> the octet this lane stores: quad 2j's octet for lanes 0-31, quad 2j+1's for lanes 32-63
+__device__ __forceinline__ uint4 f6_octet(uint2 prev, uint2 cur) {
+  typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+  const v2u_t s0 = __builtin_amdgcn_permlane32_swap(prev.x, cur.x, false, false);
+  const v2u_t s1 = __builtin_amdgcn_permlane32_swap(prev.y, cur.y, false, false);
+  return make_uint4(s0.x, s1.x, s0.y, s1.y);
+}
+__device__ __forceinline__ void f6_store16(void* p, uint4 v) {
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  const v4u_t w = {v.x, v.y, v.z, v.w};
+  if (NEAT_F6_NT) __builtin_nontemporal_store(w, reinterpret_cast<v4u_t*>(p));
+  else *reinterpret_cast<v4u_t*>(p) = w;
+}
 __device__ __forceinline__ void f6_store8(void* p, uint2 v) {
   typedef unsigned long long u64_t;
   if (NEAT_F6_NT) __builtin_nontemporal_store(__builtin_bit_cast(u64_t, v), reinterpret_cast<u64_t*>(p));
@@ -142,7 +169,16 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
     const int nb = 32 * (RT * wave + i) + 8 * q + 4 * hi + 2 * pr;          // rows nb, nb + 1 of the layer's output
     if (h == 0) {
       if (E::SPLIT > 0) {
-        const unsigned hw = __float_as_uint(pr ? bq[g].y : bq[g].x);
+        unsigned hw;
+        if (NEAT_ADJ_WIDE) {      // bq[q even] = the raw octet this lane loaded (load_h): first use of a quad pair swaps the halves (hs = quad q | quad q+1)
+          if ((q & 1) == 0 && pr == 0) {
+            typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+            const v2u_t s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(bq[g].x), __float_as_uint(bq[g].z), false, false);
+            const v2u_t s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(bq[g].y), __float_as_uint(bq[g].w), false, false);
+            st.hs[0] = s0.x; st.hs[1] = s1.x; st.hs[2] = s0.y; st.hs[3] = s1.y;
+          }
+          hw = st.hs[2 * (q & 1) + pr];
+        } else hw = __float_as_uint(pr ? bq[g].y : bq[g].x);
         st.m0 = x0 * dphi_fast(bf_lo(hw));      // (the streaming EPI_REV epilogue's expression: bit-identical results)
         st.m1 = x1 * dphi_fast(bf_hi(hw));
       }
@@ -164,8 +200,12 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
     if (pr == 0) { st.lo = pk; return; }
     const uint2 v = make_uint2(st.lo, pk);
     if (E::SPLIT > 0) *reinterpret_cast<uint2*>(L.quad[E::DST] + ((i * 4 + q) * BP + t * 32) * 16) = v;
-    if (E::SAVE && (FULL || t < nt))
-      f6_store8(reinterpret_cast<char*>(hout) + ((unsigned)(i * 4 + q) * L.ldp16 + L.gquad) + t * 512, v);
+    if (E::SAVE && (FULL || t < nt) && !(NEAT_ADJ_ABLATE & 1)) {
+      if (NEAT_ADJ_WIDE) {
+        if (q & 1) f6_store16(reinterpret_cast<char*>(hout) + ((unsigned)(i * 4 + q - 1) * L.ldp16 + L.goct) + t * 512, f6_octet(st.vprev, v));
+        else st.vprev = v;
+      } else f6_store8(reinterpret_cast<char*>(hout) + ((unsigned)(i * 4 + q) * L.ldp16 + L.gquad) + t * 512, v);
+    }
     return;
   }
   // The bias is already in the accumulator (f6_stage CINIT): x = W in + b.  Softplus with beta = 100 (rend_a :94):
@@ -202,8 +242,12 @@ __device__ __forceinline__ void f6_epi_half(const F6Lane& L, const f32x16 (&ae)[
   }
   if (E::ACT && NEAT_F6_ABLATE != 5) *reinterpret_cast<uint2*>(L.quad[E::DST] + ((i * 4 + q) * BP + t * 32) * 16) = v;
   if (NEAT_F6_ABLATE == 5) asm volatile("" :: "v"(v.x), "v"(v.y));
-  if (E::SAVE && NEAT_F6_ABLATE != 9 && (FULL || t < nt))                     // wave-uniform row base + per-lane 32-bit offset + immediate
-    f6_store8(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q) * L.ldp16) + t * 512) + (size_t)L.gquad, v);
+  if (E::SAVE && NEAT_F6_ABLATE != 9 && (FULL || t < nt)) {                   // wave-uniform row base + per-lane 32-bit offset + immediate
+    if (NEAT_F6_WIDE) {      // 16-byte stores: the even quad waits for its odd neighbour, lanes 0-31 store the even quad's octet, lanes 32-63 the odd one's
+      if (q & 1) f6_store16(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q - 1) * L.ldp16) + t * 512) + (size_t)L.goct, f6_octet(st.vprev, v));
+      else st.vprev = v;
+    } else f6_store8(reinterpret_cast<char*>(hout) + ((size_t)((i * 4 + q) * L.ldp16) + t * 512) + (size_t)L.gquad, v);
+  }
 }
 
 // MMA = false: drain stage (epilogue only).  KS k-steps of layer input region SRC (0 = XA, 1 = XB, 2 = PE), tile t; the epilogue
@@ -368,6 +412,7 @@ __global__ __launch_bounds__(64 * (8 / RT), 2 / RT) void sdf_fused_w64_kernel(Fu
     const int p0 = (tile0 + sub) * 32;
     const int nt = ntb == NT ? NT : 1;
     L.gquad = ((unsigned)(4 * RT * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
+    L.goct = ((unsigned)(4 * RT * wave + hi) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u;
 
     auto chain = [&](auto single_tag) {
       constexpr bool FULL = true, SINGLE = decltype(single_tag)::value;
@@ -662,6 +707,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
     const int p0 = (tile0 + sub) * 32;
     const int nt = (ntb == NT || !NEAT_ADJ_SINGLE) ? ntb : 1;
     L.gquad = ((unsigned)(4 * RT * wave) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u + 8u * hi;
+    L.goct = ((unsigned)(4 * RT * wave + hi) * (unsigned)a.ldp + (unsigned)(p0 + (lane & 31))) * 16u;
     L.fcol = (unsigned)(p0 + (lane & 31));
     // the row stride as an opaque per-batch VGPR: with a loop-invariant stride the 64 (array, quad) row bases of the sixteen h / u
     // arrays are hoisted out of the batch loop as scalar pairs and spilled
@@ -671,13 +717,22 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
     auto chain = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
       // the saved activation quads of this lane for point tile t: rows 32 wave + 8 q + 4 hi .. + 3, raw bf16 (see F6RevCfg)
-      auto load_h = [&](float4 (&dst)[4 * RT], const u16* hsrc, int t) {
+      auto load_h = [&](float4 (&dst)[4 * RT], const u16* hsrc, int t, bool wide = NEAT_ADJ_WIDE != 0) {
         if (!(FULL || t < nt)) return;
+        if (NEAT_ADJ_ABLATE & 2) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { dst[q].x = 0.0f; dst[q].y = 0.0f; } return; }
+        if (wide) {      // two 16-byte loads: lanes 0-31 the octets of quads 0 / 2, lanes 32-63 those of quads 1 / 3, kept RAW in dst[0] / dst[2]; the
+          // halves the other lane needs are swapped where the epilogue uses them (f6_epi_half) -- a swap here would wait for the load at once
+          typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+          for (int qq = 0; qq < 4; qq += 2) {
+            const v4u_t* hp = reinterpret_cast<const v4u_t*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)qq * L.ldp16 + L.goct) + t * 512);
+            const v4u_t o = NEAT_ADJ_NT_LOAD ? __builtin_nontemporal_load(hp) : *hp;
+            dst[qq].x = __uint_as_float(o.x); dst[qq].y = __uint_as_float(o.y); dst[qq].z = __uint_as_float(o.z); dst[qq].w = __uint_as_float(o.w);
+          }
+          return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {      // kernarg base + one 32-bit per-lane offset (the arrays are < 4 GB) + immediate
-#ifndef NEAT_ADJ_NT_LOAD
-#define NEAT_ADJ_NT_LOAD 1      // the saved h quads arrive with non-temporal loads (round 5: 284 -> 271 us at C2)
-#endif
           typedef unsigned long long u64_t;
           const u64_t* hp = reinterpret_cast<const u64_t*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)q * L.ldp16 + L.gquad) + t * 512);
           const uint2 v = NEAT_ADJ_NT_LOAD ? __builtin_bit_cast(uint2, __builtin_nontemporal_load(hp)) : *reinterpret_cast<const uint2*>(hp);
@@ -704,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
             for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(L.quad[0] + (q * BP + t * 32) * 16) = make_uint2(0u, 0u);
             continue;
           }
-          load_h(hq[0], a.h[8], t);
+          load_h(hq[0], a.h[8], t, false);      // (the seed reads its quads directly: 8-byte loads)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const unsigned h0 = __float_as_uint(hq[0][q].x), h1 = __float_as_uint(hq[0][q].y);
@@ -738,19 +793,24 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
         if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 0) % HD], HSRC_, 0);                                                              \
         if (HD == 3 && HAS_H_) load_h(hq[((S0_) + 1) % HD], HSRC_, 1);                                                              \
         ADJ_STAGE((S0_) + 0, 0, SRC_, WC_, EPREV_, HPREV_, NT - 1, L.frag[SRC_] + 1 * 512)                                         \
+        if (HD == 4 && HAS_H_) load_h(hq[((S0_) + 2) % HD], HSRC_, 2);                                                              \
         L.frows = FCUR_;                                                                                                          \
         if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 1) % HD], HSRC_, 1);                                                              \
         if (HD == 3 && HAS_H_) load_h(hq[((S0_) + 2) % HD], HSRC_, 2);                                                              \
         ADJ_STAGE((S0_) + 1, 1, SRC_, WC_, ECUR_, HCUR_, 0, L.frag[SRC_] + 2 * 512)                                                \
+        if (HD == 4 && HAS_H_) load_h(hq[((S0_) + 3) % HD], HSRC_, 3);                                                              \
         if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 2) % HD], HSRC_, 2);                                                              \
         if (HD == 3 && HAS_H_) load_h(hq[((S0_) + 3) % HD], HSRC_, 3);                                                              \
         ADJ_STAGE((S0_) + 2, 2, SRC_, WC_, ECUR_, HCUR_, 1, L.frag[SRC_] + 3 * 512)                                                \
+        if (HD == 4 && HASN_) load_h(hq[((S0_) + 4) % HD], HNEXT_, 0);                                                              \
         if (HD == 2 && HAS_H_) load_h(hq[((S0_) + 3) % HD], HSRC_, 3);                                                              \
         if (HD == 3 && HASN_) load_h(hq[((S0_) + 4) % HD], HNEXT_, 0);                                                              \
-        ADJ_STAGE_ROLL((S0_) + 3, 3, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 2 ? L.frag[(NSRC_) < 2 ? (NSRC_) : 0] : nullptr), w_addr(WNEXT_, NNEXT_)) }
+        ADJ_STAGE_ROLL((S0_) + 3, 3, SRC_, WC_, ECUR_, HCUR_, 2, ((NSRC_) < 2 ? L.frag[(NSRC_) < 2 ? (NSRC_) : 0] : nullptr), w_addr(WNEXT_, NNEXT_)) \
+        if (HD == 4 && HASN_) load_h(hq[((S0_) + 5) % HD], HNEXT_, 1); }
 #pragma unroll
       for (int j = 0; j < RD - 1; ++j) ring[j] = *reinterpret_cast<const uint4*>(L.frag[0] + j * 2 * BP * 16);
       if (HD == 3) load_h(hq[0], a.h[7], 0);
+      if (HD == 4) { load_h(hq[0], a.h[7], 0); load_h(hq[1], a.h[7], 1); }      // HD = 4: the quads of the tile whose MFMAs run two stages later, requested BEHIND a stage (and its rolling weight refills)
       ADJ_LAYER(0, 0, wA, F6NoEpi, R7, nullptr, a.u[6], 1, a.h[7], 1, nullptr, nullptr, a.Wp[6], 256, 1, a.h[6])
       ADJ_LAYER(4, 1, wA, R7, R6, a.u[6], a.u[5], 1, a.h[6], 0, nullptr, nullptr, a.Wp[5], 256, 1, a.h[5])
       ADJ_LAYER(8, 0, wA, R6, R5, a.u[5], a.u[4], 1, a.h[5], 1, nullptr, nullptr, a.Wp[4], 256, 1, a.h[4])
@@ -769,7 +829,15 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
     // epilogue, then the barrier that publishes the tile
     auto chain_single = [&]() {
       constexpr bool FULL = false;
-      auto load_h = [&](float4 (&dst)[4 * RT], const u16* hsrc) {
+      auto load_h = [&](float4 (&dst)[4 * RT], const u16* hsrc, bool wide = NEAT_ADJ_WIDE != 0) {
+        if (wide) {      // the raw octets f6_epi_half expects (see `chain` above)
+#pragma unroll
+          for (int qq = 0; qq < 4; qq += 2) {
+            const uint4 o = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)qq * L.ldp16 + L.goct));
+            dst[qq].x = __uint_as_float(o.x); dst[qq].y = __uint_as_float(o.y); dst[qq].z = __uint_as_float(o.z); dst[qq].w = __uint_as_float(o.w);
+          }
+          return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(hsrc) + ((unsigned)q * L.ldp16 + L.gquad));
@@ -781,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void sdf_adjoint_w64_kernel(AdjArgs a, int 
         float4 wq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(L.bias + (8 * q) * 4);
-        load_h(hq, a.h[8]);
+        load_h(hq, a.h[8], false);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const unsigned h0 = __float_as_uint(hq[q].x), h1 = __float_as_uint(hq[q].y);
