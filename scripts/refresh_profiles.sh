@@ -3,7 +3,7 @@
 # Every command runs under its own `timeout`: a hung profiler must not take the box with it.
 R=$PWD; O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 T="timeout 600"
-$T python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $O/tests.log
+$T python -m pytest tests -m gpu -x -q > $O/tests_full.log 2>&1; echo "pytest rc=$?" >> $O/tests_full.log; grep -v "^Extension modules" $O/tests_full.log | tail -12 | cut -c1-300 > $O/tests.log
 $T python bench.py > $O/bench_bf16.log 2>&1; grep '^{"metric"' $O/bench_bf16.log | tail -1 > $O/bench_bf16.json
 $T python bench.py --precision fp16x3 --no-secondary > $O/bench_fp16x3.log 2>&1; grep '^{"metric"' $O/bench_fp16x3.log | tail -1 > $O/bench_fp16x3.json
 $T python bench.py --precision fp32 --no-secondary --no-cpu-baseline > $O/bench_fp32.log 2>&1; grep '^{"metric"' $O/bench_fp32.log | tail -1 > $O/bench_fp32.json
